@@ -1,0 +1,301 @@
+"""PX4-style control cascades (oracle; test infrastructure).
+
+PARITY UNPINNED.  The reference calls the external C++ package
+`rlPx4Controller.pyParallelControl` (`airgym/envs/base/hovering.py:10,235-250`;
+cloned at HEAD by `configuration.sh:94-111`, not vendored, no version pin), so
+none of this arithmetic is in `/root/reference`.  What the reference fixes is the
+*interface*: per control mode the action layout, the state handed over
+(`set_status(pos, q_wxyz, linvel, angvel, 0.01)` / `set_q_world(q_wxyz)`), the
+fixed controller dt of 0.01 s and the output, four normalised rotor commands.
+This file is the build's own written spec of the public PX4 multicopter
+structure that package says it mirrors (README.md:64,72):
+
+    PY  (pos) : position P            -> velocity setpoint
+    LV  (vel) : velocity PID          -> acceleration -> thrust vector + yaw -> attitude setpoint
+    CTA (atti): quaternion attitude P -> body-rate setpoint
+    CTBR(rate): body-rate PID         -> normalised torque
+    mixer     : quad-X                -> 4 rotor commands in [0,1]
+    SRT (prop): pass-through (`hovering.py:251-252`)
+
+Frames: world z-up, body FLU, quaternions xyzw body->world, angular velocity
+arrives in the WORLD frame (IsaacGym convention) and is rotated into the body
+frame first.  All arithmetic is float32, written component-wise in the exact
+order `airgym_amd/csrc/env_math.hpp` evaluates it.
+
+Gains are PX4 v1.14 multicopter defaults (MC_ROLLRATE_P/I/D 0.15/0.2/0.003,
+MC_YAWRATE_P/I 0.2/0.1, MC_RR_INT_LIM 0.3, MC_ROLL_P 6.5, MC_YAW_P 2.8,
+MC_YAW_WEIGHT 0.4, MC_ROLLRATE_MAX 220 deg/s, MC_YAWRATE_MAX 200 deg/s,
+MPC_XY_VEL_P/I/D_ACC 1.8/0.4/0.2, MPC_Z_VEL_P/I_ACC 4/2, MPC_XY_P 0.95,
+MPC_Z_P 1.0, MPC_TILTMAX_AIR 45 deg).  Hover thrust is the per-rotor command
+that balances gravity: 0.601*9.81/(4*9.59) = 0.1537.
+
+Deviation from the reference, documented: controller state is cleared when an
+env resets (the reference never resets the C++ controller objects,
+`hovering.py:310-335`).
+"""
+import math
+
+import torch
+
+from .rigid_body import quat_rotate_inverse_xyzw
+
+CTL_DT = 0.01
+INV_CTL_DT = 100.0
+
+RATE_KP = (0.15, 0.15, 0.2)
+RATE_KI = (0.2, 0.2, 0.1)
+RATE_KD = (0.003, 0.003, 0.0)
+RATE_INT_LIM = 0.3
+RATE_I_ATTEN_INV = 1.0 / math.radians(400.0)
+
+MIX_RP = 0.70710678
+MIX_YAW = 1.0
+
+ATT_GAIN = (6.5, 6.5, 2.8 / 0.4)
+ATT_YAW_W = 0.4
+ATT_RATE_LIM = (math.radians(220.0), math.radians(220.0), math.radians(200.0))
+
+VEL_KP = (1.8, 1.8, 4.0)
+VEL_KI = (0.4, 0.4, 2.0)
+VEL_KD = (0.2, 0.2, 0.0)
+VEL_INT_LIM = 9.81
+GRAV = 9.81
+HOVER_THRUST = 0.1537
+HOVER_OVER_G = HOVER_THRUST / GRAV
+THR_MIN = 0.03
+THR_MAX = 1.0
+COS_TILT_MAX = math.cos(math.radians(45.0))
+SIN_TILT_MAX = math.sin(math.radians(45.0))
+
+POS_KP = (0.95, 0.95, 1.0)
+POS_VEL_XY_MAX = 12.0
+POS_VEL_UP_MAX = 3.0
+POS_VEL_DN_MAX = 1.5
+
+
+def _clamp(x, lo, hi):
+    return torch.clamp(x, min=lo, max=hi)
+
+
+# ----------------------------------------------------------------------------
+# quaternion helpers, xyzw, component tuples of [N] tensors
+# ----------------------------------------------------------------------------
+def qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return (
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by + ay * bw + az * bx - ax * bz,
+        aw * bz + az * bw + ax * by - ay * bx,
+        aw * bw - ax * bx - ay * by - az * bz,
+    )
+
+
+def qconj(a):
+    return (-a[0], -a[1], -a[2], a[3])
+
+
+def q_body_z(q):
+    x, y, z, w = q
+    return (2.0 * (x * z + w * y), 2.0 * (y * z - w * x), 1.0 - 2.0 * (x * x + y * y))
+
+
+def qnormalize(q):
+    inv = 1.0 / torch.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    return (q[0] * inv, q[1] * inv, q[2] * inv, q[3] * inv)
+
+
+# ----------------------------------------------------------------------------
+# state
+# ----------------------------------------------------------------------------
+class CascadeState:
+    """Per-env controller memory (SoA): rate integrator, previous body rate,
+    velocity integrator, previous velocity."""
+
+    def __init__(self, n):
+        self.rate_int = torch.zeros(n, 3)
+        self.prev_rate = torch.zeros(n, 3)
+        self.vel_int = torch.zeros(n, 3)
+        self.prev_vel = torch.zeros(n, 3)
+
+    def reset(self, ids, root_states):
+        """Clear on env reset; the D-terms see zero derivative on the next step."""
+        self.rate_int[ids] = 0.0
+        self.vel_int[ids] = 0.0
+        rs = root_states[ids]
+        self.prev_rate[ids] = quat_rotate_inverse_xyzw(rs[:, 3:7], rs[:, 10:13])
+        self.prev_vel[ids] = rs[:, 7:10]
+
+
+# ----------------------------------------------------------------------------
+# CTBR: body-rate PID  (PX4 RateControl::update)
+# ----------------------------------------------------------------------------
+def rate_control(st, rate_sp, wb):
+    """rate_sp, wb: tuples of 3 [N] tensors (body frame).  Returns torque (3)."""
+    out = []
+    new_int = []
+    for i in range(3):
+        err = rate_sp[i] - wb[i]
+        wdot = (wb[i] - st.prev_rate[:, i]) * INV_CTL_DT
+        u = RATE_KP[i] * err + st.rate_int[:, i] - RATE_KD[i] * wdot
+        out.append(u)
+        # integrator update happens after the torque is formed (old integral is used above)
+        a = err * RATE_I_ATTEN_INV
+        i_factor = torch.clamp(1.0 - a * a, min=0.0)
+        ri = st.rate_int[:, i] + i_factor * RATE_KI[i] * err * CTL_DT
+        new_int.append(_clamp(ri, -RATE_INT_LIM, RATE_INT_LIM))
+    st.rate_int = torch.stack(new_int, dim=-1)
+    st.prev_rate = torch.stack(wb, dim=-1)
+    return tuple(out)
+
+
+def mix_quad_x(thrust, u):
+    """Rotor i torque-sign pattern (roll, pitch, yaw) in FLU with rotors at
+    (+,-), (-,+), (+,+), (-,-):  1:(-,-,-)  2:(+,+,-)  3:(+,-,+)  4:(-,+,+)."""
+    r = MIX_RP * u[0]
+    p = MIX_RP * u[1]
+    y = MIX_YAW * u[2]
+    c1 = _clamp(thrust - r - p - y, 0.0, 1.0)
+    c2 = _clamp(thrust + r + p - y, 0.0, 1.0)
+    c3 = _clamp(thrust + r - p + y, 0.0, 1.0)
+    c4 = _clamp(thrust - r + p + y, 0.0, 1.0)
+    return torch.stack((c1, c2, c3, c4), dim=-1)
+
+
+# ----------------------------------------------------------------------------
+# CTA: quaternion attitude P  (PX4 AttitudeControl::update)
+# ----------------------------------------------------------------------------
+def attitude_control(q, qd):
+    """q current attitude, qd setpoint (both xyzw tuples, qd need not be unit).
+    Returns body-rate setpoint (3)."""
+    n2 = qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3]
+    bad = n2 < 1e-12
+    one = torch.ones_like(n2)
+    zero = torch.zeros_like(n2)
+    inv = 1.0 / torch.sqrt(torch.where(bad, one, n2))
+    qd = (
+        torch.where(bad, zero, qd[0] * inv),
+        torch.where(bad, zero, qd[1] * inv),
+        torch.where(bad, zero, qd[2] * inv),
+        torch.where(bad, one, qd[3] * inv),
+    )
+    ez = q_body_z(q)
+    ezd = q_body_z(qd)
+    # shortest rotation ez -> ezd (world frame)
+    cx = ez[1] * ezd[2] - ez[2] * ezd[1]
+    cy = ez[2] * ezd[0] - ez[0] * ezd[2]
+    cz = ez[0] * ezd[1] - ez[1] * ezd[0]
+    dot = ez[0] * ezd[0] + ez[1] * ezd[1] + ez[2] * ezd[2]
+    rw = dot + 1.0
+    # opposite thrust directions: no unique reduced rotation, fall back to the full setpoint
+    singular = rw < 1e-5
+    rn = 1.0 / torch.sqrt(torch.where(singular, one, cx * cx + cy * cy + cz * cz + rw * rw))
+    red = (cx * rn, cy * rn, cz * rn, rw * rn)
+    red = qmul(red, q)
+    red = tuple(torch.where(singular, qd[i], red[i]) for i in range(4))
+    # mix in the full setpoint's yaw with weight ATT_YAW_W
+    qmix = qmul(qconj(red), qd)
+    sgn = torch.where(qmix[3] < 0.0, -one, one)
+    mw = _clamp(qmix[3] * sgn, -1.0, 1.0)
+    mz = _clamp(qmix[2] * sgn, -1.0, 1.0)
+    yaw_q = (zero, zero, torch.sin(ATT_YAW_W * torch.asin(mz)), torch.cos(ATT_YAW_W * torch.acos(mw)))
+    qdd = qmul(red, yaw_q)
+    qe = qmul(qconj(q), qdd)
+    s2 = torch.where(qe[3] < 0.0, -2.0 * one, 2.0 * one)
+    out = []
+    for i in range(3):
+        r = ATT_GAIN[i] * (s2 * qe[i])
+        out.append(_clamp(r, -ATT_RATE_LIM[i], ATT_RATE_LIM[i]))
+    return tuple(out)
+
+
+# ----------------------------------------------------------------------------
+# LV: velocity PID -> thrust vector -> attitude setpoint  (PX4 PositionControl)
+# ----------------------------------------------------------------------------
+def velocity_control(st, vel_sp, vel, yaw_sp):
+    """Returns (q_sp xyzw tuple, collective thrust)."""
+    err = [vel_sp[i] - vel[i] for i in range(3)]
+    acc = []
+    for i in range(3):
+        vdot = (vel[i] - st.prev_vel[:, i]) * INV_CTL_DT
+        acc.append(VEL_KP[i] * err[i] + st.vel_int[:, i] - VEL_KD[i] * vdot)
+    # desired body z: horizontal acceleration against gravity (vertical decoupled)
+    bn = 1.0 / torch.sqrt(acc[0] * acc[0] + acc[1] * acc[1] + GRAV * GRAV)
+    bx = acc[0] * bn
+    by = acc[1] * bn
+    bz = GRAV * bn
+    # tilt limit
+    over = bz < COS_TILT_MAX
+    hn = torch.sqrt(bx * bx + by * by)
+    hs = SIN_TILT_MAX / torch.where(over, hn, torch.ones_like(hn))
+    bx = torch.where(over, bx * hs, bx)
+    by = torch.where(over, by * hs, by)
+    bz = torch.where(over, torch.full_like(bz, COS_TILT_MAX), bz)
+    coll_raw = (acc[2] + GRAV) * HOVER_OVER_G / bz
+    coll = _clamp(coll_raw, THR_MIN, THR_MAX)
+    # integrator, vertical anti-windup
+    sat = ((coll_raw >= THR_MAX) & (err[2] >= 0.0)) | ((coll_raw <= THR_MIN) & (err[2] <= 0.0))
+    err[2] = torch.where(sat, torch.zeros_like(err[2]), err[2])
+    new_int = []
+    for i in range(3):
+        vi = st.vel_int[:, i] + VEL_KI[i] * err[i] * CTL_DT
+        new_int.append(_clamp(vi, -VEL_INT_LIM, VEL_INT_LIM))
+    st.vel_int = torch.stack(new_int, dim=-1)
+    st.prev_vel = torch.stack(vel, dim=-1)
+    # attitude setpoint = tilt(e_z -> b) * yaw(z)
+    tw = 1.0 + bz
+    tn = 1.0 / torch.sqrt(bx * bx + by * by + tw * tw)
+    q_tilt = (-by * tn, bx * tn, torch.zeros_like(bx), tw * tn)
+    half = 0.5 * yaw_sp
+    q_yaw = (torch.zeros_like(bx), torch.zeros_like(bx), torch.sin(half), torch.cos(half))
+    return qmul(q_tilt, q_yaw), coll
+
+
+# ----------------------------------------------------------------------------
+# PY: position P -> velocity setpoint
+# ----------------------------------------------------------------------------
+def position_control(pos_sp, pos):
+    vx = POS_KP[0] * (pos_sp[0] - pos[0])
+    vy = POS_KP[1] * (pos_sp[1] - pos[1])
+    vz = POS_KP[2] * (pos_sp[2] - pos[2])
+    n = torch.sqrt(vx * vx + vy * vy)
+    over = n > POS_VEL_XY_MAX
+    s = POS_VEL_XY_MAX / torch.where(over, n, torch.ones_like(n))
+    vx = torch.where(over, vx * s, vx)
+    vy = torch.where(over, vy * s, vy)
+    vz = _clamp(vz, -POS_VEL_DN_MAX, POS_VEL_UP_MAX)
+    return (vx, vy, vz)
+
+
+# ----------------------------------------------------------------------------
+# dispatch: what `pre_physics_step` calls (hovering.py:234-254)
+# ----------------------------------------------------------------------------
+def controller_update(ctl_mode, st, actions, root_states):
+    """actions [N,A] already pre-processed/clamped; root_states [N,13] with the
+    quaternion canonicalised (w >= 0).  Returns cmd_thrusts [N,4] float32."""
+    if ctl_mode == "prop":
+        return actions.clone()
+    q = tuple(root_states[:, 3 + i] for i in range(4))
+    wb_t = quat_rotate_inverse_xyzw(root_states[:, 3:7], root_states[:, 10:13])
+    wb = tuple(wb_t[:, i] for i in range(3))
+    if ctl_mode == "rate":
+        rate_sp = tuple(actions[:, i] for i in range(3))
+        thrust = actions[:, 3]
+    elif ctl_mode == "atti":
+        # action = (qw, qx, qy, qz, thrust), hovering.py:105
+        qd = (actions[:, 1], actions[:, 2], actions[:, 3], actions[:, 0])
+        rate_sp = attitude_control(q, qd)
+        thrust = actions[:, 4]
+    elif ctl_mode in ("vel", "pos"):
+        vel = tuple(root_states[:, 7 + i] for i in range(3))
+        if ctl_mode == "pos":
+            pos = tuple(root_states[:, i] for i in range(3))
+            vel_sp = position_control(tuple(actions[:, i] for i in range(3)), pos)
+        else:
+            vel_sp = tuple(actions[:, i] for i in range(3))
+        qd, thrust = velocity_control(st, vel_sp, vel, actions[:, 3])
+        rate_sp = attitude_control(q, qd)
+    else:
+        raise ValueError(f"unknown ctl_mode {ctl_mode!r}")
+    u = rate_control(st, rate_sp, wb)
+    return mix_quad_x(thrust, u)
