@@ -1,0 +1,453 @@
+// airgym_hip.hip - C ABI (include/airgym_hip.h) over the gfx950 step kernels.
+//
+// Host side of the hot path: arena carving, parameter block, launcher dispatch and the small
+// non-hot kernels (reset-all, state pack/unpack, reset-id compaction).  No CPU execution path:
+// every entry point that computes launches a HIP kernel on the handle's device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/airgym_hip.h"
+#include "kernel_args.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define AG_HIP_CHECK(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(AG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    } while (0)
+
+constexpr int kPad = 256;
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Layout {
+    size_t S[4], C[4], PA, PA4, obs, rew, reset, timeout, mask, reset_ids, reset_count, terms[9], cmd, total;
+};
+
+Layout make_layout(int n, int num_obs, bool terms) {
+    const size_t np = align_up((size_t)n, kPad);
+    Layout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    for (int j = 0; j < 4; ++j) L.S[j] = take(np * 16);
+    for (int j = 0; j < 4; ++j) L.C[j] = take(np * 16);
+    L.PA = take(np * 16);
+    L.PA4 = take(np * 4);
+    L.obs = take(np * num_obs * 4);
+    L.rew = take(np * 4);
+    L.reset = take(np * 8);
+    L.timeout = take(np);
+    L.mask = take(np / 64 * 8);
+    L.reset_ids = take(np * 4);
+    L.reset_count = take(256);
+    for (int t = 0; t < 9; ++t) L.terms[t] = terms ? take(np * 4) : 0;
+    L.cmd = terms ? take(np * 16) : 0;
+    L.total = off;
+    return L;
+}
+
+const ag::StepLauncher kLaunchers[2][5] = {
+    {ag::launch_step_0_0, ag::launch_step_0_1, ag::launch_step_0_2, ag::launch_step_0_3, ag::launch_step_0_4},
+    {ag::launch_step_1_0, ag::launch_step_1_1, ag::launch_step_1_2, ag::launch_step_1_3, ag::launch_step_1_4},
+};
+
+}  // namespace
+
+struct ag_env {
+    ag_config cfg;
+    int num_obs, num_actions, n_pad;
+    char* arena;
+    bool owns_arena;
+    Layout L;
+    ag::KArgs k;       // pointers + StepParams template for launches
+    uint64_t tick;
+    int block;
+    int obs_via_lds;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ small kernels
+__global__ void reset_all_kernel(ag::KArgs k, int n_pad, int num_actions, int num_obs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    ag::EnvState s;
+    ag::CtlState c;
+    float pre_a[AG_MAX_ACTIONS];
+    ag::env_reset(s, c, pre_a, num_actions, k.P, k.P.env_id_offset + (uint32_t)i);
+    ag::store_env(k, i, s);
+    ag::store_ctl<ag::CTL_POS>(k, i, c);  // writes all four controller arrays
+    k.PA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    k.PA4[i] = 0.f;
+    if (i < k.n) {
+        k.rew[i] = 0.f;
+        k.reset[i] = 1;      // base_task.py:75 reset_buf = ones; hovering.py:332
+        k.timeout[i] = 0;
+        if ((i & 63) == 0) k.mask[i >> 6] = 0ull;
+    }
+}
+
+__global__ void get_state_kernel(ag::KArgs k, ag_state_view v, int num_actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k.n) return;
+    ag::EnvState s;
+    ag::load_env(k, i, s);
+    if (v.root_states_dev) {
+        float* r = v.root_states_dev + (size_t)i * 13;
+        r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z;
+        r[3] = s.q.x; r[4] = s.q.y; r[5] = s.q.z; r[6] = s.q.w;
+        r[7] = s.v.x; r[8] = s.v.y; r[9] = s.v.z;
+        r[10] = s.w.x; r[11] = s.w.y; r[12] = s.w.z;
+    }
+    if (v.ctl_state_dev) {
+        float* c = v.ctl_state_dev + (size_t)i * 12;
+        for (int j = 0; j < 4; ++j) {
+            const float4 x = k.C[j][i];
+            c[3 * j] = x.x; c[3 * j + 1] = x.y; c[3 * j + 2] = x.z;
+        }
+    }
+    if (v.pre_actions_dev) {
+        const float4 p = k.PA[i];
+        float* a = v.pre_actions_dev + (size_t)i * num_actions;
+        a[0] = p.x; a[1] = p.y; a[2] = p.z; a[3] = p.w;
+        if (num_actions == 5) a[4] = k.PA4[i];
+    }
+    if (v.progress_dev) v.progress_dev[i] = s.progress;
+    if (v.was_reset_dev) v.was_reset_dev[i] = s.was_reset;
+}
+
+__global__ void set_state_kernel(ag::KArgs k, ag_state_view v, int num_actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k.n) return;
+    ag::EnvState s;
+    ag::load_env(k, i, s);
+    if (v.root_states_dev) {
+        const float* r = v.root_states_dev + (size_t)i * 13;
+        s.p = ag::V3{r[0], r[1], r[2]};
+        s.q = ag::Q4{r[3], r[4], r[5], r[6]};
+        s.v = ag::V3{r[7], r[8], r[9]};
+        s.w = ag::V3{r[10], r[11], r[12]};
+    }
+    if (v.progress_dev) s.progress = v.progress_dev[i];
+    if (v.was_reset_dev) s.was_reset = v.was_reset_dev[i];
+    ag::store_env(k, i, s);
+    if (v.ctl_state_dev) {
+        const float* c = v.ctl_state_dev + (size_t)i * 12;
+        for (int j = 0; j < 4; ++j) k.C[j][i] = make_float4(c[3 * j], c[3 * j + 1], c[3 * j + 2], 0.f);
+    }
+    if (v.pre_actions_dev) {
+        const float* a = v.pre_actions_dev + (size_t)i * num_actions;
+        k.PA[i] = make_float4(a[0], a[1], a[2], a[3]);
+        if (num_actions == 5) k.PA4[i] = a[4];
+    }
+}
+
+// Ascending list of done env ids from the per-wavefront ballot words: the device-side equivalent
+// of reset_buf.nonzero().squeeze(-1) (hovering.py:209,300).  One block; scan of popcounts in LDS.
+__global__ __launch_bounds__(1024) void compact_reset_ids_kernel(const unsigned long long* mask, int n_words,
+                                                                 int* ids, int* count) {
+    __shared__ int scan[1024];
+    __shared__ int base;
+    const int tid = threadIdx.x;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int w0 = 0; w0 < n_words; w0 += 1024) {
+        const int w = w0 + tid;
+        const unsigned long long m = (w < n_words) ? mask[w] : 0ull;
+        const int cnt = __popcll(m);
+        scan[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            const int v = (tid >= off) ? scan[tid - off] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        int pos = base + scan[tid] - cnt;
+        unsigned long long mm = m;
+        while (mm) {
+            const int b = __ffsll((long long)mm) - 1;
+            ids[pos++] = w * 64 + b;
+            mm &= mm - 1;
+        }
+        __syncthreads();
+        if (tid == 1023) base += scan[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *count = base;
+}
+
+void fill_params(ag_env* h) {
+    h->k.P = ag::make_step_params(h->cfg.task, h->cfg.dt, h->cfg.max_episode_length, h->cfg.target_state, h->cfg.seed,
+                                  h->cfg.env_id_offset, (h->cfg.flags & AG_FLAG_OBS_NOISE_OFF) != 0);
+}
+
+int validate(const ag_config* cfg) {
+    if (!cfg) return fail(AG_ERR_INVALID_ARG, "cfg is NULL");
+    if (cfg->struct_size != sizeof(ag_config))
+        return fail(AG_ERR_INVALID_ARG, "ag_config.struct_size mismatch (ABI): got " + std::to_string(cfg->struct_size) +
+                                            ", expected " + std::to_string(sizeof(ag_config)));
+    if (cfg->task != AG_TASK_HOVERING && cfg->task != AG_TASK_TRACKING)
+        return fail(AG_ERR_UNKNOWN_TASK, "Task with id " + std::to_string(cfg->task) + " was not registered");
+    if (cfg->ctl_mode < AG_CTL_POS || cfg->ctl_mode > AG_CTL_PROP)
+        return fail(AG_ERR_UNKNOWN_CTL, "unknown ctl_mode " + std::to_string(cfg->ctl_mode) + " (expected pos|vel|atti|rate|prop)");
+    if (cfg->num_envs <= 0) return fail(AG_ERR_INVALID_ARG, "num_envs must be > 0");
+    if (!(cfg->dt > 0.0)) return fail(AG_ERR_INVALID_ARG, "dt must be > 0");
+    return AG_OK;
+}
+
+int ensure_device(ag_env* h) {
+    int cur = -1;
+    AG_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != h->cfg.device) AG_HIP_CHECK(hipSetDevice(h->cfg.device));
+    return AG_OK;
+}
+
+int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int64_t* reset_out,
+            const float* noise, const float* uniforms, void* stream) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    if (!actions) return fail(AG_ERR_INVALID_ARG, "actions_dev is NULL");
+    if (h->num_actions == 4 && ((uintptr_t)actions & 15)) return fail(AG_ERR_INVALID_ARG, "actions_dev must be 16-byte aligned");
+    if (obs_out && ((uintptr_t)obs_out & 15)) return fail(AG_ERR_INVALID_ARG, "obs_out_dev must be 16-byte aligned");
+    if ((noise == nullptr) != (uniforms == nullptr))
+        return fail(AG_ERR_INVALID_ARG, "noise_dev and reset_uniforms_dev must be given together");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    ag::KArgs k = h->k;
+    k.actions = actions;
+    if (obs_out) k.obs = obs_out;
+    if (rew_out) k.rew = rew_out;
+    if (reset_out) k.reset = (long long*)reset_out;
+    k.ext_noise = noise;
+    k.ext_uniforms = uniforms;
+    k.P.tick = (uint32_t)h->tick;
+    hipError_t e = kLaunchers[h->cfg.task][h->cfg.ctl_mode](k, h->block, h->obs_via_lds, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
+    h->tick += 1;
+    return AG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ag_version(void) { return AG_VERSION; }
+
+const char* ag_last_error(void) { return g_last_error.c_str(); }
+
+int ag_num_obs(int task) {
+    if (task == AG_TASK_HOVERING) return 18;  // hovering_config.py:14
+    if (task == AG_TASK_TRACKING) return 48;  // tracking_config.py:13
+    return fail(AG_ERR_UNKNOWN_TASK, "unknown task");
+}
+
+int ag_num_actions(int ctl_mode) {
+    if (ctl_mode < AG_CTL_POS || ctl_mode > AG_CTL_PROP) return fail(AG_ERR_UNKNOWN_CTL, "unknown ctl_mode");
+    return ctl_mode == AG_CTL_ATTI ? 5 : 4;  // hovering.py:47
+}
+
+int ag_default_episode_length(int task, double dt) {
+    if (!(dt > 0.0)) return fail(AG_ERR_INVALID_ARG, "dt must be > 0");
+    const double secs = (task == AG_TASK_TRACKING) ? 36.0 : 24.0;  // tracking_config.py:17, hovering_config.py:17
+    if (task != AG_TASK_HOVERING && task != AG_TASK_TRACKING) return fail(AG_ERR_UNKNOWN_TASK, "unknown task");
+    return (int)(secs / dt);  // int(episode_length_s / dt), hovering.py:48
+}
+
+size_t ag_arena_bytes(const ag_config* cfg) {
+    if (validate(cfg) != AG_OK) return 0;
+    return make_layout(cfg->num_envs, ag_num_obs(cfg->task), (cfg->flags & AG_FLAG_REWARD_TERMS) != 0).total;
+}
+
+int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
+    if (!out) return fail(AG_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (arena_dev && ((uintptr_t)arena_dev & 255)) return fail(AG_ERR_INVALID_ARG, "arena_dev must be 256-byte aligned");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(AG_ERR_NO_DEVICE, "no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(AG_ERR_NO_DEVICE, "device ordinal out of range");
+    AG_HIP_CHECK(hipSetDevice(cfg->device));
+
+    ag_env* h = new (std::nothrow) ag_env();
+    if (!h) return fail(AG_ERR_INVALID_ARG, "out of host memory");
+    h->cfg = *cfg;
+    h->num_obs = ag_num_obs(cfg->task);
+    h->num_actions = ag_num_actions(cfg->ctl_mode);
+    if (h->cfg.max_episode_length <= 0) h->cfg.max_episode_length = ag_default_episode_length(cfg->task, cfg->dt);
+    h->n_pad = (int)align_up((size_t)cfg->num_envs, kPad);
+    const bool terms = (cfg->flags & AG_FLAG_REWARD_TERMS) != 0;
+    h->L = make_layout(cfg->num_envs, h->num_obs, terms);
+    h->owns_arena = (arena_dev == nullptr);
+    if (h->owns_arena) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, h->L.total);
+        if (e != hipSuccess) {
+            delete h;
+            return fail(AG_ERR_HIP, std::string("hipMalloc(arena): ") + hipGetErrorString(e));
+        }
+        h->arena = (char*)p;
+    } else {
+        h->arena = (char*)arena_dev;
+    }
+    ag::KArgs& k = h->k;
+    memset(&k, 0, sizeof(k));
+    for (int j = 0; j < 4; ++j) k.S[j] = (float4*)(h->arena + h->L.S[j]);
+    for (int j = 0; j < 4; ++j) k.C[j] = (float4*)(h->arena + h->L.C[j]);
+    k.PA = (float4*)(h->arena + h->L.PA);
+    k.PA4 = (float*)(h->arena + h->L.PA4);
+    k.obs = (float*)(h->arena + h->L.obs);
+    k.rew = (float*)(h->arena + h->L.rew);
+    k.reset = (long long*)(h->arena + h->L.reset);
+    k.timeout = (uint8_t*)(h->arena + h->L.timeout);
+    k.mask = (unsigned long long*)(h->arena + h->L.mask);
+    if (terms) {
+        for (int t = 0; t < 9; ++t) k.terms[t] = (float*)(h->arena + h->L.terms[t]);
+        k.cmd = (float4*)(h->arena + h->L.cmd);
+    }
+    k.n = cfg->num_envs;
+    fill_params(h);
+    h->tick = 0;
+    h->block = 64;
+    h->obs_via_lds = 1;
+    // valid state from the start: everything randomised and flagged reset (base_task.py:75)
+    hipError_t e = hipMemsetAsync(h->arena, 0, h->L.total, 0);
+    if (e == hipSuccess) {
+        *out = h;
+        rc = ag_reset_all(h, nullptr);
+        if (rc == AG_OK) e = hipStreamSynchronize(0);
+    }
+    if (e != hipSuccess || rc != AG_OK) {
+        if (e != hipSuccess) fail(AG_ERR_HIP, std::string("arena init: ") + hipGetErrorString(e));
+        *out = nullptr;
+        if (h->owns_arena) (void)hipFree(h->arena);
+        delete h;
+        return rc != AG_OK ? rc : AG_ERR_HIP;
+    }
+    return AG_OK;
+}
+
+int ag_destroy(ag_handle h) {
+    if (!h) return AG_OK;
+    if (h->owns_arena && h->arena) (void)hipFree(h->arena);
+    delete h;
+    return AG_OK;
+}
+
+int ag_reset_all(ag_handle h, void* stream) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    ag::KArgs k = h->k;
+    k.P.tick = (uint32_t)h->tick;
+    hipLaunchKernelGGL(reset_all_kernel, dim3(h->n_pad / 256), dim3(256), 0, (hipStream_t)stream, k, h->n_pad,
+                       h->num_actions, h->num_obs);
+    AG_HIP_CHECK(hipGetLastError());
+    h->tick += 1;
+    return AG_OK;
+}
+
+int ag_step(ag_handle h, const float* actions_dev, void* stream) {
+    return do_step(h, actions_dev, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int ag_step_into(ag_handle h, const float* actions_dev, float* obs_out_dev, float* rew_out_dev, int64_t* reset_out_dev,
+                 void* stream) {
+    return do_step(h, actions_dev, obs_out_dev, rew_out_dev, reset_out_dev, nullptr, nullptr, stream);
+}
+
+int ag_step_with_inputs(ag_handle h, const float* actions_dev, const float* noise_dev, const float* reset_uniforms_dev,
+                        void* stream) {
+    if (!noise_dev || !reset_uniforms_dev) return fail(AG_ERR_INVALID_ARG, "noise_dev / reset_uniforms_dev is NULL");
+    return do_step(h, actions_dev, nullptr, nullptr, nullptr, noise_dev, reset_uniforms_dev, stream);
+}
+
+int ag_get_buffers(ag_handle h, ag_buffers* out) {
+    if (!h || !out) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    out->num_envs = h->cfg.num_envs;
+    out->num_obs = h->num_obs;
+    out->num_actions = h->num_actions;
+    out->max_episode_length = h->cfg.max_episode_length;
+    out->obs_dev = h->k.obs;
+    out->rew_dev = h->k.rew;
+    out->reset_dev = (int64_t*)h->k.reset;
+    out->timeout_dev = h->k.timeout;
+    out->reset_mask_dev = (uint64_t*)h->k.mask;
+    out->reset_ids_dev = (int32_t*)(h->arena + h->L.reset_ids);
+    out->reset_count_dev = (int32_t*)(h->arena + h->L.reset_count);
+    for (int t = 0; t < 9; ++t) out->reward_terms_dev[t] = h->k.terms[t];
+    out->cmd_thrusts_dev = (float*)h->k.cmd;
+    return AG_OK;
+}
+
+int ag_get_state(ag_handle h, const ag_state_view* view, void* stream) {
+    if (!h || !view) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(get_state_kernel, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->k,
+                       *view, h->num_actions);
+    AG_HIP_CHECK(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_set_state(ag_handle h, const ag_state_view* view, void* stream) {
+    if (!h || !view) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(set_state_kernel, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->k,
+                       *view, h->num_actions);
+    AG_HIP_CHECK(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_compact_reset_ids(ag_handle h, void* stream) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    const int n_words = (h->cfg.num_envs + 63) / 64;
+    hipLaunchKernelGGL(compact_reset_ids_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, h->k.mask, n_words,
+                       (int*)(h->arena + h->L.reset_ids), (int*)(h->arena + h->L.reset_count));
+    AG_HIP_CHECK(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_set_target_state(ag_handle h, const float* target_state18) {
+    if (!h || !target_state18) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    memcpy(h->cfg.target_state, target_state18, sizeof(h->cfg.target_state));
+    fill_params(h);
+    return AG_OK;
+}
+
+uint64_t ag_get_tick(ag_handle h) { return h ? h->tick : 0; }
+
+int ag_set_tick(ag_handle h, uint64_t tick) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    h->tick = tick;
+    return AG_OK;
+}
+
+int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    if (block_size != 64 && block_size != 128 && block_size != 256)
+        return fail(AG_ERR_INVALID_ARG, "block_size must be 64, 128 or 256");
+    h->block = block_size;
+    h->obs_via_lds = obs_via_lds ? 1 : 0;
+    return AG_OK;
+}
+
+}  // extern "C"

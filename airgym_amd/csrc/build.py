@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 11 translation units compiled in parallel).
+
+    python airgym_amd/csrc/build.py [--force] [--jobs N]
+
+The library lands in-tree at airgym_amd/lib/libairgym_hip.so (git-ignored, shipped to the GPU box by gpurun).
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIB_DIR = os.path.join(PKG, "lib")
+OBJ_DIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIB_DIR, "libairgym_hip.so")
+ARCH = "gfx950"
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+COMMON = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+HEADERS = ["env_math.hpp", "kernel_args.hpp", os.path.join("..", "..", "include", "airgym_hip.h")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def units():
+    out = []
+    for task in (0, 1):
+        for ctl in range(5):
+            out.append((os.path.join(OBJ_DIR, f"step_{task}_{ctl}.o"), "step_kernel.hip", [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}"]))
+    out.append((os.path.join(OBJ_DIR, "airgym_hip.o"), "airgym_hip.hip", []))
+    return out
+
+
+def compile_one(obj, src, defs, extra):
+    cmd = COMMON + extra + defs + ["-c", os.path.join(HERE, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return obj, r.returncode, (r.stdout + r.stderr).strip(), " ".join(cmd)
+
+
+def build(force=False, jobs=None, extra=(), verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    todo = [(o, s, d) for (o, s, d) in units() if force or _newer(o, [os.path.join(HERE, s)] + hdrs)]
+    t0 = time.time()
+    if todo:
+        jobs = jobs or min(len(todo), os.cpu_count() or 4)
+        with cf.ThreadPoolExecutor(jobs) as ex:
+            for obj, rc, log, cmd in ex.map(lambda u: compile_one(*u, list(extra)), todo):
+                if log and verbose:
+                    print(log)
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed ({rc}): {cmd}\n{log}")
+    objs = [o for (o, _, _) in units()]
+    if todo or _newer(LIB, objs):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed: {' '.join(cmd)}\n{r.stdout}{r.stderr}")
+    if verbose:
+        print(f"[airgym_amd] {LIB} ready ({len(todo)} units rebuilt, {time.time() - t0:.1f}s)")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("extra", nargs="*", help="extra hipcc flags, e.g. -Rpass-analysis=kernel-resource-usage")
+    a = ap.parse_args()
+    try:
+        build(a.force, a.jobs, a.extra)
+    except RuntimeError as e:
+        print(e, file=sys.stderr)
+        sys.exit(1)

@@ -1,0 +1,91 @@
+// kernel_args.hpp - device-side view of a handle's arena, shared by the step kernels
+// (step_kernel.hip, one translation unit per task x ctl_mode) and the C-ABI (airgym_hip.hip).
+//
+// HBM layout (SoA, one env per lane, every array padded to a multiple of 256 envs):
+//   S0 = (pos.xyz, progress as int bits)   S1 = quat xyzw
+//   S2 = (linvel.xyz, was_reset as int bits)   S3 = (angvel.xyz, 0)
+//   C0 = rate integrator, C1 = previous body rate, C2 = velocity integrator, C3 = previous velocity
+//   PA = previous processed action (xyzw), PA4 = its 5th component (atti mode only)
+// Each is a float4 array: one 16-byte load per lane, 1 KiB per wave-instruction, fully coalesced.
+// This replaces the reference's AoS root tensor view [N, actors, 13] (hovering.py:70-77).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "env_math.hpp"
+
+namespace ag {
+
+struct KArgs {
+    float4* S[4];
+    float4* C[4];
+    float4* PA;
+    float* PA4;
+    const float* actions;        // [n, A]
+    float* obs;                  // [n, NOBS]
+    float* rew;                  // [n]
+    long long* reset;            // [n] int64
+    uint8_t* timeout;            // [n]
+    unsigned long long* mask;    // [ceil(n/64)]
+    float* terms[9];             // each [n] or null
+    float4* cmd;                 // [n] or null
+    const float* ext_noise;      // [n,18] or null
+    const float* ext_uniforms;   // [n,12] or null
+    int n;
+    StepParams P;
+};
+
+typedef hipError_t (*StepLauncher)(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
+
+// defined in step_kernel.hip compiled with -DAG_TASK=<t> -DAG_CTL=<c>
+#define AG_DECL_LAUNCHER(t, c) hipError_t launch_step_##t##_##c(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
+AG_DECL_LAUNCHER(0, 0) AG_DECL_LAUNCHER(0, 1) AG_DECL_LAUNCHER(0, 2) AG_DECL_LAUNCHER(0, 3) AG_DECL_LAUNCHER(0, 4)
+AG_DECL_LAUNCHER(1, 0) AG_DECL_LAUNCHER(1, 1) AG_DECL_LAUNCHER(1, 2) AG_DECL_LAUNCHER(1, 3) AG_DECL_LAUNCHER(1, 4)
+#undef AG_DECL_LAUNCHER
+
+__device__ __forceinline__ void load_env(const KArgs& k, int i, EnvState& s) {
+    const float4 a = k.S[0][i], b = k.S[1][i], c = k.S[2][i], d = k.S[3][i];
+    s.p = V3{a.x, a.y, a.z};
+    s.progress = __float_as_int(a.w);
+    s.q = Q4{b.x, b.y, b.z, b.w};
+    s.v = V3{c.x, c.y, c.z};
+    s.was_reset = __float_as_int(c.w);
+    s.w = V3{d.x, d.y, d.z};
+}
+
+__device__ __forceinline__ void store_env(const KArgs& k, int i, const EnvState& s) {
+    k.S[0][i] = make_float4(s.p.x, s.p.y, s.p.z, __int_as_float(s.progress));
+    k.S[1][i] = make_float4(s.q.x, s.q.y, s.q.z, s.q.w);
+    k.S[2][i] = make_float4(s.v.x, s.v.y, s.v.z, __int_as_float(s.was_reset));
+    k.S[3][i] = make_float4(s.w.x, s.w.y, s.w.z, 0.0f);
+}
+
+// controller memory each mode actually touches: rate/atti use C0,C1; vel/pos use C0..C3; prop none
+template <int CTL>
+__device__ __forceinline__ void load_ctl(const KArgs& k, int i, CtlState& c) {
+    if (CTL != CTL_PROP) {
+        const float4 a = k.C[0][i], b = k.C[1][i];
+        c.rate_int[0] = a.x; c.rate_int[1] = a.y; c.rate_int[2] = a.z;
+        c.prev_rate[0] = b.x; c.prev_rate[1] = b.y; c.prev_rate[2] = b.z;
+    }
+    if (CTL == CTL_VEL || CTL == CTL_POS) {
+        const float4 a = k.C[2][i], b = k.C[3][i];
+        c.vel_int[0] = a.x; c.vel_int[1] = a.y; c.vel_int[2] = a.z;
+        c.prev_vel[0] = b.x; c.prev_vel[1] = b.y; c.prev_vel[2] = b.z;
+    }
+}
+
+template <int CTL>
+__device__ __forceinline__ void store_ctl(const KArgs& k, int i, const CtlState& c) {
+    if (CTL != CTL_PROP) {
+        k.C[0][i] = make_float4(c.rate_int[0], c.rate_int[1], c.rate_int[2], 0.0f);
+        k.C[1][i] = make_float4(c.prev_rate[0], c.prev_rate[1], c.prev_rate[2], 0.0f);
+    }
+    if (CTL == CTL_VEL || CTL == CTL_POS) {
+        k.C[2][i] = make_float4(c.vel_int[0], c.vel_int[1], c.vel_int[2], 0.0f);
+        k.C[3][i] = make_float4(c.prev_vel[0], c.prev_vel[1], c.prev_vel[2], 0.0f);
+    }
+}
+
+}  // namespace ag

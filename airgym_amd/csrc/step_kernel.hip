@@ -1,0 +1,163 @@
+// step_kernel.hip - the fused env-step kernel for gfx950 (MI355X).
+// Compiled once per (task, ctl_mode):  hipcc -DAG_TASK=<0|1> -DAG_CTL=<0..4> -c step_kernel.hip
+//
+// One env per lane, 64 envs per wavefront.  Per lane:
+//   16-byte coalesced loads of the SoA state (kernel_args.hpp)  -> registers
+//   env_step<TASK,CTL>()  (env_math.hpp: Hovering.step, hovering.py:286-308)
+//   16-byte coalesced stores of the new state
+//   observation rows ([n, NOBS] row-major, the layout the reference API exposes,
+//   base_task.py:73) staged through LDS so that the block writes its NOBS*BLOCK
+//   contiguous floats as full 16-byte-per-lane lines instead of 72-byte strided rows
+//   one __ballot per wavefront publishes the done mask (hovering.py:300 nonzero) and lets a
+//   wavefront with no done lane skip the reset path entirely.
+#include <hip/hip_runtime.h>
+
+#include "kernel_args.hpp"
+
+#ifndef AG_TASK
+#error "compile with -DAG_TASK=<0|1> -DAG_CTL=<0..4>"
+#endif
+
+namespace ag {
+
+template <int TASK, int CTL, int BLOCK, bool OBS_LDS, bool EXT>
+__global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs k) {
+    constexpr int NOBS = TaskTraits<TASK>::kNumObs;
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    constexpr int LDS_STRIDE = NOBS + 1;  // odd stride: conflict-free row writes (19 / 49 dwords)
+    __shared__ float tile[OBS_LDS ? BLOCK * LDS_STRIDE : 1];
+
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BLOCK + tid;
+    const bool active = i < k.n;
+
+    EnvState s;
+    CtlState c;
+    load_env(k, i, s);          // arena is padded to a multiple of 256 envs: always in bounds
+    load_ctl<CTL>(k, i, c);
+    float pre_a[A], raw_a[A];
+    {
+        const float4 pa = k.PA[i];
+        pre_a[0] = pa.x; pre_a[1] = pa.y; pre_a[2] = pa.z; pre_a[3] = pa.w;
+        if (A == 5) pre_a[A - 1] = k.PA4[i];
+    }
+    if (active) {
+        if (A == 4) {
+            const float4 a = reinterpret_cast<const float4*>(k.actions)[i];
+            raw_a[0] = a.x; raw_a[1] = a.y; raw_a[2] = a.z; raw_a[3] = a.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < A; ++j) raw_a[j] = k.actions[(size_t)i * A + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A; ++j) raw_a[j] = 0.0f;
+    }
+
+    // parity mode: random numbers supplied by the caller
+    float ext_z[EXT ? 18 : 1], ext_u[EXT ? 12 : 1];
+    if (EXT) {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) ext_z[j] = k.ext_noise[(size_t)i * 18 + j];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) ext_u[j] = k.ext_uniforms[(size_t)i * 12 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) ext_z[j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) ext_u[j] = 0.5f;
+        }
+    }
+
+    float obs[NOBS];
+    StepOut o;
+    const uint32_t env_global = k.P.env_id_offset + (uint32_t)i;
+    env_step<TASK, CTL, EXT>(s, c, pre_a, raw_a, k.P, env_global, ext_z, ext_u, obs, o);
+
+    // ---- state back to HBM
+    store_env(k, i, s);
+    store_ctl<CTL>(k, i, c);
+    k.PA[i] = make_float4(pre_a[0], pre_a[1], pre_a[2], pre_a[3]);
+    if (A == 5) k.PA4[i] = pre_a[A - 1];
+
+    // ---- per-env outputs
+    const unsigned long long ballot = __ballot(active && o.done);
+    if (active) {
+        k.rew[i] = o.rew;
+        k.reset[i] = (long long)o.done;
+        k.timeout[i] = (uint8_t)o.timeout;
+        if ((tid & 63) == 0) k.mask[i >> 6] = ballot;
+        if (k.cmd != nullptr) {
+            k.cmd[i] = make_float4(o.cmd[0], o.cmd[1], o.cmd[2], o.cmd[3]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) k.terms[t][i] = o.terms[t];
+        }
+    }
+
+    // ---- observations
+    if (OBS_LDS) {
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) tile[tid * LDS_STRIDE + j] = obs[j];
+        __syncthreads();
+        const int block_env0 = blockIdx.x * BLOCK;
+        const int valid = min(BLOCK, k.n - block_env0) * NOBS;  // floats of this block that exist
+        float* out = k.obs + (size_t)block_env0 * NOBS;
+        constexpr int NV4 = BLOCK * NOBS / 4;
+        constexpr int ITERS = (NV4 + BLOCK - 1) / BLOCK;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int m = tid + it * BLOCK;
+            if (m >= NV4) break;
+            const int e = 4 * m;
+            if (e + 3 < valid) {
+                float4 v;
+                v.x = tile[(e + 0) / NOBS * LDS_STRIDE + (e + 0) % NOBS];
+                v.y = tile[(e + 1) / NOBS * LDS_STRIDE + (e + 1) % NOBS];
+                v.z = tile[(e + 2) / NOBS * LDS_STRIDE + (e + 2) % NOBS];
+                v.w = tile[(e + 3) / NOBS * LDS_STRIDE + (e + 3) % NOBS];
+                reinterpret_cast<float4*>(out)[m] = v;
+            } else {
+                for (int q = e; q < e + 4 && q < valid; ++q) out[q] = tile[q / NOBS * LDS_STRIDE + q % NOBS];
+            }
+        }
+    } else if (active) {
+        float* out = k.obs + (size_t)i * NOBS;
+        if (NOBS % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < NOBS / 4; ++j)
+                reinterpret_cast<float4*>(out)[j] = make_float4(obs[4 * j], obs[4 * j + 1], obs[4 * j + 2], obs[4 * j + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NOBS / 2; ++j) reinterpret_cast<float2*>(out)[j] = make_float2(obs[2 * j], obs[2 * j + 1]);
+        }
+    }
+}
+
+template <int TASK, int CTL>
+static hipError_t launch_step(const KArgs& k, int block, int obs_via_lds, hipStream_t stream) {
+    const int n = k.n;
+#define AG_LAUNCH(B, L)                                                                          \
+    do {                                                                                         \
+        const int grid = (n + (B)-1) / (B);                                                      \
+        hipLaunchKernelGGL((step_kernel<TASK, CTL, B, L, false>), dim3(grid), dim3(B), 0, stream, k); \
+        return hipGetLastError();                                                                \
+    } while (0)
+    if (k.ext_noise != nullptr) {  // parity mode: one geometry only
+        hipLaunchKernelGGL((step_kernel<TASK, CTL, 64, true, true>), dim3((n + 63) / 64), dim3(64), 0, stream, k);
+        return hipGetLastError();
+    }
+    if (block == 64) { if (obs_via_lds) AG_LAUNCH(64, true); else AG_LAUNCH(64, false); }
+    if (block == 128) { if (obs_via_lds) AG_LAUNCH(128, true); else AG_LAUNCH(128, false); }
+    if (block == 256) { if (obs_via_lds) AG_LAUNCH(256, true); else AG_LAUNCH(256, false); }
+#undef AG_LAUNCH
+    return hipErrorInvalidValue;
+}
+
+#define AG_CAT_(a, b, c) launch_step_##a##_##b
+#define AG_CAT(a, b) AG_CAT_(a, b, 0)
+hipError_t AG_CAT(AG_TASK, AG_CTL)(const KArgs& k, int block, int obs_via_lds, hipStream_t stream) {
+    return launch_step<AG_TASK, AG_CTL>(k, block, obs_via_lds, stream);
+}
+
+}  // namespace ag

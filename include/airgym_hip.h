@@ -1,0 +1,174 @@
+/*
+ * airgym_hip.h - C ABI of libairgym_hip.so, the MI355X (gfx950) hot path of the
+ * AirGym vectorised quadrotor environments.
+ *
+ * One handle owns the SoA state of `num_envs` environments on one HIP device and
+ * advances all of them with ONE fused kernel launch per env step:
+ *
+ *   action map -> control cascade -> rotor wrench -> RK4 rigid body -> progress++
+ *   -> observation (+noise) -> reward + termination -> in-place reset of done envs
+ *
+ * What each entry point replaces in the reference (emNavi/AirGym, paths relative
+ * to the reference root):
+ *
+ *   ag_create            BaseTask.__init__ buffer allocation + create_sim/_create_envs
+ *                        (airgym/envs/base/base_task.py:40-95, airgym/envs/base/hovering.py:42-152,173-201)
+ *                        and ParallelRate/Atti/Vel/PosControl(num_envs) (hovering.py:93-123)
+ *   ag_reset_all         BaseTask.reset()'s reset_idx(all) half (base_task.py:107-111, hovering.py:310-335)
+ *   ag_step / _into      Hovering.step (hovering.py:286-308) incl. pre_physics_step (:203-281),
+ *                        gym.simulate + refresh (PhysX, :290,:283-284), compute_observations (:337-358),
+ *                        compute_reward (:360-459), reset_idx (:310-335); Tracking overrides
+ *                        (airgym/envs/task/tracking.py:159-296); the rlPx4Controller calls
+ *                        set_q_world/set_status/update (hovering.py:235-250)
+ *   ag_step_with_inputs  same, random numbers supplied by the caller (parity mode)
+ *   ag_get_buffers       the tensors the env exposes: obs_buf, rew_buf, reset_buf, time_out_buf,
+ *                        extras["item_reward_info"] (base_task.py:72-76, hovering.py:304-308,448-457)
+ *   ag_get_state / ag_set_state
+ *                        root_states view of gym.acquire_actor_root_state_tensor (hovering.py:60-77)
+ *                        and gym.set_actor_root_state_tensor (:331); progress_buf (:164-165);
+ *                        pre_actions (:138); controller memory (inside rlPx4Controller objects)
+ *   ag_compact_reset_ids reset_buf.nonzero(as_tuple=False).squeeze(-1) (hovering.py:209,300)
+ *   ag_set_target_state  Hovering.callback (hovering.py:154-156)
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ag_status on failure;
+ *     ag_last_error() returns a human-readable message for the calling thread.
+ *   - all pointers named *_dev are DEVICE pointers on the handle's device; the
+ *     library never synchronises the host inside ag_step*; work is enqueued on the
+ *     `stream` argument (a hipStream_t passed as void*, NULL = the null stream).
+ *   - one handle is not thread-safe; distinct handles are independent.
+ *   - memory: if `arena_dev` passed to ag_create is NULL the library hipMalloc()s
+ *     ag_arena_bytes(cfg) bytes and frees them in ag_destroy; otherwise the caller
+ *     owns the arena (>= ag_arena_bytes(cfg), 256-byte aligned) and must keep it
+ *     alive until ag_destroy.  Pointers returned by ag_get_buffers point into the
+ *     arena and stay valid until ag_destroy.
+ */
+#ifndef AIRGYM_HIP_H
+#define AIRGYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AG_VERSION 100 /* 0.1.0 */
+
+typedef struct ag_env* ag_handle;
+
+typedef enum ag_status {
+    AG_OK = 0,
+    AG_ERR_INVALID_ARG = -1,   /* NULL pointer, bad enum, num_envs <= 0, ... */
+    AG_ERR_UNKNOWN_TASK = -2,  /* task_registry.py:78-79 raises ValueError */
+    AG_ERR_UNKNOWN_CTL = -3,   /* hovering.py:122-123 only prints "Mode Error!"; here it is an error */
+    AG_ERR_HIP = -4,           /* a HIP runtime call failed; message has hipGetErrorString */
+    AG_ERR_NO_DEVICE = -5,     /* no usable gfx950 device */
+    AG_ERR_UNSUPPORTED = -6    /* valid request this build has no kernel for */
+} ag_status;
+
+typedef enum ag_task {
+    AG_TASK_HOVERING = 0, /* airgym/envs/base/hovering.py, 18 obs, 24 s episodes */
+    AG_TASK_TRACKING = 1  /* airgym/envs/task/tracking.py, 48 obs, 36 s episodes */
+} ag_task;
+
+/* --ctl_mode pos|vel|atti|rate|prop  (README: PY / LV / CTA / CTBR / SRT) */
+typedef enum ag_ctl_mode {
+    AG_CTL_POS = 0,
+    AG_CTL_VEL = 1,
+    AG_CTL_ATTI = 2,
+    AG_CTL_RATE = 3,
+    AG_CTL_PROP = 4
+} ag_ctl_mode;
+
+enum {
+    AG_FLAG_REWARD_TERMS = 1u << 0, /* emit the 9 item_reward_info arrays + cmd_thrusts each step */
+    AG_FLAG_OBS_NOISE_OFF = 1u << 1 /* testing aid: skip add_noise (reference: always on, hovering.py:343) */
+};
+
+#define AG_NUM_REWARD_TERMS 9
+#define AG_MAX_ACTIONS 5
+#define AG_STATE_DIM 13     /* pos3 quat_xyzw4 linvel3 angvel3 (world frame), hovering.py:73-77 */
+#define AG_CTL_STATE_DIM 12 /* rate_int3 prev_body_rate3 vel_int3 prev_vel3 */
+#define AG_NOISE_DIM 18
+#define AG_RESET_UNIFORMS 12
+
+typedef struct ag_config {
+    uint32_t struct_size;       /* = sizeof(ag_config), ABI guard */
+    int32_t task;               /* ag_task */
+    int32_t ctl_mode;           /* ag_ctl_mode */
+    int32_t num_envs;           /* envs owned by this handle (one GPU's shard) */
+    int32_t device;             /* HIP device ordinal */
+    uint32_t flags;             /* AG_FLAG_* */
+    uint64_t seed;              /* Philox key */
+    uint32_t env_id_offset;     /* global id of local env 0: results do not depend on the sharding */
+    double dt;                  /* sim.dt, 0.01 in every shipped config (double: the oracle rounds dt/6 etc. once) */
+    int32_t max_episode_length; /* int(episode_length_s / dt); <= 0 selects the task default */
+    float target_state[18];     /* cfg.env.target_state: flattened 3x3 attitude, pos3, linvel3, angvel3 */
+} ag_config;
+
+/* Reward-term order in ag_buffers.reward_terms[k] (each float[num_envs]).
+ * Hovering (hovering.py:448-457): continous_action, effort, thrust, pos, vel_direction, ups, spin, yaw, reward
+ * Tracking (tracking.py:285-294): dist_norm, dist_reward, yaw, spin, continous_action, thrust, effort, ups, reward */
+typedef struct ag_buffers {
+    int32_t num_envs;
+    int32_t num_obs;
+    int32_t num_actions;
+    int32_t max_episode_length;
+    float* obs_dev;           /* [num_envs, num_obs] row-major f32 */
+    float* rew_dev;           /* [num_envs] f32 */
+    int64_t* reset_dev;       /* [num_envs] int64 0/1 (base_task.py:75) */
+    uint8_t* timeout_dev;     /* [num_envs] u8  progress > max_episode_length (hovering.py:304) */
+    uint64_t* reset_mask_dev; /* [ceil(num_envs/64)] one ballot word per wavefront, bit l = env 64*w+l done */
+    int32_t* reset_ids_dev;   /* [num_envs] ascending ids, valid after ag_compact_reset_ids */
+    int32_t* reset_count_dev; /* [1] */
+    float* reward_terms_dev[AG_NUM_REWARD_TERMS]; /* NULL unless AG_FLAG_REWARD_TERMS */
+    float* cmd_thrusts_dev;   /* [num_envs,4] NULL unless AG_FLAG_REWARD_TERMS */
+} ag_buffers;
+
+/* Host-visible view of the env state for checkpoints and tests; every member is a
+ * DEVICE pointer supplied by the caller, any of them may be NULL (skipped). */
+typedef struct ag_state_view {
+    float* root_states_dev;   /* [num_envs, 13] */
+    float* ctl_state_dev;     /* [num_envs, 12] */
+    float* pre_actions_dev;   /* [num_envs, num_actions] */
+    int32_t* progress_dev;    /* [num_envs] */
+    int32_t* was_reset_dev;   /* [num_envs] 1 = reset at the end of the previous step (thrust zeroed next step) */
+} ag_state_view;
+
+int ag_version(void);
+const char* ag_last_error(void);
+
+int ag_num_obs(int task);                      /* 18 / 48, <0 on unknown task */
+int ag_num_actions(int ctl_mode);              /* 5 for atti else 4 (hovering.py:47) */
+int ag_default_episode_length(int task, double dt);
+size_t ag_arena_bytes(const ag_config* cfg);   /* 0 on invalid cfg */
+
+int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out);
+int ag_destroy(ag_handle h);
+
+int ag_reset_all(ag_handle h, void* stream);
+int ag_step(ag_handle h, const float* actions_dev, void* stream);
+/* Same as ag_step but obs / reward / done flags are written to caller buffers (e.g. slot t of a
+ * rollout buffer) instead of the handle's own; any of the three may be NULL = use the handle's. */
+int ag_step_into(ag_handle h, const float* actions_dev, float* obs_out_dev, float* rew_out_dev,
+                 int64_t* reset_out_dev, void* stream);
+/* Parity mode: noise_dev [num_envs,18] standard normals, reset_uniforms_dev [num_envs,12] U[0,1). */
+int ag_step_with_inputs(ag_handle h, const float* actions_dev, const float* noise_dev,
+                        const float* reset_uniforms_dev, void* stream);
+
+int ag_get_buffers(ag_handle h, ag_buffers* out);
+int ag_get_state(ag_handle h, const ag_state_view* view, void* stream);
+int ag_set_state(ag_handle h, const ag_state_view* view, void* stream);
+int ag_compact_reset_ids(ag_handle h, void* stream);
+int ag_set_target_state(ag_handle h, const float* target_state18);
+uint64_t ag_get_tick(ag_handle h);
+int ag_set_tick(ag_handle h, uint64_t tick);
+
+/* Launch geometry knobs for benchmarking (block size 64/128/256; obs staged through LDS or not). */
+int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRGYM_HIP_H */

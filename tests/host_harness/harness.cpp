@@ -1,0 +1,125 @@
+// TEST AID (never part of the product): compiles airgym_amd/csrc/env_math.hpp - the exact source the
+// gfx950 kernel inlines - with g++ so that `pytest -m "not gpu"` can check the kernel arithmetic
+// against the oracle on the GPU-less build box.  The shipped library has no CPU path; this harness is
+// built into tests/host_harness/_build/ and loaded only by tests/test_host_harness.py.
+#include <stdint.h>
+#include <string.h>
+
+#include "../../airgym_amd/csrc/env_math.hpp"
+
+using namespace ag;
+
+namespace {
+
+struct Arrays {
+    int n;
+    float* root_states;   // [n,13]
+    float* ctl_state;     // [n,12]
+    float* pre_actions;   // [n,A]
+    int32_t* progress;    // [n]
+    int32_t* was_reset;   // [n]
+};
+
+void load(const Arrays& a, int i, int A, EnvState& s, CtlState& c, float* pre_a) {
+    const float* r = a.root_states + (size_t)i * 13;
+    s.p = V3{r[0], r[1], r[2]};
+    s.q = Q4{r[3], r[4], r[5], r[6]};
+    s.v = V3{r[7], r[8], r[9]};
+    s.w = V3{r[10], r[11], r[12]};
+    s.progress = a.progress[i];
+    s.was_reset = a.was_reset[i];
+    const float* cs = a.ctl_state + (size_t)i * 12;
+    for (int j = 0; j < 3; ++j) {
+        c.rate_int[j] = cs[j]; c.prev_rate[j] = cs[3 + j]; c.vel_int[j] = cs[6 + j]; c.prev_vel[j] = cs[9 + j];
+    }
+    for (int j = 0; j < A; ++j) pre_a[j] = a.pre_actions[(size_t)i * A + j];
+}
+
+void store(const Arrays& a, int i, int A, const EnvState& s, const CtlState& c, const float* pre_a) {
+    float* r = a.root_states + (size_t)i * 13;
+    r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z;
+    r[3] = s.q.x; r[4] = s.q.y; r[5] = s.q.z; r[6] = s.q.w;
+    r[7] = s.v.x; r[8] = s.v.y; r[9] = s.v.z;
+    r[10] = s.w.x; r[11] = s.w.y; r[12] = s.w.z;
+    a.progress[i] = s.progress;
+    a.was_reset[i] = s.was_reset;
+    float* cs = a.ctl_state + (size_t)i * 12;
+    for (int j = 0; j < 3; ++j) {
+        cs[j] = c.rate_int[j]; cs[3 + j] = c.prev_rate[j]; cs[6 + j] = c.vel_int[j]; cs[9 + j] = c.prev_vel[j];
+    }
+    for (int j = 0; j < A; ++j) a.pre_actions[(size_t)i * A + j] = pre_a[j];
+}
+
+template <int TASK, int CTL>
+void run_step(const Arrays& a, const StepParams& P, const float* actions, const float* noise, const float* uniforms,
+              float* obs, float* rew, int32_t* done, int32_t* timeout, float* terms, float* cmd) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    constexpr int NOBS = TaskTraits<TASK>::kNumObs;
+    for (int i = 0; i < a.n; ++i) {
+        EnvState s;
+        CtlState c;
+        memset(&c, 0, sizeof(c));
+        float pre_a[A];
+        load(a, i, A, s, c, pre_a);
+        StepOut o;
+        float ob[NOBS];
+        const uint32_t eg = P.env_id_offset + (uint32_t)i;
+        if (noise)
+            env_step<TASK, CTL, true>(s, c, pre_a, actions + (size_t)i * A, P, eg, noise + (size_t)i * 18,
+                                      uniforms + (size_t)i * 12, ob, o);
+        else
+            env_step<TASK, CTL, false>(s, c, pre_a, actions + (size_t)i * A, P, eg, nullptr, nullptr, ob, o);
+        store(a, i, A, s, c, pre_a);
+        for (int j = 0; j < NOBS; ++j) obs[(size_t)i * NOBS + j] = ob[j];
+        rew[i] = o.rew;
+        done[i] = o.done;
+        timeout[i] = o.timeout;
+        for (int t = 0; t < 9; ++t) terms[(size_t)i * 9 + t] = o.terms[t];
+        for (int t = 0; t < 4; ++t) cmd[(size_t)i * 4 + t] = o.cmd[t];
+    }
+}
+
+typedef void (*StepFn)(const Arrays&, const StepParams&, const float*, const float*, const float*, float*, float*,
+                       int32_t*, int32_t*, float*, float*);
+
+#define ROW(T) {run_step<T, 0>, run_step<T, 1>, run_step<T, 2>, run_step<T, 3>, run_step<T, 4>}
+const StepFn kTable[2][5] = {ROW(0), ROW(1)};
+
+}  // namespace
+
+extern "C" {
+
+int agh_step(int task, int ctl, int n, double dt, int max_len, const float* target18, uint64_t seed, uint32_t tick,
+             uint32_t env_id_offset, int noise_off, float* root_states, float* ctl_state, float* pre_actions,
+             int32_t* progress, int32_t* was_reset, const float* actions, const float* noise, const float* uniforms,
+             float* obs, float* rew, int32_t* done, int32_t* timeout, float* terms, float* cmd) {
+    if (task < 0 || task > 1 || ctl < 0 || ctl > 4) return -1;
+    StepParams P = make_step_params(task, dt, max_len, target18, seed, env_id_offset, noise_off != 0);
+    P.tick = tick;
+    Arrays a{n, root_states, ctl_state, pre_actions, progress, was_reset};
+    kTable[task][ctl](a, P, actions, noise, uniforms, obs, rew, done, timeout, terms, cmd);
+    return 0;
+}
+
+int agh_reset_all(int task, int num_actions, int n, double dt, int max_len, const float* target18, uint64_t seed,
+                  uint32_t tick, uint32_t env_id_offset, float* root_states, float* ctl_state, float* pre_actions,
+                  int32_t* progress, int32_t* was_reset) {
+    StepParams P = make_step_params(task, dt, max_len, target18, seed, env_id_offset, false);
+    P.tick = tick;
+    Arrays a{n, root_states, ctl_state, pre_actions, progress, was_reset};
+    for (int i = 0; i < n; ++i) {
+        EnvState s;
+        CtlState c;
+        float pre_a[5];
+        env_reset(s, c, pre_a, num_actions, P, env_id_offset + (uint32_t)i);
+        store(a, i, num_actions, s, c, pre_a);
+    }
+    return 0;
+}
+
+void agh_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+    const U4 r = philox4x32_10(c0, c1, c2, c3, k0, k1);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+"""CPU check of the kernel arithmetic: airgym_amd/csrc/env_math.hpp (the source the gfx950 kernel
+inlines) compiled with g++ by tests/host_harness, stepped side by side with the oracle.
+
+This is what lets the kernel math be debugged on the GPU-less build box; the GPU parity tests proper
+(tests/test_gpu_parity.py, -m gpu) go through the C-ABI of libairgym_hip.so.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+from oracle.hovering_ref import HoveringRef
+from oracle.tracking_ref import TrackingRef
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_harness", "harness.cpp")
+OUT = os.path.join(HERE, "host_harness", "_build", "libagh.so")
+HDR = os.path.join(os.path.dirname(HERE), "airgym_amd", "csrc", "env_math.hpp")
+
+TASKS = {"hovering": (0, HoveringRef, 18), "tracking": (1, TrackingRef, 48)}
+CTLS = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if (not os.path.exists(OUT)) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", SRC, "-o", OUT])
+    return ctypes.CDLL(OUT)
+
+
+def fp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class HarnessEnv:
+    def __init__(self, lib, task, ctl, n, seed, env_id_offset=0):
+        self.lib = lib
+        self.task_id, _, self.nobs = TASKS[task]
+        self.ctl_id = CTLS[ctl]
+        self.A = 5 if ctl == "atti" else 4
+        self.n = n
+        self.seed = seed
+        self.off = env_id_offset
+        self.max_len = 3600 if task == "tracking" else 2400
+        self.target = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1] + [0] * 9, dtype=np.float32)
+        self.rs = np.zeros((n, 13), np.float32)
+        self.cs = np.zeros((n, 12), np.float32)
+        self.pa = np.zeros((n, self.A), np.float32)
+        self.progress = np.zeros(n, np.int32)
+        self.was_reset = np.zeros(n, np.int32)
+        self.tick = 0
+        self.reset_all()
+
+    def reset_all(self):
+        rc = self.lib.agh_reset_all(self.task_id, self.A, self.n, ctypes.c_double(0.01), self.max_len, fp(self.target),
+                                    ctypes.c_uint64(self.seed), ctypes.c_uint32(self.tick), ctypes.c_uint32(self.off),
+                                    fp(self.rs), fp(self.cs), fp(self.pa), fp(self.progress), fp(self.was_reset))
+        assert rc == 0
+        self.tick += 1
+
+    def step(self, actions, noise=None, uniforms=None):
+        n = self.n
+        actions = np.ascontiguousarray(actions, np.float32)
+        self.obs = np.zeros((n, self.nobs), np.float32)
+        self.rew = np.zeros(n, np.float32)
+        self.done = np.zeros(n, np.int32)
+        self.timeout = np.zeros(n, np.int32)
+        self.terms = np.zeros((n, 9), np.float32)
+        self.cmd = np.zeros((n, 4), np.float32)
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float32)
+            uniforms = np.ascontiguousarray(uniforms, np.float32)
+        rc = self.lib.agh_step(self.task_id, self.ctl_id, n, ctypes.c_double(0.01), self.max_len, fp(self.target),
+                               ctypes.c_uint64(self.seed), ctypes.c_uint32(self.tick), ctypes.c_uint32(self.off), 0,
+                               fp(self.rs), fp(self.cs), fp(self.pa), fp(self.progress), fp(self.was_reset),
+                               fp(actions), fp(noise) if noise is not None else None,
+                               fp(uniforms) if uniforms is not None else None,
+                               fp(self.obs), fp(self.rew), fp(self.done), fp(self.timeout), fp(self.terms), fp(self.cmd))
+        assert rc == 0
+        self.tick += 1
+
+
+def test_philox_matches_oracle(lib):
+    out = (ctypes.c_uint32 * 4)()
+    for ctr, key in [((0, 0, 0, 0), (0, 0)), ((5, 77, 1, 3), (123, 456)),
+                     ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0))]:
+        lib.agh_philox(*[ctypes.c_uint32(c) for c in ctr], *[ctypes.c_uint32(k) for k in key], out)
+        ref = philox.philox4x32_10(*ctr, *key)
+        assert [int(x) for x in out] == [int(r) for r in ref]
+
+
+def scripted_actions(rng, n, A, t, ctl):
+    """random + scripted mix, kept away from clamp edges (SURVEY section 7 'hard parts')."""
+    a = rng.uniform(-0.8, 0.8, size=(n, A)).astype(np.float32)
+    if ctl in ("rate", "atti"):
+        a[:, -1] = rng.uniform(-0.9, -0.3, size=n)   # thrust 0.05 .. 0.35 after the 0.5+0.5a map
+    if ctl == "atti":
+        a[:, 0] = rng.uniform(0.6, 0.95, size=n)     # qw > 0
+        a[:, 1:4] *= 0.3
+    if ctl == "prop":
+        a = rng.uniform(0.05, 0.3, size=(n, A)).astype(np.float32)
+    if t % 7 == 0:
+        a[: n // 4] = a[0]                            # a block of identical actions
+    return a
+
+
+@pytest.mark.parametrize("task", ["hovering", "tracking"])
+@pytest.mark.parametrize("ctl", ["rate", "vel", "atti", "pos", "prop"])
+def test_100_step_trajectory_matches_oracle(lib, task, ctl):
+    n, steps, seed = 64, 100, 1234
+    _, cls, nobs = TASKS[task]
+    ora = cls(n, ctl_mode=ctl, seed=seed)
+    har = HarnessEnv(lib, task, ctl, n, seed)
+    # identical initial state from the counter RNG (reset keyed by (seed, env, tick 0))
+    np.testing.assert_allclose(har.rs, ora.root_states.numpy(), rtol=0, atol=1e-6)
+    rng = np.random.default_rng(7)
+    n_resets = 0
+    for t in range(steps):
+        a = scripted_actions(rng, n, har.A, t, ctl)
+        obs, _, rew, reset, extras = ora.step(torch.from_numpy(a))
+        har.step(a)
+        # integer reset indices bit-exact
+        assert np.array_equal(np.nonzero(har.done)[0], ora.last_reset_env_ids.numpy()), f"step {t}"
+        n_resets += int(har.done.sum())
+        np.testing.assert_allclose(har.rs, ora.root_states.numpy(), rtol=0, atol=1e-5, err_msg=f"state step {t}")
+        np.testing.assert_allclose(har.obs, obs.numpy(), rtol=0, atol=2e-5, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(har.rew, rew.numpy(), rtol=0, atol=1e-5, err_msg=f"rew step {t}")
+        np.testing.assert_allclose(har.cmd, ora.cmd_thrusts.numpy(), rtol=0, atol=1e-5, err_msg=f"cmd step {t}")
+        assert np.array_equal(har.progress, ora.progress_buf.numpy().astype(np.int32))
+        assert np.array_equal(har.was_reset, ora.reset_buf.numpy().astype(np.int32))
+    assert har.tick == ora.tick
+    if task == "tracking":
+        assert n_resets > 0   # random actions leave the 1 m tube quickly: the reset path is exercised
+
+
+@pytest.mark.parametrize("task", ["hovering", "tracking"])
+def test_parity_mode_with_supplied_randoms(lib, task):
+    n, seed = 64, 5
+    _, cls, nobs = TASKS[task]
+    ora = cls(n, ctl_mode="rate", seed=seed)
+    har = HarnessEnv(lib, task, "rate", n, seed)
+    rng = np.random.default_rng(3)
+    for t in range(30):
+        a = scripted_actions(rng, n, 4, t, "rate")
+        noise = rng.standard_normal((n, 18)).astype(np.float32)
+        uni = rng.random((n, 12)).astype(np.float32)
+        obs, _, rew, reset, _ = ora.step(torch.from_numpy(a), noise=torch.from_numpy(noise),
+                                         reset_uniforms=torch.from_numpy(uni))
+        har.step(a, noise, uni)
+        assert np.array_equal(har.done, reset.numpy().astype(np.int32))
+        np.testing.assert_allclose(har.obs, obs.numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(har.rs, ora.root_states.numpy(), rtol=0, atol=1e-5)
+
+
+def test_episode_end_reset_and_thrust_zero_quirk(lib):
+    """progress >= max_len-1 terminates (hovering.py:435); the following step runs with zero thrust (Q2)."""
+    n, seed = 64, 9
+    ora = HoveringRef(n, "rate", seed=seed)
+    har = HarnessEnv(lib, "hovering", "rate", n, seed)
+    ora.progress_buf[:] = 2397
+    har.progress[:] = 2397
+    a = np.zeros((n, 4), np.float32)
+    a[:, 3] = -0.7
+    ora.step(torch.from_numpy(a)); har.step(a)
+    assert har.done.sum() == 0 or (har.done == ora.reset_buf.numpy()).all()
+    ora.step(torch.from_numpy(a)); har.step(a)
+    assert (har.done == 1).all() and (ora.reset_buf == 1).all()      # progress hit 2399
+    assert (har.progress == 0).all() and (har.pa == 0).all()
+    np.testing.assert_allclose(har.rs, ora.root_states.numpy(), rtol=0, atol=1e-6)
+    vz0 = har.rs[:, 9].copy()
+    ora.step(torch.from_numpy(a)); har.step(a)
+    # free fall for one step: dv_z = -9.81 * 0.01 regardless of the commanded thrust
+    np.testing.assert_allclose(har.rs[:, 9] - vz0, -0.0981, atol=2e-5)
+    np.testing.assert_allclose(har.rs, ora.root_states.numpy(), rtol=0, atol=1e-5)
