@@ -1,0 +1,14 @@
+"""airgym_amd - MI355X-native hot path of the AirGym vectorised quadrotor environments.
+
+Layout
+  csrc/        HIP kernels for gfx950 + the C ABI (include/airgym_hip.h)
+  _native/     ctypes binding; libairgym_hip.so is built in-tree here
+  hip_env.py   HipEnvHandle: zero-copy torch views of the library's device buffers
+  envs/, utils/ host-side mirror of the reference's task API (task_registry.make_env, Hovering, Tracking)
+  lib/         PPO loop mirror of the reference's lib/ (PyTorch-ROCm policy, RCCL grad all-reduce)
+"""
+import os
+
+AIRGYM_ROOT_DIR = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+
+__version__ = "0.1.0"

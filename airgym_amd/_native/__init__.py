@@ -1,0 +1,145 @@
+"""ctypes binding of libairgym_hip.so (C ABI: include/airgym_hip.h).
+
+The library is the ONLY execution path of the environments: if it is missing and cannot be
+built, importing this module raises - there is no CPU / PyTorch fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libairgym_hip.so")
+
+AG_TASKS = {"hovering": 0, "tracking": 1}
+AG_CTL_MODES = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
+AG_FLAG_REWARD_TERMS = 1 << 0
+AG_FLAG_OBS_NOISE_OFF = 1 << 1
+AG_NUM_REWARD_TERMS = 9
+
+AG_ERR_UNKNOWN_TASK = -2
+AG_ERR_UNKNOWN_CTL = -3
+
+# order of ag_buffers.reward_terms (include/airgym_hip.h)
+REWARD_TERM_NAMES = {
+    "hovering": ["continous_action_reward", "effort_reward", "thrust_reward", "pos_reward", "vel_direction_reward",
+                 "ups_reward", "spin_reward", "yaw_reward", "reward"],
+    "tracking": ["dist_norm", "dist_reward", "yaw_reward", "spin_reward", "continous_action_reward", "thrust_reward",
+                 "effort_reward", "ups_reward", "reward"],
+}
+
+
+class AgConfig(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("task", ctypes.c_int32),
+        ("ctl_mode", ctypes.c_int32),
+        ("num_envs", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("seed", ctypes.c_uint64),
+        ("env_id_offset", ctypes.c_uint32),
+        ("dt", ctypes.c_double),
+        ("max_episode_length", ctypes.c_int32),
+        ("target_state", ctypes.c_float * 18),
+    ]
+
+
+class AgBuffers(ctypes.Structure):
+    _fields_ = [
+        ("num_envs", ctypes.c_int32),
+        ("num_obs", ctypes.c_int32),
+        ("num_actions", ctypes.c_int32),
+        ("max_episode_length", ctypes.c_int32),
+        ("obs_dev", ctypes.c_void_p),
+        ("rew_dev", ctypes.c_void_p),
+        ("reset_dev", ctypes.c_void_p),
+        ("timeout_dev", ctypes.c_void_p),
+        ("reset_mask_dev", ctypes.c_void_p),
+        ("reset_ids_dev", ctypes.c_void_p),
+        ("reset_count_dev", ctypes.c_void_p),
+        ("reward_terms_dev", ctypes.c_void_p * AG_NUM_REWARD_TERMS),
+        ("cmd_thrusts_dev", ctypes.c_void_p),
+    ]
+
+
+class AgStateView(ctypes.Structure):
+    _fields_ = [
+        ("root_states_dev", ctypes.c_void_p),
+        ("ctl_state_dev", ctypes.c_void_p),
+        ("pre_actions_dev", ctypes.c_void_p),
+        ("progress_dev", ctypes.c_void_p),
+        ("was_reset_dev", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/airgym_hip.h declares: (name, restype, argtypes)
+_P = ctypes.c_void_p
+SYMBOLS = [
+    ("ag_version", ctypes.c_int, []),
+    ("ag_last_error", ctypes.c_char_p, []),
+    ("ag_num_obs", ctypes.c_int, [ctypes.c_int]),
+    ("ag_num_actions", ctypes.c_int, [ctypes.c_int]),
+    ("ag_default_episode_length", ctypes.c_int, [ctypes.c_int, ctypes.c_double]),
+    ("ag_arena_bytes", ctypes.c_size_t, [ctypes.POINTER(AgConfig)]),
+    ("ag_create", ctypes.c_int, [ctypes.POINTER(AgConfig), _P, ctypes.POINTER(_P)]),
+    ("ag_destroy", ctypes.c_int, [_P]),
+    ("ag_reset_all", ctypes.c_int, [_P, _P]),
+    ("ag_step", ctypes.c_int, [_P, _P, _P]),
+    ("ag_step_into", ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("ag_step_with_inputs", ctypes.c_int, [_P, _P, _P, _P, _P]),
+    ("ag_get_buffers", ctypes.c_int, [_P, ctypes.POINTER(AgBuffers)]),
+    ("ag_get_state", ctypes.c_int, [_P, ctypes.POINTER(AgStateView), _P]),
+    ("ag_set_state", ctypes.c_int, [_P, ctypes.POINTER(AgStateView), _P]),
+    ("ag_compact_reset_ids", ctypes.c_int, [_P, _P]),
+    ("ag_set_target_state", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
+    ("ag_get_tick", ctypes.c_uint64, [_P]),
+    ("ag_set_tick", ctypes.c_int, [_P, ctypes.c_uint64]),
+    ("ag_set_launch_params", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
+]
+
+_lib = None
+
+
+def _build():
+    from airgym_amd.csrc import build as _b
+    return _b.build(verbose=False)
+
+
+def load(rebuild_if_missing=True):
+    """Load (building first if needed) libairgym_hip.so.  Raises RuntimeError when the HIP library is
+    unavailable - the environments never fall back to a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not rebuild_if_missing:
+            raise RuntimeError(f"{LIB_PATH} is missing; run `python airgym_amd/csrc/build.py`")
+        try:
+            _build()
+        except Exception as e:  # hipcc missing or compile error
+            raise RuntimeError(
+                f"libairgym_hip.so is missing and could not be built with hipcc ({e}). "
+                "airgym_amd has no CPU fallback: build it with `python airgym_amd/csrc/build.py`.") from e
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError = the .so is stale w.r.t. the header
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().ag_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    """Map ag_status to the exceptions the reference raises (task_registry.py:78-79 ValueError)."""
+    if rc == 0:
+        return
+    msg = f"{what}: {last_error()} (ag_status {rc})"
+    if rc in (AG_ERR_UNKNOWN_TASK, AG_ERR_UNKNOWN_CTL, -1):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -35,7 +35,7 @@ constexpr int kPad = 256;
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-    size_t S[4], C[4], PA, PA4, obs, rew, reset, timeout, mask, reset_ids, reset_count, terms[9], cmd, total;
+    size_t S[4], C[4], PA, PA4, obs, rew, reset, timeout, mask, reset_ids, reset_count, tick, terms[9], cmd, total;
 };
 
 Layout make_layout(int n, int num_obs, bool terms) {
@@ -54,6 +54,7 @@ Layout make_layout(int n, int num_obs, bool terms) {
     L.mask = take(np / 64 * 8);
     L.reset_ids = take(np * 4);
     L.reset_count = take(256);
+    L.tick = take(256);
     for (int t = 0; t < 9; ++t) L.terms[t] = terms ? take(np * 4) : 0;
     L.cmd = terms ? take(np * 16) : 0;
     L.total = off;
@@ -74,7 +75,8 @@ struct ag_env {
     bool owns_arena;
     Layout L;
     ag::KArgs k;       // pointers + StepParams template for launches
-    uint64_t tick;
+    uint64_t tick;     // host mirror of the device tick (exact unless a captured graph is being replayed)
+    int parity;        // which of the two device tick slots the next launch reads
     int block;
     int obs_via_lds;
 };
@@ -88,7 +90,10 @@ __global__ void reset_all_kernel(ag::KArgs k, int n_pad, int num_actions, int nu
     ag::EnvState s;
     ag::CtlState c;
     float pre_a[AG_MAX_ACTIONS];
-    ag::env_reset(s, c, pre_a, num_actions, k.P, k.P.env_id_offset + (uint32_t)i);
+    ag::StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (i == 0) *k.tick_out = P.tick + 1u;
+    ag::env_reset(s, c, pre_a, num_actions, P, P.env_id_offset + (uint32_t)i);
     ag::store_env(k, i, s);
     ag::store_ctl<ag::CTL_POS>(k, i, c);  // writes all four controller arrays
     k.PA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -217,6 +222,14 @@ int ensure_device(ag_env* h) {
     return AG_OK;
 }
 
+void bind_tick(ag_env* h, ag::KArgs& k) {
+    uint32_t* slots = (uint32_t*)(h->arena + h->L.tick);
+    k.tick_in = slots + h->parity;
+    k.tick_out = slots + (h->parity ^ 1);
+    h->parity ^= 1;
+    h->tick += 1;
+}
+
 int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int64_t* reset_out,
             const float* noise, const float* uniforms, void* stream) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
@@ -234,10 +247,9 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
     if (reset_out) k.reset = (long long*)reset_out;
     k.ext_noise = noise;
     k.ext_uniforms = uniforms;
-    k.P.tick = (uint32_t)h->tick;
+    bind_tick(h, k);
     hipError_t e = kLaunchers[h->cfg.task][h->cfg.ctl_mode](k, h->block, h->obs_via_lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
-    h->tick += 1;
     return AG_OK;
 }
 
@@ -322,6 +334,7 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     k.n = cfg->num_envs;
     fill_params(h);
     h->tick = 0;
+    h->parity = 0;
     h->block = 64;
     h->obs_via_lds = 1;
     // valid state from the start: everything randomised and flagged reset (base_task.py:75)
@@ -353,11 +366,10 @@ int ag_reset_all(ag_handle h, void* stream) {
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
-    k.P.tick = (uint32_t)h->tick;
+    bind_tick(h, k);
     hipLaunchKernelGGL(reset_all_kernel, dim3(h->n_pad / 256), dim3(256), 0, (hipStream_t)stream, k, h->n_pad,
                        h->num_actions, h->num_obs);
     AG_HIP_CHECK(hipGetLastError());
-    h->tick += 1;
     return AG_OK;
 }
 
@@ -437,6 +449,11 @@ uint64_t ag_get_tick(ag_handle h) { return h ? h->tick : 0; }
 
 int ag_set_tick(ag_handle h, uint64_t tick) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    const uint32_t t[2] = {(uint32_t)tick, (uint32_t)tick};
+    AG_HIP_CHECK(hipDeviceSynchronize());
+    AG_HIP_CHECK(hipMemcpy(h->arena + h->L.tick, t, sizeof(t), hipMemcpyHostToDevice));
     h->tick = tick;
     return AG_OK;
 }

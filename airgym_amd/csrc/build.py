@@ -3,7 +3,7 @@
 
     python airgym_amd/csrc/build.py [--force] [--jobs N]
 
-The library lands in-tree at airgym_amd/lib/libairgym_hip.so (git-ignored, shipped to the GPU box by gpurun).
+The library lands in-tree at airgym_amd/_native/libairgym_hip.so (git-ignored, shipped to the GPU box by gpurun).
 """
 import argparse
 import concurrent.futures as cf
@@ -15,7 +15,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-LIB_DIR = os.path.join(PKG, "lib")
+LIB_DIR = os.path.join(PKG, "_native")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIB_DIR, "libairgym_hip.so")
 ARCH = "gfx950"

@@ -32,6 +32,11 @@ struct KArgs {
     float4* cmd;                 // [n] or null
     const float* ext_noise;      // [n,18] or null
     const float* ext_uniforms;   // [n,12] or null
+    // RNG tick lives in device memory so that a captured hipGraph of env steps replays with fresh
+    // counters: each launch reads tick_in and thread 0 publishes tick+1 to tick_out (the two slots
+    // alternate launch to launch; stream order between launches makes the hand-off race-free).
+    const uint32_t* tick_in;
+    uint32_t* tick_out;
     int n;
     StepParams P;
 };

@@ -70,10 +70,14 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs k) {
         }
     }
 
+    StepParams P = k.P;          // uniform: stays in SGPRs
+    P.tick = *k.tick_in;
+    if (blockIdx.x == 0 && tid == 0) *k.tick_out = P.tick + 1u;
+
     float obs[NOBS];
     StepOut o;
-    const uint32_t env_global = k.P.env_id_offset + (uint32_t)i;
-    env_step<TASK, CTL, EXT>(s, c, pre_a, raw_a, k.P, env_global, ext_z, ext_u, obs, o);
+    const uint32_t env_global = P.env_id_offset + (uint32_t)i;
+    env_step<TASK, CTL, EXT>(s, c, pre_a, raw_a, P, env_global, ext_z, ext_u, obs, o);
 
     // ---- state back to HBM
     store_env(k, i, s);

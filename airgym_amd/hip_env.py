@@ -1,0 +1,189 @@
+"""HipEnvHandle: owns one libairgym_hip.so handle and exposes its device buffers as torch tensors
+(zero copy).  This is the only place where Python touches the C ABI; the task classes
+(`airgym_amd/envs/...`) and the PPO runner build on it.
+
+Memory: the arena is a torch uint8 CUDA tensor whose pointer is handed to `ag_create`, so every
+buffer the kernel writes (obs_buf, rew_buf, reset_buf, ...) is a *view* of that tensor - the same
+ownership rule as the reference (env-owned persistent tensors mutated in place, base_task.py:72-76).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+class HipEnvHandle:
+    def __init__(self, task, ctl_mode, num_envs, device="cuda:0", seed=0, env_id_offset=0, dt=0.01,
+                 max_episode_length=0, target_state=None, reward_terms=True, obs_noise=True):
+        if task not in N.AG_TASKS:
+            raise ValueError(f"Task with name: {task} was not registered")
+        if ctl_mode not in N.AG_CTL_MODES:
+            raise ValueError(f"unknown ctl_mode {ctl_mode!r}; options: pos, vel, atti, rate, prop")
+        self.lib = N.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"airgym_amd environments run on a HIP device only (got device={device!r})")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: airgym_amd has no CPU fallback")
+        self.task = task
+        self.ctl_mode = ctl_mode
+        self.num_envs = int(num_envs)
+        cfg = N.AgConfig()
+        cfg.struct_size = ctypes.sizeof(N.AgConfig)
+        cfg.task = N.AG_TASKS[task]
+        cfg.ctl_mode = N.AG_CTL_MODES[ctl_mode]
+        cfg.num_envs = self.num_envs
+        cfg.device = self.device.index or 0
+        cfg.flags = (N.AG_FLAG_REWARD_TERMS if reward_terms else 0) | (0 if obs_noise else N.AG_FLAG_OBS_NOISE_OFF)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.env_id_offset = int(env_id_offset)
+        cfg.dt = float(dt)
+        cfg.max_episode_length = int(max_episode_length)
+        if target_state is None:
+            target_state = [1, 0, 0, 0, 1, 0, 0, 0, 1] + [0] * 9
+        ts = np.asarray(target_state, dtype=np.float32).reshape(18)
+        for i in range(18):
+            cfg.target_state[i] = float(ts[i])
+        self.cfg = cfg
+        nbytes = self.lib.ag_arena_bytes(ctypes.byref(cfg))
+        if nbytes == 0:
+            N.check(-1, "ag_arena_bytes")
+        with torch.cuda.device(self.device):
+            self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            torch.cuda.synchronize(self.device)
+            h = ctypes.c_void_p()
+            N.check(self.lib.ag_create(ctypes.byref(cfg), self.arena.data_ptr(), ctypes.byref(h)), "ag_create")
+        self.h = h
+        b = N.AgBuffers()
+        N.check(self.lib.ag_get_buffers(self.h, ctypes.byref(b)), "ag_get_buffers")
+        self.num_obs, self.num_actions, self.max_episode_length = b.num_obs, b.num_actions, b.max_episode_length
+        n = self.num_envs
+        self.obs_buf = self._view(b.obs_dev, torch.float32, (n, self.num_obs))
+        self.rew_buf = self._view(b.rew_dev, torch.float32, (n,))
+        self.reset_buf = self._view(b.reset_dev, torch.int64, (n,))
+        self.time_out_buf = self._view(b.timeout_dev, torch.uint8, (n,)).view(torch.bool)
+        self.reset_mask = self._view(b.reset_mask_dev, torch.int64, ((n + 63) // 64,))
+        self.reset_ids = self._view(b.reset_ids_dev, torch.int32, (n,))
+        self.reset_count = self._view(b.reset_count_dev, torch.int32, (1,))
+        self.reward_terms = None
+        self.cmd_thrusts = None
+        if reward_terms:
+            self.reward_terms = {
+                name: self._view(b.reward_terms_dev[i], torch.float32, (n,))
+                for i, name in enumerate(N.REWARD_TERM_NAMES[task])
+            }
+            self.cmd_thrusts = self._view(b.cmd_thrusts_dev, torch.float32, (n, 4))
+
+    # ------------------------------------------------------------------ helpers
+    def _view(self, ptr, dtype, shape):
+        off = int(ptr) - self.arena.data_ptr()
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        assert 0 <= off and off + nbytes <= self.arena.numel(), "buffer outside the arena"
+        return self.arena[off:off + nbytes].view(dtype).view(*shape)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_actions(self, actions):
+        if actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        if actions.shape != (self.num_envs, self.num_actions):
+            raise ValueError(f"actions must be [{self.num_envs}, {self.num_actions}], got {tuple(actions.shape)}")
+        return actions
+
+    # ---------------------------------------------------------------------- API
+    def reset_all(self):
+        N.check(self.lib.ag_reset_all(self.h, self._stream()), "ag_reset_all")
+
+    def step(self, actions):
+        actions = self._check_actions(actions)
+        N.check(self.lib.ag_step(self.h, actions.data_ptr(), self._stream()), "ag_step")
+
+    def step_into(self, actions, obs_out=None, rew_out=None, reset_out=None):
+        """Write obs / reward / done straight into caller tensors (e.g. slot t of a rollout buffer)."""
+        actions = self._check_actions(actions)
+
+        def ptr(t, dtype, numel):
+            if t is None:
+                return None
+            assert t.is_contiguous() and t.dtype == dtype and t.numel() == numel and t.device == self.device
+            return t.data_ptr()
+        N.check(self.lib.ag_step_into(self.h, actions.data_ptr(),
+                                      ptr(obs_out, torch.float32, self.num_envs * self.num_obs),
+                                      ptr(rew_out, torch.float32, self.num_envs),
+                                      ptr(reset_out, torch.int64, self.num_envs), self._stream()), "ag_step_into")
+
+    def step_with_inputs(self, actions, noise, reset_uniforms):
+        actions = self._check_actions(actions)
+        noise = noise.to(device=self.device, dtype=torch.float32).contiguous()
+        reset_uniforms = reset_uniforms.to(device=self.device, dtype=torch.float32).contiguous()
+        assert noise.shape == (self.num_envs, 18) and reset_uniforms.shape == (self.num_envs, 12)
+        N.check(self.lib.ag_step_with_inputs(self.h, actions.data_ptr(), noise.data_ptr(), reset_uniforms.data_ptr(),
+                                             self._stream()), "ag_step_with_inputs")
+
+    def get_state(self):
+        n = self.num_envs
+        out = {
+            "root_states": torch.empty(n, 13, device=self.device),
+            "ctl_state": torch.empty(n, 12, device=self.device),
+            "pre_actions": torch.empty(n, self.num_actions, device=self.device),
+            "progress": torch.empty(n, dtype=torch.int32, device=self.device),
+            "was_reset": torch.empty(n, dtype=torch.int32, device=self.device),
+        }
+        v = N.AgStateView(out["root_states"].data_ptr(), out["ctl_state"].data_ptr(), out["pre_actions"].data_ptr(),
+                          out["progress"].data_ptr(), out["was_reset"].data_ptr())
+        N.check(self.lib.ag_get_state(self.h, ctypes.byref(v), self._stream()), "ag_get_state")
+        return out
+
+    def set_state(self, root_states=None, ctl_state=None, pre_actions=None, progress=None, was_reset=None):
+        keep = []
+
+        def p(t, dtype, shape):
+            if t is None:
+                return None
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+            assert tuple(t.shape) == shape, (tuple(t.shape), shape)
+            keep.append(t)
+            return t.data_ptr()
+        n = self.num_envs
+        v = N.AgStateView(p(root_states, torch.float32, (n, 13)), p(ctl_state, torch.float32, (n, 12)),
+                          p(pre_actions, torch.float32, (n, self.num_actions)), p(progress, torch.int32, (n,)),
+                          p(was_reset, torch.int32, (n,)))
+        N.check(self.lib.ag_set_state(self.h, ctypes.byref(v), self._stream()), "ag_set_state")
+        torch.cuda.current_stream(self.device).synchronize()  # `keep` must outlive the kernel
+
+    def compact_reset_ids(self):
+        """Ascending ids of the envs flagged done by the last step == reset_buf.nonzero().squeeze(-1)."""
+        N.check(self.lib.ag_compact_reset_ids(self.h, self._stream()), "ag_compact_reset_ids")
+        k = int(self.reset_count.item())
+        return self.reset_ids[:k]
+
+    def set_target_state(self, target_state):
+        ts = np.asarray(target_state, dtype=np.float32).reshape(18)
+        arr = (ctypes.c_float * 18)(*[float(x) for x in ts])
+        N.check(self.lib.ag_set_target_state(self.h, arr), "ag_set_target_state")
+
+    def set_launch_params(self, block_size=64, obs_via_lds=True):
+        N.check(self.lib.ag_set_launch_params(self.h, int(block_size), int(bool(obs_via_lds))), "ag_set_launch_params")
+
+    @property
+    def tick(self):
+        return int(self.lib.ag_get_tick(self.h))
+
+    @tick.setter
+    def tick(self, v):
+        N.check(self.lib.ag_set_tick(self.h, int(v)), "ag_set_tick")
+
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.ag_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

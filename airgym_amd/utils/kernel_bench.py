@@ -1,0 +1,73 @@
+"""Measure the env-step kernel in isolation: HIP events around a replayed hipGraph of K launches.
+
+Used by bench.py (the `roofline` object) and by tools/sweep_env_kernel.py.  Events are recorded on the
+stream the kernels are launched on (torch's current stream is handed to ag_step as the hipStream_t).
+"""
+import torch
+
+# algorithmic HBM bytes per env-step, fp32 SoA, state + action + controller
+# memory in, state + obs + reward + flags out.
+ALGO_BYTES_PER_ENV_STEP = {
+    ("hovering", "rate"): 287,
+    ("tracking", "vel"): 543,
+}
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algo_bytes(task, ctl_mode, num_obs, num_actions):
+    key = (task, ctl_mode)
+    if key in ALGO_BYTES_PER_ENV_STEP:
+        return ALGO_BYTES_PER_ENV_STEP[key]
+    ctl_floats = {"prop": 0, "rate": 6, "atti": 6, "vel": 12, "pos": 12}[ctl_mode]
+    reads = 13 * 4 + num_actions * 4 * 2 + ctl_floats * 4 + 4 + 1
+    writes = 13 * 4 + num_actions * 4 + ctl_floats * 4 + 4 + num_obs * 4 + 4 + 1 + 1
+    return reads + writes
+
+
+def measure_env_kernel(env, steps_per_graph=48, replays=20, warmup_replays=3, use_graph=True, seed=1):
+    """Returns dict(us_per_step, env_steps_per_s, gbps_algorithmic).  `env` is a HipEnvHandle."""
+    assert steps_per_graph % 2 == 0, "capture an even number of steps (device tick ping-pong)"
+    dev = env.device
+    n, A = env.num_envs, env.num_actions
+    g = torch.Generator(device=dev).manual_seed(seed)
+    # what a freshly initialised policy emits: N(0,1) clamped to [-1,1]
+    actions = torch.randn(steps_per_graph, n, A, generator=g, device=dev).clamp_(-1.0, 1.0)
+    stream = torch.cuda.Stream(device=dev)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for t in range(4):
+            env.step(actions[t])
+        stream.synchronize()
+        graph = None
+        if use_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for t in range(steps_per_graph):
+                    env.step(actions[t])
+
+        def run():
+            if graph is not None:
+                graph.replay()
+            else:
+                for t in range(steps_per_graph):
+                    env.step(actions[t])
+        for _ in range(warmup_replays):
+            run()
+        stream.synchronize()
+        start.record(stream)
+        for _ in range(replays):
+            run()
+        stop.record(stream)
+        stop.synchronize()
+    ms = start.elapsed_time(stop)
+    total_steps = steps_per_graph * replays
+    us = ms * 1e3 / total_steps
+    b = algo_bytes(env.task, env.ctl_mode, env.num_obs, A)
+    return {
+        "us_per_step": us,
+        "env_steps_per_s": n / (us * 1e-6),
+        "gbps_algorithmic": n * b / (us * 1e-6) / 1e9,
+        "algo_bytes_per_env_step": b,
+        "graph": bool(use_graph),
+        "steps_timed": total_steps,
+    }
