@@ -6,6 +6,11 @@ built, importing this module raises - there is no CPU / PyTorch fallback.
 import ctypes
 import os
 
+# torch must initialise its bundled HIP runtime BEFORE libairgym_hip.so is dlopen'ed: loading the
+# library first binds it to /opt/rocm's libamdhip64 and the process ends up with two runtimes
+# (symptom on the GPU box: hipGetDeviceCount() == 0 inside ag_create).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libairgym_hip.so")
 

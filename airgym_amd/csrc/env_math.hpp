@@ -178,6 +178,31 @@ AG_HD void action_limits(float* lo, float* hi) {
 AG_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 // ---------------------------------------------------------------------------
+// Transcendental units.  On gfx950 these map to single quarter-rate VALU instructions
+// (v_rcp/v_rsq/v_sqrt/v_log/v_exp/v_sin/v_cos, <= 1 ulp; v_sin/v_cos take REVOLUTIONS, so
+// sin(2*pi*u) needs no multiply and no range reduction).  OCML's correctly-rounded sinf/cosf carry
+// a Payne-Hanek path that made up ~40 % of the kernel's instructions.  The host build (test harness)
+// uses libm; both stay inside the 1e-5 parity budget.
+// ---------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+AG_HD float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+AG_HD float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+AG_HD float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+AG_HD float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
+AG_HD float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504089f); }
+AG_HD float sin_2pi(float rev) { return __builtin_amdgcn_sinf(rev); }
+AG_HD float cos_2pi(float rev) { return __builtin_amdgcn_cosf(rev); }
+#else
+AG_HD float fast_rcp(float x) { return 1.0f / x; }
+AG_HD float fast_rsq(float x) { return 1.0f / sqrtf(x); }
+AG_HD float fast_sqrt(float x) { return sqrtf(x); }
+AG_HD float fast_ln(float x) { return logf(x); }
+AG_HD float fast_exp(float x) { return expf(x); }
+AG_HD float sin_2pi(float rev) { return sinf(6.283185307179586f * rev); }
+AG_HD float cos_2pi(float rev) { return cosf(6.283185307179586f * rev); }
+#endif
+
+// ---------------------------------------------------------------------------
 // Philox4x32-10 (oracle/philox.py; Salmon et al. SC'11)
 // ---------------------------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
@@ -219,10 +244,9 @@ AG_HD void reset_uniforms(const StepParams& P, uint32_t env_global, float* u) {
 AG_HD void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
     const float u1 = u32_to_open_unit(a);
     const float u2 = u32_to_unit(b);
-    const float r = sqrtf(-2.0f * logf(u1));
-    const float th = kTwoPi * u2;
-    z0 = r * cosf(th);
-    z1 = r * sinf(th);
+    const float r = fast_sqrt(-2.0f * fast_ln(u1));
+    z0 = r * cos_2pi(u2);
+    z1 = r * sin_2pi(u2);
 }
 
 // 18 N(0,1) for add_noise (hovering.py:349-358)
@@ -307,7 +331,7 @@ AG_HD void mix_quad_x(float thrust, const float* u, float* cmd) {
 AG_HD void attitude_control(Q4 q, Q4 qd, float* rate_sp) {
     const float n2 = qd.x * qd.x + qd.y * qd.y + qd.z * qd.z + qd.w * qd.w;
     const bool bad = n2 < 1e-12f;
-    const float inv = 1.0f / sqrtf(bad ? 1.0f : n2);
+    const float inv = fast_rsq(bad ? 1.0f : n2);
     qd = Q4{bad ? 0.0f : qd.x * inv, bad ? 0.0f : qd.y * inv, bad ? 0.0f : qd.z * inv, bad ? 1.0f : qd.w * inv};
     const V3 ez = q_body_z(q);
     const V3 ezd = q_body_z(qd);
@@ -317,7 +341,7 @@ AG_HD void attitude_control(Q4 q, Q4 qd, float* rate_sp) {
     const float dot = ez.x * ezd.x + ez.y * ezd.y + ez.z * ezd.z;
     const float rw = dot + 1.0f;
     const bool singular = rw < 1e-5f;
-    const float rn = 1.0f / sqrtf(singular ? 1.0f : cx * cx + cy * cy + cz * cz + rw * rw);
+    const float rn = fast_rsq(singular ? 1.0f : cx * cx + cy * cy + cz * cz + rw * rw);
     Q4 red = qmul(Q4{cx * rn, cy * rn, cz * rn, rw * rn}, q);
     if (singular) red = qd;
     const Q4 qmix = qmul(qconj(red), qd);
@@ -341,7 +365,7 @@ AG_HD void velocity_control(CtlState& c, const float* vel_sp, const float* vel, 
         const float vdot = (vel[i] - c.prev_vel[i]) * kInvCtlDt;
         acc[i] = kVelKp[i] * err[i] + c.vel_int[i] - kVelKd[i] * vdot;
     }
-    const float bn = 1.0f / sqrtf(acc[0] * acc[0] + acc[1] * acc[1] + kGrav * kGrav);
+    const float bn = fast_rsq(acc[0] * acc[0] + acc[1] * acc[1] + kGrav * kGrav);
     float bx = acc[0] * bn, by = acc[1] * bn, bz = kGrav * bn;
     const bool over = bz < kCosTiltMax;
     const float hn = sqrtf(bx * bx + by * by);
@@ -360,7 +384,7 @@ AG_HD void velocity_control(CtlState& c, const float* vel_sp, const float* vel, 
         c.prev_vel[i] = vel[i];
     }
     const float tw = 1.0f + bz;
-    const float tn = 1.0f / sqrtf(bx * bx + by * by + tw * tw);
+    const float tn = fast_rsq(bx * bx + by * by + tw * tw);
     const Q4 q_tilt{-by * tn, bx * tn, 0.0f, tw * tn};
     const float half = 0.5f * yaw_sp;
     const Q4 q_yaw{0.0f, 0.0f, sinf(half), cosf(half)};
@@ -451,7 +475,7 @@ AG_HD Deriv rb_deriv(Q4 q, V3 wb, float fz, V3 tau) {
 }
 
 AG_HD V3 clamp_norm(V3 v, float vmax) {
-    const float n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const float n = fast_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
     if (n > vmax) {
         const float s = vmax / n;
         v.x *= s; v.y *= s; v.z *= s;
@@ -487,7 +511,7 @@ AG_HD void rk4_step(EnvState& s, float fz, V3 tau, const StepParams& P) {
     const V3 wbn{wb.x + s6 * AG_RK_SUM(k1.alpha.x, k2.alpha.x, k3.alpha.x, k4.alpha.x),
                  wb.y + s6 * AG_RK_SUM(k1.alpha.y, k2.alpha.y, k3.alpha.y, k4.alpha.y),
                  wb.z + s6 * AG_RK_SUM(k1.alpha.z, k2.alpha.z, k3.alpha.z, k4.alpha.z)};
-    const float inv = 1.0f / sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+    const float inv = fast_rsq(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
     qn = Q4{qn.x * inv, qn.y * inv, qn.z * inv, qn.w * inv};
     s.q = qn;
     s.v = clamp_norm(vn, kMaxLinVel);
@@ -530,7 +554,7 @@ AG_HD void reset_state_from_uniforms(EnvState& s, const float* u, const StepPara
 // quaternion_to_matrix (pytorch3d convention; oracle/rotations.py), row-major R[9]
 AG_HD void quat_to_matrix(Q4 q, float* R) {
     const float r = q.w, i = q.x, j = q.y, k = q.z;
-    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    const float two_s = 2.0f * fast_rcp(r * r + i * i + j * j + k * k);
     R[0] = 1.0f - two_s * (j * j + k * k);
     R[1] = two_s * (i * j - k * r);
     R[2] = two_s * (i * k + j * r);
@@ -554,8 +578,8 @@ AG_HD float yaw_diff(float a, float b) {
 AG_HD V3 lemniscate_ref(int progress, int k, float dt) {
     const float t = (float)(progress + 5 * k) * dt * 0.25f;
     const float st = sinf(t), ct = cosf(t);
-    const float den = 1.0f + ct * ct;
-    return V3{3.0f * st / den, 3.0f * st * ct / den, 1.0f};
+    const float iden = fast_rcp(1.0f + ct * ct);
+    return V3{3.0f * st * iden, 3.0f * st * ct * iden, 1.0f};
 }
 
 struct StepOut {
@@ -607,7 +631,7 @@ AG_HD void compute_reward(const EnvState& s, const float* R, const float* a, con
     constexpr bool kHasThrust = (CTL == CTL_RATE || CTL == CTL_ATTI);
     const float c0 = clampf(cmd[0], 0.0f, 1.0f), c1 = clampf(cmd[1], 0.0f, 1.0f);
     const float c2 = clampf(cmd[2], 0.0f, 1.0f), c3 = clampf(cmd[3], 0.0f, 1.0f);
-    const float effort = 0.1f * ((1.0f - c0) + (1.0f - c1) + (1.0f - c2) + (1.0f - c3)) / 4.0f;
+    const float effort = 0.1f * ((1.0f - c0) + (1.0f - c1) + (1.0f - c2) + (1.0f - c3)) * 0.25f;
 
     float d[A];
 #pragma unroll
@@ -617,7 +641,7 @@ AG_HD void compute_reward(const EnvState& s, const float* R, const float* a, con
         float n2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < A; ++i) n2 += d[i] * d[i];
-        cont = 0.2f * expf(-sqrtf(n2));
+        cont = 0.2f * fast_exp(-fast_sqrt(n2));
     } else {
         float n2 = 0.0f;
 #pragma unroll
@@ -625,38 +649,41 @@ AG_HD void compute_reward(const EnvState& s, const float* R, const float* a, con
         const float dl = d[A - 1];
         if (TASK == TASK_HOVERING) {
             const float t3 = 3.0f * dl;
-            cont = 0.2f * expf(-sqrtf(n2)) + 0.5f / (1.0f + t3 * t3);
+            cont = 0.2f * fast_exp(-fast_sqrt(n2)) + 0.5f * fast_rcp(1.0f + t3 * t3);
         } else {
             const float t2 = 2.0f * dl;
-            cont = 0.1f * expf(-sqrtf(n2)) + 0.5f / (1.0f + t2 * t2);
+            cont = 0.1f * fast_exp(-fast_sqrt(n2)) + 0.5f * fast_rcp(1.0f + t2 * t2);
         }
         thrust_reward = 0.1f * (1.0f - fabsf(0.1533f - a[A - 1]));
     }
 
     // yaw from R: matrix_to_euler_angles(R,'XYZ')[2] = atan2(-R01, R00)
     const float yaw = atan2f(-R[1], R[0]);
-    const float yd = yaw_diff(P.target_yaw, yaw) / kPi;
+    const float yd = yaw_diff(P.target_yaw, yaw) * (1.0f / kPi);
     const float spinnage = s.w.z * s.w.z;
     // ups = quat_axis(q, 2).z via quat_rotate, hovering.py:464-481: (2w^2-1) + 2 z^2
     const float ups_z = (2.0f * (s.q.w * s.q.w) - 1.0f) + 0.0f + s.q.z * s.q.z * 2.0f;
-    const float hu = (ups_z + 1.0f) / 2.0f;
+    const float hu = (ups_z + 1.0f) * 0.5f;
     const float ups_reward = hu * hu;
 
     int done = (s.progress >= P.max_episode_length - 1) ? 1 : 0;
     float reward;
     if (TASK == TASK_HOVERING) {
         const float rx = P.target[9] - s.p.x, ry = P.target[10] - s.p.y, rz = P.target[11] - s.p.z;
-        const float pos_diff = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float pd2 = rx * rx + ry * ry + rz * rz;
+        const float pos_diff = fast_sqrt(pd2);
         const float pd = 1.6f * pos_diff;
-        const float pos_reward = 0.7f / (1.0f + pd * pd);
-        const float vn = sqrtf(s.v.x * s.v.x + s.v.y * s.v.y + s.v.z * s.v.z);
-        const float dotp = (rx / pos_diff) * (s.v.x / vn) + (ry / pos_diff) * (s.v.y / vn) + (rz / pos_diff) * (s.v.z / vn);
+        const float pos_reward = 0.7f * fast_rcp(1.0f + pd * pd);
+        // (rel/|rel|) . (v/|v|) with one rsq per vector (0/0 -> NaN as in the reference, Q8)
+        const float ipd = fast_rsq(pd2);
+        const float ivn = fast_rsq(s.v.x * s.v.x + s.v.y * s.v.y + s.v.z * s.v.z);
+        const float dotp = (rx * ipd) * (s.v.x * ivn) + (ry * ipd) * (s.v.y * ivn) + (rz * ipd) * (s.v.z * ivn);
         const float angle = fabsf(acosf(clampf(dotp, -1.0f, 1.0f)));
-        const float vel_dir = 0.1f * expf(-angle / kPi);
+        const float vel_dir = 0.1f * fast_exp(-angle * (1.0f / kPi));
         const float y3 = 3.0f * yd;
-        const float yaw_reward = 1.0f / (1.0f + y3 * y3);
+        const float yaw_reward = fast_rcp(1.0f + y3 * y3);
         const float s3 = 3.0f * spinnage;
-        const float spin_reward = 1.0f / (1.0f + s3 * s3);
+        const float spin_reward = fast_rcp(1.0f + s3 * s3);
         if (!kHasThrust)
             reward = cont + effort + pos_reward + pos_reward * (vel_dir + ups_reward + spin_reward + yaw_reward);
         else
@@ -670,13 +697,13 @@ AG_HD void compute_reward(const EnvState& s, const float* R, const float* a, con
     } else {
         const V3 r0 = lemniscate_ref(s.progress, 0, P.dt);
         const float dx = r0.x - s.p.x, dy = r0.y - s.p.y, dz = r0.z - s.p.z;
-        const float dist_norm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float dist_norm = fast_sqrt(dx * dx + dy * dy + dz * dz);
         const float dn = 1.8f * dist_norm;
-        const float dist_reward = 1.0f / (1.0f + dn * dn);
+        const float dist_reward = fast_rcp(1.0f + dn * dn);
         const float y4 = 4.0f * yd;
-        const float yaw_reward = 1.0f / (1.0f + y4 * y4);
+        const float yaw_reward = fast_rcp(1.0f + y4 * y4);
         const float s2 = 2.0f * spinnage;
-        const float spin_reward = 1.0f / (1.0f + s2 * s2);
+        const float spin_reward = fast_rcp(1.0f + s2 * s2);
         if (!kHasThrust)
             reward = cont + effort + dist_reward + dist_reward * (spin_reward + yaw_reward + ups_reward);
         else

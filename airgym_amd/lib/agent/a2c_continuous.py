@@ -1,0 +1,631 @@
+"""Continuous-action PPO agent - the loop that drives the env hot path.
+
+Mirrors the reference's `lib/agent/a2c_base.py::A2CBase` + `lib/agent/a2c_continuous.py::A2CAgent`
+(same YAML keys, same math, same checkpoint layout) but is organised MI355X-first:
+
+  * rollout tensors are allocated once; the env kernel writes obs / reward / done of step t straight
+    into slot t of the rollout buffer (`ag_step_into`), no copy kernels (reference: experience buffer
+    `update_data` copies, a2c_base.py:662-678);
+  * no host synchronisation inside the rollout: episode statistics are reduced on the device per
+    step and read back once per epoch (reference: `dones.nonzero()` every step, a2c_base.py:680-689);
+  * all parameters live in ONE flat fp32 buffer and all gradients in another; the data-parallel
+    exchange is a single RCCL all-reduce per optimizer step on that buffer with the KL scalar appended
+    (reference: cat/all_reduce/copy-back + two scalar all-reduces + an LR broadcast per minibatch,
+    a2c_base.py:293-309,348-352, a2c_continuous.py:111-123);
+  * Adam, gradient clipping and the KL-adaptive LR rule run on device tensors, so one optimizer step
+    is a fixed launch sequence that can be captured in a hipGraph (`use_hip_graph`).
+
+Math restated from: play_steps a2c_base.py:651-711; discount_values (GAE) :463-478; prepare_dataset
+a2c_continuous.py:140-177; calc_gradients :299-369; trancate_gradients_and_step a2c_base.py:293-316;
+train_epoch a2c_continuous.py:78-138.  Pinned by tests/golden/ppo.npz, gae.npz (reference outputs).
+"""
+import math
+import os
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from airgym_amd.lib.core import common_losses, schedulers, torch_ext
+from airgym_amd.lib.core.datasets import PPODataset
+from airgym_amd.lib.model.a2c_continuous_logstd_model import ModelA2CContinuousLogStd
+from airgym_amd.lib.utils import vecenv
+from airgym_amd.lib.utils.tr_helpers import DefaultRewardsShaper
+
+
+def swap_and_flatten01(arr):
+    """[H, N, ...] -> [N*H, ...] env-major (a2c_base.py:26-33)."""
+    if arr is None:
+        return arr
+    s = arr.size()
+    return arr.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+
+def rescale_actions(low, high, action):
+    d = (high - low) / 2.0
+    m = (high + low) / 2.0
+    return action * d + m
+
+
+def discount_values(fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma, tau):
+    """GAE(gamma, tau), a2c_base.py:463-478.  [H,N,1] tensors."""
+    horizon = mb_rewards.shape[0]
+    lastgaelam = 0
+    mb_advs = torch.zeros_like(mb_rewards)
+    for t in reversed(range(horizon)):
+        if t == horizon - 1:
+            nextnonterminal = 1.0 - fdones
+            nextvalues = last_values
+        else:
+            nextnonterminal = 1.0 - mb_fdones[t + 1]
+            nextvalues = mb_values[t + 1]
+        nextnonterminal = nextnonterminal.unsqueeze(1)
+        delta = mb_rewards[t] + gamma * nextvalues * nextnonterminal - mb_values[t]
+        mb_advs[t] = lastgaelam = delta + gamma * tau * nextnonterminal * lastgaelam
+    return mb_advs
+
+
+class FlatAdam:
+    """Adam (eps 1e-8, no weight decay unless given) over ONE flat parameter / gradient buffer.
+    All state and the learning rate are device tensors: the step is capturable and has no host sync.
+    Same update rule as torch.optim.Adam (reference: optim.Adam(..., eps=1e-08), a2c_continuous.py:401)."""
+
+    def __init__(self, flat_param, flat_grad, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.p, self.g = flat_param, flat_grad
+        self.b1, self.b2 = betas
+        self.eps, self.wd = eps, weight_decay
+        dev = flat_param.device
+        self.lr = torch.tensor(float(lr), dtype=torch.float64, device=dev)
+        self.exp_avg = torch.zeros_like(flat_param)
+        self.exp_avg_sq = torch.zeros_like(flat_param)
+        self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
+
+    @torch.no_grad()
+    def step(self):
+        g = self.g
+        if self.wd != 0.0:
+            g = g.add(self.p, alpha=self.wd)
+        self.step_t += 1.0
+        self.exp_avg.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+        self.exp_avg_sq.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+        bc1 = 1.0 - torch.pow(self.b1, self.step_t)
+        bc2 = 1.0 - torch.pow(self.b2, self.step_t)
+        step_size = (self.lr / bc1).float()
+        denom = (self.exp_avg_sq.sqrt() / bc2.sqrt().float()).add_(self.eps)
+        self.p.sub_(step_size * (self.exp_avg / denom))
+
+    def state_dict(self):
+        return {"lr": self.lr.item(), "step": self.step_t.item(), "exp_avg": self.exp_avg.clone(),
+                "exp_avg_sq": self.exp_avg_sq.clone(), "betas": (self.b1, self.b2), "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        self.lr.fill_(sd["lr"])
+        self.step_t.fill_(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class A2CAgent:
+    def __init__(self, base_name, params):
+        self.name = base_name
+        self.params = params
+        self.network_config = params["network"]
+        self.config = config = params["config"]
+        self.experiment_name = config.get("full_experiment_name") or \
+            config["name"] + datetime.now().strftime("_%d-%H-%M-%S")
+
+        # ---- distributed setup: one process per GPU, torchrun-style env vars (a2c_base.py:102-123)
+        self.multi_gpu = config.get("multi_gpu", False)
+        self.local_rank, self.global_rank, self.world_size = 0, 0, 1
+        if self.multi_gpu:
+            self.local_rank = int(os.getenv("LOCAL_RANK", "0"))
+            self.global_rank = int(os.getenv("RANK", "0"))
+            self.world_size = int(os.getenv("WORLD_SIZE", "1"))
+            backend = config.get("dist_backend", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" for CPU tests
+            if not dist.is_initialized():
+                dist.init_process_group(backend, rank=self.global_rank, world_size=self.world_size)
+            if backend == "nccl":
+                config["device"] = "cuda:" + str(self.local_rank)
+            if self.global_rank != 0:
+                config["print_stats"] = False
+        self.ppo_device = config.get("device", "cuda:0")
+        if str(self.ppo_device).startswith("cuda"):
+            torch.cuda.set_device(self.ppo_device)
+
+        # ---- environment (sharded by rank: env ids are global)
+        self.num_actors = config["num_actors"]
+        self.env_name = config["env_name"]
+        self.env_config = dict(config.get("env_config", {}))
+        if self.multi_gpu:
+            self.env_config.setdefault("env_id_offset", self.global_rank * self.num_actors)
+            self.env_config.setdefault("sim_device", self.ppo_device)
+        self.vec_env = config.get("vec_env") or vecenv.create_vec_env(self.env_name, self.num_actors, **self.env_config)
+        self.env_info = self.vec_env.get_env_info()
+        self.value_size = self.env_info.get("value_size", 1)
+        self.observation_space = self.env_info["observation_space"]
+        self.obs_shape = self.observation_space.shape
+        action_space = self.env_info["action_space"]
+        self.actions_num = action_space.shape[0]
+        self.actions_low = torch.from_numpy(action_space.low.copy()).float().to(self.ppo_device)
+        self.actions_high = torch.from_numpy(action_space.high.copy()).float().to(self.ppo_device)
+        self.num_agents = self.env_info.get("agents", 1)
+
+        # ---- hyper-parameters (same YAML keys as scripts/config/ppo_*.yaml)
+        self.weight_decay = config.get("weight_decay", 0.0)
+        self.truncate_grads = config.get("truncate_grads", False)
+        self.grad_norm = config.get("grad_norm", 1.0)
+        self.save_freq = config.get("save_frequency", 0)
+        self.save_best_after = config.get("save_best_after", 100)
+        self.print_stats = config.get("print_stats", True)
+        self.ppo = config.get("ppo", True)
+        self.max_epochs = config.get("max_epochs", -1)
+        self.max_frames = config.get("max_frames", -1)
+        self.is_adaptive_lr = config.get("lr_schedule") == "adaptive"
+        self.linear_lr = config.get("lr_schedule") == "linear"
+        self.schedule_type = config.get("schedule_type", "legacy")
+        if self.is_adaptive_lr:
+            self.kl_threshold = config["kl_threshold"]
+            self.scheduler = schedulers.AdaptiveScheduler(self.kl_threshold)
+        elif self.linear_lr:
+            self.scheduler = schedulers.LinearScheduler(float(config["learning_rate"]),
+                                                        max_steps=self.max_epochs if self.max_epochs != -1 else self.max_frames,
+                                                        use_epochs=self.max_epochs != -1)
+        else:
+            self.scheduler = schedulers.IdentityScheduler()
+        self.e_clip = config["e_clip"]
+        self.clip_value = config["clip_value"]
+        self.horizon_length = config["horizon_length"]
+        self.normalize_advantage = config["normalize_advantage"]
+        self.normalize_input = config.get("normalize_input", False)
+        self.normalize_value = config.get("normalize_value", False)
+        self.critic_coef = config["critic_coef"]
+        self.gamma = config["gamma"]
+        self.tau = config["tau"]
+        self.entropy_coef = config["entropy_coef"]
+        self.bounds_loss_coef = config.get("bounds_loss_coef", None)
+        self.bound_loss_type = config.get("bound_loss_type", "bound")
+        self.clip_actions = config.get("clip_actions", True)
+        self.value_bootstrap = config.get("value_bootstrap", False)
+        self.mini_epochs_num = config["mini_epochs"]
+        self.batch_size_envs = self.horizon_length * self.num_actors
+        self.batch_size = self.batch_size_envs * self.num_agents
+        self.minibatch_size = config.get("minibatch_size", self.batch_size)
+        self.num_minibatches = self.batch_size // self.minibatch_size
+        assert self.batch_size % self.minibatch_size == 0
+        self.last_lr = float(config["learning_rate"])
+        self.use_hip_graph = config.get("use_hip_graph", False)
+        self.sync_normalizers = config.get("sync_normalizers", True)
+        self.frame = 0
+        self.epoch_num = 0
+        self.curr_frames = 0
+        self.mean_rewards = self.last_mean_rewards = -100500
+        self.games_to_track = config.get("games_to_track", 100)
+        self.game_rewards = torch_ext.AverageMeter(self.value_size, self.games_to_track)
+        self.game_shaped_rewards = torch_ext.AverageMeter(self.value_size, self.games_to_track)
+        self.game_lengths = torch_ext.AverageMeter(1, self.games_to_track)
+        rs = config.get("reward_shaper", {}) or {}
+        self.rewards_shaper = rs if callable(rs) else DefaultRewardsShaper(**rs)
+        self.algo_observer = (config.get("features") or {}).get("observer")
+
+        # ---- model, flat parameter / gradient storage, optimizer
+        keys = {"actions_num": self.actions_num, "input_shape": self.obs_shape,
+                "num_seqs": self.num_actors * self.num_agents, "value_size": self.value_size,
+                "normalize_value": self.normalize_value, "normalize_input": self.normalize_input}
+        self.model = ModelA2CContinuousLogStd(params, keys).to(self.ppo_device)
+        self._flatten_parameters()
+        self.optimizer = FlatAdam(self.flat_param, self.flat_grad[:-1], self.last_lr, eps=1e-8,
+                                  weight_decay=self.weight_decay)
+        self.value_mean_std = self.model.value_mean_std if self.normalize_value else None
+        self.dataset = PPODataset(self.batch_size, self.minibatch_size, False, self.ppo_device)
+        self.has_value_loss = config.get("use_experimental_cv", True)
+        self.group = dist.group.WORLD if self.multi_gpu else None
+
+        # ---- logging (rank 0)
+        self.train_dir = config.get("train_dir", "runs")
+        self.experiment_dir = os.path.join(self.train_dir, self.experiment_name)
+        self.nn_dir = os.path.join(self.experiment_dir, "nn")
+        self.summaries_dir = os.path.join(self.experiment_dir, "summaries")
+        self.writer = None
+        if self.global_rank == 0 and config.get("write_summaries", True):
+            os.makedirs(self.nn_dir, exist_ok=True)
+            os.makedirs(self.summaries_dir, exist_ok=True)
+            from airgym_amd.lib.utils.summary import make_writer
+            self.writer = make_writer(self.summaries_dir)
+        self._graphs = {}
+        self.obs = None
+
+    # ------------------------------------------------------------------ parameters
+    def _flatten_parameters(self):
+        """Re-home every parameter (and its .grad) as a view into one flat buffer.  The last element
+        of the gradient buffer carries the KL scalar through the same all-reduce."""
+        ps = [p for p in self.model.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in ps)
+        dev = self.ppo_device
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total + 1, dtype=torch.float32, device=dev)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + n].view_as(p.data)
+            p.grad = self.flat_grad[off:off + n].view_as(p.data)
+            off += n
+        self._params = ps
+
+    def broadcast_parameters(self):
+        """Initial parameter / normaliser sync from rank 0 (reference: broadcast_object_list of the
+        pickled state dict, a2c_continuous.py:188-192) - one flat tensor broadcast instead."""
+        if not self.multi_gpu:
+            return
+        dist.broadcast(self.flat_param, 0)
+        for b in self.model.buffers():
+            dist.broadcast(b, 0)
+
+    # ------------------------------------------------------------------ rollout
+    def init_tensors(self):
+        H, N, dev = self.horizon_length, self.num_actors * self.num_agents, self.ppo_device
+        f = dict(dtype=torch.float32, device=dev)
+        self.obs_buf = torch.zeros((H + 1, N) + tuple(self.obs_shape), **f)
+        self.actions_buf = torch.zeros(H, N, self.actions_num, **f)
+        self.mus_buf = torch.zeros(H, N, self.actions_num, **f)
+        self.sigmas_buf = torch.zeros(H, N, self.actions_num, **f)
+        self.neglogpacs_buf = torch.zeros(H, N, **f)
+        self.values_buf = torch.zeros(H, N, self.value_size, **f)
+        self.rewards_buf = torch.zeros(H, N, self.value_size, **f)
+        self.raw_rewards_buf = torch.zeros(H, N, **f)
+        self.dones_buf = torch.ones(H + 1, N, dtype=torch.int64, device=dev)   # dones[t] = done entering step t
+        self.current_rewards = torch.zeros(N, self.value_size, **f)
+        self.current_shaped_rewards = torch.zeros(N, self.value_size, **f)
+        self.current_lengths = torch.zeros(N, **f)
+        self.ep_stats = torch.zeros(H, 4, dtype=torch.float64, device=dev)    # count, sum rew, sum shaped, sum len
+        self._hip_env = getattr(getattr(self.vec_env, "env", None), "hip", None)   # zero-copy path if available
+
+    def preprocess_actions(self, actions):
+        if self.clip_actions:
+            clamped = torch.clamp(actions, -1.0, 1.0)
+            return rescale_actions(self.actions_low, self.actions_high, clamped)
+        return actions
+
+    def env_reset(self):
+        obs = self.vec_env.reset()
+        self.obs_buf[0].copy_(obs)
+        self.dones_buf[0].fill_(1)          # a2c_base.py:404: dones start as ones
+        return self.obs_buf[0]
+
+    @torch.no_grad()
+    def get_action_values(self, obs):
+        self.model.eval()
+        return self.model({"is_train": False, "prev_actions": None, "obs": obs})
+
+    @torch.no_grad()
+    def _rollout_step(self, n):
+        """One step of play_steps (a2c_base.py:651-695) with every tensor written in place."""
+        res = self.get_action_values(self.obs_buf[n])
+        self.actions_buf[n].copy_(res["actions"])
+        self.neglogpacs_buf[n].copy_(res["neglogpacs"])
+        self.values_buf[n].copy_(res["values"])
+        self.mus_buf[n].copy_(res["mus"])
+        self.sigmas_buf[n].copy_(res["sigmas"])
+        env_actions = self.preprocess_actions(res["actions"])
+        if self._hip_env is not None:
+            self._hip_env.step_into(env_actions, self.obs_buf[n + 1], self.raw_rewards_buf[n], self.dones_buf[n + 1])
+            time_outs = self._hip_env.time_out_buf
+        else:
+            obs, rewards, dones, infos = self.vec_env.step(env_actions)
+            self.obs_buf[n + 1].copy_(obs)
+            self.raw_rewards_buf[n].copy_(rewards)
+            self.dones_buf[n + 1].copy_(dones)
+            time_outs = infos.get("time_outs") if isinstance(infos, dict) else None
+        rewards = self.raw_rewards_buf[n].unsqueeze(1)
+        shaped = self.rewards_shaper(rewards)
+        if self.value_bootstrap and time_outs is not None:
+            shaped = shaped + self.gamma * res["values"] * time_outs.unsqueeze(1).float()
+        self.rewards_buf[n].copy_(shaped)
+        # episode statistics, reduced on device (a2c_base.py:678-695)
+        self.current_rewards += rewards
+        self.current_shaped_rewards += shaped
+        self.current_lengths += 1
+        done_f = self.dones_buf[n + 1].float()
+        st = self.ep_stats[n]
+        st[0] = done_f.sum()
+        st[1] = (self.current_rewards[:, 0] * done_f).sum()
+        st[2] = (self.current_shaped_rewards[:, 0] * done_f).sum()
+        st[3] = (self.current_lengths * done_f).sum()
+        not_done = 1.0 - done_f
+        self.current_rewards *= not_done.unsqueeze(1)
+        self.current_shaped_rewards *= not_done.unsqueeze(1)
+        self.current_lengths *= not_done
+
+    @torch.no_grad()
+    def play_steps(self):
+        H = self.horizon_length
+        if self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0:
+            g = self._graphs.get("rollout")
+            if g is None:
+                g = self._capture(lambda: [self._rollout_step(n) for n in range(H)], warmup=False)
+                self._graphs["rollout"] = g
+            g.replay()
+        else:
+            for n in range(H):
+                self._rollout_step(n)
+        self.model.eval()
+        last_values = self.model({"is_train": False, "obs": self.obs_buf[H]})["values"]
+        fdones = self.dones_buf[H].float()
+        mb_fdones = self.dones_buf[:H].float()
+        mb_advs = self._gae(fdones, last_values, mb_fdones)
+        mb_returns = mb_advs + self.values_buf
+        batch = {
+            "obses": swap_and_flatten01(self.obs_buf[:H]),
+            "dones": swap_and_flatten01(self.dones_buf[:H]),
+            "actions": swap_and_flatten01(self.actions_buf),
+            "neglogpacs": swap_and_flatten01(self.neglogpacs_buf),
+            "values": swap_and_flatten01(self.values_buf),
+            "mus": swap_and_flatten01(self.mus_buf),
+            "sigmas": swap_and_flatten01(self.sigmas_buf),
+            "returns": swap_and_flatten01(mb_returns),
+            "played_frames": self.batch_size,
+        }
+        # the last observation / done flags become slot 0 of the next rollout
+        self.obs_buf[0].copy_(self.obs_buf[H])
+        self.dones_buf[0].copy_(self.dones_buf[H])
+        return batch
+
+    def _gae(self, fdones, last_values, mb_fdones):
+        return discount_values(fdones, last_values, mb_fdones, self.values_buf, self.rewards_buf, self.gamma, self.tau)
+
+    # ------------------------------------------------------------------ update
+    @torch.no_grad()
+    def prepare_dataset(self, batch_dict):
+        """a2c_continuous.py:140-177"""
+        returns, values = batch_dict["returns"], batch_dict["values"]
+        advantages = returns - values
+        if self.normalize_value:
+            grp = self.group if (self.multi_gpu and self.sync_normalizers) else None
+            self.value_mean_std.eval()      # statistics are merged explicitly (and optionally across ranks)
+            self.value_mean_std.update(values, grp)
+            values = self.value_mean_std(values)
+            self.value_mean_std.update(returns, grp)
+            returns = self.value_mean_std(returns)
+        advantages = torch.sum(advantages, axis=1)
+        if self.normalize_advantage:
+            advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+        self.dataset.update_values_dict({
+            "old_values": values, "old_logp_actions": batch_dict["neglogpacs"], "advantages": advantages,
+            "returns": returns, "actions": batch_dict["actions"], "obs": batch_dict["obses"],
+            "dones": batch_dict["dones"], "mu": batch_dict["mus"], "sigma": batch_dict["sigmas"],
+        })
+
+    def _loss_and_backward(self, mb):
+        """calc_gradients up to backward(), a2c_continuous.py:299-350."""
+        res = self.model({"is_train": True, "prev_actions": mb["actions"], "obs": mb["obs"]})
+        a_loss = common_losses.actor_loss(mb["old_logp_actions"], res["prev_neglogp"], mb["advantages"], self.ppo, self.e_clip)
+        if self.has_value_loss:
+            c_loss = common_losses.critic_loss(mb["old_values"], res["values"], self.e_clip, mb["returns"], self.clip_value)
+        else:
+            c_loss = torch.zeros(1, device=self.ppo_device)
+        mu, sigma = res["mus"], res["sigmas"]
+        if self.bounds_loss_coef is None:
+            b_loss = torch.zeros(1, device=self.ppo_device)
+        elif self.bound_loss_type == "regularisation":
+            b_loss = common_losses.reg_loss(mu)
+        else:
+            b_loss = common_losses.bound_loss(mu)
+        a_loss, c_loss, entropy, b_loss = a_loss.mean(), c_loss.mean(), res["entropy"].mean(), b_loss.mean()
+        loss = a_loss + 0.5 * c_loss * self.critic_coef - entropy * self.entropy_coef \
+            + b_loss * (self.bounds_loss_coef or 0.0)
+        self.flat_grad.zero_()
+        loss.backward()
+        with torch.no_grad():
+            kl = torch_ext.policy_kl(mu.detach(), sigma.detach(), mb["mu"], mb["sigma"], True)
+            self.flat_grad[-1] = kl
+        return a_loss.detach(), c_loss.detach(), entropy.detach(), b_loss.detach(), mu.detach(), sigma.detach()
+
+    @torch.no_grad()
+    def _reduce_clip_step(self):
+        """trancate_gradients_and_step (a2c_base.py:293-316) + the legacy per-minibatch KL schedule
+        (a2c_continuous.py:111-118): one all-reduce, clip-by-norm, Adam, LR update - all on device."""
+        if self.multi_gpu:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat_grad /= self.world_size
+        kl = self.flat_grad[-1].double()
+        g = self.flat_grad[:-1]
+        if self.truncate_grads:
+            total_norm = torch.linalg.vector_norm(g)
+            g.mul_(torch.clamp(self.grad_norm / (total_norm + 1e-6), max=1.0))
+        self.optimizer.step()
+        if self.is_adaptive_lr and self.schedule_type == "legacy":
+            lr = self.optimizer.lr
+            thr = self.kl_threshold
+            down = torch.clamp(lr / 1.5, min=self.scheduler.min_lr)
+            up = torch.clamp(lr * 1.5, max=self.scheduler.max_lr)
+            lr.copy_(torch.where(kl > 2.0 * thr, down, torch.where(kl < 0.5 * thr, up, lr)))
+        return kl
+
+    def train_actor_critic(self, idx):
+        """One optimizer step on minibatch idx; returns device scalars (no sync)."""
+        mb = self.dataset[idx]
+        a, c, e, b, mu, sigma = self._loss_and_backward(mb)
+        kl = self._reduce_clip_step()
+        self.dataset.update_mu_sigma(mu, sigma)
+        return a, c, e, b, kl
+
+    def _capture(self, fn, warmup=True):
+        """Capture fn() into a hipGraph on a side stream (torch.cuda.graph); returns the graph."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            if warmup:
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = fn()
+        g.outputs = out
+        return g
+
+    def train_epoch(self):
+        """a2c_continuous.py:78-138"""
+        play_time_start = time.time()
+        batch_dict = self.play_steps()
+        if str(self.ppo_device).startswith("cuda"):
+            torch.cuda.synchronize()
+        play_time_end = time.time()
+        update_time_start = play_time_end
+        self.model.train()
+        self.curr_frames = batch_dict.pop("played_frames")
+        self.prepare_dataset(batch_dict)
+        a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
+        rms = self.model.running_mean_std if self.normalize_input else None
+        for mini_ep in range(self.mini_epochs_num):
+            ep_kls = []
+            for i in range(len(self.dataset)):
+                if rms is not None:
+                    rms.eval()       # statistics are merged explicitly below, never inside forward()
+                    if mini_ep == 0:  # "don't need to update statistics more than one miniepoch", a2c_continuous.py:130-131
+                        mb_obs = self.dataset[i]["obs"]
+                        rms.update(mb_obs, self.group if (self.multi_gpu and self.sync_normalizers) else None)
+                a, c, e, b, kl = self.train_actor_critic(i)
+                a_losses.append(a); c_losses.append(c); entropies.append(e); ep_kls.append(kl)
+                if self.bounds_loss_coef is not None:
+                    b_losses.append(b)
+            av_kls = torch_ext.mean_list(ep_kls)
+            if self.is_adaptive_lr and self.schedule_type == "standard":
+                if self.multi_gpu:
+                    dist.all_reduce(av_kls, op=dist.ReduceOp.SUM, group=self.group)
+                    av_kls /= self.world_size
+                self.last_lr, self.entropy_coef = self.scheduler.update(self.optimizer.lr.item(), self.entropy_coef,
+                                                                        self.epoch_num, 0, av_kls.item())
+                self.optimizer.lr.fill_(self.last_lr)
+            kls.append(av_kls)
+        if self.linear_lr:
+            self.last_lr, self.entropy_coef = self.scheduler.update(self.last_lr, self.entropy_coef, self.epoch_num,
+                                                                    self.frame, 0.0)
+            self.optimizer.lr.fill_(self.last_lr)
+        if str(self.ppo_device).startswith("cuda"):
+            torch.cuda.synchronize()
+        update_time_end = time.time()
+        self.last_lr = float(self.optimizer.lr.item())
+        self._flush_episode_stats()
+        return {
+            "play_time": play_time_end - play_time_start, "update_time": update_time_end - update_time_start,
+            "total_time": update_time_end - play_time_start,
+            "a_loss": torch_ext.mean_list(a_losses).item(), "c_loss": torch_ext.mean_list(c_losses).item(),
+            "entropy": torch_ext.mean_list(entropies).item(), "kl": torch_ext.mean_list(kls).item(),
+            "b_loss": torch_ext.mean_list(b_losses).item() if b_losses else 0.0, "last_lr": self.last_lr,
+        }
+
+    def _flush_episode_stats(self):
+        """One device->host read per epoch; replays the reference's per-step AverageMeter updates."""
+        st = self.ep_stats.cpu().numpy()
+        for n in range(st.shape[0]):
+            cnt = st[n, 0]
+            self.game_rewards.update_from_sum([st[n, 1]], cnt)
+            self.game_shaped_rewards.update_from_sum([st[n, 2]], cnt)
+            self.game_lengths.update_from_sum([st[n, 3]], cnt)
+
+    # ------------------------------------------------------------------ training loop
+    def train(self):
+        """a2c_continuous.py:179-294"""
+        self.init_tensors()
+        self.last_mean_rewards = -100500
+        total_time = 0
+        self.obs = self.env_reset()
+        self.curr_frames = self.batch_size_envs
+        self.broadcast_parameters()
+        while True:
+            self.epoch_num += 1
+            epoch_num = self.epoch_num
+            stats = self.train_epoch()
+            total_time += stats["total_time"]
+            should_exit = False
+            curr_frames = self.curr_frames * self.world_size if self.multi_gpu else self.curr_frames
+            self.frame += curr_frames
+            frame = self.frame // self.num_agents
+            if self.global_rank == 0:
+                if self.print_stats:
+                    fps_step_inference = curr_frames / max(stats["play_time"], 1e-9)
+                    fps_total = curr_frames / max(stats["total_time"], 1e-9)
+                    print(f"fps step and policy inference: {fps_step_inference:.0f} fps total: {fps_total:.0f} "
+                          f"epoch: {epoch_num:.0f}/{self.max_epochs:.0f} frames: {frame:.0f}")
+                self.write_stats(total_time, epoch_num, stats, frame, curr_frames)
+                if self.game_rewards.current_size > 0:
+                    mean_rewards = self.game_rewards.get_mean()
+                    self.mean_rewards = mean_rewards[0]
+                    checkpoint_name = self.config["name"] + "_ep_" + str(epoch_num) + "_rew_" + str(mean_rewards[0])
+                    if self.save_freq > 0 and epoch_num % self.save_freq == 0:
+                        self.save(os.path.join(self.nn_dir, "last_" + checkpoint_name))
+                    if mean_rewards[0] > self.last_mean_rewards and epoch_num >= self.save_best_after:
+                        print("saving next best rewards: ", mean_rewards)
+                        self.last_mean_rewards = mean_rewards[0]
+                        self.save(os.path.join(self.nn_dir, self.config["name"]))
+                        if "score_to_win" in self.config and self.last_mean_rewards > self.config["score_to_win"]:
+                            print("Maximum reward achieved. Network won!")
+                            self.save(os.path.join(self.nn_dir, checkpoint_name))
+                            should_exit = True
+                if epoch_num >= self.max_epochs and self.max_epochs != -1:
+                    mean_rewards = self.game_rewards.get_mean() if self.game_rewards.current_size > 0 else -np.inf
+                    self.save(os.path.join(self.nn_dir, "last_" + self.config["name"] + "_ep_" + str(epoch_num)
+                                           + "_rew_" + str(mean_rewards).replace("[", "_").replace("]", "_")))
+                    print("MAX EPOCHS NUM!")
+                    should_exit = True
+                if self.frame >= self.max_frames and self.max_frames != -1:
+                    print("MAX FRAMES NUM!")
+                    should_exit = True
+            if self.multi_gpu:
+                t = torch.tensor(float(should_exit), device=self.ppo_device)
+                dist.broadcast(t, 0)
+                should_exit = bool(t.item())
+            if should_exit:
+                return self.last_mean_rewards, epoch_num
+
+    def write_stats(self, total_time, epoch_num, stats, frame, curr_frames):
+        """Same TensorBoard tags as a2c_base.py:318-336 and a2c_continuous.py:225-242."""
+        w = self.writer
+        if w is None:
+            return
+        w.add_scalar("performance/step_inference_rl_update_fps", curr_frames / max(stats["total_time"], 1e-9), frame)
+        w.add_scalar("performance/step_inference_fps", curr_frames / max(stats["play_time"], 1e-9), frame)
+        w.add_scalar("performance/rl_update_time", stats["update_time"], frame)
+        w.add_scalar("performance/step_inference_time", stats["play_time"], frame)
+        w.add_scalar("losses/a_loss", stats["a_loss"], frame)
+        w.add_scalar("losses/c_loss", stats["c_loss"], frame)
+        w.add_scalar("losses/entropy", stats["entropy"], frame)
+        w.add_scalar("losses/bounds_loss", stats["b_loss"], frame)
+        w.add_scalar("info/last_lr", stats["last_lr"], frame)
+        w.add_scalar("info/lr_mul", 1.0, frame)
+        w.add_scalar("info/e_clip", self.e_clip, frame)
+        w.add_scalar("info/kl", stats["kl"], frame)
+        w.add_scalar("info/epochs", epoch_num, frame)
+        if self.game_rewards.current_size > 0:
+            mr, ms, ml = self.game_rewards.get_mean()[0], self.game_shaped_rewards.get_mean()[0], self.game_lengths.get_mean()[0]
+            for tag, x in (("step", frame), ("iter", epoch_num), ("time", total_time)):
+                w.add_scalar("rewards/" + tag, mr, x)
+                w.add_scalar("shaped_rewards/" + tag, ms, x)
+                w.add_scalar("episode_lengths/" + tag, ml, x)
+
+    # ------------------------------------------------------------------ checkpoints (a2c_base.py:528-587)
+    def get_full_state_weights(self):
+        state = {"model": self.model.state_dict(), "epoch": self.epoch_num, "frame": self.frame,
+                 "optimizer": self.optimizer.state_dict(), "last_mean_rewards": self.last_mean_rewards,
+                 "env_state": self.vec_env.get_env_state()}
+        return state
+
+    def set_full_state_weights(self, weights, set_epoch=True):
+        self.model.load_state_dict(weights["model"])
+        if set_epoch:
+            self.epoch_num = weights.get("epoch", 0)
+            self.frame = weights.get("frame", 0)
+        opt = weights.get("optimizer")
+        if isinstance(opt, dict) and "exp_avg" in opt:
+            self.optimizer.load_state_dict(opt)
+        self.last_mean_rewards = weights.get("last_mean_rewards", -100500)
+        self.vec_env.set_env_state(weights.get("env_state"))
+
+    def save(self, fn):
+        torch_ext.save_checkpoint(fn, self.get_full_state_weights())
+
+    def restore(self, fn, set_epoch=True):
+        self.set_full_state_weights(torch_ext.load_checkpoint(fn), set_epoch=set_epoch)

@@ -1,0 +1,62 @@
+"""RunningMeanStd - input / value normaliser (reference: lib/core/running_mean_std.py:8-81).
+
+Float64 statistics, parallel-variance merge of batch moments, clamp to +-5 after normalisation.
+State-dict keys (`running_mean`, `running_var`, `count`) match the reference so checkpoints are
+interchangeable.  The statistics are updated IN PLACE so that a captured hipGraph keeps reading the
+same device addresses."""
+import torch
+import torch.nn as nn
+
+
+class RunningMeanStd(nn.Module):
+    def __init__(self, insize, epsilon=1e-05, per_channel=False, norm_only=False):
+        super().__init__()
+        self.insize = insize
+        self.epsilon = epsilon
+        self.norm_only = norm_only
+        if per_channel:
+            raise NotImplementedError("per_channel statistics are only used by the image pipelines")
+        self.axis = [0]
+        self.register_buffer("running_mean", torch.zeros(insize, dtype=torch.float64))
+        self.register_buffer("running_var", torch.ones(insize, dtype=torch.float64))
+        self.register_buffer("count", torch.ones((), dtype=torch.float64))
+
+    @torch.no_grad()
+    def update(self, x, group=None):
+        """Merge the moments of batch x ([B, ...]).  With `group` (torch.distributed) the batch moments
+        are first combined across ranks so that every replica keeps identical statistics (the reference
+        lets them drift)."""
+        batch_count = float(x.size()[0])
+        mean = x.mean(self.axis).double()
+        var = x.var(self.axis).double()
+        if group is not None:
+            import torch.distributed as dist
+            ws = dist.get_world_size(group)
+            if ws > 1:
+                # equal batch sizes per rank: pooled mean / unbiased variance from per-rank moments
+                stats = torch.stack((mean, var * (batch_count - 1) + batch_count * mean * mean))
+                dist.all_reduce(stats, group=group)
+                tot = batch_count * ws
+                mean = stats[0] / ws
+                var = (stats[1] - tot * mean * mean) / (tot - 1)
+                batch_count = tot
+        delta = mean - self.running_mean
+        tot_count = self.count + batch_count
+        new_mean = self.running_mean + delta * batch_count / tot_count
+        m2 = self.running_var * self.count + var * batch_count + delta ** 2 * self.count * batch_count / tot_count
+        self.running_mean.copy_(new_mean)
+        self.running_var.copy_(m2 / tot_count)
+        self.count.copy_(tot_count)
+
+    def forward(self, input, denorm=False, mask=None):
+        if self.training:
+            self.update(input)
+        mean = self.running_mean.float()
+        var = self.running_var.float()
+        if denorm:
+            y = torch.clamp(input, min=-5.0, max=5.0)
+            return torch.sqrt(var + self.epsilon) * y + mean
+        if self.norm_only:
+            return input / torch.sqrt(var + self.epsilon)
+        y = (input - mean) / torch.sqrt(var + self.epsilon)
+        return torch.clamp(y, min=-5.0, max=5.0)

