@@ -234,6 +234,7 @@ class A2CAgent:
             from airgym_amd.lib.utils.summary import make_writer
             self.writer = make_writer(self.summaries_dir)
         self._graphs = {}
+        self._rollouts_done = 0
         self.obs = None
 
     # ------------------------------------------------------------------ parameters
@@ -341,15 +342,17 @@ class A2CAgent:
     @torch.no_grad()
     def play_steps(self):
         H = self.horizon_length
-        if self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0:
-            g = self._graphs.get("rollout")
-            if g is None:
-                g = self._capture(lambda: [self._rollout_step(n) for n in range(H)], warmup=False)
-                self._graphs["rollout"] = g
-            g.replay()
+        graphable = self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0
+        if graphable and "rollout" not in self._graphs and self._rollouts_done >= 1:
+            # the first rollout ran eagerly (lazy library initialisation); capture the whole H-step
+            # rollout - policy inference + env kernel, 2H launches of the device-tick ping-pong - once
+            self._graphs["rollout"] = self._capture(lambda: [self._rollout_step(n) for n in range(H)], warmup=False)
+        if "rollout" in self._graphs:
+            self._graphs["rollout"].replay()
         else:
             for n in range(H):
                 self._rollout_step(n)
+        self._rollouts_done += 1
         self.model.eval()
         last_values = self.model({"is_train": False, "obs": self.obs_buf[H]})["values"]
         fdones = self.dones_buf[H].float()

@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark: env-steps/sec of the Hovering PPO job, 65 536 envs per GPU.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one PPO epoch on synthetic (random-init policy) data: a 24-step rollout of 65 536 envs per
+GPU through the fused HIP env kernel with MLP(256,256) policy inference, GAE, and 5 mini-epochs of PPO
+updates (fp32, Adam, grad-clip, KL-adaptive LR; one RCCL all-reduce per optimizer step when N > 1).
+`value` = N * 65536 * 24 * K / wall time, wall time = max over ranks between two barriers.
+
+Extra objects on the same JSON line (rank 0, N == 1 only for cpu_baseline):
+  roofline     - the env-step kernel alone: K launches replayed from a hipGraph, timed with HIP events on the
+                 launch stream; achieved = 287 B/env-step * 65536 / duration vs 8 TB/s HBM peak
+  env_only     - env-steps/s of that kernel-only loop (what `cpu_baseline` is comparable to)
+  cpu_baseline - the oracle (torch-CPU restatement of the reference env step, all host cores) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import yaml  # noqa: E402
+
+ENVS_PER_GPU = 65536
+HBM_PEAK_GBPS = 8000.0
+
+
+def build_params(args, world_size):
+    with open(os.path.join(REPO, "scripts", "config", "ppo_hovering.yaml")) as f:
+        params = yaml.safe_load(f)["params"]
+    c = params["config"]
+    params["network"]["mlp"]["units"] = [256, 256]          # BASELINE.json config 1: MLP(256,256)
+    c["num_actors"] = args.envs
+    c["minibatch_size"] = args.envs * c["horizon_length"] // args.minibatches
+    c["env_config"] = {"use_image": False, "num_envs": args.envs, "ctl_mode": "rate", "seed": 0,
+                       "sim_device": f"cuda:{int(os.getenv('LOCAL_RANK', '0'))}", "headless": True}
+    c["device"] = f"cuda:{int(os.getenv('LOCAL_RANK', '0'))}"
+    c["multi_gpu"] = world_size > 1
+    c["max_epochs"] = -1
+    c["write_summaries"] = False
+    c["print_stats"] = False
+    c["save_frequency"] = 0
+    c["save_best_after"] = 10 ** 9
+    c["use_hip_graph"] = bool(args.graph)
+    params["seed"] = 0
+    return params
+
+
+def cpu_baseline(seconds_target=15.0):
+    """Oracle env step (torch CPU, all cores) on a bounded sample of the same workload."""
+    from oracle.hovering_ref import HoveringRef   # checker, used here only as the reported CPU baseline
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = ENVS_PER_GPU
+    env = HoveringRef(n, "rate", seed=0)
+    g = torch.Generator().manual_seed(1)
+    acts = [torch.randn(n, 4, generator=g).clamp_(-1, 1) for _ in range(8)]
+    for i in range(2):
+        env.step(acts[i])
+    t0 = time.time()
+    steps = 0
+    while time.time() - t0 < seconds_target:
+        env.step(acts[steps % 8])
+        steps += 1
+    dt = time.time() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} env steps x {n} envs (Hovering, CTBR), oracle torch-CPU restatement of "
+                      f"hovering.py:203-459 with {cores} torch threads, env step only (no policy), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (BASELINE: 65536)")
+    ap.add_argument("--minibatches", type=int, default=8, help="optimizer steps per mini-epoch")
+    ap.add_argument("--graph", type=int, default=1, help="capture the rollout in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.getenv("WORLD_SIZE", "1"))
+    rank = int(os.getenv("RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    params = build_params(args, world)
+    agent = A2CAgent("bench", params)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.broadcast_parameters()
+    dev = agent.ppo_device
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        agent.epoch_num += 1
+        agent.train_epoch()
+    barrier()
+    t0 = time.perf_counter()
+    play = update = 0.0
+    for _ in range(args.steps):
+        agent.epoch_num += 1
+        st = agent.train_epoch()
+        play += st["play_time"]
+        update += st["update_time"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    H = agent.horizon_length
+    total_env_steps = world * args.envs * H * args.steps
+    out = {
+        "metric": "env_steps_per_sec_hovering_65536_envs_per_gpu",
+        "value": total_env_steps / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "hovering_ctbr_ppo_epoch", "task": "hovering", "ctl_mode": "rate",
+                   "envs_per_gpu": args.envs, "global_envs": world * args.envs, "horizon_length": H,
+                   "mini_epochs": agent.mini_epochs_num, "minibatch_size": agent.minibatch_size,
+                   "policy": "MLP(256,256) actor-critic, fixed sigma", "parallelism": f"dp{world}",
+                   "hip_graph_rollout": bool(args.graph)},
+        "phases": {"rollout_s": play, "update_s": update, "final_lr": agent.last_lr,
+                   "kl_finite": True},
+    }
+    if rank == 0:
+        hip = agent._hip_env
+        if not args.no_roofline and hip is not None:
+            from airgym_amd.utils.kernel_bench import measure_env_kernel
+            r = measure_env_kernel(hip, steps_per_graph=48, replays=20)
+            out["roofline"] = {
+                "bound": "hbm", "achieved": r["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "ag::step_kernel<hovering, rate>", "us_per_launch": r["us_per_step"],
+                "algo_bytes_per_env_step": r["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
+            }
+            out["env_only"] = {"value": r["env_steps_per_s"], "unit": "env-steps/s",
+                               "note": "env-step kernel only, synthetic N(0,1) clamped actions, hipGraph replay"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
