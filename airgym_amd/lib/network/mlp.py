@@ -4,6 +4,8 @@ Module/parameter names (`layers.<i>.weight`) match the reference's state dict.""
 import torch
 import torch.nn as nn
 
+from airgym_amd.lib.network.splitk_linear import linear
+
 ACTIVATIONS = {
     "tanh": torch.tanh,
     "relu": torch.relu,
@@ -29,5 +31,5 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for layer in self.layers:
-            x = self.activation(layer(x))
+            x = self.activation(linear(x, layer.weight, layer.bias))
         return x

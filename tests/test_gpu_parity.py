@@ -201,3 +201,23 @@ def test_full_size_properties(Handle):
     d = env.obs_buf[~done, 9:12] - st["root_states"][~done, 0:3]
     assert abs(d.std().item() - 5e-3) < 2e-4 and abs(d.mean().item()) < 1e-4
     env.close()
+
+
+def test_splitk_linear_matches_plain_autograd(Handle):
+    """split-K weight gradient (airgym_amd/lib/network/splitk_linear.py) == torch autograd of F.linear."""
+    import torch.nn.functional as F
+    from airgym_amd.lib.network.splitk_linear import linear
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for K, N in [(18, 256), (256, 256), (256, 5)]:
+        x = torch.randn(16384, K, device="cuda", generator=g, requires_grad=True)
+        w = torch.randn(N, K, device="cuda", generator=g, requires_grad=True)
+        b = torch.randn(N, device="cuda", generator=g, requires_grad=True)
+        go = torch.randn(16384, N, device="cuda", generator=g)
+        y = linear(x, w, b); y.backward(go)
+        got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+        for t_ in (x, w, b):
+            t_.grad = None
+        y2 = F.linear(x, w, b); y2.backward(go)
+        ref = (y2.detach(), x.grad, w.grad, b.grad)
+        for a_, r_ in zip(got, ref):
+            assert torch.allclose(a_, r_, rtol=1e-4, atol=1e-3 * r_.abs().max().item())
