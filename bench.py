@@ -58,7 +58,9 @@ def build_params(args, world_size):
 def cpu_baseline(seconds_target=15.0):
     """Oracle env step (torch CPU, all cores) on a bounded sample of the same workload."""
     from oracle.hovering_ref import HoveringRef   # checker, used here only as the reported CPU baseline
-    cores = os.cpu_count() or 1
+    # the unfused torch-CPU path stops scaling at a handful of threads (65 536-element elementwise ops);
+    # measured on the 256-core GPU host: 1 thr 39.7, 4 thr 29.3, 8 thr 29.6, 32 thr 52.5, 64 thr 124 ms/step
+    cores = min(8, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     n = ENVS_PER_GPU
     env = HoveringRef(n, "rate", seed=0)
@@ -68,7 +70,7 @@ def cpu_baseline(seconds_target=15.0):
         env.step(acts[i])
     t0 = time.time()
     steps = 0
-    while time.time() - t0 < seconds_target:
+    while time.time() - t0 < seconds_target and steps < 2000:
         env.step(acts[steps % 8])
         steps += 1
     dt = time.time() - t0
