@@ -343,15 +343,15 @@ class A2CAgent:
     def play_steps(self):
         H = self.horizon_length
         graphable = self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0
-        if graphable and "rollout" not in self._graphs and self._rollouts_done >= 1:
-            # the first rollout ran eagerly (lazy library initialisation); capture the whole H-step
-            # rollout - policy inference + env kernel, 2H launches of the device-tick ping-pong - once
-            self._graphs["rollout"] = self._capture(lambda: [self._rollout_step(n) for n in range(H)], warmup=False)
         if "rollout" in self._graphs:
             self._graphs["rollout"].replay()
         else:
             for n in range(H):
                 self._rollout_step(n)
+            if graphable:
+                # the first rollout ran eagerly (lazy library initialisation); now capture the whole H-step
+                # rollout - policy inference + env kernel, H launches of the device-tick ping-pong - for replay
+                self._graphs["rollout"] = self._capture(lambda: [self._rollout_step(n) for n in range(H)], warmup=False)
         self._rollouts_done += 1
         self.model.eval()
         last_values = self.model({"is_train": False, "obs": self.obs_buf[H]})["values"]

@@ -158,9 +158,14 @@ def main():
         if not args.no_roofline and hip is not None:
             from airgym_amd.utils.kernel_bench import measure_env_kernel
             r = measure_env_kernel(hip, steps_per_graph=48, replays=20)
+            traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (cannot be read live)
+            pmc = os.path.join(REPO, "profiles", "r01_env_kernel_pmc.json")
+            if os.path.exists(pmc) and args.envs == ENVS_PER_GPU:
+                traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": r["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": None,
+                "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": "profiles/r01_env_kernel_pmc.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
                 "kernel": "ag::step_kernel<hovering, rate>", "us_per_launch": r["us_per_step"],
                 "algo_bytes_per_env_step": r["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
             }
