@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 11 translation units compiled in parallel).
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 12 translation units compiled in parallel).
 
     python airgym_amd/csrc/build.py [--force] [--jobs N]
 
@@ -39,6 +39,7 @@ def units():
         for ctl in range(5):
             out.append((os.path.join(OBJ_DIR, f"step_{task}_{ctl}.o"), "step_kernel.hip", [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}"]))
     out.append((os.path.join(OBJ_DIR, "airgym_hip.o"), "airgym_hip.hip", []))
+    out.append((os.path.join(OBJ_DIR, "ppo_kernels.o"), "ppo_kernels.hip", []))
     return out
 
 

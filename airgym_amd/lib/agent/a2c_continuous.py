@@ -400,8 +400,30 @@ class A2CAgent:
             "dones": batch_dict["dones"], "mu": batch_dict["mus"], "sigma": batch_dict["sigmas"],
         })
 
+    def _fused_loss_ok(self):
+        m = self.model
+        return (str(self.ppo_device).startswith("cuda") and self.config.get("use_fused_loss", True) and self.ppo
+                and self.has_value_loss and not m.separate and m.fixed_sigma and self.value_size == 1)
+
+    def _loss_and_backward_fused(self, mb):
+        """Same quantities as _loss_and_backward, per-row math in one HIP kernel (ag_ppo_loss)."""
+        from airgym_amd.lib.core.fused_loss import fused_ppo_loss
+        self.model.trunk(mb["obs"])
+        loss, stats = fused_ppo_loss(
+            self.model.last_heads, self.model.logstd, mb["actions"], mb["old_logp_actions"], mb["advantages"],
+            mb["returns"], mb["old_values"], mb["mu"], mb["sigma"], e_clip=self.e_clip, critic_coef=self.critic_coef,
+            entropy_coef=self.entropy_coef, bounds_loss_coef=self.bounds_loss_coef, clip_value=self.clip_value,
+            bound_loss_type=self.bound_loss_type, write_back=True)
+        self.flat_grad.zero_()
+        loss.backward()
+        with torch.no_grad():
+            self.flat_grad[-1] = stats[4]
+        return stats[0], stats[1], stats[2], stats[3], None, None
+
     def _loss_and_backward(self, mb):
         """calc_gradients up to backward(), a2c_continuous.py:299-350."""
+        if self._fused_loss_ok():
+            return self._loss_and_backward_fused(mb)
         res = self.model({"is_train": True, "prev_actions": mb["actions"], "obs": mb["obs"]})
         a_loss = common_losses.actor_loss(mb["old_logp_actions"], res["prev_neglogp"], mb["advantages"], self.ppo, self.e_clip)
         if self.has_value_loss:
@@ -451,7 +473,8 @@ class A2CAgent:
         mb = self.dataset[idx]
         a, c, e, b, mu, sigma = self._loss_and_backward(mb)
         kl = self._reduce_clip_step()
-        self.dataset.update_mu_sigma(mu, sigma)
+        if mu is not None:      # the fused kernel already wrote the new rows back in place
+            self.dataset.update_mu_sigma(mu, sigma)
         return a, c, e, b, kl
 
     def _capture(self, fn, warmup=True):

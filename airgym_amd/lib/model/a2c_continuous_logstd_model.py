@@ -74,6 +74,7 @@ class ModelA2CContinuousLogStd(nn.Module):
             n_act = self.mu.weight.shape[0]
             heads = linear(a_out, torch.cat((self.mu.weight, self.value_head.weight), 0),
                            torch.cat((self.mu.bias, self.value_head.bias), 0))
+            self.last_heads = heads      # [*, A+1] GEMM output, consumed by the fused PPO-loss kernel
             mu, value = heads[:, :n_act], heads[:, n_act:]
         else:
             mu = self.mu(a_out)

@@ -124,6 +124,7 @@ def main():
         st = agent.train_epoch()
         play += st["play_time"]
         update += st["update_time"]
+        last_stats = st
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -151,7 +152,9 @@ def main():
                    "policy": "MLP(256,256) actor-critic, fixed sigma", "parallelism": f"dp{world}",
                    "hip_graph_rollout": bool(args.graph)},
         "phases": {"rollout_s": play, "update_s": update, "final_lr": agent.last_lr,
-                   "kl_finite": True},
+                   "last_kl": last_stats["kl"], "last_a_loss": last_stats["a_loss"], "last_c_loss": last_stats["c_loss"],
+                   "finite": bool(all(map(lambda x: x == x and abs(x) != float("inf"),
+                                          (last_stats["kl"], last_stats["a_loss"], last_stats["c_loss"]))))},
     }
     if rank == 0:
         hip = agent._hip_env

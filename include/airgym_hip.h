@@ -165,6 +165,26 @@ int ag_set_target_state(ag_handle h, const float* target_state18);
 uint64_t ag_get_tick(ag_handle h);
 int ag_set_tick(ag_handle h, uint64_t tick);
 
+/* ---- PPO minibatch loss, fused (airgym_amd/csrc/ppo_kernels.hip) -------------------------------------
+ * Replaces the eager op chain of ContinuousA2CBase.calc_gradients (lib/agent/a2c_continuous.py:299-369):
+ * neglogp (lib/model/a2c_continuous_logstd_model.py:195-198), actor_loss / critic_loss
+ * (lib/core/common_losses.py:10-20,39-48), bound_loss (a2c_continuous.py:382-390), policy_kl
+ * (lib/core/torch_ext.py:27-36) and PPODataset.update_mu_sigma (lib/core/datasets.py:20-24).
+ *   heads_dev [M, A+1]: mu columns then the value column (one GEMM output); logstd_dev [A].
+ *   d_heads_dev [M, A+1]: d(a_loss.mean + 0.5*critic_coef*c_loss.mean + bounds_coef*b_loss.mean)/d heads.
+ *   partials_dev [ag_ppo_loss_max_blocks(), ag_ppo_loss_num_sums()]: per-block sums of
+ *       {a_loss, c_loss, b_loss, kl, d(sum_i a_i)/d logstd_0..A-1}; *num_blocks_out rows are valid; the caller
+ *       reduces them (deterministic) and divides by M.  bound_type: 0 none, 1 'bound', 2 'regularisation'.
+ *   new_mu_dev / new_sigma_dev [M, A]: optional write-back of the current policy rows (both or neither). */
+int ag_ppo_loss_num_sums(void);
+int ag_ppo_loss_max_blocks(void);
+int ag_ppo_loss(const float* heads_dev, const float* logstd_dev, const float* actions_dev,
+                const float* old_neglogp_dev, const float* advantages_dev, const float* returns_dev,
+                const float* old_values_dev, const float* old_mu_dev, const float* old_sigma_dev, int M, int A,
+                float e_clip, float critic_coef, float bounds_loss_coef, int clip_value, int bound_type,
+                float* d_heads_dev, float* new_mu_dev, float* new_sigma_dev, float* partials_dev,
+                int* num_blocks_out, void* stream);
+
 /* Launch geometry knobs for benchmarking (block size 64/128/256; obs staged through LDS or not). */
 int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
 

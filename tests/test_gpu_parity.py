@@ -221,3 +221,50 @@ def test_splitk_linear_matches_plain_autograd(Handle):
         ref = (y2.detach(), x.grad, w.grad, b.grad)
         for a_, r_ in zip(got, ref):
             assert torch.allclose(a_, r_, rtol=1e-4, atol=1e-3 * r_.abs().max().item())
+
+
+def test_fused_ppo_loss_matches_composed_torch_ops(Handle):
+    """ag_ppo_loss (one kernel) vs the composed torch ops that restate calc_gradients: loss terms, KL,
+    gradients w.r.t. heads and logstd, and the mu/sigma write-back."""
+    from airgym_amd.lib.core import common_losses, torch_ext
+    from airgym_amd.lib.core.fused_loss import fused_ppo_loss
+    from airgym_amd.lib.model.a2c_continuous_logstd_model import ModelA2CContinuousLogStd
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for A, clip_value, btype in [(4, False, "bound"), (5, True, "regularisation"), (4, True, "bound")]:
+        M = 70001
+        heads = torch.randn(M, A + 1, device="cuda", generator=g)
+        heads[:, :A] *= 1.5                                   # some |mu| > 1.1 so the bound loss is active
+        heads.requires_grad_(True)
+        logstd = (0.3 * torch.randn(A, device="cuda", generator=g)).requires_grad_(True)
+        actions = torch.randn(M, A, device="cuda", generator=g)
+        old_mu = torch.randn(M, A, device="cuda", generator=g) * 0.1
+        old_sigma = torch.rand(M, A, device="cuda", generator=g) + 0.5
+        adv = torch.randn(M, device="cuda", generator=g)
+        returns = torch.randn(M, 1, device="cuda", generator=g)
+        old_values = returns + 0.3 * torch.randn(M, 1, device="cuda", generator=g)
+        cfg = dict(e_clip=0.2, critic_coef=2.0, entropy_coef=0.01, bounds_loss_coef=1e-4)
+        # composed reference path
+        mu, value = heads[:, :A], heads[:, A:]
+        ls = mu * 0.0 + logstd
+        sigma = torch.exp(ls)
+        nlp = ModelA2CContinuousLogStd.neglogp(actions, mu, sigma, ls)
+        old_nlp = (nlp.detach() + 0.3 * torch.randn(M, device="cuda", generator=g)).contiguous()
+        a = common_losses.actor_loss(old_nlp, nlp, adv, True, 0.2).mean()
+        c = common_losses.critic_loss(old_values, value, 0.2, returns, clip_value).mean()
+        b = (common_losses.bound_loss(mu) if btype == "bound" else common_losses.reg_loss(mu)).mean()
+        ent = (0.5 + 0.5 * np.log(2 * np.pi) + ls).sum(-1).mean()
+        loss_ref = a + 0.5 * c * 2.0 - ent * 0.01 + b * 1e-4
+        loss_ref.backward()
+        g_heads_ref, g_ls_ref = heads.grad.clone(), logstd.grad.clone()
+        kl_ref = torch_ext.policy_kl(mu.detach(), sigma.detach(), old_mu, old_sigma)
+        heads.grad = None; logstd.grad = None
+        om, osig = old_mu.clone(), old_sigma.clone()
+        loss, stats = fused_ppo_loss(heads, logstd, actions, old_nlp, adv, returns, old_values, om, osig,
+                                     clip_value=clip_value, bound_loss_type=btype, write_back=True, **cfg)
+        loss.backward()
+        assert torch.allclose(loss, loss_ref, rtol=1e-5, atol=1e-6)
+        for got, ref in zip(stats, (a, c, ent, b, kl_ref)):
+            assert torch.allclose(got, ref.detach(), rtol=2e-5, atol=1e-6), (got.item(), ref.item())
+        assert torch.allclose(heads.grad, g_heads_ref, rtol=1e-4, atol=1e-10)
+        assert torch.allclose(logstd.grad, g_ls_ref, rtol=1e-4, atol=1e-7)
+        assert torch.equal(om, mu.detach()) and torch.allclose(osig, sigma.detach())

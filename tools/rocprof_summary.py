@@ -27,8 +27,16 @@ def main(db_path, out_path, cmd=""):
             mm[name] = (mn, mx)
     except sqlite3.Error:
         pass
+    tot = sum(r[2] for r in rows)
+    ncalls = sum(r[1] for r in rows)
+    try:
+        t0, t1 = list(cur.execute("select min(start), max(end) from kernels"))[0]
+        span = (t1 - t0) / 1000.0
+    except sqlite3.Error:
+        span = float("nan")
     with open(out_path, "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\n")
+        f.write(f"total: {ncalls} dispatches, {tot:.0f} us of kernel time over a {span:.0f} us first-to-last span\n\n")
         f.write("durations in microseconds (rocpd `top_kernels` view; total_duration in us)\n\n")
         f.write("| kernel | calls | total us | avg us | min us | max us | % | vgpr | sgpr | lds B | grid | wg |\n")
         f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
