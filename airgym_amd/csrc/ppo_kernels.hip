@@ -175,3 +175,134 @@ extern "C" int ag_ppo_loss(const float* heads, const float* logstd, const float*
         return AG_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// ELU backward fused with the bias gradient of the Linear that produced the pre-activation.
+//   dz[m,c] = dh[m,c] * (h[m,c] > 0 ? 1 : h[m,c] + 1)      (ELU alpha = 1, h = ELU(z): ELU'(z) = h + 1 for z <= 0)
+//   db_partials[block, c] = sum over the block's rows of dz[m,c]
+// Replaces elu_backward (read 2, write 1) + a separate column-sum pass (read 1) of the [M, C] gradient
+// (lib/network/mlp.py:36-39 under autograd).  One pass: read dh, h; write dz.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kEluRowsPerBlock = 128;
+
+__global__ __launch_bounds__(256) void elu_bwd_bias_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                           float* __restrict__ dz, float* __restrict__ db_partials,
+                                                           int M, int C) {
+    // thread layout: C/4 threads cover one row with float4; 256 / (C/4) rows are processed per pass
+    __shared__ float4 red[256];
+    const int tpr = C >> 2;                     // threads per row
+    const int rpp = 256 / tpr;                  // rows per pass
+    const int col4 = threadIdx.x % tpr;
+    const int rsub = threadIdx.x / tpr;
+    const int row0 = blockIdx.x * kEluRowsPerBlock;
+    const int row_end = min(row0 + kEluRowsPerBlock, M);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rsub < rpp) {
+        for (int r = row0 + rsub; r < row_end; r += rpp) {
+            const size_t idx = (size_t)r * tpr + col4;
+            const float4 g = reinterpret_cast<const float4*>(dh)[idx];
+            const float4 y = reinterpret_cast<const float4*>(h)[idx];
+            float4 o;
+            o.x = g.x * (y.x > 0.f ? 1.f : y.x + 1.f);
+            o.y = g.y * (y.y > 0.f ? 1.f : y.y + 1.f);
+            o.z = g.z * (y.z > 0.f ? 1.f : y.z + 1.f);
+            o.w = g.w * (y.w > 0.f ? 1.f : y.w + 1.f);
+            reinterpret_cast<float4*>(dz)[idx] = o;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < tpr) {
+        float4 s = red[threadIdx.x];
+        for (int j = 1; j < rpp; ++j) {
+            const float4 t = red[threadIdx.x + j * tpr];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        reinterpret_cast<float4*>(db_partials)[(size_t)blockIdx.x * tpr + threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Gradient clip-by-norm + Adam + KL-adaptive learning rate in ONE single-workgroup launch over the flat
+// parameter buffer (trancate_gradients_and_step, lib/agent/a2c_base.py:293-316; AdaptiveScheduler,
+// lib/core/schedulers.py:19-32; torch.optim.Adam update rule, eps outside the bias-corrected sqrt).
+// state_dev: double[2] = {lr, step};  kl is read from grad[n] (the scalar appended to the flat gradient).
+// Replaces ~35 tiny launches per optimizer step; the buffer is 72 k floats, one CU is plenty.
+// ---------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float* p; float* g; float* m; float* v;
+    double* state;
+    int n;
+    float beta1, beta2, eps, weight_decay, max_grad_norm;   // max_grad_norm <= 0: no clipping
+    float kl_threshold, min_lr, max_lr;                     // kl_threshold <= 0: LR not adapted
+};
+
+__global__ __launch_bounds__(1024) void adam_clip_step_kernel(const AdamArgs k) {
+    __shared__ float red[16];
+    __shared__ float s_coef, s_step_size, s_bc2_rsqrt;
+    const int tid = threadIdx.x;
+    float ss = 0.f;
+    for (int i = tid; i < k.n; i += 1024) { const float x = k.g[i]; ss += x * x; }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        const float norm = sqrtf(tot);
+        s_coef = (k.max_grad_norm > 0.f) ? fminf(k.max_grad_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+        const double lr = k.state[0];
+        const double step = k.state[1] + 1.0;
+        const double bc1 = 1.0 - pow((double)k.beta1, step);
+        const double bc2 = 1.0 - pow((double)k.beta2, step);
+        s_step_size = (float)(lr / bc1);
+        s_bc2_rsqrt = (float)(1.0 / sqrt(bc2));
+        k.state[1] = step;
+        if (k.kl_threshold > 0.f) {      // legacy schedule: evaluated every minibatch, applies to the NEXT step
+            const double kl = (double)k.g[k.n];
+            double nlr = lr;
+            if (kl > 2.0 * k.kl_threshold) nlr = fmax(lr / 1.5, (double)k.min_lr);
+            if (kl < 0.5 * k.kl_threshold) nlr = fmin(lr * 1.5, (double)k.max_lr);
+            k.state[0] = nlr;
+        }
+    }
+    __syncthreads();
+    const float coef = s_coef, step_size = s_step_size, bc2r = s_bc2_rsqrt;
+    for (int i = tid; i < k.n; i += 1024) {
+        float g = k.g[i] * coef;
+        k.g[i] = g;
+        const float p = k.p[i];
+        if (k.weight_decay != 0.f) g += k.weight_decay * p;
+        const float m = k.beta1 * k.m[i] + (1.f - k.beta1) * g;
+        const float v = k.beta2 * k.v[i] + (1.f - k.beta2) * g * g;
+        k.m[i] = m;
+        k.v[i] = v;
+        const float denom = sqrtf(v) * bc2r + k.eps;
+        k.p[i] = p - step_size * (m / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int ag_elu_bwd_bias_rows_per_block(void) { return kEluRowsPerBlock; }
+
+extern "C" int ag_elu_bwd_bias(const float* dh, const float* h, float* dz, float* db_partials, int M, int C, void* stream) {
+    if (!dh || !h || !dz || !db_partials || M <= 0) return AG_ERR_INVALID_ARG;
+    if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
+    const int grid = (M + kEluRowsPerBlock - 1) / kEluRowsPerBlock;
+    hipLaunchKernelGGL(elu_bwd_bias_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dh, h, dz, db_partials, M, C);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_adam_clip_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, double* state, int n,
+                                 float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                                 float kl_threshold, float min_lr, float max_lr, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state || n <= 0) return AG_ERR_INVALID_ARG;
+    AdamArgs k{param, grad, exp_avg, exp_avg_sq, state, n, beta1, beta2, eps, weight_decay, max_grad_norm,
+               kl_threshold, min_lr, max_lr};
+    hipLaunchKernelGGL(adam_clip_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, k);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}

@@ -77,10 +77,11 @@ class FlatAdam:
         self.b1, self.b2 = betas
         self.eps, self.wd = eps, weight_decay
         dev = flat_param.device
-        self.lr = torch.tensor(float(lr), dtype=torch.float64, device=dev)
+        self.state = torch.tensor([float(lr), 0.0], dtype=torch.float64, device=dev)   # {lr, step}: one device buffer
+        self.lr = self.state[0]
+        self.step_t = self.state[1]
         self.exp_avg = torch.zeros_like(flat_param)
         self.exp_avg_sq = torch.zeros_like(flat_param)
-        self.step_t = torch.zeros((), dtype=torch.float64, device=dev)
 
     @torch.no_grad()
     def step(self):
@@ -95,6 +96,20 @@ class FlatAdam:
         step_size = (self.lr / bc1).float()
         denom = (self.exp_avg_sq.sqrt() / bc2.sqrt().float()).add_(self.eps)
         self.p.sub_(step_size * (self.exp_avg / denom))
+
+    @torch.no_grad()
+    def fused_clip_step(self, grad_with_kl, max_grad_norm, kl_threshold, min_lr, max_lr):
+        """clip-by-norm + Adam + KL-adaptive LR in one HIP launch (`ag_adam_clip_step`); grad_with_kl is the flat
+        gradient buffer whose last element is the minibatch KL."""
+        import ctypes
+
+        from airgym_amd import _native as N
+        lib = N.load()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.p.device).cuda_stream)
+        N.check(lib.ag_adam_clip_step(self.p.data_ptr(), grad_with_kl.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), self.state.data_ptr(), self.p.numel(),
+                                      self.b1, self.b2, self.eps, self.wd, float(max_grad_norm), float(kl_threshold),
+                                      float(min_lr), float(max_lr), stream), "ag_adam_clip_step")
 
     def state_dict(self):
         return {"lr": self.lr.item(), "step": self.step_t.item(), "exp_avg": self.exp_avg.clone(),
@@ -408,7 +423,7 @@ class A2CAgent:
     def _loss_and_backward_fused(self, mb):
         """Same quantities as _loss_and_backward, per-row math in one HIP kernel (ag_ppo_loss)."""
         from airgym_amd.lib.core.fused_loss import fused_ppo_loss
-        self.model.trunk(mb["obs"])
+        self.model.trunk(mb["obs"], heads_only=True)
         loss, stats = fused_ppo_loss(
             self.model.last_heads, self.model.logstd, mb["actions"], mb["old_logp_actions"], mb["advantages"],
             mb["returns"], mb["old_values"], mb["mu"], mb["sigma"], e_clip=self.e_clip, critic_coef=self.critic_coef,
@@ -455,12 +470,19 @@ class A2CAgent:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad /= self.world_size
         kl = self.flat_grad[-1].double()
+        adaptive = self.is_adaptive_lr and self.schedule_type == "legacy"
+        if self.flat_grad.is_cuda and self.config.get("use_fused_adam", True):
+            self.optimizer.fused_clip_step(
+                self.flat_grad, self.grad_norm if self.truncate_grads else 0.0,
+                self.kl_threshold if adaptive else 0.0, getattr(self.scheduler, "min_lr", 0.0),
+                getattr(self.scheduler, "max_lr", 1.0))
+            return kl
         g = self.flat_grad[:-1]
         if self.truncate_grads:
             total_norm = torch.linalg.vector_norm(g)
             g.mul_(torch.clamp(self.grad_norm / (total_norm + 1e-6), max=1.0))
         self.optimizer.step()
-        if self.is_adaptive_lr and self.schedule_type == "legacy":
+        if adaptive:
             lr = self.optimizer.lr
             thr = self.kl_threshold
             down = torch.clamp(lr / 1.5, min=self.scheduler.min_lr)

@@ -64,7 +64,7 @@ class ModelA2CContinuousLogStd(nn.Module):
     def denorm_value(self, value):
         return self.value_mean_std(value, denorm=True) if self.normalize_value else value
 
-    def trunk(self, obs):
+    def trunk(self, obs, heads_only=False):
         norm_out = self.norm_obs(obs)
         a_out = self.actor_mlp(norm_out)
         c_out = self.critic_mlp(norm_out) if self.separate else a_out
@@ -75,6 +75,8 @@ class ModelA2CContinuousLogStd(nn.Module):
             heads = linear(a_out, torch.cat((self.mu.weight, self.value_head.weight), 0),
                            torch.cat((self.mu.bias, self.value_head.bias), 0))
             self.last_heads = heads      # [*, A+1] GEMM output, consumed by the fused PPO-loss kernel
+            if heads_only:
+                return heads
             mu, value = heads[:, :n_act], heads[:, n_act:]
         else:
             mu = self.mu(a_out)

@@ -185,6 +185,22 @@ int ag_ppo_loss(const float* heads_dev, const float* logstd_dev, const float* ac
                 float* d_heads_dev, float* new_mu_dev, float* new_sigma_dev, float* partials_dev,
                 int* num_blocks_out, void* stream);
 
+/* ELU backward fused with the bias gradient of the producing Linear (lib/network/mlp.py:36-39 under autograd):
+ * dz = dh * ELU'(z) computed from h = ELU(z); db_partials_dev [ceil(M / rows_per_block), C] per-block column sums of dz
+ * (caller reduces).  C % 4 == 0 and 256 % (C/4) == 0 (C = 64, 128, 256, 512, 1024 ...). */
+int ag_elu_bwd_bias_rows_per_block(void);
+int ag_elu_bwd_bias(const float* dh_dev, const float* h_dev, float* dz_dev, float* db_partials_dev, int M, int C,
+                    void* stream);
+
+/* Clip-by-norm + Adam + KL-adaptive LR over a flat parameter buffer in one launch
+ * (trancate_gradients_and_step, lib/agent/a2c_base.py:293-316; AdaptiveScheduler, lib/core/schedulers.py:19-32).
+ * grad_dev has n + 1 elements: element n is the (already all-reduced) KL of this minibatch.
+ * state_dev: double[2] = {learning rate, step count}, updated in place.  max_grad_norm <= 0 disables clipping,
+ * kl_threshold <= 0 disables the LR adaptation. */
+int ag_adam_clip_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, double* state_dev,
+                      int n, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                      float kl_threshold, float min_lr, float max_lr, void* stream);
+
 /* Launch geometry knobs for benchmarking (block size 64/128/256; obs staged through LDS or not). */
 int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
 

@@ -268,3 +268,49 @@ def test_fused_ppo_loss_matches_composed_torch_ops(Handle):
         assert torch.allclose(heads.grad, g_heads_ref, rtol=1e-4, atol=1e-10)
         assert torch.allclose(logstd.grad, g_ls_ref, rtol=1e-4, atol=1e-7)
         assert torch.equal(om, mu.detach()) and torch.allclose(osig, sigma.detach())
+
+
+def test_fused_linear_elu_backward(Handle):
+    """ag_elu_bwd_bias + split-K wgrad inside _LinearEluFn == autograd of F.elu(F.linear(...))."""
+    import torch.nn.functional as F
+    from airgym_amd.lib.network.splitk_linear import linear_elu
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for K, C, M in [(18, 256, 16384), (256, 256, 24576), (32, 64, 8192)]:
+        x = torch.randn(M, K, device="cuda", generator=g, requires_grad=True)
+        w = (torch.randn(C, K, device="cuda", generator=g) / K ** 0.5).requires_grad_(True)
+        b = torch.randn(C, device="cuda", generator=g, requires_grad=True)
+        go = torch.randn(M, C, device="cuda", generator=g)
+        y = linear_elu(x, w, b); y.backward(go)
+        got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+        for t_ in (x, w, b):
+            t_.grad = None
+        y2 = F.elu(F.linear(x, w, b)); y2.backward(go)
+        for a_, r_ in zip(got, (y2.detach(), x.grad, w.grad, b.grad)):
+            assert torch.allclose(a_, r_, rtol=1e-4, atol=1e-3 * r_.abs().max().item())
+
+
+def test_fused_adam_clip_lr_step(Handle):
+    """ag_adam_clip_step == clip_grad_norm + FlatAdam.step + AdaptiveScheduler (the python/torch path)."""
+    from airgym_amd.lib.agent.a2c_continuous import FlatAdam
+    from airgym_amd.lib.core.schedulers import AdaptiveScheduler
+    sch = AdaptiveScheduler(0.008)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    n = 71945
+    p0 = torch.randn(n, device="cuda", generator=g)
+    gbuf_a = torch.zeros(n + 1, device="cuda"); gbuf_b = torch.zeros(n + 1, device="cuda")
+    a = FlatAdam(p0.clone(), gbuf_a[:-1], 3e-4)
+    b = FlatAdam(p0.clone(), gbuf_b[:-1], 3e-4)
+    lr_host = 3e-4
+    for it, kl in enumerate([0.0, 0.02, 0.003, 0.009, 0.1, 0.001, 0.001]):
+        grad = torch.randn(n, device="cuda", generator=g) * (0.001 if it % 2 else 0.05)
+        gbuf_a[:-1] = grad; gbuf_a[-1] = kl
+        gbuf_b[:-1] = grad; gbuf_b[-1] = kl
+        a.fused_clip_step(gbuf_a, 1.5, 0.008, sch.min_lr, sch.max_lr)
+        gb = gbuf_b[:-1]
+        gb.mul_(torch.clamp(1.5 / (torch.linalg.vector_norm(gb) + 1e-6), max=1.0))
+        b.step()
+        lr_host = sch.update(lr_host, 0, 0, 0, float(np.float32(kl)))[0]
+        b.lr.fill_(lr_host)
+        assert torch.allclose(a.p, b.p, rtol=0, atol=2e-6), it
+        assert abs(a.lr.item() - lr_host) < 1e-12 and a.step_t.item() == it + 1
+        assert torch.allclose(gbuf_a[:-1], gbuf_b[:-1], rtol=1e-5, atol=1e-9)     # clipped gradient left in place
