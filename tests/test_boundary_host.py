@@ -1,0 +1,82 @@
+"""Host-side drop-in boundary (no GPU): config field trees, registry errors, CLI flags, YAML values,
+vecenv registration, spaces."""
+import json
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import yaml
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _norm(d):
+    if isinstance(d, dict):
+        return {k: _norm(v) for k, v in d.items() if k != "init_member_classes"}
+    if isinstance(d, np.ndarray):
+        return d.tolist()
+    if isinstance(d, (list, tuple)):
+        return [_norm(x) for x in d]
+    return d
+
+
+def test_config_field_trees_equal_reference():
+    """tests/golden/config_trees.json = class_to_dict() of the reference's HoveringCfg / TrackingCfg instances
+    (airgym/envs/base/hovering_config.py, airgym/envs/task/tracking_config.py), dumped in the build container."""
+    from airgym_amd.envs.base.hovering_config import HoveringCfg
+    from airgym_amd.envs.task.tracking_config import TrackingCfg
+    from airgym_amd.utils.helpers import class_to_dict
+    ref = json.load(open(os.path.join(REPO, "tests", "golden", "config_trees.json")))
+    assert _norm(class_to_dict(HoveringCfg())) == ref["hovering"]
+    assert _norm(class_to_dict(TrackingCfg())) == ref["tracking"]
+    # instances are independent, class-level access still works (reference idiom: Cfg.env.num_envs)
+    a, b = HoveringCfg(), HoveringCfg()
+    a.env.num_envs = 7
+    assert b.env.num_envs == 256 and HoveringCfg.env.num_envs == 256
+
+
+def test_registry_and_errors():
+    import airgym_amd.envs  # noqa: F401
+    from airgym_amd.utils.task_registry import task_registry
+    assert task_registry.get_registered_tasks() == ["hovering", "tracking"]
+    with pytest.raises(ValueError, match="was not registered"):            # task_registry.py:78-79
+        task_registry.make_env("planning", Namespace(num_envs=4, ctl_mode="rate", seed=1))
+    with pytest.raises((ValueError, RuntimeError)):                        # bad ctl_mode is an error, not a print
+        task_registry.make_env("hovering", Namespace(num_envs=4, ctl_mode="warp", seed=1, sim_device="cuda:0",
+                                                     headless=True))
+
+
+def test_cli_flags_match_reference():
+    from airgym_amd.utils.helpers import get_args
+    a = get_args(["--task", "tracking", "--ctl_mode", "vel", "--num_envs", "128", "--headless", "--seed", "3",
+                  "--sim_device", "cuda:1", "--rl_device", "cuda:1"])
+    assert (a.task, a.ctl_mode, a.num_envs, a.headless, a.seed) == ("tracking", "vel", 128, True, 3)
+    assert a.sim_device == "cuda:1" and a.sim_device_id == 1 and a.use_gpu_pipeline
+    with pytest.raises(SystemExit):
+        get_args(["--task", "hovering"])           # --ctl_mode is required (helpers.py:101)
+    assert get_args(["--ctl_mode", "rate"]).num_envs == 4096          # default, helpers.py:89
+
+
+def test_yaml_hyperparameters():
+    c = yaml.safe_load(open(os.path.join(REPO, "scripts", "config", "ppo_hovering.yaml")))["params"]
+    cfg = c["config"]
+    expect = dict(gamma=0.99, tau=0.95, learning_rate=3e-4, kl_threshold=0.008, grad_norm=1.5, e_clip=0.2,
+                  horizon_length=24, minibatch_size=2048, mini_epochs=5, critic_coef=2, bounds_loss_coef=0.0001,
+                  num_actors=4096, max_epochs=200, entropy_coef=0, lr_schedule="adaptive")
+    for k, v in expect.items():
+        assert cfg[k] == v, k
+    assert cfg["reward_shaper"] == {"scale_value": 0.1} and c["network"]["mlp"]["units"] == [64, 128, 64]
+    t = yaml.safe_load(open(os.path.join(REPO, "scripts", "config", "ppo_tracking.yaml")))["params"]["config"]
+    assert t["env_name"] == "tracking" and t["max_epochs"] == 300
+
+
+def test_vecenv_registration_and_spaces():
+    from airgym_amd.lib.utils import env_configurations, vecenv
+    from airgym_amd.lib.utils.spaces import Box
+    assert {"hovering", "tracking"} <= set(env_configurations.configurations)
+    assert "AirGym-RLGPU" in vecenv.vecenv_config
+    b = Box(-np.ones(4), np.ones(4))
+    assert b.shape == (4,) and b.low.min() == -1 and b.high.max() == 1
+    with pytest.raises(NotImplementedError):
+        vecenv.AirGymRLGPUEnv("hovering", 4, use_image=True)
