@@ -99,6 +99,7 @@ SYMBOLS = [
     ("ag_get_tick", ctypes.c_uint64, [_P]),
     ("ag_set_tick", ctypes.c_int, [_P, ctypes.c_uint64]),
     ("ag_set_launch_params", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
+    ("ag_debug_touch", ctypes.c_int, [_P, _P, _P]),
     ("ag_elu_bwd_bias_rows_per_block", ctypes.c_int, []),
     ("ag_elu_bwd_bias", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_adam_clip_step", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int] + [ctypes.c_float] * 8 + [_P]),

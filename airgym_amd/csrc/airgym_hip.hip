@@ -196,6 +196,30 @@ __global__ __launch_bounds__(1024) void compact_reset_ids_kernel(const unsigned 
     if (tid == 0) *count = base;
 }
 
+// Diagnostic: same loads/stores as the Hovering/CTBR step (7 float4 in, 7 float4 + obs row + reward + flags out),
+// no arithmetic.  Its duration is the launch + memory-latency floor any one-launch-per-step design pays.
+__global__ __launch_bounds__(64) void touch_kernel(ag::KArgs k, const float* actions, int num_obs) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    ag::EnvState s;
+    ag::CtlState c;
+    ag::load_env(k, i, s);
+    ag::load_ctl<ag::CTL_RATE>(k, i, c);
+    const float4 pa = k.PA[i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < k.n) a = reinterpret_cast<const float4*>(actions)[i];
+    s.p.x += 1e-30f * (pa.x + a.x);
+    ag::store_env(k, i, s);
+    ag::store_ctl<ag::CTL_RATE>(k, i, c);
+    k.PA[i] = a;
+    if (i < k.n) {
+        k.rew[i] = s.p.x;
+        k.reset[i] = 0;
+        k.timeout[i] = 0;
+        float* o = k.obs + (size_t)i * num_obs;
+        for (int j = 0; j < num_obs; j += 2) reinterpret_cast<float2*>(o)[j >> 1] = make_float2(s.p.y, s.p.z);
+    }
+}
+
 void fill_params(ag_env* h) {
     h->k.P = ag::make_step_params(h->cfg.task, h->cfg.dt, h->cfg.max_episode_length, h->cfg.target_state, h->cfg.seed,
                                   h->cfg.env_id_offset, (h->cfg.flags & AG_FLAG_OBS_NOISE_OFF) != 0);
@@ -335,7 +359,7 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     fill_params(h);
     h->tick = 0;
     h->parity = 0;
-    h->block = 64;
+    h->block = 0;      // wave-specialised kernel
     h->obs_via_lds = 1;
     // valid state from the start: everything randomised and flagged reset (base_task.py:75)
     hipError_t e = hipMemsetAsync(h->arena, 0, h->L.total, 0);
@@ -458,10 +482,18 @@ int ag_set_tick(ag_handle h, uint64_t tick) {
     return AG_OK;
 }
 
+int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream) {
+    if (!h || !actions_dev) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    hipLaunchKernelGGL(touch_kernel, dim3((h->cfg.num_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->k,
+                       actions_dev, h->num_obs);
+    AG_HIP_CHECK(hipGetLastError());
+    return AG_OK;
+}
+
 int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
-    if (block_size != 64 && block_size != 128 && block_size != 256)
-        return fail(AG_ERR_INVALID_ARG, "block_size must be 64, 128 or 256");
+    if (block_size != 0 && block_size != 64 && block_size != 128 && block_size != 256)
+        return fail(AG_ERR_INVALID_ARG, "block_size must be 0 (wave-specialised), 64, 128 or 256");
     h->block = block_size;
     h->obs_via_lds = obs_via_lds ? 1 : 0;
     return AG_OK;

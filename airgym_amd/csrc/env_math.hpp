@@ -590,9 +590,9 @@ struct StepOut {
     float cmd[4];
 };
 
-// compute_observations + add_noise, hovering.py:337-358 / tracking.py:202-214.  z = 18 standard normals.
+// compute_observations, hovering.py:337-342 / tracking.py:202-211: the noise-free part.
 template <int TASK>
-AG_HD void compute_observations(const EnvState& s, const float* R, const float* z, const StepParams& P, float* obs) {
+AG_HD void fill_clean_observations(const EnvState& s, const float* R, const StepParams& P, float* obs) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) obs[i] = R[i];
     obs[9] = s.p.x; obs[10] = s.p.y; obs[11] = s.p.z;
@@ -607,19 +607,22 @@ AG_HD void compute_observations(const EnvState& s, const float* R, const float* 
             obs[18 + 3 * k + 2] = r.z - s.p.z;
         }
     }
+}
+
+// sigma_j for observation column j < 18 (add_noise, hovering.py:349-358)
+AG_HD float noise_sigma(int j) { return j < 9 ? kSigMat : (j < 12 ? kSigPos : (j < 15 ? kSigVel : kSigAng)); }
+
+// add_noise (hovering.py:343,349-358) then target subtraction (hovering.py:345; Tracking does not subtract).
+// z = 18 standard normals.
+template <int TASK>
+AG_HD void apply_noise_and_target(float* obs, const float* z, const StepParams& P) {
     if (!P.noise_off) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) obs[i] += kSigMat * z[i];
-#pragma unroll
-        for (int i = 9; i < 12; ++i) obs[i] += kSigPos * z[i];
-#pragma unroll
-        for (int i = 12; i < 15; ++i) obs[i] += kSigVel * z[i];
-#pragma unroll
-        for (int i = 15; i < 18; ++i) obs[i] += kSigAng * z[i];
+        for (int i = 0; i < 18; ++i) obs[i] += noise_sigma(i) * z[i];
     }
     if (TASK == TASK_HOVERING) {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) obs[i] -= P.target[i];  // hovering.py:345 (Tracking does not subtract)
+        for (int i = 0; i < 18; ++i) obs[i] -= P.target[i];
     }
 }
 
@@ -723,8 +726,9 @@ AG_HD void compute_reward(const EnvState& s, const float* R, const float* a, con
 //   raw_action : what the agent passed (A floats)
 //   pre_a      : in: previous processed action; out: this step's (zeroed if the env reset)
 //   EXT = parity mode: ext_noise[18] / ext_uniforms[12] supplied by the caller instead of Philox
+//   CLEAN_OBS = obs[] is returned WITHOUT noise and target subtraction (added by the noise wave's data later)
 // ---------------------------------------------------------------------------
-template <int TASK, int CTL, bool EXT>
+template <int TASK, int CTL, bool EXT, bool CLEAN_OBS = false>
 AG_HD void env_step(EnvState& s, CtlState& c, float* pre_a, const float* raw_action, const StepParams& P,
                     uint32_t env_global, const float* ext_noise, const float* ext_uniforms, float* obs, StepOut& o) {
     constexpr int A = CtlTraits<CTL>::kNumActions;
@@ -750,17 +754,20 @@ AG_HD void env_step(EnvState& s, CtlState& c, float* pre_a, const float* raw_act
     s.progress += 1;
     float R[9];
     quat_to_matrix(s.q, R);
-    float z[18];
-    if (EXT) {
+    fill_clean_observations<TASK>(s, R, P, obs);
+    if (!CLEAN_OBS) {   // CLEAN_OBS: noise + target are applied by the caller (wave-specialised kernel)
+        float z[18];
+        if (EXT) {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) z[i] = ext_noise[i];
-    } else if (!P.noise_off) {
-        obs_noise_normals(P, env_global, z);
-    } else {
+            for (int i = 0; i < 18; ++i) z[i] = ext_noise[i];
+        } else if (!P.noise_off) {
+            obs_noise_normals(P, env_global, z);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) z[i] = 0.0f;
+            for (int i = 0; i < 18; ++i) z[i] = 0.0f;
+        }
+        apply_noise_and_target<TASK>(obs, z, P);
     }
-    compute_observations<TASK>(s, R, z, P, obs);
     compute_reward<TASK, CTL>(s, R, a, pre_a, o.cmd, P, o);
 #pragma unroll
     for (int i = 0; i < A; ++i) pre_a[i] = a[i];  // hovering.py:369

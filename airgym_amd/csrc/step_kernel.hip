@@ -138,6 +138,119 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const KArgs k) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised variant: 128-thread workgroup = 2 wavefronts for the same 64 envs.
+//   wave 0 ("physics"): state I/O, controller, RK4, reward/termination, reset  -> clean obs row to LDS tile A
+//   wave 1 ("noise")  : Philox4x32-10 + Box-Muller for the 18 noisy columns    -> sigma*z row to LDS tile B
+//   barrier, then all 128 lanes write (A + B) - target as 16-byte-per-lane contiguous lines.
+// Why: at 65 536 envs a one-env-per-lane launch is 1 024 waves on 1 024 SIMDs; a lone wave issues about one
+// VALU instruction per 4 cycles (the SIMD-32 needs a second wave to reach 2), so the kernel is bound by ONE
+// wave's instruction count, ~25 % of which is observation noise that does not depend on the physics.  Splitting
+// it off halves the critical path and puts two waves on every SIMD (profiles/r01_env_kernel_pmc.md, N-scaling).
+// Results are bit-identical to step_kernel<...> (same expressions, same order).
+// ---------------------------------------------------------------------------------------------------
+template <int TASK, int CTL>
+__global__ __launch_bounds__(128) void step_kernel_ws(const KArgs k) {
+    constexpr int NOBS = TaskTraits<TASK>::kNumObs;
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    constexpr int SA = NOBS + 1;   // odd strides: conflict-free row writes
+    constexpr int SB = 19;
+    __shared__ float tileA[64 * SA];
+    __shared__ float tileB[64 * SB];
+    __shared__ float tgt[18];
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 64 + lane;
+    const bool active = i < k.n;
+    StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *k.tick_out = P.tick + 1u;
+    const uint32_t env_global = P.env_id_offset + (uint32_t)i;
+
+    if (wave == 0) {
+        EnvState s;
+        CtlState c;
+        load_env(k, i, s);
+        load_ctl<CTL>(k, i, c);
+        float pre_a[A], raw_a[A];
+        {
+            const float4 pa = k.PA[i];
+            pre_a[0] = pa.x; pre_a[1] = pa.y; pre_a[2] = pa.z; pre_a[3] = pa.w;
+            if (A == 5) pre_a[A - 1] = k.PA4[i];
+        }
+        if (active) {
+            if (A == 4) {
+                const float4 a = reinterpret_cast<const float4*>(k.actions)[i];
+                raw_a[0] = a.x; raw_a[1] = a.y; raw_a[2] = a.z; raw_a[3] = a.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < A; ++j) raw_a[j] = k.actions[(size_t)i * A + j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A; ++j) raw_a[j] = 0.0f;
+        }
+        float obs[NOBS];
+        StepOut o;
+        env_step<TASK, CTL, false, true>(s, c, pre_a, raw_a, P, env_global, nullptr, nullptr, obs, o);
+#pragma unroll
+        for (int j = 0; j < NOBS; ++j) tileA[lane * SA + j] = obs[j];
+        store_env(k, i, s);
+        store_ctl<CTL>(k, i, c);
+        k.PA[i] = make_float4(pre_a[0], pre_a[1], pre_a[2], pre_a[3]);
+        if (A == 5) k.PA4[i] = pre_a[A - 1];
+        const unsigned long long ballot = __ballot(active && o.done);
+        if (active) {
+            k.rew[i] = o.rew;
+            k.reset[i] = (long long)o.done;
+            k.timeout[i] = (uint8_t)o.timeout;
+            if (lane == 0) k.mask[i >> 6] = ballot;
+            if (k.cmd != nullptr) {
+                k.cmd[i] = make_float4(o.cmd[0], o.cmd[1], o.cmd[2], o.cmd[3]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) k.terms[t][i] = o.terms[t];
+            }
+        }
+    } else {
+        float z[18];
+        if (!P.noise_off) {
+            obs_noise_normals(P, env_global, z);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) z[j] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 18; ++j) tileB[lane * SB + j] = noise_sigma(j) * z[j];
+        if (lane < 18) tgt[lane] = (TASK == TASK_HOVERING) ? k.P.target[lane] : 0.0f;
+    }
+    __syncthreads();
+
+    // obs = (clean + sigma*z) - target for the 18 noisy columns (hovering.py:343-345), clean elsewhere
+    const int block_env0 = blockIdx.x * 64;
+    const int valid = min(64, k.n - block_env0) * NOBS;
+    float* out = k.obs + (size_t)block_env0 * NOBS;
+    constexpr int NV4 = 64 * NOBS / 4;
+    constexpr int ITERS = (NV4 + 127) / 128;
+    auto elem = [&](int e) -> float {
+        const int row = e / NOBS, col = e - row * NOBS;
+        float v = tileA[row * SA + col];
+        if (col < 18) v = (v + tileB[row * SB + col]) - tgt[col];
+        return v;
+    };
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int m = (int)threadIdx.x + it * 128;
+        if (m >= NV4) break;
+        const int e = 4 * m;
+        if (e + 3 < valid) {
+            reinterpret_cast<float4*>(out)[m] = make_float4(elem(e), elem(e + 1), elem(e + 2), elem(e + 3));
+        } else {
+            for (int q = e; q < e + 4 && q < valid; ++q) out[q] = elem(q);
+        }
+    }
+}
+
 template <int TASK, int CTL>
 static hipError_t launch_step(const KArgs& k, int block, int obs_via_lds, hipStream_t stream) {
     const int n = k.n;
@@ -149,6 +262,10 @@ static hipError_t launch_step(const KArgs& k, int block, int obs_via_lds, hipStr
     } while (0)
     if (k.ext_noise != nullptr) {  // parity mode: one geometry only
         hipLaunchKernelGGL((step_kernel<TASK, CTL, 64, true, true>), dim3((n + 63) / 64), dim3(64), 0, stream, k);
+        return hipGetLastError();
+    }
+    if (block == 0) {   // wave-specialised geometry (default)
+        hipLaunchKernelGGL((step_kernel_ws<TASK, CTL>), dim3((n + 63) / 64), dim3(128), 0, stream, k);
         return hipGetLastError();
     }
     if (block == 64) { if (obs_via_lds) AG_LAUNCH(64, true); else AG_LAUNCH(64, false); }

@@ -201,7 +201,11 @@ int ag_adam_clip_step(float* param_dev, float* grad_dev, float* exp_avg_dev, flo
                       int n, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                       float kl_threshold, float min_lr, float max_lr, void* stream);
 
-/* Launch geometry knobs for benchmarking (block size 64/128/256; obs staged through LDS or not). */
+/* Diagnostic: a kernel with the step's loads/stores and no arithmetic (launch + memory-latency floor). */
+int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream);
+
+/* Launch geometry knobs for benchmarking: block_size 0 = wave-specialised kernel (default: physics wave + noise wave
+ * per 64 envs), 64/128/256 = one-wave-per-64-envs kernel with that workgroup size (obs staged through LDS or not). */
 int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
 
 #ifdef __cplusplus

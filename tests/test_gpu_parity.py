@@ -91,7 +91,7 @@ def test_ragged_sizes(Handle, n):
     env.close()
 
 
-@pytest.mark.parametrize("block,lds", [(64, True), (64, False), (128, True), (256, True), (256, False)])
+@pytest.mark.parametrize("block,lds", [(0, True), (64, True), (64, False), (128, True), (256, True), (256, False)])
 def test_launch_geometries_agree(Handle, block, lds):
     n = 700
     ora = TrackingRef(n, "vel", seed=11)
@@ -314,3 +314,21 @@ def test_fused_adam_clip_lr_step(Handle):
         assert torch.allclose(a.p, b.p, rtol=0, atol=2e-6), it
         assert abs(a.lr.item() - lr_host) < 1e-12 and a.step_t.item() == it + 1
         assert torch.allclose(gbuf_a[:-1], gbuf_b[:-1], rtol=1e-5, atol=1e-9)     # clipped gradient left in place
+
+
+def test_wave_specialised_kernel_matches_single_wave(Handle):
+    """block_size 0 (physics wave + noise wave) and block_size 64 (one wave does everything) evaluate the same
+    expressions; only FMA contraction may differ between the two compilations (<= 1 ulp per op)."""
+    for task, ctl, n in [("hovering", "rate", 1000), ("tracking", "vel", 777), ("hovering", "atti", 130)]:
+        a = Handle(task, ctl, n, seed=17); a.set_launch_params(0, True)
+        b = Handle(task, ctl, n, seed=17); b.set_launch_params(64, True)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for t in range(40):
+            act = torch.randn(n, a.num_actions, generator=g, device="cuda").clamp(-1, 1)
+            a.step(act); b.step(act)
+            assert torch.allclose(a.obs_buf, b.obs_buf, rtol=0, atol=2e-6), (task, t)
+            assert torch.allclose(a.rew_buf, b.rew_buf, rtol=0, atol=2e-6) and torch.equal(a.reset_buf, b.reset_buf)
+        sa, sb = a.get_state(), b.get_state()
+        for k_ in sa:
+            assert torch.allclose(sa[k_].float(), sb[k_].float(), rtol=0, atol=2e-6), k_
+        a.close(); b.close()

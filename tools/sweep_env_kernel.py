@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--task", default="hovering")
 ap.add_argument("--ctl", default="rate")
 ap.add_argument("--envs", type=int, nargs="+", default=[65536])
-ap.add_argument("--blocks", type=int, nargs="+", default=[64, 128, 256])
+ap.add_argument("--blocks", type=int, nargs="+", default=[0, 64, 256])
 ap.add_argument("--terms", type=int, default=1)
 ap.add_argument("--nograph", action="store_true")
 a = ap.parse_args()
