@@ -297,6 +297,12 @@ class A2CAgent:
         self.current_lengths = torch.zeros(N, **f)
         self.ep_stats = torch.zeros(H, 4, dtype=torch.float64, device=dev)    # count, sum rew, sum shaped, sum len
         self._hip_env = getattr(getattr(self.vec_env, "env", None), "hip", None)   # zero-copy path if available
+        # Episode/<reward term>: per-step means accumulated on device (reference: RLGPUAlgoObserver.process_infos
+        # appends every step's item_reward_info and averages at print time, lib/utils/isaacgym_utils.py:66-99)
+        terms = getattr(self._hip_env, "reward_terms", None) if self._hip_env is not None else None
+        self._term_names = list(terms.keys()) if terms else []
+        self._term_sums = torch.zeros(len(self._term_names), dtype=torch.float64, device=dev)
+        self._term_steps = 0
 
     def preprocess_actions(self, actions):
         if self.clip_actions:
@@ -349,6 +355,9 @@ class A2CAgent:
         st[1] = (self.current_rewards[:, 0] * done_f).sum()
         st[2] = (self.current_shaped_rewards[:, 0] * done_f).sum()
         st[3] = (self.current_lengths * done_f).sum()
+        if self._term_names and self.config.get("log_reward_terms", True):
+            rt = self._hip_env.reward_terms
+            self._term_sums += torch.stack([rt[k].mean() for k in self._term_names]).double()
         not_done = 1.0 - done_f
         self.current_rewards *= not_done.unsqueeze(1)
         self.current_shaped_rewards *= not_done.unsqueeze(1)
@@ -567,6 +576,11 @@ class A2CAgent:
 
     def _flush_episode_stats(self):
         """One device->host read per epoch; replays the reference's per-step AverageMeter updates."""
+        self.episode_term_means = {}
+        if self._term_names and self.config.get("log_reward_terms", True):
+            sums = (self._term_sums / self.horizon_length).cpu().tolist()
+            self._term_sums.zero_()
+            self.episode_term_means = dict(zip(self._term_names, sums))
         st = self.ep_stats.cpu().numpy()
         for n in range(st.shape[0]):
             cnt = st[n, 0]
@@ -647,6 +661,8 @@ class A2CAgent:
         w.add_scalar("info/e_clip", self.e_clip, frame)
         w.add_scalar("info/kl", stats["kl"], frame)
         w.add_scalar("info/epochs", epoch_num, frame)
+        for k, v in getattr(self, "episode_term_means", {}).items():
+            w.add_scalar("Episode/" + k, v, epoch_num)
         if self.game_rewards.current_size > 0:
             mr, ms, ml = self.game_rewards.get_mean()[0], self.game_shaped_rewards.get_mean()[0], self.game_lengths.get_mean()[0]
             for tag, x in (("step", frame), ("iter", epoch_num), ("time", total_time)):

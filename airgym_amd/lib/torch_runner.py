@@ -61,7 +61,12 @@ class Runner:
         return agent.train()
 
     def run_play(self, args):
-        raise NotImplementedError("play/inference loop (lib/agent/players.py) is SURVEY 8(f)-2 'next'")
+        print("Started to play")
+        from airgym_amd.lib.agent.players import A2CPlayer
+        player = A2CPlayer(self.params)
+        if args.get("checkpoint"):
+            player.restore(args["checkpoint"])
+        return player.run()
 
     def run(self, args):
         if args.get("train", True) and not args.get("play", False):

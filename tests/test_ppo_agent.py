@@ -218,3 +218,24 @@ def test_data_parallel_gloo_world2():
     # full training: bit-identical replicas, whole-job frame count
     assert torch.equal(r0["trained"], r1["trained"]) and torch.equal(r0["trained_rms"], r1["trained_rms"])
     assert r0["frames"] == 2 * 2 * 32 * 4
+
+
+def test_player_loads_checkpoint_and_runs(tmp_path):
+    """lib/agent/players.py mirror: checkpoint in the reference layout -> deterministic play loop."""
+    from airgym_amd.lib.agent.players import A2CPlayer
+    torch.manual_seed(4)
+    a = A2CAgent("run", _stub_env.ppo_params(max_epochs=1))
+    a.train()
+    fn = str(tmp_path / "ck")
+    a.save(fn)
+    params = _stub_env.ppo_params()
+    params["config"]["player"] = {"deterministic": True, "games_num": 3, "max_steps": 40, "print_stats": False}
+    p = A2CPlayer(params)
+    p.restore(fn + ".pth")
+    assert torch.equal(p.model.mu.weight, a.model.mu.weight)
+    obs = torch.randn(64, 18)
+    act = p.get_action(obs)
+    assert act.shape == (64, 4) and act.abs().max() <= 1.0
+    assert torch.equal(act, p.get_action(obs))             # deterministic: mu, no sampling
+    res = p.run(print_every=10)
+    assert res["games"] >= 0 and np.isfinite(res["av_reward"])
