@@ -417,6 +417,106 @@ def gen_gae(out):
                       mb_rewards=mb_rewards, advs=advs)
 
 
+def gen_planning(out):
+    """Planning's own tensor code (airgym/envs/task/planning.py) + the depth post-processing of
+    airgym/envs/base/customized.py:399-435, called unbound on a hand-built self."""
+    import airgym.envs.task.planning as P
+    import airgym.envs.base.customized as C
+    g = torch.Generator().manual_seed(91)
+    n = 256
+    s = object.__new__(P.Planning)
+    s.num_envs, s.device, s.ctl_mode, s.max_episode_length = n, "cpu", "rate", 1600
+    rs = torch.zeros(n, 13)
+    rs[:, 0] = (torch.rand(n, generator=g) * 2 - 1) * 9.0
+    rs[:, 1] = (torch.rand(n, generator=g) * 2 - 1) * 4.4
+    rs[:, 2] = 1.5 + (torch.rand(n, generator=g) * 2 - 1) * 0.4
+    q = torch.zeros(n, 4); q[:, :3] = 0.25 * torch.randn(n, 3, generator=g); q[:, 3] = 1.0
+    rs[:, 3:7] = q / q.norm(dim=-1, keepdim=True)
+    rs[:, 7:10] = torch.randn(n, 3, generator=g)
+    rs[:, 10:13] = 0.5 * torch.randn(n, 3, generator=g)
+    s.root_states = rs.clone()
+    s.root_positions, s.root_quats = s.root_states[..., 0:3], s.root_states[..., 3:7]
+    s.root_linvels, s.root_angvels = s.root_states[..., 7:10], s.root_states[..., 10:13]
+    goal = torch.zeros(n, 3); goal[:, 0] = 8.5; goal[:, 1] = (torch.rand(n, generator=g) * 2 - 1) * 1.5; goal[:, 2] = 1.5
+    goal[0:4] = s.root_positions[0:4] + torch.tensor([[0.29, 0, 0], [0.31, 0, 0], [0.1, 0.1, 0.1], [0.2, 0.2, 0.15]])
+    s.goal_positions = goal
+    s.obs_buf = torch.zeros(n, 16)
+    s.actions_local = torch.rand(n, 4, generator=g) * 2 - 1
+    s.actions = s.actions_local
+    s.pre_actions = torch.rand(n, 4, generator=g) * 2 - 1
+    s.pre_root_positions = s.root_positions + 0.02 * torch.randn(n, 3, generator=g)
+    s.progress_buf = torch.randint(0, 1597, (n,), generator=g).long()
+    s.progress_buf[4:8] = torch.tensor([1597, 1598, 1599, 1600])
+    s.reset_buf = torch.zeros(n, dtype=torch.long)
+    s.collisions = (torch.rand(n, generator=g) < 0.1).float()
+    s.esdf_dist = torch.rand(n, generator=g) * 1.2
+    s.esdf_dist[8:10] = torch.tensor([0.2999, 0.3001])
+    P.Planning.compute_observations(s)
+    reward, reset, info = P.Planning.compute_quadcopter_reward(s)
+    d = dict(root_states=rs, goal=goal, actions=s.actions, pre_actions=s.pre_actions,
+             pre_root_positions=s.pre_root_positions, progress=s.progress_buf, collisions=s.collisions,
+             esdf_dist=s.esdf_dist, obs=s.obs_buf, reward=reward, reset=reset, related_dist=s.related_dist)
+    for k, v in info.items():
+        d["info_" + k] = v
+    out["planning_obs_reward"] = d
+
+    # ---- reset_idx with recorded draws (planning.py:63-136); 41 assets = goal ball + 40 thin obstacles
+    k, na = 64, 41
+    s2 = object.__new__(P.Planning)
+    s2.device, s2.num_envs, s2.num_assets = "cpu", k, na
+    s2.env_asset_root_states = torch.zeros(k, na, 13)
+    s2.goal_states = s2.env_asset_root_states[:, 0, :]
+    s2.root_states = torch.zeros(k, 13)
+    s2.root_quats = s2.root_states[..., 3:7]
+    s2.reset_buf = torch.zeros(k, dtype=torch.long)
+    s2.progress_buf = torch.full((k,), 9, dtype=torch.long)
+    s2.pre_actions = torch.ones(k, 4)
+    s2.prev_related_dist = torch.ones(k)
+    s2.pre_root_positions = torch.ones(k, 3)
+    s2.pre_root_angvels = torch.ones(k, 3)
+    s2.gym = types.SimpleNamespace(set_actor_root_state_tensor=lambda *a: None)
+    s2.sim = s2.root_tensor = None
+    ux, uy, uyaw = (torch.rand(k, na, 1, generator=g) for _ in range(3))
+    ugoal = torch.rand(k, 1, generator=g)
+    junk = lambda *shape: torch.rand(*shape, generator=g)
+    draws = iter([ux, uy, junk(k, na, 2), uyaw, ugoal, junk(k, 1), junk(k, 1), junk(k, 2), junk(k, 1), junk(k, 3), junk(k, 3)])
+    orig = P.torch_rand_float
+    P.torch_rand_float = lambda lo, hi, shape, device: (hi - lo) * next(draws).clone() + lo
+    try:
+        P.Planning.reset_idx(s2, torch.arange(k))
+    finally:
+        P.torch_rand_float = orig
+    out["planning_reset"] = dict(ux=ux, uy=uy, uyaw=uyaw, ugoal=ugoal, asset_states=s2.env_asset_root_states,
+                                 root_states=s2.root_states, reset_buf=s2.reset_buf, progress=s2.progress_buf,
+                                 pre_actions=s2.pre_actions, pre_root_positions=s2.pre_root_positions,
+                                 prev_related_dist=s2.prev_related_dist)
+
+    # ---- dump_images (customized.py:399-435): depth post-processing with recorded randoms
+    ne, W, H = 1, 212, 120
+    s3 = object.__new__(C.Customized)
+    s3.num_envs = ne
+    cam = -(torch.rand(ne, H, W, generator=g) * 7.0)          # IsaacGym depth tensor: negative z, [H, W]
+    cam[0, :10] = -float("inf")                                 # no-hit pixels
+    s3.camera_tensors = [cam[e] for e in range(ne)]
+    s3.full_camera_array = torch.zeros(ne, 1, W, H)
+    add = torch.randn(ne, 1, W, H, generator=g)
+    mul = torch.randn(ne, 1, W, H, generator=g)
+    ker = torch.randint(0, 256, (ne, 5, 5), generator=g).float()
+    seq_n = iter([x for e in range(ne) for x in (add[e], mul[e])])
+    seq_k = iter([ker[e] for e in range(ne)])
+    o_normal, o_randint = torch.normal, torch.randint
+    torch.normal = lambda mean, std, size=None, device=None, **kw: mean + std * next(seq_n).clone()
+    torch.randint = lambda lo, hi, size, dtype=None, **kw: next(seq_k).clone()
+    C.cv2.normalize = lambda *a, **k_: np.zeros((H, W), np.uint8)
+    C.cv2.applyColorMap = lambda *a, **k_: None
+    C.cv2.NORM_MINMAX = C.cv2.CV_8UC1 = C.cv2.COLORMAP_PLASMA = 0
+    try:
+        C.Customized.dump_images(s3)
+    finally:
+        torch.normal, torch.randint = o_normal, o_randint
+    out["planning_images"] = dict(cam=cam, add=add[:, 0], mul=mul[:, 0], kernel=ker / 256.0, image=s3.full_camera_array)
+
+
 def main():
     install_stubs()
     import airgym.envs.base.hovering as H
@@ -434,6 +534,7 @@ def main():
     gen_lemniscate(T, out)
     gen_ppo(out)
     gen_gae(out)
+    gen_planning(out)
     for name, d in out.items():
         arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
         path = os.path.join(HERE, f"{name}.npz")

@@ -171,3 +171,87 @@ def test_gae(golden):
     advs = ppo_ref.gae(t(g["fdones"]), t(g["last_values"]), t(g["mb_fdones"]), t(g["mb_values"]),
                        t(g["mb_rewards"]), 0.99, 0.95)
     assert torch.equal(advs, t(g["advs"]))
+
+
+# ----------------------------------------------------------------------------- Planning
+def test_planning_observations_reward_done(golden):
+    from oracle.planning_ref import PlanningRef
+    g = golden("planning_obs_reward")
+    n = g["root_states"].shape[0]
+    env = PlanningRef(n, "rate")
+    env.root_states = t(g["root_states"]).clone()
+    env.goal_positions = t(g["goal"]).clone()
+    env.actions = t(g["actions"]).clone()
+    env.pre_actions = t(g["pre_actions"]).clone()
+    env.pre_root_positions = t(g["pre_root_positions"]).clone()
+    env.progress_buf = t(g["progress"]).clone()
+    env.collisions = t(g["collisions"]).clone()
+    env.esdf_dist = t(g["esdf_dist"]).clone()
+    env.compute_observations()
+    assert torch.equal(env.obs_buf, t(g["obs"]))
+    assert torch.equal(env.related_dist, t(g["related_dist"]))
+    reward, reset, info = env.compute_quadcopter_reward()
+    assert torch.equal(reset, t(g["reset"])) and reset.sum() > 8 and (reset == 0).sum() > 8
+    assert torch.equal(reward, t(g["reward"]))
+    for k, v in info.items():
+        assert torch.equal(v, t(g["info_" + k])), k
+    # goal within 0.3 m -> +200 and done (rows 0, 2); just outside (row 1) -> no bonus
+    assert g["info_reach_goal_reward"][0] == 200.0 and g["info_reach_goal_reward"][1] == 0.0
+    assert list(g["info_alive_reward"][8:10]) == [-1.0, 0.0]          # esdf 0.2999 / 0.3001
+
+
+def test_planning_reset(golden):
+    from oracle.planning_ref import NUM_OBSTACLES, PlanningRef
+    g = golden("planning_reset")
+    k = g["ux"].shape[0]
+    env = PlanningRef(k, "rate")
+    env.progress_buf[:] = 9; env.pre_actions[:] = 1; env.prev_related_dist[:] = 1; env.pre_root_positions[:] = 1
+    env.reset_buf[:] = 0
+    # reference draws for 41 assets (asset 0 = goal ball, overwritten afterwards); obstacles are assets 1..40
+    u = np.concatenate([np.stack((g["ux"][:, 1:, 0], g["uy"][:, 1:, 0], g["uyaw"][:, 1:, 0]), -1).reshape(k, -1),
+                        g["ugoal"]], axis=1).astype(np.float32)
+    env.reset_idx(torch.arange(k), t(u))
+    a = g["asset_states"]
+    np.testing.assert_allclose(env.obstacles[:, :, 0].numpy(), a[:, 1:, 0], atol=1e-6)
+    np.testing.assert_allclose(env.obstacles[:, :, 1].numpy(), a[:, 1:, 1], atol=1e-6)
+    assert np.abs(a[:, 1:, 2]).max() == 0
+    # obstacle yaw: the reference stores a quaternion (0, 0, sin(yaw/2), cos(yaw/2)) up to sign
+    half = 0.5 * env.obstacles[:, :, 2].numpy()
+    qz, qw = a[:, 1:, 5], a[:, 1:, 6]
+    sgn = np.sign(qw * np.cos(half) + qz * np.sin(half))
+    np.testing.assert_allclose(np.sin(half), sgn * qz, atol=2e-6)
+    np.testing.assert_allclose(np.cos(half), sgn * qw, atol=2e-6)
+    np.testing.assert_allclose(env.goal_positions.numpy(), a[:, 0, 0:3], atol=1e-6)
+    np.testing.assert_allclose(env.root_states.numpy(), g["root_states"], atol=1e-6)
+    for name, ref in (("reset_buf", "reset_buf"), ("progress_buf", "progress"), ("pre_actions", "pre_actions"),
+                      ("pre_root_positions", "pre_root_positions"), ("prev_related_dist", "prev_related_dist")):
+        assert torch.equal(getattr(env, name), t(g[ref])), name
+
+
+def test_planning_depth_post_processing(golden):
+    from oracle.planning_ref import post_process_depth
+    g = golden("planning_images")
+    cam = -t(g["cam"])                                   # the reference negates IsaacGym's depth tensor
+    for e in range(cam.shape[0]):
+        img = post_process_depth(cam[e], t(g["add"][e]), t(g["mul"][e]), t(g["kernel"][e]))
+        assert torch.equal(img, t(g["image"][e]))
+
+
+def test_planning_scene_and_raycast_sanity():
+    """The ray-caster is the build's spec (IsaacGym's rasteriser is closed): geometric self-checks."""
+    from oracle import planning_ref as P
+    tab = P.load_variant_table()
+    assert tab.shape == (100, 8) and np.allclose(np.linalg.norm(tab[:, 3:6], axis=1), 1.0, atol=1e-6)
+    # one vertical cylinder 2 m ahead of a level camera at the origin height 1.5
+    centre = torch.tensor([[2.15, 0.0, 1.5]]); axis = torch.tensor([[0.0, 0.0, 1.0]])
+    r = torch.tensor([0.1]); h = torch.tensor([2.0])
+    img = P.render_depth_one(torch.tensor([0.0, 0.0, 1.4]), torch.tensor([0.0, 0, 0, 1]), centre, axis, r, h,
+                             torch.tensor([100.0, 0, 0]))
+    c = img[P.CAM_H // 2, P.CAM_W // 2].item()
+    assert abs(c - 1.9) < 5e-3                           # camera sits 0.15 m ahead of the body: 2.15 - 0.15 - 0.1
+    assert torch.isinf(img[P.CAM_H // 2, 5])             # far left column looks past the cylinder (and past 5 m)
+    assert img[-1, P.CAM_W // 2] < 4.0                   # bottom row sees the ground plane
+    d = P.point_capped_cylinder_distance(torch.tensor([[2.15, 0.3, 1.5], [2.15, 0.0, 3.8]]),
+                                         centre[None].expand(2, 1, 3), axis[None].expand(2, 1, 3), r[None].expand(2, 1),
+                                         h[None].expand(2, 1))
+    assert abs(d[0, 0].item() - 0.2) < 1e-6 and abs(d[1, 0].item() - 0.3) < 1e-6
