@@ -14,11 +14,11 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libairgym_hip.so")
 
-AG_TASKS = {"hovering": 0, "tracking": 1}
+AG_TASKS = {"hovering": 0, "tracking": 1, "planning": 2}
 AG_CTL_MODES = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
 AG_FLAG_REWARD_TERMS = 1 << 0
 AG_FLAG_OBS_NOISE_OFF = 1 << 1
-AG_NUM_REWARD_TERMS = 9
+AG_NUM_REWARD_TERMS = 11
 
 AG_ERR_UNKNOWN_TASK = -2
 AG_ERR_UNKNOWN_CTL = -3
@@ -29,6 +29,8 @@ REWARD_TERM_NAMES = {
                  "ups_reward", "spin_reward", "yaw_reward", "reward"],
     "tracking": ["dist_norm", "dist_reward", "yaw_reward", "spin_reward", "continous_action_reward", "thrust_reward",
                  "effort_reward", "ups_reward", "reward"],
+    "planning": ["continous_action_reward", "heading_reward", "speed_reward", "forward_reward", "alive_reward",
+                 "ups_reward", "z_reward", "esdf_reward", "thrust_reward", "reach_goal_reward", "reward"],
 }
 
 
@@ -66,6 +68,14 @@ class AgBuffers(ctypes.Structure):
     ]
 
 
+class AgPlanningBuffers(ctypes.Structure):
+    _fields_ = [("image_dev", ctypes.c_void_p), ("collisions_dev", ctypes.c_void_p)]
+
+
+class AgPlanningStateView(ctypes.Structure):
+    _fields_ = [("obstacles_dev", ctypes.c_void_p), ("goal_dev", ctypes.c_void_p), ("extra_dev", ctypes.c_void_p)]
+
+
 class AgStateView(ctypes.Structure):
     _fields_ = [
         ("root_states_dev", ctypes.c_void_p),
@@ -100,6 +110,12 @@ SYMBOLS = [
     ("ag_set_tick", ctypes.c_int, [_P, ctypes.c_uint64]),
     ("ag_set_launch_params", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     ("ag_debug_touch", ctypes.c_int, [_P, _P, _P]),
+    ("ag_planning_set_obstacle_table", ctypes.c_int, [_P, _P, ctypes.c_int]),
+    ("ag_planning_get_buffers", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningBuffers)]),
+    ("ag_planning_get_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),
+    ("ag_planning_set_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),
+    ("ag_planning_step_with_uniforms", ctypes.c_int, [_P, _P, _P, _P]),
+    ("ag_planning_render_now", ctypes.c_int, [_P, _P]),
     ("ag_elu_bwd_bias_rows_per_block", ctypes.c_int, []),
     ("ag_elu_bwd_bias", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_adam_clip_step", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int] + [ctypes.c_float] * 8 + [_P]),

@@ -13,6 +13,7 @@
 
 #include "../../include/airgym_hip.h"
 #include "kernel_args.hpp"
+#include "planning_math.hpp"
 
 namespace {
 
@@ -35,10 +36,11 @@ constexpr int kPad = 256;
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Layout {
-    size_t S[4], C[4], PA, PA4, obs, rew, reset, timeout, mask, reset_ids, reset_count, tick, terms[9], cmd, total;
+    size_t S[4], C[4], PA, PA4, obs, rew, reset, timeout, mask, reset_ids, reset_count, tick, terms[11], cmd, total;
+    size_t OB, GOAL, PRP, image, collisions, table;   // planning only
 };
 
-Layout make_layout(int n, int num_obs, bool terms) {
+Layout make_layout(int n, int num_obs, bool terms, int task = 0) {
     const size_t np = align_up((size_t)n, kPad);
     Layout L;
     size_t off = 0;
@@ -55,8 +57,18 @@ Layout make_layout(int n, int num_obs, bool terms) {
     L.reset_ids = take(np * 4);
     L.reset_count = take(256);
     L.tick = take(256);
-    for (int t = 0; t < 9; ++t) L.terms[t] = terms ? take(np * 4) : 0;
-    L.cmd = terms ? take(np * 16) : 0;
+    const int nterms = (task == AG_TASK_PLANNING) ? 11 : 9;
+    for (int t = 0; t < 11; ++t) L.terms[t] = (terms && t < nterms) ? take(np * 4) : 0;
+    L.cmd = (terms && task != AG_TASK_PLANNING) ? take(np * 16) : 0;
+    L.OB = L.GOAL = L.PRP = L.image = L.collisions = L.table = 0;
+    if (task == AG_TASK_PLANNING) {
+        L.OB = take((size_t)ag::kNumObst * np * 16);
+        L.GOAL = take(np * 16);
+        L.PRP = take(np * 16);
+        L.collisions = take(np * 4);
+        L.table = take((size_t)ag::kNumVariants * 8 * 4);
+        L.image = take((size_t)n * ag::kCamPix * 4);
+    }
     L.total = off;
     return L;
 }
@@ -75,6 +87,10 @@ struct ag_env {
     bool owns_arena;
     Layout L;
     ag::KArgs k;       // pointers + StepParams template for launches
+    ag::PlanArgs pa;   // planning extras
+    bool table_set;    // planning: obstacle variant table uploaded
+    uint64_t counter;  // planning: pre_physics_step counter driving the camera schedule (planning.py:153-156)
+    int force_render;  // planning: render on the next step regardless of the schedule
     uint64_t tick;     // host mirror of the device tick (exact unless a captured graph is being replayed)
     int parity;        // which of the two device tick slots the next launch reads
     int block;
@@ -220,6 +236,37 @@ __global__ __launch_bounds__(64) void touch_kernel(ag::KArgs k, const float* act
     }
 }
 
+__global__ void planning_get_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_planning_state_view v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k.n) return;
+    if (v.obstacles_dev) {
+        for (int j = 0; j < ag::kNumObst; ++j) {
+            const float4 ob = pa.OB[(size_t)j * pa.n_pad + i];
+            float* o = v.obstacles_dev + ((size_t)i * ag::kNumObst + j) * 4;
+            o[0] = ob.x; o[1] = ob.y; o[2] = ob.z; o[3] = (float)__float_as_int(ob.w);
+        }
+    }
+    const float4 g = pa.GOAL[i], e = pa.PRP[i];
+    if (v.goal_dev) { float* o = v.goal_dev + (size_t)i * 3; o[0] = g.x; o[1] = g.y; o[2] = g.z; }
+    if (v.extra_dev) { float* o = v.extra_dev + (size_t)i * 5; o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = e.w; o[4] = g.w; }
+}
+
+__global__ void planning_set_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_planning_state_view v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k.n) return;
+    if (v.obstacles_dev) {
+        for (int j = 0; j < ag::kNumObst; ++j) {
+            const float* o = v.obstacles_dev + ((size_t)i * ag::kNumObst + j) * 4;
+            pa.OB[(size_t)j * pa.n_pad + i] = make_float4(o[0], o[1], o[2], __int_as_float((int)o[3]));
+        }
+    }
+    float4 g = pa.GOAL[i], e = pa.PRP[i];
+    if (v.goal_dev) { const float* o = v.goal_dev + (size_t)i * 3; g.x = o[0]; g.y = o[1]; g.z = o[2]; }
+    if (v.extra_dev) { const float* o = v.extra_dev + (size_t)i * 5; e = make_float4(o[0], o[1], o[2], o[3]); g.w = o[4]; }
+    pa.GOAL[i] = g;
+    pa.PRP[i] = e;
+}
+
 void fill_params(ag_env* h) {
     h->k.P = ag::make_step_params(h->cfg.task, h->cfg.dt, h->cfg.max_episode_length, h->cfg.target_state, h->cfg.seed,
                                   h->cfg.env_id_offset, (h->cfg.flags & AG_FLAG_OBS_NOISE_OFF) != 0);
@@ -230,10 +277,12 @@ int validate(const ag_config* cfg) {
     if (cfg->struct_size != sizeof(ag_config))
         return fail(AG_ERR_INVALID_ARG, "ag_config.struct_size mismatch (ABI): got " + std::to_string(cfg->struct_size) +
                                             ", expected " + std::to_string(sizeof(ag_config)));
-    if (cfg->task != AG_TASK_HOVERING && cfg->task != AG_TASK_TRACKING)
+    if (cfg->task != AG_TASK_HOVERING && cfg->task != AG_TASK_TRACKING && cfg->task != AG_TASK_PLANNING)
         return fail(AG_ERR_UNKNOWN_TASK, "Task with id " + std::to_string(cfg->task) + " was not registered");
     if (cfg->ctl_mode < AG_CTL_POS || cfg->ctl_mode > AG_CTL_PROP)
         return fail(AG_ERR_UNKNOWN_CTL, "unknown ctl_mode " + std::to_string(cfg->ctl_mode) + " (expected pos|vel|atti|rate|prop)");
+    if (cfg->task == AG_TASK_PLANNING && cfg->ctl_mode == AG_CTL_ATTI)
+        return fail(AG_ERR_UNSUPPORTED, "planning has 4-dim action observations (planning.py:214): ctl_mode atti (5 actions) is not supported");
     if (cfg->num_envs <= 0) return fail(AG_ERR_INVALID_ARG, "num_envs must be > 0");
     if (!(cfg->dt > 0.0)) return fail(AG_ERR_INVALID_ARG, "dt must be > 0");
     return AG_OK;
@@ -260,7 +309,7 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
     if (!actions) return fail(AG_ERR_INVALID_ARG, "actions_dev is NULL");
     if (h->num_actions == 4 && ((uintptr_t)actions & 15)) return fail(AG_ERR_INVALID_ARG, "actions_dev must be 16-byte aligned");
     if (obs_out && ((uintptr_t)obs_out & 15)) return fail(AG_ERR_INVALID_ARG, "obs_out_dev must be 16-byte aligned");
-    if ((noise == nullptr) != (uniforms == nullptr))
+    if (h->cfg.task != AG_TASK_PLANNING && (noise == nullptr) != (uniforms == nullptr))
         return fail(AG_ERR_INVALID_ARG, "noise_dev and reset_uniforms_dev must be given together");
     int rc = ensure_device(h);
     if (rc) return rc;
@@ -269,6 +318,31 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
     if (obs_out) k.obs = obs_out;
     if (rew_out) k.rew = rew_out;
     if (reset_out) k.reset = (long long*)reset_out;
+    if (h->cfg.task == AG_TASK_PLANNING) {
+        if (!h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
+        if (noise != nullptr) return fail(AG_ERR_UNSUPPORTED, "planning: use ag_planning_step_with_uniforms");
+        ag::PlanArgs pa = h->pa;
+        pa.ext_uniforms = uniforms;
+        h->counter += 1;
+        const bool render = h->force_render || (h->counter % 4 == 0);   // cam_dt / dt = 4, planning.py:153-156
+        h->force_render = 0;
+        // every kernel of this step reads the same tick; only the last one publishes tick + 1
+        uint32_t* slots = (uint32_t*)(h->arena + h->L.tick);
+        k.tick_in = slots + h->parity;
+        k.tick_out = slots + (h->parity ^ 1);
+        hipError_t e;
+        if (render) {
+            e = ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 1, (hipStream_t)stream);
+            if (e == hipSuccess) e = ag::launch_planning_render(k, pa, (hipStream_t)stream);
+            if (e == hipSuccess) e = ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 2, (hipStream_t)stream);
+        } else {
+            e = ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 0, (hipStream_t)stream);
+        }
+        if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("planning step launch: ") + hipGetErrorString(e));
+        h->parity ^= 1;
+        h->tick += 1;
+        return AG_OK;
+    }
     k.ext_noise = noise;
     k.ext_uniforms = uniforms;
     bind_tick(h, k);
@@ -288,6 +362,7 @@ const char* ag_last_error(void) { return g_last_error.c_str(); }
 int ag_num_obs(int task) {
     if (task == AG_TASK_HOVERING) return 18;  // hovering_config.py:14
     if (task == AG_TASK_TRACKING) return 48;  // tracking_config.py:13
+    if (task == AG_TASK_PLANNING) return 16;  // planning_config.py:13
     return fail(AG_ERR_UNKNOWN_TASK, "unknown task");
 }
 
@@ -298,14 +373,15 @@ int ag_num_actions(int ctl_mode) {
 
 int ag_default_episode_length(int task, double dt) {
     if (!(dt > 0.0)) return fail(AG_ERR_INVALID_ARG, "dt must be > 0");
-    const double secs = (task == AG_TASK_TRACKING) ? 36.0 : 24.0;  // tracking_config.py:17, hovering_config.py:17
-    if (task != AG_TASK_HOVERING && task != AG_TASK_TRACKING) return fail(AG_ERR_UNKNOWN_TASK, "unknown task");
+    // tracking_config.py:17, hovering_config.py:17, planning_config.py:17
+    const double secs = (task == AG_TASK_TRACKING) ? 36.0 : ((task == AG_TASK_PLANNING) ? 16.0 : 24.0);
+    if (task < AG_TASK_HOVERING || task > AG_TASK_PLANNING) return fail(AG_ERR_UNKNOWN_TASK, "unknown task");
     return (int)(secs / dt);  // int(episode_length_s / dt), hovering.py:48
 }
 
 size_t ag_arena_bytes(const ag_config* cfg) {
     if (validate(cfg) != AG_OK) return 0;
-    return make_layout(cfg->num_envs, ag_num_obs(cfg->task), (cfg->flags & AG_FLAG_REWARD_TERMS) != 0).total;
+    return make_layout(cfg->num_envs, ag_num_obs(cfg->task), (cfg->flags & AG_FLAG_REWARD_TERMS) != 0, cfg->task).total;
 }
 
 int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
@@ -327,7 +403,7 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     if (h->cfg.max_episode_length <= 0) h->cfg.max_episode_length = ag_default_episode_length(cfg->task, cfg->dt);
     h->n_pad = (int)align_up((size_t)cfg->num_envs, kPad);
     const bool terms = (cfg->flags & AG_FLAG_REWARD_TERMS) != 0;
-    h->L = make_layout(cfg->num_envs, h->num_obs, terms);
+    h->L = make_layout(cfg->num_envs, h->num_obs, terms, cfg->task);
     h->owns_arena = (arena_dev == nullptr);
     if (h->owns_arena) {
         void* p = nullptr;
@@ -351,9 +427,25 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     k.reset = (long long*)(h->arena + h->L.reset);
     k.timeout = (uint8_t*)(h->arena + h->L.timeout);
     k.mask = (unsigned long long*)(h->arena + h->L.mask);
-    if (terms) {
+    const bool planning = (cfg->task == AG_TASK_PLANNING);
+    if (terms && !planning) {
         for (int t = 0; t < 9; ++t) k.terms[t] = (float*)(h->arena + h->L.terms[t]);
         k.cmd = (float4*)(h->arena + h->L.cmd);
+    }
+    memset(&h->pa, 0, sizeof(h->pa));
+    h->table_set = false;
+    h->counter = 0;
+    h->force_render = 0;
+    if (planning) {
+        ag::PlanArgs& pa = h->pa;
+        pa.OB = (float4*)(h->arena + h->L.OB);
+        pa.GOAL = (float4*)(h->arena + h->L.GOAL);
+        pa.PRP = (float4*)(h->arena + h->L.PRP);
+        pa.image = (float*)(h->arena + h->L.image);
+        pa.collisions = (float*)(h->arena + h->L.collisions);
+        pa.table = (const float*)(h->arena + h->L.table);
+        pa.n_pad = h->n_pad;
+        if (terms) for (int t = 0; t < 11; ++t) pa.terms[t] = (float*)(h->arena + h->L.terms[t]);
     }
     k.n = cfg->num_envs;
     fill_params(h);
@@ -365,7 +457,8 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     hipError_t e = hipMemsetAsync(h->arena, 0, h->L.total, 0);
     if (e == hipSuccess) {
         *out = h;
-        rc = ag_reset_all(h, nullptr);
+        // planning needs its obstacle table first: the caller runs ag_planning_set_obstacle_table + ag_reset_all
+        rc = planning ? AG_OK : ag_reset_all(h, nullptr);
         if (rc == AG_OK) e = hipStreamSynchronize(0);
     }
     if (e != hipSuccess || rc != AG_OK) {
@@ -390,6 +483,12 @@ int ag_reset_all(ag_handle h, void* stream) {
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
+    if (h->cfg.task == AG_TASK_PLANNING) {
+        if (!h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
+        bind_tick(h, k);
+        AG_HIP_CHECK(ag::launch_planning_reset_all(k, h->pa, h->num_actions, (hipStream_t)stream));
+        return AG_OK;
+    }
     bind_tick(h, k);
     hipLaunchKernelGGL(reset_all_kernel, dim3(h->n_pad / 256), dim3(256), 0, (hipStream_t)stream, k, h->n_pad,
                        h->num_actions, h->num_obs);
@@ -426,7 +525,8 @@ int ag_get_buffers(ag_handle h, ag_buffers* out) {
     out->reset_mask_dev = (uint64_t*)h->k.mask;
     out->reset_ids_dev = (int32_t*)(h->arena + h->L.reset_ids);
     out->reset_count_dev = (int32_t*)(h->arena + h->L.reset_count);
-    for (int t = 0; t < 9; ++t) out->reward_terms_dev[t] = h->k.terms[t];
+    for (int t = 0; t < 11; ++t)
+        out->reward_terms_dev[t] = (h->cfg.task == AG_TASK_PLANNING) ? h->pa.terms[t] : (t < 9 ? h->k.terms[t] : nullptr);
     out->cmd_thrusts_dev = (float*)h->k.cmd;
     return AG_OK;
 }
@@ -479,6 +579,55 @@ int ag_set_tick(ag_handle h, uint64_t tick) {
     AG_HIP_CHECK(hipDeviceSynchronize());
     AG_HIP_CHECK(hipMemcpy(h->arena + h->L.tick, t, sizeof(t), hipMemcpyHostToDevice));
     h->tick = tick;
+    return AG_OK;
+}
+
+int ag_planning_set_obstacle_table(ag_handle h, const float* table_host, int n_variants) {
+    if (!h || !table_host) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    if (h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    if (n_variants != ag::kNumVariants) return fail(AG_ERR_INVALID_ARG, "the obstacle table must have 100 rows of 8 floats");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    AG_HIP_CHECK(hipMemcpy(h->arena + h->L.table, table_host, (size_t)n_variants * 8 * sizeof(float), hipMemcpyHostToDevice));
+    h->table_set = true;
+    return AG_OK;
+}
+
+int ag_planning_get_buffers(ag_handle h, ag_planning_buffers* out) {
+    if (!h || !out) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    if (h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    out->image_dev = h->pa.image;
+    out->collisions_dev = h->pa.collisions;
+    return AG_OK;
+}
+
+int ag_planning_get_state(ag_handle h, const ag_planning_state_view* view, void* stream) {
+    if (!h || !view) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    if (h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    hipLaunchKernelGGL(planning_get_state_kernel, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       h->k, h->pa, *view);
+    AG_HIP_CHECK(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_planning_set_state(ag_handle h, const ag_planning_state_view* view, void* stream) {
+    if (!h || !view) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    if (h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    hipLaunchKernelGGL(planning_set_state_kernel, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       h->k, h->pa, *view);
+    AG_HIP_CHECK(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_planning_step_with_uniforms(ag_handle h, const float* actions_dev, const float* reset_uniforms_dev, void* stream) {
+    if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    return do_step(h, actions_dev, nullptr, nullptr, nullptr, nullptr, reset_uniforms_dev, stream);
+}
+
+int ag_planning_render_now(ag_handle h, void* stream) {
+    (void)stream;
+    if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    h->force_render = 1;
     return AG_OK;
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 12 translation units compiled in parallel).
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 13 translation units compiled in parallel).
 
     python airgym_amd/csrc/build.py [--force] [--jobs N]
 
@@ -23,7 +23,7 @@ ARCH = "gfx950"
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
-HEADERS = ["env_math.hpp", "kernel_args.hpp", os.path.join("..", "..", "include", "airgym_hip.h")]
+HEADERS = ["env_math.hpp", "planning_math.hpp", "kernel_args.hpp", os.path.join("..", "..", "include", "airgym_hip.h")]
 
 
 def _newer(target, deps):
@@ -40,6 +40,7 @@ def units():
             out.append((os.path.join(OBJ_DIR, f"step_{task}_{ctl}.o"), "step_kernel.hip", [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}"]))
     out.append((os.path.join(OBJ_DIR, "airgym_hip.o"), "airgym_hip.hip", []))
     out.append((os.path.join(OBJ_DIR, "ppo_kernels.o"), "ppo_kernels.hip", []))
+    out.append((os.path.join(OBJ_DIR, "planning_kernel.o"), "planning_kernel.hip", []))
     return out
 
 

@@ -41,6 +41,23 @@ struct KArgs {
     StepParams P;
 };
 
+// Planning-task extras (airgym_amd/csrc/planning_kernel.hip)
+struct PlanArgs {
+    float4* OB;                  // [40][n_pad] obstacle root pose: (x, y, yaw, variant index as int bits)
+    float4* GOAL;                // [n_pad] (goal xyz, prev_related_dist)
+    float4* PRP;                 // [n_pad] (pre_root_positions xyz, esdf_dist)
+    float* image;                // [n, 212*120]  == full_camera_array [n, 1, 212, 120]
+    float* collisions;           // [n]
+    float* terms[11];            // item_reward_info arrays or null
+    const float* table;          // [100, 8] obstacle variants (centre3, axis3, radius, half length)
+    const float* ext_uniforms;   // [n, 121] or null (parity mode)
+    int n_pad;
+};
+
+hipError_t launch_planning_step(const KArgs& k, const PlanArgs& pa, int ctl, int phase, hipStream_t st);
+hipError_t launch_planning_render(const KArgs& k, const PlanArgs& pa, hipStream_t st);
+hipError_t launch_planning_reset_all(const KArgs& k, const PlanArgs& pa, int num_actions, hipStream_t st);
+
 typedef hipError_t (*StepLauncher)(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
 
 // defined in step_kernel.hip compiled with -DAG_TASK=<t> -DAG_CTL=<c>

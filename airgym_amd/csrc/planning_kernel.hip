@@ -1,0 +1,339 @@
+// planning_kernel.hip - gfx950 kernels of the Planning task.
+//
+//   planning_step_kernel<CTL, PHASE>   one env per lane.  PHASE_PHYS = pre_physics_step + simulate
+//                                      (customized.py:216-298, planning.py:146-151); PHASE_POST = progress++,
+//                                      collision check, observations, reward/termination, in-place reset
+//                                      (planning.py:158-183); PHASE_BOTH = both in one launch (steps without a
+//                                      camera render, 3 of every 4).
+//   planning_render_kernel             one WORKGROUP per env: ray-cast the 212x120 depth image into LDS, then the
+//                                      reference's post-processing (customized.py:399-435: clip/normalise,
+//                                      additive N(0,.1), multiplicative N(1,.3), random 5x5 kernel) and the min
+//                                      pixel ("esdf_dist", planning.py:162-163).  The whole image (101 760 B)
+//                                      lives in the CU's 160 KB LDS: it is written to HBM exactly once.
+#include <hip/hip_runtime.h>
+
+#include "kernel_args.hpp"
+#include "planning_math.hpp"
+
+namespace ag {
+
+enum : int { PHASE_BOTH = 0, PHASE_PHYS = 1, PHASE_POST = 2 };
+
+__device__ __forceinline__ float int_as_f(int v) { return __int_as_float(v); }
+
+template <int CTL, int PHASE>
+__global__ __launch_bounds__(64) void planning_step_kernel(const KArgs k, const PlanArgs pa) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    __shared__ float tab[kNumVariants * 8];
+    __shared__ float tile[64 * (kPlanNumObs + 1)];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 64 + tid;
+    const bool active = i < k.n;
+    if (PHASE != PHASE_PHYS) {
+        for (int t = tid; t < kNumVariants * 8; t += 64) tab[t] = pa.table[t];
+        __syncthreads();
+    }
+    StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (PHASE != PHASE_PHYS && blockIdx.x == 0 && tid == 0) *k.tick_out = P.tick + 1u;
+    const uint32_t env_global = P.env_id_offset + (uint32_t)i;
+
+    EnvState s;
+    CtlState c;
+    load_env(k, i, s);
+    load_ctl<CTL>(k, i, c);
+    float raw_a[A];
+    if (active) {
+        if (A == 4) {
+            const float4 a = reinterpret_cast<const float4*>(k.actions)[i];
+            raw_a[0] = a.x; raw_a[1] = a.y; raw_a[2] = a.z; raw_a[3] = a.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < A; ++j) raw_a[j] = k.actions[(size_t)i * A + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < A; ++j) raw_a[j] = 0.0f;
+    }
+
+    if (PHASE != PHASE_POST) planning_physics<CTL>(s, c, raw_a, P);
+
+    if (PHASE == PHASE_PHYS) {
+        store_env(k, i, s);
+        store_ctl<CTL>(k, i, c);
+        return;
+    }
+
+    // ---- POST
+    float pre_a[A];
+    {
+        const float4 p4 = k.PA[i];
+        pre_a[0] = p4.x; pre_a[1] = p4.y; pre_a[2] = p4.z; pre_a[3] = p4.w;
+        if (A == 5) pre_a[A - 1] = k.PA4[i];
+    }
+    PlanExtra x;
+    {
+        const float4 g = pa.GOAL[i], e = pa.PRP[i];
+        x.goal = V3{g.x, g.y, g.z}; x.prev_related_dist = g.w;
+        x.pre_pos = V3{e.x, e.y, e.z}; x.esdf = e.w;
+    }
+    // check_collisions (customized.py:393-397 -> analytic): robot sphere vs the 40 capped cylinders and the ground
+    int collided = (s.p.z <= kRobotRadius) ? 1 : 0;
+    for (int j = 0; j < kNumObst; ++j) {
+        const float4 ob = pa.OB[(size_t)j * pa.n_pad + i];
+        const float dx = s.p.x - ob.x, dy = s.p.y - ob.y;
+        if (dx * dx + dy * dy < 9.0f) {   // every cylinder stays within 2.7 m (xy) of its root: farther ones cannot touch
+            const Cyl w = world_cylinder(ob.x, ob.y, ob.z, &tab[(__float_as_int(ob.w) % kNumVariants) * 8]);
+            if (point_cylinder_distance(s.p, w) <= kRobotRadius) collided = 1;
+        }
+    }
+    float obs[kPlanNumObs];
+    PlanOut o;
+    planning_post<CTL>(s, x, pre_a, raw_a, collided, P, obs, o);
+    if (o.done) {
+        float u[124];
+        if (pa.ext_uniforms != nullptr) {
+            for (int j = 0; j < kPlanResetUniforms; ++j) u[j] = active ? pa.ext_uniforms[(size_t)i * kPlanResetUniforms + j] : 0.5f;
+        } else {
+            planning_reset_uniforms(P, env_global, u);
+        }
+        float* ob = reinterpret_cast<float*>(pa.OB) + (size_t)i * 4;
+        planning_reset(s, c, x, pre_a, A, u, ob, (size_t)pa.n_pad * 4);
+    }
+    x.prev_related_dist = o.related_dist;   // planning.py:183 runs after the optional reset, for every env
+    o.timeout = (s.progress > P.max_episode_length) ? 1 : 0;
+
+    store_env(k, i, s);
+    store_ctl<CTL>(k, i, c);
+    k.PA[i] = make_float4(pre_a[0], pre_a[1], pre_a[2], pre_a[3]);
+    if (A == 5) k.PA4[i] = pre_a[A - 1];
+    pa.GOAL[i] = make_float4(x.goal.x, x.goal.y, x.goal.z, x.prev_related_dist);
+    pa.PRP[i] = make_float4(x.pre_pos.x, x.pre_pos.y, x.pre_pos.z, x.esdf);
+    const unsigned long long ballot = __ballot(active && o.done);
+    if (active) {
+        k.rew[i] = o.rew;
+        k.reset[i] = (long long)o.done;
+        k.timeout[i] = (uint8_t)o.timeout;
+        pa.collisions[i] = (float)collided;
+        if (tid == 0) k.mask[i >> 6] = ballot;
+        if (pa.terms[0] != nullptr) {
+#pragma unroll
+            for (int t = 0; t < kPlanNumTerms; ++t) pa.terms[t][i] = o.terms[t];
+        }
+    }
+    // obs rows [n,16]: stage through LDS, write 16-byte-per-lane contiguous lines
+    constexpr int ST = kPlanNumObs + 1;
+#pragma unroll
+    for (int j = 0; j < kPlanNumObs; ++j) tile[tid * ST + j] = obs[j];
+    __syncthreads();
+    const int env0 = blockIdx.x * 64;
+    const int valid = min(64, k.n - env0) * kPlanNumObs;
+    float* out = k.obs + (size_t)env0 * kPlanNumObs;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int m = tid + it * 64;          // 64*16/4 = 256 float4
+        const int e = 4 * m;
+        if (e + 3 < valid) {
+            const int row = e >> 4, col = e & 15;
+            reinterpret_cast<float4*>(out)[m] = make_float4(tile[row * ST + col], tile[row * ST + col + 1],
+                                                            tile[row * ST + col + 2], tile[row * ST + col + 3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRenderThreads = 1024;
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_down(v, off, 64);
+        v = is_max ? fmaxf(v, o) : fminf(v, o);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < kRenderThreads / 64; ++w) r = is_max ? fmaxf(r, red[w]) : fminf(r, red[w]);
+    return r;
+}
+
+__global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const KArgs k, const PlanArgs pa) {
+    extern __shared__ float lds[];
+    float* img = lds;                                   // [kCamW][kCamH]
+    Cyl* cyl = reinterpret_cast<Cyl*>(lds + kCamPix);   // [40]
+    float* red = lds + kCamPix + kNumObst * 8;          // [16]
+    float* ker = red + 16;                              // [25]
+    int* ncand = reinterpret_cast<int*>(ker + 25);
+    const int env = blockIdx.x;
+    const int tid = threadIdx.x;
+    StepParams P = k.P;
+    P.tick = *k.tick_in;
+    const uint32_t env_global = P.env_id_offset + (uint32_t)env;
+    EnvState s;
+    load_env(k, env, s);
+    const Camera cam = make_camera(s.p, s.q);
+    const float4 g4 = pa.GOAL[env];
+    const V3 goal{g4.x, g4.y, g4.z};
+    if (tid == 0) *ncand = 0;
+    __syncthreads();
+    if (tid < kNumObst) {
+        const float4 ob = pa.OB[(size_t)tid * pa.n_pad + env];
+        // a cylinder farther than far plane + its own extent from the camera cannot be seen: skip it for every pixel
+        const float dx = ob.x - cam.o.x, dy = ob.y - cam.o.y;
+        if (dx * dx + dy * dy < (kCamFar + 2.7f) * (kCamFar + 2.7f)) {
+            const int slot = atomicAdd(ncand, 1);
+            cyl[slot] = world_cylinder(ob.x, ob.y, ob.z, pa.table + (__float_as_int(ob.w) % kNumVariants) * 8);
+        }
+    }
+    if (tid < 25) {   // random 5x5 "blur" kernel: randint(0, 256) / 256, customized.py:417-419
+        const U4 r = philox4x32_10(env_global, P.tick, STREAM_IMG_KERNEL, (uint32_t)(tid >> 2), P.key0, P.key1);
+        const uint32_t w = (tid & 3) == 0 ? r.x : ((tid & 3) == 1 ? r.y : ((tid & 3) == 2 ? r.z : r.w));
+        ker[tid] = (float)(w >> 24) / 256.0f;
+    }
+    __syncthreads();
+    const int n = *ncand;
+    // ---- pass 1: ray-cast, clip to 4.5 m, normalise (customized.py:402-404); index p = u * H + v ([W][H] layout)
+    float vmax = 0.0f;
+    for (int p = tid; p < kCamPix; p += kRenderThreads) {
+        const int u = p / kCamH, v = p - u * kCamH;
+        float d = depth_pixel(cam, pixel_direction(cam, u, v), cyl, n, goal);
+        d = d > 4.5f ? 4.5f : d;
+        d = fminf(fmaxf(d, 0.0f), 4.5f) / 4.5f;
+        img[p] = d;
+        vmax = fmaxf(vmax, d);
+    }
+    float mx = block_reduce(vmax, red, true);
+    // ---- pass 2: additive N(0, 0.1), clamp to [0, max] (customized.py:406-409); 4 pixels per Philox block
+    vmax = 0.0f;
+    for (int b = tid; b < kCamPix / 4; b += kRenderThreads) {
+        const U4 r = philox4x32_10(env_global, P.tick, STREAM_IMG_ADD, (uint32_t)b, P.key0, P.key1);
+        float z[4];
+        box_muller(r.x, r.y, z[0], z[1]);
+        box_muller(r.z, r.w, z[2], z[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = fminf(fmaxf(img[4 * b + q] + (0.0f + 0.1f * z[q]), 0.0f), mx);
+            img[4 * b + q] = d;
+            vmax = fmaxf(vmax, d);
+        }
+    }
+    mx = block_reduce(vmax, red, true);
+    // ---- pass 3: multiplicative N(1, 0.3), clamp to [0, max] (customized.py:411-414)
+    for (int b = tid; b < kCamPix / 4; b += kRenderThreads) {
+        const U4 r = philox4x32_10(env_global, P.tick, STREAM_IMG_MUL, (uint32_t)b, P.key0, P.key1);
+        float z[4];
+        box_muller(r.x, r.y, z[0], z[1]);
+        box_muller(r.z, r.w, z[2], z[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) img[4 * b + q] = fminf(fmaxf(img[4 * b + q] * (1.0f + 0.3f * z[q]), 0.0f), mx);
+    }
+    __syncthreads();
+    // ---- pass 4: 5x5 cross-correlation with zero padding (F.conv2d, customized.py:416-424), min pixel
+    float vmin = kInf;
+    float* out = pa.image + (size_t)env * kCamPix;
+    for (int p = tid; p < kCamPix; p += kRenderThreads) {
+        const int u = p / kCamH, v = p - u * kCamH;
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            const int uu = u + a - 2;
+            if (uu < 0 || uu >= kCamW) continue;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const int vv = v + b - 2;
+                if (vv >= 0 && vv < kCamH) acc += ker[a * 5 + b] * img[uu * kCamH + vv];
+            }
+        }
+        out[p] = acc;
+        vmin = fminf(vmin, acc);
+    }
+    const float mn = block_reduce(vmin, red, false);
+    if (tid == 0) {
+        float4 e = pa.PRP[env];
+        e.w = mn;
+        pa.PRP[env] = e;
+    }
+}
+
+__global__ void planning_reset_all_kernel(const KArgs k, const PlanArgs pa, int num_actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pa.n_pad) return;
+    StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (i == 0) *k.tick_out = P.tick + 1u;
+    const uint32_t env_global = P.env_id_offset + (uint32_t)i;
+    // obstacle variants: drawn once per env from the counter RNG, fixed for the env's lifetime
+    for (int b = 0; b < kNumObst / 4; ++b) {
+        const U4 r = philox4x32_10(env_global, 0xFFFFFFFFu, STREAM_VARIANT, (uint32_t)b, P.key0, P.key1);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        for (int q = 0; q < 4; ++q) {
+            float4 ob = pa.OB[(size_t)(4 * b + q) * pa.n_pad + i];
+            ob.w = __int_as_float((int)(w[q] % kNumVariants));
+            pa.OB[(size_t)(4 * b + q) * pa.n_pad + i] = ob;
+        }
+    }
+    EnvState s;
+    CtlState c;
+    PlanExtra x;
+    float pre_a[5];
+    float u[124];
+    planning_reset_uniforms(P, env_global, u);
+    planning_reset(s, c, x, pre_a, num_actions, u, reinterpret_cast<float*>(pa.OB) + (size_t)i * 4, (size_t)pa.n_pad * 4);
+    // esdf_dist is re-derived from the (possibly stale) image every step (planning.py:162-163), so the value set at
+    // planning.py:136 is never observed: keep the min of the image currently in memory (0 for the initial zeros)
+    x.esdf = pa.PRP[i].w;
+    store_env(k, i, s);
+    store_ctl<CTL_POS>(k, i, c);
+    k.PA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    k.PA4[i] = 0.f;
+    pa.GOAL[i] = make_float4(x.goal.x, x.goal.y, x.goal.z, 0.0f);
+    pa.PRP[i] = make_float4(0.f, 0.f, 0.f, x.esdf);
+    if (i < k.n) {
+        k.rew[i] = 0.f;
+        k.reset[i] = 1;
+        k.timeout[i] = 0;
+        pa.collisions[i] = 0.f;
+        if ((i & 63) == 0) k.mask[i >> 6] = 0ull;
+    }
+}
+
+size_t planning_render_lds_bytes() { return (size_t)(kCamPix + kNumObst * 8 + 16 + 25 + 4) * sizeof(float); }
+
+template <int CTL>
+static hipError_t launch_phase(const KArgs& k, const PlanArgs& pa, int phase, hipStream_t st) {
+    const dim3 grid((k.n + 63) / 64), block(64);
+    if (phase == PHASE_BOTH) hipLaunchKernelGGL((planning_step_kernel<CTL, PHASE_BOTH>), grid, block, 0, st, k, pa);
+    else if (phase == PHASE_PHYS) hipLaunchKernelGGL((planning_step_kernel<CTL, PHASE_PHYS>), grid, block, 0, st, k, pa);
+    else hipLaunchKernelGGL((planning_step_kernel<CTL, PHASE_POST>), grid, block, 0, st, k, pa);
+    return hipGetLastError();
+}
+
+hipError_t launch_planning_step(const KArgs& k, const PlanArgs& pa, int ctl, int phase, hipStream_t st) {
+    switch (ctl) {
+        case CTL_POS: return launch_phase<CTL_POS>(k, pa, phase, st);
+        case CTL_VEL: return launch_phase<CTL_VEL>(k, pa, phase, st);
+        case CTL_RATE: return launch_phase<CTL_RATE>(k, pa, phase, st);
+        case CTL_PROP: return launch_phase<CTL_PROP>(k, pa, phase, st);
+        default: return hipErrorInvalidValue;   // atti has 5 actions: planning's 16-dim obs holds 4 (planning.py:214)
+    }
+}
+
+hipError_t launch_planning_render(const KArgs& k, const PlanArgs& pa, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = planning_render_lds_bytes();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planning_render_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(planning_render_kernel, dim3(k.n), dim3(kRenderThreads), lds, st, k, pa);
+    return hipGetLastError();
+}
+
+hipError_t launch_planning_reset_all(const KArgs& k, const PlanArgs& pa, int num_actions, hipStream_t st) {
+    hipLaunchKernelGGL(planning_reset_all_kernel, dim3(pa.n_pad / 256), dim3(256), 0, st, k, pa, num_actions);
+    return hipGetLastError();
+}
+
+}  // namespace ag

@@ -67,6 +67,20 @@ class HipEnvHandle:
         self.reset_mask = self._view(b.reset_mask_dev, torch.int64, ((n + 63) // 64,))
         self.reset_ids = self._view(b.reset_ids_dev, torch.int32, (n,))
         self.reset_count = self._view(b.reset_count_dev, torch.int32, (1,))
+        self.image = None
+        self.collisions = None
+        if task == "planning":
+            from airgym_amd.envs.task.planning_scene import load_variant_table
+            table = load_variant_table()
+            N.check(self.lib.ag_planning_set_obstacle_table(self.h, table.ctypes.data_as(ctypes.c_void_p), table.shape[0]),
+                    "ag_planning_set_obstacle_table")
+            with torch.cuda.device(self.device):
+                N.check(self.lib.ag_reset_all(self.h, None), "ag_reset_all")
+                torch.cuda.synchronize(self.device)
+            pb = N.AgPlanningBuffers()
+            N.check(self.lib.ag_planning_get_buffers(self.h, ctypes.byref(pb)), "ag_planning_get_buffers")
+            self.image = self._view(pb.image_dev, torch.float32, (n, 1, 212, 120))
+            self.collisions = self._view(pb.collisions_dev, torch.float32, (n,))
         self.reward_terms = None
         self.cmd_thrusts = None
         if reward_terms:
@@ -74,7 +88,8 @@ class HipEnvHandle:
                 name: self._view(b.reward_terms_dev[i], torch.float32, (n,))
                 for i, name in enumerate(N.REWARD_TERM_NAMES[task])
             }
-            self.cmd_thrusts = self._view(b.cmd_thrusts_dev, torch.float32, (n, 4))
+            if b.cmd_thrusts_dev:
+                self.cmd_thrusts = self._view(b.cmd_thrusts_dev, torch.float32, (n, 4))
 
     # ------------------------------------------------------------------ helpers
     def _view(self, ptr, dtype, shape):
@@ -153,6 +168,40 @@ class HipEnvHandle:
                           p(was_reset, torch.int32, (n,)))
         N.check(self.lib.ag_set_state(self.h, ctypes.byref(v), self._stream()), "ag_set_state")
         torch.cuda.current_stream(self.device).synchronize()  # `keep` must outlive the kernel
+
+    # ---- planning extras
+    def planning_step_with_uniforms(self, actions, reset_uniforms):
+        actions = self._check_actions(actions)
+        ru = reset_uniforms.to(device=self.device, dtype=torch.float32).contiguous()
+        assert ru.shape == (self.num_envs, 121)
+        N.check(self.lib.ag_planning_step_with_uniforms(self.h, actions.data_ptr(), ru.data_ptr(), self._stream()),
+                "ag_planning_step_with_uniforms")
+
+    def planning_render_next_step(self):
+        N.check(self.lib.ag_planning_render_now(self.h, None), "ag_planning_render_now")
+
+    def planning_get_state(self):
+        n = self.num_envs
+        out = {"obstacles": torch.empty(n, 40, 4, device=self.device), "goal": torch.empty(n, 3, device=self.device),
+               "extra": torch.empty(n, 5, device=self.device)}
+        v = N.AgPlanningStateView(out["obstacles"].data_ptr(), out["goal"].data_ptr(), out["extra"].data_ptr())
+        N.check(self.lib.ag_planning_get_state(self.h, ctypes.byref(v), self._stream()), "ag_planning_get_state")
+        return out
+
+    def planning_set_state(self, obstacles=None, goal=None, extra=None):
+        keep = []
+
+        def p(t, shape):
+            if t is None:
+                return None
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            assert tuple(t.shape) == shape
+            keep.append(t)
+            return t.data_ptr()
+        n = self.num_envs
+        v = N.AgPlanningStateView(p(obstacles, (n, 40, 4)), p(goal, (n, 3)), p(extra, (n, 5)))
+        N.check(self.lib.ag_planning_set_state(self.h, ctypes.byref(v), self._stream()), "ag_planning_set_state")
+        torch.cuda.current_stream(self.device).synchronize()
 
     def compact_reset_ids(self):
         """Ascending ids of the envs flagged done by the last step == reset_buf.nonzero().squeeze(-1)."""

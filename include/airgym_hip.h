@@ -69,7 +69,9 @@ typedef enum ag_status {
 
 typedef enum ag_task {
     AG_TASK_HOVERING = 0, /* airgym/envs/base/hovering.py, 18 obs, 24 s episodes */
-    AG_TASK_TRACKING = 1  /* airgym/envs/task/tracking.py, 48 obs, 36 s episodes */
+    AG_TASK_TRACKING = 1, /* airgym/envs/task/tracking.py, 48 obs, 36 s episodes */
+    AG_TASK_PLANNING = 2  /* airgym/envs/task/planning.py (on base/customized.py): 16 obs + 212x120 depth image,
+                             16 s episodes, 40 cylinder obstacles + goal per env; ctl_mode pos|vel|rate|prop */
 } ag_task;
 
 /* --ctl_mode pos|vel|atti|rate|prop  (README: PY / LV / CTA / CTBR / SRT) */
@@ -86,7 +88,7 @@ enum {
     AG_FLAG_OBS_NOISE_OFF = 1u << 1 /* testing aid: skip add_noise (reference: always on, hovering.py:343) */
 };
 
-#define AG_NUM_REWARD_TERMS 9
+#define AG_NUM_REWARD_TERMS 11 /* Hovering/Tracking use the first 9, Planning all 11 */
 #define AG_MAX_ACTIONS 5
 #define AG_STATE_DIM 13     /* pos3 quat_xyzw4 linvel3 angvel3 (world frame), hovering.py:73-77 */
 #define AG_CTL_STATE_DIM 12 /* rate_int3 prev_body_rate3 vel_int3 prev_vel3 */
@@ -109,7 +111,8 @@ typedef struct ag_config {
 
 /* Reward-term order in ag_buffers.reward_terms[k] (each float[num_envs]).
  * Hovering (hovering.py:448-457): continous_action, effort, thrust, pos, vel_direction, ups, spin, yaw, reward
- * Tracking (tracking.py:285-294): dist_norm, dist_reward, yaw, spin, continous_action, thrust, effort, ups, reward */
+ * Tracking (tracking.py:285-294): dist_norm, dist_reward, yaw, spin, continous_action, thrust, effort, ups, reward
+ * Planning (planning.py:294-305): continous_action, heading, speed, forward, alive, ups, z, esdf, thrust, reach_goal, reward */
 typedef struct ag_buffers {
     int32_t num_envs;
     int32_t num_obs;
@@ -200,6 +203,40 @@ int ag_elu_bwd_bias(const float* dh_dev, const float* h_dev, float* dz_dev, floa
 int ag_adam_clip_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, double* state_dev,
                       int n, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                       float kl_threshold, float min_lr, float max_lr, void* stream);
+
+/* ---- Planning task (AG_TASK_PLANNING) -------------------------------------------------------------------
+ * Replaces, on top of the entries above: Planning.reset_idx / step / compute_observations /
+ * compute_quadcopter_reward (airgym/envs/task/planning.py:63-307), Customized.pre_physics_step, check_collisions,
+ * render_cameras + dump_images (airgym/envs/base/customized.py:216-298,386-435) and the IsaacGym camera /
+ * contact-force tensors behind them (customized.py:51-55,138,387-390).
+ * ag_step* on a planning handle = physics kernel, then (every 4th step, cam_dt/dt) the render kernel, then the
+ * observation/reward/reset kernel.  Before the first ag_reset_all/ag_step the obstacle variant table must be set. */
+#define AG_PLANNING_NUM_OBSTACLES 40
+#define AG_PLANNING_CAM_W 212
+#define AG_PLANNING_CAM_H 120
+#define AG_PLANNING_RESET_UNIFORMS 121
+
+typedef struct ag_planning_buffers {
+    float* image_dev;       /* [num_envs, 1, 212, 120] f32 == full_camera_array (customized.py:144) */
+    float* collisions_dev;  /* [num_envs] f32 0/1 (customized.py:141,393-397) */
+} ag_planning_buffers;
+
+typedef struct ag_planning_state_view {   /* all DEVICE pointers, any may be NULL */
+    float* obstacles_dev;   /* [num_envs, 40, 4]: root x, y, yaw, variant index (as float) */
+    float* goal_dev;        /* [num_envs, 3] */
+    float* extra_dev;       /* [num_envs, 5]: pre_root_positions xyz, esdf_dist, prev_related_dist */
+} ag_planning_state_view;
+
+/* table_host: [n_variants <= 100, 8] = centre xyz, unit axis xyz, radius, half length of each obstacle variant in
+ * its own frame (airgym_amd/assets/thin_trees.json).  Host pointer; copied. */
+int ag_planning_set_obstacle_table(ag_handle h, const float* table_host, int n_variants);
+int ag_planning_get_buffers(ag_handle h, ag_planning_buffers* out);
+int ag_planning_get_state(ag_handle h, const ag_planning_state_view* view, void* stream);
+int ag_planning_set_state(ag_handle h, const ag_planning_state_view* view, void* stream);
+/* Parity mode: per-env reset uniforms [num_envs, 121] supplied by the caller (NULL = counter RNG). */
+int ag_planning_step_with_uniforms(ag_handle h, const float* actions_dev, const float* reset_uniforms_dev, void* stream);
+/* Force / suppress the camera render of the NEXT step (tests); -1 restores the every-4th-step schedule. */
+int ag_planning_render_now(ag_handle h, void* stream);
 
 /* Diagnostic: a kernel with the step's loads/stores and no arithmetic (launch + memory-latency floor). */
 int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream);

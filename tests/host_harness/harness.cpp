@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../airgym_amd/csrc/env_math.hpp"
+#include "../../airgym_amd/csrc/planning_math.hpp"
 
 using namespace ag;
 
@@ -113,6 +114,83 @@ int agh_reset_all(int task, int num_actions, int n, double dt, int max_len, cons
         float pre_a[5];
         env_reset(s, c, pre_a, num_actions, P, env_id_offset + (uint32_t)i);
         store(a, i, num_actions, s, c, pre_a);
+    }
+    return 0;
+}
+
+// ---- Planning: the same per-env functions the gfx950 kernels inline (planning_math.hpp)
+int agh_plan_render(const float* pos3, const float* quat4, const float* obst /*[40,4]*/, const float* table,
+                    const float* goal3, float* out_hw /*[H][W] raw z-depth, inf = no hit*/) {
+    Cyl cyl[kNumObst];
+    for (int j = 0; j < kNumObst; ++j)
+        cyl[j] = world_cylinder(obst[4 * j], obst[4 * j + 1], obst[4 * j + 2], table + ((int)obst[4 * j + 3] % kNumVariants) * 8);
+    const Camera cam = make_camera(V3{pos3[0], pos3[1], pos3[2]}, Q4{quat4[0], quat4[1], quat4[2], quat4[3]});
+    const V3 goal{goal3[0], goal3[1], goal3[2]};
+    for (int v = 0; v < kCamH; ++v)
+        for (int u = 0; u < kCamW; ++u) out_hw[v * kCamW + u] = depth_pixel(cam, pixel_direction(cam, u, v), cyl, kNumObst, goal);
+    return 0;
+}
+
+}  // extern "C"
+
+template <int CTL>
+static void plan_step_t(int n, const StepParams& P, float* rs, float* cs, float* pa, int32_t* progress, int32_t* was_reset,
+                        const float* actions, float* obst, float* goal, float* extra, const float* table,
+                        const float* ext_u, float* obs, float* rew, int32_t* done, float* terms, float* coll) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    Arrays a{n, rs, cs, pa, progress, was_reset};
+    for (int i = 0; i < n; ++i) {
+        EnvState s;
+        CtlState c;
+        float pre_a[A];
+        load(a, i, A, s, c, pre_a);
+        planning_physics<CTL>(s, c, actions + (size_t)i * A, P);
+        PlanExtra x;
+        x.goal = V3{goal[3 * i], goal[3 * i + 1], goal[3 * i + 2]};
+        x.pre_pos = V3{extra[5 * i], extra[5 * i + 1], extra[5 * i + 2]};
+        x.esdf = extra[5 * i + 3];
+        x.prev_related_dist = extra[5 * i + 4];
+        float* ob = obst + (size_t)i * kNumObst * 4;
+        int collided = (s.p.z <= kRobotRadius) ? 1 : 0;
+        for (int j = 0; j < kNumObst; ++j) {
+            const Cyl w = world_cylinder(ob[4 * j], ob[4 * j + 1], ob[4 * j + 2], table + ((int)ob[4 * j + 3] % kNumVariants) * 8);
+            if (point_cylinder_distance(s.p, w) <= kRobotRadius) collided = 1;
+        }
+        PlanOut o;
+        float ob16[kPlanNumObs];
+        planning_post<CTL>(s, x, pre_a, actions + (size_t)i * A, collided, P, ob16, o);
+        if (o.done) {
+            float u[124];
+            if (ext_u) for (int j = 0; j < kPlanResetUniforms; ++j) u[j] = ext_u[(size_t)i * kPlanResetUniforms + j];
+            else planning_reset_uniforms(P, P.env_id_offset + (uint32_t)i, u);
+            planning_reset(s, c, x, pre_a, A, u, ob, 4);
+        }
+        x.prev_related_dist = o.related_dist;
+        store(a, i, A, s, c, pre_a);
+        goal[3 * i] = x.goal.x; goal[3 * i + 1] = x.goal.y; goal[3 * i + 2] = x.goal.z;
+        extra[5 * i] = x.pre_pos.x; extra[5 * i + 1] = x.pre_pos.y; extra[5 * i + 2] = x.pre_pos.z;
+        extra[5 * i + 3] = x.esdf; extra[5 * i + 4] = x.prev_related_dist;
+        for (int j = 0; j < kPlanNumObs; ++j) obs[(size_t)i * kPlanNumObs + j] = ob16[j];
+        rew[i] = o.rew; done[i] = o.done; coll[i] = (float)collided;
+        for (int t = 0; t < kPlanNumTerms; ++t) terms[(size_t)i * kPlanNumTerms + t] = o.terms[t];
+    }
+}
+
+extern "C" {
+
+int agh_plan_step(int ctl, int n, double dt, int max_len, uint64_t seed, uint32_t tick, uint32_t env_id_offset,
+                  float* rs, float* cs, float* pa, int32_t* progress, int32_t* was_reset, const float* actions,
+                  float* obst, float* goal, float* extra, const float* table, const float* ext_u, float* obs, float* rew,
+                  int32_t* done, float* terms, float* coll) {
+    float target[18] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    StepParams P = make_step_params(2, dt, max_len, target, seed, env_id_offset, true);
+    P.tick = tick;
+    switch (ctl) {
+        case CTL_POS: plan_step_t<CTL_POS>(n, P, rs, cs, pa, progress, was_reset, actions, obst, goal, extra, table, ext_u, obs, rew, done, terms, coll); break;
+        case CTL_VEL: plan_step_t<CTL_VEL>(n, P, rs, cs, pa, progress, was_reset, actions, obst, goal, extra, table, ext_u, obs, rew, done, terms, coll); break;
+        case CTL_RATE: plan_step_t<CTL_RATE>(n, P, rs, cs, pa, progress, was_reset, actions, obst, goal, extra, table, ext_u, obs, rew, done, terms, coll); break;
+        case CTL_PROP: plan_step_t<CTL_PROP>(n, P, rs, cs, pa, progress, was_reset, actions, obst, goal, extra, table, ext_u, obs, rew, done, terms, coll); break;
+        default: return -1;
     }
     return 0;
 }

@@ -1,0 +1,138 @@
+"""Planning task on the MI355X: HIP kernels through the C ABI vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TERMS = ["continous_action_reward", "heading_reward", "speed_reward", "forward_reward", "alive_reward", "ups_reward",
+         "z_reward", "esdf_reward", "thrust_reward", "reach_goal_reward", "reward"]
+
+
+@pytest.fixture(scope="module")
+def Handle():
+    from airgym_amd.hip_env import HipEnvHandle
+    assert torch.cuda.is_available()
+    return HipEnvHandle
+
+
+def _actions(rng, n, t):
+    a = rng.uniform(-0.4, 0.4, size=(n, 4)).astype(np.float32)
+    a[:, 3] = rng.uniform(-0.72, -0.66, size=n)      # thrust around hover (0.1537 -> -0.6926)
+    a[:, 1] = rng.uniform(0.0, 0.5, size=n)          # pitch forward, into the obstacle field
+    return a
+
+
+def test_initial_state_and_scene_match_oracle(Handle):
+    from oracle.planning_ref import PlanningRef
+    n = 8
+    ora = PlanningRef(n, "rate", seed=7)
+    env = Handle("planning", "rate", n, seed=7)
+    st, ps = env.get_state(), env.planning_get_state()
+    np.testing.assert_allclose(st["root_states"].cpu().numpy(), ora.root_states.numpy(), atol=1e-6)
+    np.testing.assert_allclose(ps["obstacles"][..., :3].cpu().numpy(), ora.obstacles.numpy(), atol=1e-5)
+    assert np.array_equal(ps["obstacles"][..., 3].cpu().numpy().astype(np.int64), ora.variants.numpy())
+    np.testing.assert_allclose(ps["goal"].cpu().numpy(), ora.goal_positions.numpy(), atol=1e-6)
+    assert (env.reset_buf == 1).all() and env.image.shape == (n, 1, 212, 120)
+    env.close()
+
+
+def test_closed_loop_with_rendering_vs_oracle(Handle):
+    from oracle.planning_ref import PlanningRef
+    n, seed = 4, 3
+    ora = PlanningRef(n, "rate", seed=seed)
+    env = Handle("planning", "rate", n, seed=seed)
+    rng = np.random.default_rng(0)
+    for t in range(12):                      # renders at steps 4, 8, 12 (counter % 4 == 0)
+        a = _actions(rng, n, t)
+        o, _, rew, done, ex = ora.step(torch.from_numpy(a))
+        env.step(torch.from_numpy(a).cuda())
+        assert np.array_equal(env.reset_buf.cpu().numpy(), done.numpy()), f"done step {t}"
+        np.testing.assert_allclose(env.get_state()["root_states"].cpu().numpy(), ora.root_states.numpy(), atol=1e-5)
+        np.testing.assert_allclose(env.obs_buf.cpu().numpy(), o["observation"].numpy(), atol=2e-5, err_msg=f"obs {t}")
+        img, ref = env.image.cpu().numpy(), o["image"].numpy()
+        bad = np.abs(img - ref) > 2e-3
+        assert bad.mean() < 0.01, f"step {t}: {bad.mean():.3%} image pixels differ"
+        esdf = env.planning_get_state()["extra"][:, 3].cpu().numpy()
+        np.testing.assert_allclose(esdf, ora.esdf_dist.numpy(), atol=5e-3, err_msg=f"esdf {t}")
+        np.testing.assert_allclose(esdf, img.reshape(n, -1).min(1), atol=1e-6)      # esdf IS the min pixel (Q16)
+        # reward terms that do not depend on the image are tight; esdf/alive/total follow the image tolerance
+        for k in TERMS:
+            tol = 5e-3 if k in ("esdf_reward", "reward") else 2e-5
+            np.testing.assert_allclose(env.reward_terms[k].cpu().numpy(), ex["item_reward_info"][k].numpy(), atol=tol,
+                                       err_msg=f"{k} step {t}")
+    assert env.image.max() > 1.5       # rendered + blurred (kernel sum ~12): not the initial zeros
+    env.close()
+
+
+def test_parity_mode_reset_uniforms(Handle):
+    from oracle.planning_ref import PlanningRef
+    n, seed = 64, 9
+    ora = PlanningRef(n, "vel", seed=seed)
+    env = Handle("planning", "vel", n, seed=seed)
+    ora.cam_rate = 10 ** 9
+    rng = np.random.default_rng(2)
+    n_done = 0
+    for t in range(3):                       # keep the step count below the first scheduled render (step 4)
+        a = rng.uniform(-1, 1, size=(n, 4)).astype(np.float32)
+        a[:, 2] = 3.0 if t == 1 else a[:, 2]             # climb hard: leave the 0.6 m height corridor
+        u = rng.random((n, 121)).astype(np.float32)
+        o, _, rew, done, _ = ora.step(torch.from_numpy(a), reset_uniforms=torch.from_numpy(u))
+        env.planning_step_with_uniforms(torch.from_numpy(a).cuda(), torch.from_numpy(u))
+        assert np.array_equal(env.reset_buf.cpu().numpy(), done.numpy())
+        n_done += int(done.sum())
+        ps = env.planning_get_state()
+        np.testing.assert_allclose(ps["obstacles"][..., :3].cpu().numpy(), ora.obstacles.numpy(), atol=1e-5)
+        np.testing.assert_allclose(ps["goal"].cpu().numpy(), ora.goal_positions.numpy(), atol=1e-6)
+        np.testing.assert_allclose(env.get_state()["root_states"].cpu().numpy(), ora.root_states.numpy(), atol=1e-5)
+        np.testing.assert_allclose(env.rew_buf.cpu().numpy(), rew.numpy(), atol=2e-5)
+    env.close()
+
+
+def test_collision_flag_and_done(Handle):
+    """Put the robot inside an obstacle: collisions = 1 and the env terminates (planning.py:286)."""
+    from oracle import planning_ref as P
+    n = 64
+    env = Handle("planning", "rate", n, seed=1)
+    ps = env.planning_get_state()
+    table = torch.from_numpy(P.load_variant_table()).cuda()
+    ob = ps["obstacles"]
+    centre, axis, r, h = P.world_cylinders(ob[..., :3].cpu(), ob[..., 3].long().cpu(), P.load_variant_table())
+    st = env.get_state()["root_states"].clone()
+    # robot i sits on the axis of its obstacle 0 at the flight height (if the cylinder reaches it)
+    c0, a0 = centre[:, 0], axis[:, 0]
+    tpar = (1.5 - c0[:, 2]) / a0[:, 2]
+    inside = tpar.abs() <= h[:, 0]
+    pos = c0 + tpar[:, None] * a0
+    st[:, 0:3] = pos.cuda()
+    env.set_state(root_states=st, was_reset=torch.zeros(n, dtype=torch.int32))
+    a = torch.zeros(n, 4, device="cuda"); a[:, 3] = -0.69
+    env.step(a)
+    hit = env.collisions.bool().cpu()
+    assert inside.sum() > 10 and (hit[inside]).all()
+    assert (env.reset_buf.cpu().bool()[inside]).all()
+    env.close()
+
+
+def test_full_size_properties(Handle):
+    """BASELINE config 4 per-GPU size is 16 384 envs; here 4 096 envs x 24 steps: size-independent properties."""
+    n = 4096
+    env = Handle("planning", "rate", n, seed=0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    tot = 0
+    for t in range(24):
+        a = torch.randn(n, 4, generator=g, device="cuda").clamp(-1, 1) * 0.3
+        a[:, 3] = -0.69
+        env.step(a)
+        assert torch.equal(env.compact_reset_ids().long(), env.reset_buf.nonzero().squeeze(-1))
+        tot += int(env.reset_buf.sum())
+    assert torch.isfinite(env.obs_buf).all() and torch.isfinite(env.rew_buf).all() and torch.isfinite(env.image).all()
+    assert env.image.min() >= 0.0 and env.image.max() < 40.0
+    ps, st = env.planning_get_state(), env.get_state()
+    assert torch.allclose(ps["extra"][:, 3], env.image.reshape(n, -1).min(1).values)
+    assert (ps["obstacles"][..., 0].abs() <= 8.0).all() and (ps["obstacles"][..., 1].abs() <= 4.0).all()
+    assert (ps["goal"][:, 0] == 8.5).all() and (ps["goal"][:, 1].abs() <= 1.5).all()
+    q = st["root_states"][:, 3:7]
+    assert torch.allclose(q.norm(dim=-1), torch.ones(n, device="cuda"), atol=1e-5)
+    assert tot > 0
+    env.close()

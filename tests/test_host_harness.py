@@ -20,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "host_harness", "harness.cpp")
 OUT = os.path.join(HERE, "host_harness", "_build", "libagh.so")
 HDR = os.path.join(os.path.dirname(HERE), "airgym_amd", "csrc", "env_math.hpp")
+HDR2 = os.path.join(os.path.dirname(HERE), "airgym_amd", "csrc", "planning_math.hpp")
 
 TASKS = {"hovering": (0, HoveringRef, 18), "tracking": (1, TrackingRef, 48)}
 CTLS = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
@@ -28,7 +29,7 @@ CTLS = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
 @pytest.fixture(scope="module")
 def lib():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if (not os.path.exists(OUT)) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+    if (not os.path.exists(OUT)) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR2)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", SRC, "-o", OUT])
     return ctypes.CDLL(OUT)
 
@@ -177,3 +178,85 @@ def test_episode_end_reset_and_thrust_zero_quirk(lib):
     # free fall for one step: dv_z = -9.81 * 0.01 regardless of the commanded thrust
     np.testing.assert_allclose(har.rs[:, 9] - vz0, -0.0981, atol=2e-5)
     np.testing.assert_allclose(har.rs, ora.root_states.numpy(), rtol=0, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- Planning (planning_math.hpp)
+def _plan_pair(lib, ctl, n, seed):
+    from oracle.planning_ref import PlanningRef
+    ora = PlanningRef(n, ctl, seed=seed)
+    st = dict(rs=ora.root_states.numpy().copy(), cs=np.zeros((n, 12), np.float32),
+              pa=np.zeros((n, 4), np.float32), progress=np.zeros(n, np.int32), was_reset=np.ones(n, np.int32),
+              obst=np.concatenate([ora.obstacles.numpy(), ora.variants.numpy()[..., None].astype(np.float32)], -1).astype(np.float32).copy(),
+              goal=ora.goal_positions.numpy().copy(), extra=np.zeros((n, 5), np.float32))
+    st["extra"][:, 3] = 10.0      # esdf: these tests pin the image min at 10 on both sides
+    cs = st["cs"]
+    cs[:, 3:6] = 0.0
+    cs[:, 9:12] = ora.root_states[:, 7:10].numpy()
+    return ora, st
+
+
+def test_planning_raycast_matches_oracle(lib):
+    from oracle import planning_ref as P
+    ora, st = _plan_pair(lib, "rate", 3, 11)
+    # move the robots into the obstacle field so that cylinders are in view
+    ora.root_states[:, 0] = torch.tensor([-4.0, 0.0, 3.0]); ora.root_states[:, 1] = torch.tensor([0.5, -1.0, 1.0])
+    q = torch.tensor([[0.02, -0.03, 0.1, 1.0], [0.0, 0.05, -0.3, 1.0], [0.03, 0.0, 0.6, 1.0]])
+    ora.root_states[:, 3:7] = q / q.norm(dim=-1, keepdim=True)
+    table = P.load_variant_table()
+    centre, axis, r, h = ora.scene()
+    for e in range(3):
+        ref = P.render_depth_one(ora.root_positions[e], ora.root_quats[e], centre[e], axis[e], r[e], h[e], ora.goal_positions[e]).numpy()
+        out = np.zeros((P.CAM_H, P.CAM_W), np.float32)
+        pos = ora.root_states[e, 0:3].numpy().copy(); quat = ora.root_states[e, 3:7].numpy().copy()
+        assert lib.agh_plan_render(fp(pos), fp(quat), fp(st["obst"][e]), fp(table), fp(st["goal"][e]), fp(out)) == 0
+        both_inf = np.isinf(ref) & np.isinf(out)
+        close = np.abs(np.where(both_inf, 0, ref) - np.where(both_inf, 0, out)) < 1e-4
+        frac_bad = 1.0 - (both_inf | close).mean()
+        assert frac_bad < 2e-3, f"env {e}: {frac_bad:.4%} pixels differ (silhouette flips only are tolerated)"
+        assert np.isfinite(out).mean() > 0.1          # something is actually in view
+
+
+@pytest.mark.parametrize("ctl", ["rate", "vel", "pos", "prop"])
+def test_planning_step_matches_oracle(lib, ctl):
+    """physics + collision + obs + reward/done + reset (planning.py:138-307), esdf held fixed (no render)."""
+    from oracle import planning_ref as P
+    n, seed = 32, 5
+    ora, st = _plan_pair(lib, ctl, n, seed)
+    table = P.load_variant_table()
+    ora.cam_rate = 10 ** 9                       # never render: esdf stays 10 in both
+    ora.full_camera_array[:] = 10.0
+    rng = np.random.default_rng(1)
+    tick = ora.tick
+    n_done = 0
+    for t in range(120):
+        a = rng.uniform(-0.5, 0.5, size=(n, 4)).astype(np.float32)
+        if ctl == "rate":
+            a[:, 3] = rng.uniform(-0.85, -0.5, size=n); a[:, 1] = rng.uniform(0.0, 0.4, size=n)
+        if ctl == "prop":
+            a = rng.uniform(0.14, 0.17, size=(n, 4)).astype(np.float32)
+        if ctl in ("vel", "pos"):
+            a[:, 0] = 0.8
+        obs = np.zeros((n, 16), np.float32); rew = np.zeros(n, np.float32); done = np.zeros(n, np.int32)
+        terms = np.zeros((n, 11), np.float32); coll = np.zeros(n, np.float32)
+        o, _, r_ref, d_ref, ex = ora.step(torch.from_numpy(a))
+        rc = lib.agh_plan_step(CTLS[ctl], n, ctypes.c_double(0.01), 1600, ctypes.c_uint64(seed), ctypes.c_uint32(tick),
+                               ctypes.c_uint32(0), fp(st["rs"]), fp(st["cs"]), fp(st["pa"]), fp(st["progress"]),
+                               fp(st["was_reset"]), fp(a), fp(st["obst"]), fp(st["goal"]), fp(st["extra"]), fp(table),
+                               None, fp(obs), fp(rew), fp(done), fp(terms), fp(coll))
+        assert rc == 0
+        tick += 1
+        assert np.array_equal(done, d_ref.numpy().astype(np.int32)), f"step {t}"
+        n_done += int(done.sum())
+        np.testing.assert_allclose(st["rs"], ora.root_states.numpy(), atol=1e-5, err_msg=f"state {t}")
+        np.testing.assert_allclose(obs, o["observation"].numpy(), atol=2e-5, err_msg=f"obs {t}")
+        np.testing.assert_allclose(rew, r_ref.numpy(), atol=2e-5, err_msg=f"rew {t}")
+        np.testing.assert_allclose(coll, ora.collisions.numpy(), atol=0)
+        np.testing.assert_allclose(st["obst"][..., :3], ora.obstacles.numpy(), atol=1e-5)
+        np.testing.assert_allclose(st["goal"], ora.goal_positions.numpy(), atol=1e-6)
+        np.testing.assert_allclose(st["extra"][:, 0:3], ora.pre_root_positions.numpy(), atol=1e-5)
+        np.testing.assert_allclose(st["extra"][:, 4], ora.prev_related_dist.numpy(), atol=1e-5)
+        for j, k in enumerate(["continous_action_reward", "heading_reward", "speed_reward", "forward_reward",
+                               "alive_reward", "ups_reward", "z_reward", "esdf_reward", "thrust_reward",
+                               "reach_goal_reward", "reward"]):
+            np.testing.assert_allclose(terms[:, j], ex["item_reward_info"][k].numpy(), atol=2e-5, err_msg=k)
+    assert n_done > 0       # the z corridor is 0.6 m wide: random actions leave it, resets are exercised
