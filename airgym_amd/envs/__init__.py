@@ -7,6 +7,8 @@ TASK_CONFIGS = [
      "task_module": "base.hovering", "task_class": "Hovering"},
     {"name": "tracking", "config_module": "task.tracking_config", "config_class": "TrackingCfg",
      "task_module": "task.tracking", "task_class": "Tracking"},
+    {"name": "planning", "config_module": "task.planning_config", "config_class": "PlanningCfg",
+     "task_module": "task.planning", "task_class": "Planning"},
 ]
 
 

@@ -160,7 +160,10 @@ class A2CAgent:
         self.env_info = self.vec_env.get_env_info()
         self.value_size = self.env_info.get("value_size", 1)
         self.observation_space = self.env_info["observation_space"]
-        self.obs_shape = self.observation_space.shape
+        if hasattr(self.observation_space, "spaces"):        # Dict{image, observation} (a2c_base.py:205-210)
+            self.obs_shape = {k: v.shape for k, v in self.observation_space.spaces.items()}
+        else:
+            self.obs_shape = self.observation_space.shape
         action_space = self.env_info["action_space"]
         self.actions_num = action_space.shape[0]
         self.actions_low = torch.from_numpy(action_space.low.copy()).float().to(self.ppo_device)
@@ -283,7 +286,10 @@ class A2CAgent:
     def init_tensors(self):
         H, N, dev = self.horizon_length, self.num_actors * self.num_agents, self.ppo_device
         f = dict(dtype=torch.float32, device=dev)
-        self.obs_buf = torch.zeros((H + 1, N) + tuple(self.obs_shape), **f)
+        if isinstance(self.obs_shape, dict):
+            self.obs_buf = {k: torch.zeros((H + 1, N) + tuple(shp), **f) for k, shp in self.obs_shape.items()}
+        else:
+            self.obs_buf = torch.zeros((H + 1, N) + tuple(self.obs_shape), **f)
         self.actions_buf = torch.zeros(H, N, self.actions_num, **f)
         self.mus_buf = torch.zeros(H, N, self.actions_num, **f)
         self.sigmas_buf = torch.zeros(H, N, self.actions_num, **f)
@@ -304,6 +310,16 @@ class A2CAgent:
         self._term_sums = torch.zeros(len(self._term_names), dtype=torch.float64, device=dev)
         self._term_steps = 0
 
+    def _obs_at(self, n):
+        return {k: v[n] for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict) else self.obs_buf[n]
+
+    def _obs_store(self, n, obs):
+        if isinstance(self.obs_buf, dict):
+            for k, v in self.obs_buf.items():
+                v[n].copy_(obs[k])
+        else:
+            self.obs_buf[n].copy_(obs)
+
     def preprocess_actions(self, actions):
         if self.clip_actions:
             clamped = torch.clamp(actions, -1.0, 1.0)
@@ -312,9 +328,9 @@ class A2CAgent:
 
     def env_reset(self):
         obs = self.vec_env.reset()
-        self.obs_buf[0].copy_(obs)
+        self._obs_store(0, obs)
         self.dones_buf[0].fill_(1)          # a2c_base.py:404: dones start as ones
-        return self.obs_buf[0]
+        return self._obs_at(0)
 
     @torch.no_grad()
     def get_action_values(self, obs):
@@ -324,7 +340,7 @@ class A2CAgent:
     @torch.no_grad()
     def _rollout_step(self, n):
         """One step of play_steps (a2c_base.py:651-695) with every tensor written in place."""
-        res = self.get_action_values(self.obs_buf[n])
+        res = self.get_action_values(self._obs_at(n))
         self.actions_buf[n].copy_(res["actions"])
         self.neglogpacs_buf[n].copy_(res["neglogpacs"])
         self.values_buf[n].copy_(res["values"])
@@ -332,11 +348,16 @@ class A2CAgent:
         self.sigmas_buf[n].copy_(res["sigmas"])
         env_actions = self.preprocess_actions(res["actions"])
         if self._hip_env is not None:
-            self._hip_env.step_into(env_actions, self.obs_buf[n + 1], self.raw_rewards_buf[n], self.dones_buf[n + 1])
+            if isinstance(self.obs_buf, dict):     # Planning: state vector into the slot, image copied from the camera buffer
+                self._hip_env.step_into(env_actions, self.obs_buf["observation"][n + 1], self.raw_rewards_buf[n],
+                                        self.dones_buf[n + 1])
+                self.obs_buf["image"][n + 1].copy_(self._hip_env.image)
+            else:
+                self._hip_env.step_into(env_actions, self.obs_buf[n + 1], self.raw_rewards_buf[n], self.dones_buf[n + 1])
             time_outs = self._hip_env.time_out_buf
         else:
             obs, rewards, dones, infos = self.vec_env.step(env_actions)
-            self.obs_buf[n + 1].copy_(obs)
+            self._obs_store(n + 1, obs)
             self.raw_rewards_buf[n].copy_(rewards)
             self.dones_buf[n + 1].copy_(dones)
             time_outs = infos.get("time_outs") if isinstance(infos, dict) else None
@@ -378,13 +399,14 @@ class A2CAgent:
                 self._graphs["rollout"] = self._capture(lambda: [self._rollout_step(n) for n in range(H)], warmup=False)
         self._rollouts_done += 1
         self.model.eval()
-        last_values = self.model({"is_train": False, "obs": self.obs_buf[H]})["values"]
+        last_values = self.model({"is_train": False, "obs": self._obs_at(H)})["values"]
         fdones = self.dones_buf[H].float()
         mb_fdones = self.dones_buf[:H].float()
         mb_advs = self._gae(fdones, last_values, mb_fdones)
         mb_returns = mb_advs + self.values_buf
         batch = {
-            "obses": swap_and_flatten01(self.obs_buf[:H]),
+            "obses": ({k: swap_and_flatten01(v[:H]) for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict)
+                      else swap_and_flatten01(self.obs_buf[:H])),
             "dones": swap_and_flatten01(self.dones_buf[:H]),
             "actions": swap_and_flatten01(self.actions_buf),
             "neglogpacs": swap_and_flatten01(self.neglogpacs_buf),
@@ -395,7 +417,7 @@ class A2CAgent:
             "played_frames": self.batch_size,
         }
         # the last observation / done flags become slot 0 of the next rollout
-        self.obs_buf[0].copy_(self.obs_buf[H])
+        self._obs_store(0, self._obs_at(H))
         self.dones_buf[0].copy_(self.dones_buf[H])
         return batch
 
@@ -535,15 +557,14 @@ class A2CAgent:
         self.curr_frames = batch_dict.pop("played_frames")
         self.prepare_dataset(batch_dict)
         a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
-        rms = self.model.running_mean_std if self.normalize_input else None
+        if self.normalize_input:
+            self.model.running_mean_std.eval()   # statistics are merged explicitly (model.update_stats), never by .train()
+        self.model.stats_group = self.group if (self.multi_gpu and self.sync_normalizers) else None
         for mini_ep in range(self.mini_epochs_num):
             ep_kls = []
+            # "don't need to update statistics more than one miniepoch", a2c_continuous.py:130-131
+            self.model.update_stats = self.normalize_input and mini_ep == 0
             for i in range(len(self.dataset)):
-                if rms is not None:
-                    rms.eval()       # statistics are merged explicitly below, never inside forward()
-                    if mini_ep == 0:  # "don't need to update statistics more than one miniepoch", a2c_continuous.py:130-131
-                        mb_obs = self.dataset[i]["obs"]
-                        rms.update(mb_obs, self.group if (self.multi_gpu and self.sync_normalizers) else None)
                 a, c, e, b, kl = self.train_actor_critic(i)
                 a_losses.append(a); c_losses.append(c); entropies.append(e); ep_kls.append(kl)
                 if self.bounds_loss_coef is not None:
@@ -557,6 +578,7 @@ class A2CAgent:
                                                                         self.epoch_num, 0, av_kls.item())
                 self.optimizer.lr.fill_(self.last_lr)
             kls.append(av_kls)
+        self.model.update_stats = False
         if self.linear_lr:
             self.last_lr, self.entropy_coef = self.scheduler.update(self.last_lr, self.entropy_coef, self.epoch_num,
                                                                     self.frame, 0.0)

@@ -27,4 +27,9 @@ class PPODataset:
         start = idx * self.minibatch_size
         end = (idx + 1) * self.minibatch_size
         self.last_range = (start, end)
-        return {k: v[start:end] for k, v in self.values_dict.items() if v is not None}
+        out = {}
+        for k, v in self.values_dict.items():
+            if v is None:
+                continue
+            out[k] = {kd: vd[start:end] for kd, vd in v.items()} if isinstance(v, dict) else v[start:end]
+        return out

@@ -60,3 +60,15 @@ class RunningMeanStd(nn.Module):
             return input / torch.sqrt(var + self.epsilon)
         y = (input - mean) / torch.sqrt(var + self.epsilon)
         return torch.clamp(y, min=-5.0, max=5.0)
+
+
+class RunningMeanStdObs(nn.Module):
+    """One RunningMeanStd per key of a dict observation (reference: running_mean_std.py:83-92)."""
+
+    def __init__(self, insize, epsilon=1e-05, per_channel=False, norm_only=False):
+        assert isinstance(insize, dict)
+        super().__init__()
+        self.running_mean_std = nn.ModuleDict({k: RunningMeanStd(v, epsilon, per_channel, norm_only) for k, v in insize.items()})
+
+    def forward(self, input, denorm=False):
+        return {k: self.running_mean_std[k](v, denorm) for k, v in input.items()}

@@ -1,16 +1,25 @@
-"""Actor-critic with state-independent log-std (reference: lib/model/a2c_continuous_logstd_model.py:14-227).
+"""Actor-critic with state-independent log-std (reference: lib/model/a2c_continuous_logstd_model.py:14-227,
+lib/model/base_model.py:5-35).
 
-obs -> RunningMeanStd (clamp +-5) -> MLP -> {mu Linear (x0.1 init), value_head Linear (x0.1 init)},
-logstd parameter (init 0).  State-dict keys are the reference's: `actor_mlp.layers.*`, `mu.*`,
-`logstd`, `value_head.*`, `running_mean_std.*`, `value_mean_std.*`.  The GEMMs are
-PyTorch-ROCm (hipBLASLt -> MFMA); this is the only MFMA-eligible work on the hot path.
+  vector obs :  obs -> RunningMeanStd (clamp +-5) -> MLP -> heads
+  dict obs   :  image -> RunningMeanStd['image'] -> CNN -> cat(observation, features) ->
+                RunningMeanStd['observation'] (over the 16+feature_dim concat, a2c_continuous_logstd_model.py:71-75,
+                157-161) -> MLP -> heads
+  heads      :  mu Linear (x0.1 init), value_head Linear (x0.1 init), logstd parameter (init 0)
+
+State-dict keys are the reference's (`actor_mlp.layers.*`, `actor_cnn.features.*`, `actor_cnn.fc.*`, `mu.*`, `logstd`,
+`value_head.*`, `running_mean_std.*`, `value_mean_std.*`).  The GEMMs/convolutions are PyTorch-ROCm
+(hipBLASLt / MIOpen -> MFMA); this is the only MFMA-eligible work on the hot path.
+
+Normaliser statistics are never updated implicitly inside forward(): the agent sets `update_stats` for the first
+mini-epoch (a2c_continuous.py:130-131) and the moments are merged in place (optionally all-reduced across ranks).
 """
 import math
 
 import torch
 import torch.nn as nn
 
-from airgym_amd.lib.core.running_mean_std import RunningMeanStd
+from airgym_amd.lib.core.running_mean_std import RunningMeanStd, RunningMeanStdObs
 from airgym_amd.lib.network.mlp import MLP
 from airgym_amd.lib.network.splitk_linear import linear
 
@@ -24,13 +33,24 @@ class ModelA2CContinuousLogStd(nn.Module):
         self.normalize_input = params["config"].get("normalize_input", False)
         self.value_size = params["config"].get("value_size", 1)
         self.load(params["network"])
-        if self.has_cnn or self.has_resnet or self.has_vae:
-            raise NotImplementedError("image encoders (Planning, SURVEY 8(f)-1) are not part of this build")
-        if isinstance(input_shape, dict):
-            raise NotImplementedError("dict observations (Planning) are not part of this build")
-        self.actor_mlp = MLP(input_shape[0], self.mlp_cfg["units"], self.mlp_cfg["activation"])
-        if self.separate:
-            self.critic_mlp = MLP(input_shape[0], self.mlp_cfg["units"], self.mlp_cfg["activation"])
+        if self.has_resnet or self.has_vae:
+            raise NotImplementedError("ResNet / frozen-VAE encoders are not part of this build (CNN and MLP are)")
+        self.dict_obs = isinstance(input_shape, dict)
+        if self.has_cnn != self.dict_obs:
+            raise ValueError("a 'cnn' network block needs dict observations {image, observation} and vice versa")
+        if self.has_cnn:
+            from airgym_amd.lib.network.cnn import CNNFeatureExtractor
+            input_shape = dict(input_shape)
+            self.actor_cnn = CNNFeatureExtractor(feature_dim=self.feature_dim)
+            mlp_in = input_shape["observation"][0] + self.feature_dim
+            self.actor_mlp = MLP(mlp_in, self.mlp_cfg["units"], self.mlp_cfg["activation"])
+            if self.separate:
+                self.critic_cnn = CNNFeatureExtractor(feature_dim=self.feature_dim)
+                self.critic_mlp = MLP(mlp_in, self.mlp_cfg["units"], self.mlp_cfg["activation"])
+        else:
+            self.actor_mlp = MLP(input_shape[0], self.mlp_cfg["units"], self.mlp_cfg["activation"])
+            if self.separate:
+                self.critic_mlp = MLP(input_shape[0], self.mlp_cfg["units"], self.mlp_cfg["activation"])
         out_size = self.mlp_cfg["units"][-1]
         self.mu = nn.Linear(out_size, actions_num)
         self.mu.weight.data.mul_(0.1)
@@ -46,7 +66,14 @@ class ModelA2CContinuousLogStd(nn.Module):
         if self.normalize_value:
             self.value_mean_std = RunningMeanStd((self.value_size,))
         if self.normalize_input:
-            self.running_mean_std = RunningMeanStd(input_shape)
+            if self.dict_obs:
+                input_shape["observation"] = (input_shape["observation"][0] + self.feature_dim,)
+                self.running_mean_std = RunningMeanStdObs(input_shape)
+            else:
+                self.running_mean_std = RunningMeanStd(input_shape)
+        self.update_stats = False     # set by the agent during the first mini-epoch
+        self.stats_group = None       # torch.distributed group for synchronised moments (or None)
+        self.last_heads = None
 
     def load(self, params):
         """Parse the YAML `network` block (a2c_continuous_logstd_model.py:200-227)."""
@@ -55,21 +82,52 @@ class ModelA2CContinuousLogStd(nn.Module):
         self.has_cnn = "cnn" in params
         self.has_resnet = "resnet" in params
         self.has_vae = "vae" in params
+        if self.has_cnn:
+            self.feature_dim = params["cnn"]["output_dim"]
         space = params.get("space", {}).get("continuous", {})
         self.fixed_sigma = space.get("fixed_sigma", True)
 
+    # ---- normalisers (base_model.py:21-35)
+    def _norm(self, rms, x):
+        if not self.normalize_input:
+            return x
+        with torch.no_grad():
+            if self.update_stats:
+                rms.update(x.detach(), self.stats_group)
+            mean = rms.running_mean.float()
+            std = torch.sqrt(rms.running_var.float() + rms.epsilon)
+        return torch.clamp((x - mean) / std, min=-5.0, max=5.0)      # running_mean_std.py:78-79
+
     def norm_obs(self, observation):
-        return self.running_mean_std(observation) if self.normalize_input else observation
+        return self._norm(self.running_mean_std, observation) if self.normalize_input else observation
+
+    def norm_image(self, image):
+        return self._norm(self.running_mean_std.running_mean_std["image"], image) if self.normalize_input else image
+
+    def norm_observation(self, observation):
+        return self._norm(self.running_mean_std.running_mean_std["observation"], observation) if self.normalize_input else observation
 
     def denorm_value(self, value):
         return self.value_mean_std(value, denorm=True) if self.normalize_value else value
 
+    # ---- forward
     def trunk(self, obs, heads_only=False):
-        norm_out = self.norm_obs(obs)
-        a_out = self.actor_mlp(norm_out)
-        c_out = self.critic_mlp(norm_out) if self.separate else a_out
+        if self.dict_obs:
+            normed_image = self.norm_image(obs["image"])
+            a_feat = self.actor_cnn(normed_image)
+            a_in = self.norm_observation(torch.cat((obs["observation"], a_feat), dim=-1))
+            a_out = self.actor_mlp(a_in)
+            if self.separate:
+                c_feat = self.critic_cnn(normed_image)
+                c_out = self.critic_mlp(self.norm_observation(torch.cat((obs["observation"], c_feat), dim=-1)))
+            else:
+                c_out = a_out
+        else:
+            norm_out = self.norm_obs(obs)
+            a_out = self.actor_mlp(norm_out)
+            c_out = self.critic_mlp(norm_out) if self.separate else a_out
         if not self.separate:
-            # mu and value heads read the same trunk output: one [*,256]x[256,A+1] GEMM instead of two
+            # mu and value heads read the same trunk output: one [*,H]x[H,A+1] GEMM instead of two
             # (parameters stay separate modules so the state-dict keys are the reference's)
             n_act = self.mu.weight.shape[0]
             heads = linear(a_out, torch.cat((self.mu.weight, self.value_head.weight), 0),

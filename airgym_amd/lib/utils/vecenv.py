@@ -11,7 +11,7 @@ import numpy as np
 import airgym_amd.envs  # noqa: F401  (registers the tasks)
 from airgym_amd.lib.utils import env_configurations
 from airgym_amd.lib.utils.ivecenv import IVecEnv
-from airgym_amd.lib.utils.spaces import Box
+from airgym_amd.lib.utils.spaces import Box, Dict
 from airgym_amd.utils.task_registry import task_registry
 
 vecenv_config = {}
@@ -34,8 +34,6 @@ def get_class_attributes(obj):
 class AirGymRLGPUEnv(IVecEnv):
     def __init__(self, config_name, num_actors, **kwargs):
         self.use_image = kwargs.get("use_image", False)
-        if self.use_image:
-            raise NotImplementedError("image observations (Planning) are SURVEY 8(f) 'next', not in this build")
         kwargs.setdefault("num_envs", num_actors)
         self.env, self.env_info = env_configurations.configurations[config_name]["env_creator"](**kwargs)
 
@@ -54,7 +52,13 @@ class AirGymRLGPUEnv(IVecEnv):
         info = get_class_attributes(self.env_info.env)
         info.update({k: v for k, v in vars(self.env_info.env).items() if not k.startswith("__")})
         info["action_space"] = Box(np.ones(self.env.num_actions) * -1.0, np.ones(self.env.num_actions) * 1.0)
-        info["observation_space"] = Box(np.ones(self.env.num_obs) * -np.inf, np.ones(self.env.num_obs) * np.inf)
+        obs_box = Box(np.ones(self.env.num_obs) * -np.inf, np.ones(self.env.num_obs) * np.inf)
+        if self.use_image:      # vecenv.py:93-98
+            info["observation_space"] = Dict({
+                "image": Box(0, 1, shape=(self.env.cam_channel, self.env.cam_resolution[0], self.env.cam_resolution[1])),
+                "observation": obs_box})
+        else:
+            info["observation_space"] = obs_box
         return info
 
 

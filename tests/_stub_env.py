@@ -50,3 +50,39 @@ def ppo_params(num_actors=64, horizon=8, minibatch=None, mini_epochs=2, units=(3
     network = {"name": "actor_critic", "separate": False, "space": {"continuous": {"fixed_sigma": True}},
                "mlp": {"units": list(units), "activation": "elu"}}
     return {"algo": {"name": "a2c_continuous"}, "network": network, "config": config}
+
+
+class DictObsVecEnv(IVecEnv):
+    """Dict-observation test double: oracle Hovering dynamics + a synthetic single-channel image whose mean encodes the
+    altitude (so the CNN has something to learn), for exercising the {image, observation} agent path on CPU."""
+    IMG = (1, 24, 16)
+
+    def __init__(self, config_name, num_actors, **kwargs):
+        import torch
+        self.torch = torch
+        self.inner = OracleVecEnv(config_name, num_actors, **kwargs)
+        self.num_actions, self.num_obs = self.inner.num_actions, 18
+        self.g = torch.Generator().manual_seed(kwargs.get("seed", 0))
+
+    def _wrap(self, obs):
+        t = self.torch
+        img = t.rand((obs.shape[0],) + self.IMG, generator=self.g) * 0.1 + obs[:, 11].view(-1, 1, 1, 1)
+        return {"image": img, "observation": obs}
+
+    def step(self, actions):
+        obs, rew, done, info = self.inner.step(actions)
+        return self._wrap(obs), rew, done, info
+
+    def reset(self):
+        return self._wrap(self.inner.reset())
+
+    def get_env_info(self):
+        from airgym_amd.lib.utils.spaces import Dict
+        info = self.inner.get_env_info()
+        info["observation_space"] = Dict({"image": Box(0, 1, shape=self.IMG), "observation": info["observation_space"]})
+        return info
+
+
+def register_dict():
+    env_configurations.register("oracle_dict", {"env_creator": None, "vecenv_type": "ORACLE_DICT"})
+    vecenv.register("ORACLE_DICT", lambda name, n, **kw: DictObsVecEnv(name, n, **kw))

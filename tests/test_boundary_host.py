@@ -30,6 +30,8 @@ def test_config_field_trees_equal_reference():
     ref = json.load(open(os.path.join(REPO, "tests", "golden", "config_trees.json")))
     assert _norm(class_to_dict(HoveringCfg())) == ref["hovering"]
     assert _norm(class_to_dict(TrackingCfg())) == ref["tracking"]
+    from airgym_amd.envs.task.planning_config import PlanningCfg
+    assert _norm(class_to_dict(PlanningCfg())) == ref["planning"]
     # instances are independent, class-level access still works (reference idiom: Cfg.env.num_envs)
     a, b = HoveringCfg(), HoveringCfg()
     a.env.num_envs = 7
@@ -39,9 +41,9 @@ def test_config_field_trees_equal_reference():
 def test_registry_and_errors():
     import airgym_amd.envs  # noqa: F401
     from airgym_amd.utils.task_registry import task_registry
-    assert task_registry.get_registered_tasks() == ["hovering", "tracking"]
+    assert task_registry.get_registered_tasks() == ["hovering", "tracking", "planning"]
     with pytest.raises(ValueError, match="was not registered"):            # task_registry.py:78-79
-        task_registry.make_env("planning", Namespace(num_envs=4, ctl_mode="rate", seed=1))
+        task_registry.make_env("avoid", Namespace(num_envs=4, ctl_mode="rate", seed=1))
     with pytest.raises((ValueError, RuntimeError)):                        # bad ctl_mode is an error, not a print
         task_registry.make_env("hovering", Namespace(num_envs=4, ctl_mode="warp", seed=1, sim_device="cuda:0",
                                                      headless=True))
@@ -74,9 +76,10 @@ def test_yaml_hyperparameters():
 def test_vecenv_registration_and_spaces():
     from airgym_amd.lib.utils import env_configurations, vecenv
     from airgym_amd.lib.utils.spaces import Box
-    assert {"hovering", "tracking"} <= set(env_configurations.configurations)
+    assert {"hovering", "tracking", "planning"} <= set(env_configurations.configurations)
     assert "AirGym-RLGPU" in vecenv.vecenv_config
     b = Box(-np.ones(4), np.ones(4))
     assert b.shape == (4,) and b.low.min() == -1 and b.high.max() == 1
-    with pytest.raises(NotImplementedError):
-        vecenv.AirGymRLGPUEnv("hovering", 4, use_image=True)
+    from airgym_amd.lib.utils.spaces import Dict
+    d = Dict({"image": Box(0, 1, shape=(1, 212, 120)), "observation": b})
+    assert d["image"].shape == (1, 212, 120) and set(d.spaces) == {"image", "observation"}

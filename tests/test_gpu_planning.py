@@ -136,3 +136,33 @@ def test_full_size_properties(Handle):
     assert torch.allclose(q.norm(dim=-1), torch.ones(n, device="cuda"), atol=1e-5)
     assert tot > 0
     env.close()
+
+
+def test_drop_in_api_and_ppo_epoch(Handle):
+    """task_registry.make_env('planning') -> dict observations through AirGymRLGPUEnv -> one PPO epoch with the CNN policy."""
+    import yaml, os
+    from argparse import Namespace
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    from airgym_amd.lib.utils import vecenv
+    from airgym_amd.utils.task_registry import task_registry
+    env, cfg = task_registry.make_env("planning", Namespace(num_envs=64, ctl_mode="rate", seed=3, sim_device="cuda:0", headless=True))
+    obs, priv = env.reset()
+    assert set(obs) == {"image", "observation"} and obs["image"].shape == (64, 1, 212, 120) and obs["observation"].shape == (64, 16)
+    o2, _, rew, done, extras = env.step(torch.zeros(64, 4, device="cuda"))
+    assert o2["image"] is env.full_camera_array and done.dtype == torch.int64
+    assert set(extras["item_reward_info"]) >= {"esdf_reward", "reach_goal_reward", "heading_reward", "reward"}
+    assert env.cam_resolution == (212, 120) and env.cam_channel == 1
+    env.close()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
+    c = params["config"]
+    c.update(num_actors=256, horizon_length=8, minibatch_size=512, mini_epochs=2, max_epochs=1, write_summaries=False,
+             print_stats=False, save_frequency=0, save_best_after=10 ** 9, device="cuda:0",
+             train_dir="/tmp/airgym_runs_planning",
+             env_config={"use_image": True, "num_envs": 256, "ctl_mode": "rate", "seed": 1, "sim_device": "cuda:0", "headless": True})
+    agent = A2CAgent("run", params)
+    assert agent.obs_shape == {"image": (1, 212, 120), "observation": (16,)}
+    before = agent.flat_param.clone()
+    agent.train()
+    assert agent.epoch_num == 1 and torch.isfinite(agent.flat_param).all() and not torch.equal(before, agent.flat_param)
+    assert agent.obs_buf["image"].abs().sum() > 0          # rendered images reached the rollout buffer

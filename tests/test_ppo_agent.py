@@ -166,7 +166,7 @@ def _dp_worker(rank, world, port, q):
     sl = slice(rank * N * H, (rank + 1) * N * H)
     agent.dataset.update_values_dict({k: v[sl].clone() for k, v in data.items()})
     agent.model.train(); agent.model.running_mean_std.eval()
-    agent.model.running_mean_std.update(agent.dataset[0]["obs"], agent.group)
+    agent.model.update_stats, agent.model.stats_group = True, agent.group
     agent.train_actor_critic(0)
     out = {"param": agent.flat_param.clone(), "rms_mean": agent.model.running_mean_std.running_mean.clone(),
            "rms_var": agent.model.running_mean_std.running_var.clone(), "lr": agent.optimizer.lr.item()}
@@ -176,7 +176,7 @@ def _dp_worker(rank, world, port, q):
                                                normalize_advantage=False))
         single.dataset.update_values_dict({k: v.clone() for k, v in data.items()})
         single.model.train(); single.model.running_mean_std.eval()
-        single.model.running_mean_std.update(single.dataset[0]["obs"])
+        single.model.update_stats = True
         single.train_actor_critic(0)
         out["single_param"] = single.flat_param.clone()
         out["single_rms_mean"] = single.model.running_mean_std.running_mean.clone()
@@ -239,3 +239,28 @@ def test_player_loads_checkpoint_and_runs(tmp_path):
     assert torch.equal(act, p.get_action(obs))             # deterministic: mu, no sampling
     res = p.run(print_every=10)
     assert res["games"] >= 0 and np.isfinite(res["av_reward"])
+
+
+def test_dict_observation_cnn_agent_cpu(tmp_path):
+    """{image, observation} path: CNN feature extractor -> concat -> RunningMeanStd['observation'] over 18+8 dims
+    (a2c_continuous_logstd_model.py:71-75,157-161), dict rollout buffers, dict minibatch slicing, checkpoint keys."""
+    _stub_env.register_dict()
+    torch.manual_seed(0)
+    params = _stub_env.ppo_params(num_actors=32, horizon=4, mini_epochs=2, max_epochs=2, env_name="oracle_dict")
+    params["network"]["cnn"] = {"output_dim": 8}
+    agent = A2CAgent("run", params)
+    assert isinstance(agent.obs_shape, dict) and agent.obs_shape["image"] == (1, 24, 16)
+    before = agent.flat_param.clone()
+    agent.train()
+    assert torch.isfinite(agent.flat_param).all() and not torch.equal(before, agent.flat_param)
+    sd = agent.model.state_dict()
+    for k in ("actor_cnn.features.0.weight", "actor_cnn.features.2.running_mean", "actor_cnn.fc.weight",
+              "running_mean_std.running_mean_std.image.running_mean",
+              "running_mean_std.running_mean_std.observation.running_mean", "actor_mlp.layers.0.weight"):
+        assert k in sd, k
+    assert sd["running_mean_std.running_mean_std.observation.running_mean"].shape == (18 + 8,)
+    assert sd["running_mean_std.running_mean_std.image.count"].item() == 1 + 2 * 32 * 4   # first mini-epoch only
+    assert agent.obs_buf["image"].shape == (5, 32, 1, 24, 16)
+    fn = str(tmp_path / "ck"); agent.save(fn)
+    b = A2CAgent("run", params); b.restore(fn + ".pth")
+    assert torch.equal(agent.flat_param, b.flat_param)
