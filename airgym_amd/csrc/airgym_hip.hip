@@ -323,6 +323,7 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
         if (noise != nullptr) return fail(AG_ERR_UNSUPPORTED, "planning: use ag_planning_step_with_uniforms");
         ag::PlanArgs pa = h->pa;
         pa.ext_uniforms = uniforms;
+        pa.debug_skip = h->force_render >> 1;
         h->counter += 1;
         const bool render = h->force_render || (h->counter % 4 == 0);   // cam_dt / dt = 4, planning.py:153-156
         h->force_render = 0;
@@ -625,9 +626,9 @@ int ag_planning_step_with_uniforms(ag_handle h, const float* actions_dev, const 
 }
 
 int ag_planning_render_now(ag_handle h, void* stream) {
-    (void)stream;
+    // `stream` doubles as a diagnostics mask (0 in normal use): bit0 skip ray-cast, bit1 skip noise, bit2 skip 5x5 pass
     if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
-    h->force_render = 1;
+    h->force_render = 1 | ((int)(uintptr_t)stream << 1);
     return AG_OK;
 }
 

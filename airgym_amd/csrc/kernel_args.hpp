@@ -52,6 +52,7 @@ struct PlanArgs {
     const float* table;          // [100, 8] obstacle variants (centre3, axis3, radius, half length)
     const float* ext_uniforms;   // [n, 121] or null (parity mode)
     int n_pad;
+    int debug_skip;              // diagnostics only: bit0 skip ray-cast, bit1 skip noise passes, bit2 skip the 5x5 pass
 };
 
 hipError_t launch_planning_step(const KArgs& k, const PlanArgs& pa, int ctl, int phase, hipStream_t st);

@@ -160,10 +160,12 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const KArgs k, const PlanArgs pa) {
     extern __shared__ float lds[];
     float* img = lds;                                   // [kCamW][kCamH]
-    Cyl* cyl = reinterpret_cast<Cyl*>(lds + kCamPix);   // [40]
-    float* red = lds + kCamPix + kNumObst * 8;          // [16]
+    CylView* cyl = reinterpret_cast<CylView*>(lds + kCamPix);   // [40] x 10 floats
+    float* red = lds + kCamPix + kNumObst * 10;         // [16]
     float* ker = red + 16;                              // [25]
     int* ncand = reinterpret_cast<int*>(ker + 25);
+    int* ulo = ncand + 4;                               // [40] first image column a cylinder can touch
+    int* uhi = ulo + kNumObst;                          // [40] last one
     const int env = blockIdx.x;
     const int tid = threadIdx.x;
     StepParams P = k.P;
@@ -181,8 +183,39 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
         // a cylinder farther than far plane + its own extent from the camera cannot be seen: skip it for every pixel
         const float dx = ob.x - cam.o.x, dy = ob.y - cam.o.y;
         if (dx * dx + dy * dy < (kCamFar + 2.7f) * (kCamFar + 2.7f)) {
-            const int slot = atomicAdd(ncand, 1);
-            cyl[slot] = world_cylinder(ob.x, ob.y, ob.z, pa.table + (__float_as_int(ob.w) % kNumVariants) * 8);
+            const Cyl w = world_cylinder(ob.x, ob.y, ob.z, pa.table + (__float_as_int(ob.w) % kNumVariants) * 8);
+            // conservative image-column interval: project both axis end points, inflated by the radius, onto the
+            // image plane (u = W/2 - fx * y_c / x_c).  Any end point closer than 5 cm to the camera plane -> all columns.
+            int lo = 0, hi = kCamW - 1;
+            float rmin = kInf, rmax = -kInf;
+            bool full = false;
+            int behind = 0;
+            float xc_min = kInf;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float sg = e == 0 ? w.h : -w.h;
+                const V3 d{w.cx + sg * w.nx - cam.o.x, w.cy + sg * w.ny - cam.o.y, w.cz + sg * w.nz - cam.o.z};
+                const float xc = cam.R[0] * d.x + cam.R[3] * d.y + cam.R[6] * d.z;
+                const float yc = cam.R[1] * d.x + cam.R[4] * d.y + cam.R[7] * d.z;
+                if (xc + w.r < 0.0f) ++behind;          // every pixel ray has a positive camera-x component
+                xc_min = fminf(xc_min, xc);
+                if (xc - w.r < 0.05f) { full = true; continue; }
+                const float a0 = (yc - w.r) / (xc - w.r), a1 = (yc - w.r) / (xc + w.r);
+                const float b0 = (yc + w.r) / (xc - w.r), b1 = (yc + w.r) / (xc + w.r);
+                rmin = fminf(rmin, fminf(a0, a1));
+                rmax = fmaxf(rmax, fmaxf(b0, b1));
+            }
+            if (!full) {
+                lo = max(0, (int)floorf((float)kCamW / 2.0f - kCamFx * rmax) - 2);
+                hi = min(kCamW - 1, (int)ceilf((float)kCamW / 2.0f - kCamFx * rmin) + 2);
+            }
+            // skipped: entirely behind the camera plane, or entirely beyond the far plane (z-depth > 5 m)
+            if (lo <= hi && behind < 2 && xc_min - w.r <= kCamFar) {
+                const int slot = atomicAdd(ncand, 1);
+                cyl[slot] = make_cyl_view(cam.o, w);
+                ulo[slot] = lo;
+                uhi[slot] = hi;
+            }
         }
     }
     if (tid < 25) {   // random 5x5 "blur" kernel: randint(0, 256) / 256, customized.py:417-419
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     float vmax = 0.0f;
     for (int p = tid; p < kCamPix; p += kRenderThreads) {
         const int u = p / kCamH, v = p - u * kCamH;
-        float d = depth_pixel(cam, pixel_direction(cam, u, v), cyl, n, goal);
+        float d = (pa.debug_skip & 1) ? 3.0f : depth_pixel_culled(cam, pixel_direction(cam, u, v), cyl, ulo, uhi, u, n, goal);
         d = d > 4.5f ? 4.5f : d;
         d = fminf(fmaxf(d, 0.0f), 4.5f) / 4.5f;
         img[p] = d;
@@ -205,7 +238,7 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     float mx = block_reduce(vmax, red, true);
     // ---- pass 2: additive N(0, 0.1), clamp to [0, max] (customized.py:406-409); 4 pixels per Philox block
     vmax = 0.0f;
-    for (int b = tid; b < kCamPix / 4; b += kRenderThreads) {
+    for (int b = tid; b < ((pa.debug_skip & 2) ? 0 : kCamPix / 4); b += kRenderThreads) {
         const U4 r = philox4x32_10(env_global, P.tick, STREAM_IMG_ADD, (uint32_t)b, P.key0, P.key1);
         float z[4];
         box_muller(r.x, r.y, z[0], z[1]);
@@ -219,7 +252,7 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     }
     mx = block_reduce(vmax, red, true);
     // ---- pass 3: multiplicative N(1, 0.3), clamp to [0, max] (customized.py:411-414)
-    for (int b = tid; b < kCamPix / 4; b += kRenderThreads) {
+    for (int b = tid; b < ((pa.debug_skip & 2) ? 0 : kCamPix / 4); b += kRenderThreads) {
         const U4 r = philox4x32_10(env_global, P.tick, STREAM_IMG_MUL, (uint32_t)b, P.key0, P.key1);
         float z[4];
         box_muller(r.x, r.y, z[0], z[1]);
@@ -231,17 +264,25 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     // ---- pass 4: 5x5 cross-correlation with zero padding (F.conv2d, customized.py:416-424), min pixel
     float vmin = kInf;
     float* out = pa.image + (size_t)env * kCamPix;
-    for (int p = tid; p < kCamPix; p += kRenderThreads) {
+    for (int p = tid; p < ((pa.debug_skip & 4) ? 0 : kCamPix); p += kRenderThreads) {
         const int u = p / kCamH, v = p - u * kCamH;
         float acc = 0.0f;
+        if (u >= 2 && u < kCamW - 2 && v >= 2 && v < kCamH - 2) {     // interior: no bounds checks (97 % of the pixels)
+            const float* c0 = img + (u - 2) * kCamH + (v - 2);
 #pragma unroll
-        for (int a = 0; a < 5; ++a) {
-            const int uu = u + a - 2;
-            if (uu < 0 || uu >= kCamW) continue;
+            for (int a = 0; a < 5; ++a)
 #pragma unroll
-            for (int b = 0; b < 5; ++b) {
-                const int vv = v + b - 2;
-                if (vv >= 0 && vv < kCamH) acc += ker[a * 5 + b] * img[uu * kCamH + vv];
+                for (int b = 0; b < 5; ++b) acc += ker[a * 5 + b] * c0[a * kCamH + b];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                const int uu = u + a - 2;
+                if (uu < 0 || uu >= kCamW) continue;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {
+                    const int vv = v + b - 2;
+                    if (vv >= 0 && vv < kCamH) acc += ker[a * 5 + b] * img[uu * kCamH + vv];
+                }
             }
         }
         out[p] = acc;
@@ -297,7 +338,7 @@ __global__ void planning_reset_all_kernel(const KArgs k, const PlanArgs pa, int 
     }
 }
 
-size_t planning_render_lds_bytes() { return (size_t)(kCamPix + kNumObst * 8 + 16 + 25 + 4) * sizeof(float); }
+size_t planning_render_lds_bytes() { return (size_t)(kCamPix + kNumObst * 10 + 16 + 25 + 4 + 2 * kNumObst + 8) * sizeof(float); }
 
 template <int CTL>
 static hipError_t launch_phase(const KArgs& k, const PlanArgs& pa, int phase, hipStream_t st) {

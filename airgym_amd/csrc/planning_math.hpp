@@ -63,16 +63,18 @@ AG_HD float ray_capped_cylinder(V3 o, V3 d, const Cyl& c) {
     const float disc = b * b - a * cc;
     float best = kInf;
     if (disc >= 0.0f && a > 1e-12f) {
-        const float sq = sqrtf(disc);
-        const float t0 = (-b - sq) / a, t1 = (-b + sq) / a;
+        const float sq = fast_sqrt(disc);
+        const float ia = fast_rcp(a);
+        const float t0 = (-b - sq) * ia, t1 = (-b + sq) * ia;
         if (t0 > 0.0f && fabsf(on + t0 * dn) <= c.h) best = fminf(best, t0);
         if (t1 > 0.0f && fabsf(on + t1 * dn) <= c.h) best = fminf(best, t1);
     }
     if (fabsf(dn) > 1e-12f) {
+        const float idn = fast_rcp(dn);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float sgn = k == 0 ? 1.0f : -1.0f;
-            const float t = (sgn * c.h - on) / dn;
+            const float t = (sgn * c.h - on) * idn;
             const V3 p{op.x + t * dp.x, op.y + t * dp.y, op.z + t * dp.z};
             if (t > 0.0f && (p.x * p.x + p.y * p.y + p.z * p.z) <= c.r * c.r) best = fminf(best, t);
         }
@@ -106,8 +108,9 @@ AG_HD Camera make_camera(V3 pos, Q4 q) {
 
 // world direction of pixel (u, v): body direction (1, (W/2 - (u+.5))/fx, (H/2 - (v+.5))/fx); t along it IS the z-depth
 AG_HD V3 pixel_direction(const Camera& cam, int u, int v) {
-    const float dy = ((float)kCamW / 2.0f - ((float)u + 0.5f)) / kCamFx;
-    const float dz = ((float)kCamH / 2.0f - ((float)v + 0.5f)) / kCamFx;
+    constexpr float kInvFx = (float)(1.0 / 111.70069327978202);
+    const float dy = ((float)kCamW / 2.0f - ((float)u + 0.5f)) * kInvFx;
+    const float dz = ((float)kCamH / 2.0f - ((float)v + 0.5f)) * kInvFx;
     return V3{cam.R[0] + dy * cam.R[1] + dz * cam.R[2], cam.R[3] + dy * cam.R[4] + dz * cam.R[5],
               cam.R[6] + dy * cam.R[7] + dz * cam.R[8]};
 }
@@ -117,7 +120,7 @@ AG_HD float depth_pixel(const Camera& cam, V3 d, const Cyl* cyl, int n, V3 goal)
     float t = kInf;
     for (int k = 0; k < n; ++k) t = fminf(t, ray_capped_cylinder(cam.o, d, cyl[k]));
     if (d.z < -1e-12f) {
-        const float tg = -cam.o.z / d.z;
+        const float tg = -cam.o.z * fast_rcp(d.z);
         if (tg > 0.0f) t = fminf(t, tg);
     }
     const V3 oc{cam.o.x - goal.x, cam.o.y - goal.y, cam.o.z - goal.z};
@@ -126,7 +129,74 @@ AG_HD float depth_pixel(const Camera& cam, V3 d, const Cyl* cyl, int n, V3 goal)
     const float c = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - kGoalRadius * kGoalRadius;
     const float disc = b * b - a * c;
     if (disc >= 0.0f) {
-        const float ts = (-b - sqrtf(disc)) / a;
+        const float ts = (-b - fast_sqrt(disc)) * fast_rcp(a);
+        if (ts > 0.0f) t = fminf(t, ts);
+    }
+    return t <= kCamFar ? t : kInf;
+}
+
+// Per-(camera, cylinder) constants of the ray test: everything in ray_capped_cylinder that depends on the ray ORIGIN
+// only (all pixels of an image share it).
+struct CylView { float nx, ny, nz, on, opx, opy, opz, cc, r2, h; };
+
+AG_HD CylView make_cyl_view(V3 o, const Cyl& c) {
+    CylView w;
+    const V3 oc{o.x - c.cx, o.y - c.cy, o.z - c.cz};
+    w.nx = c.nx; w.ny = c.ny; w.nz = c.nz;
+    w.on = oc.x * c.nx + oc.y * c.ny + oc.z * c.nz;
+    w.opx = oc.x - w.on * c.nx; w.opy = oc.y - w.on * c.ny; w.opz = oc.z - w.on * c.nz;
+    w.r2 = c.r * c.r;
+    w.cc = (w.opx * w.opx + w.opy * w.opy + w.opz * w.opz) - w.r2;
+    w.h = c.h;
+    return w;
+}
+
+// identical arithmetic to ray_capped_cylinder with the origin terms precomputed
+AG_HD float ray_cyl_view(V3 d, const CylView& c) {
+    const float dn = d.x * c.nx + d.y * c.ny + d.z * c.nz;
+    const V3 dp{d.x - dn * c.nx, d.y - dn * c.ny, d.z - dn * c.nz};
+    const float a = dp.x * dp.x + dp.y * dp.y + dp.z * dp.z;
+    const float b = dp.x * c.opx + dp.y * c.opy + dp.z * c.opz;
+    const float disc = b * b - a * c.cc;
+    float best = kInf;
+    if (disc >= 0.0f && a > 1e-12f) {
+        const float sq = fast_sqrt(disc);
+        const float ia = fast_rcp(a);
+        const float t0 = (-b - sq) * ia, t1 = (-b + sq) * ia;
+        if (t0 > 0.0f && fabsf(c.on + t0 * dn) <= c.h) best = fminf(best, t0);
+        if (t1 > 0.0f && fabsf(c.on + t1 * dn) <= c.h) best = fminf(best, t1);
+    }
+    if (fabsf(dn) > 1e-12f) {
+        const float idn = fast_rcp(dn);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float sgn = k == 0 ? 1.0f : -1.0f;
+            const float t = (sgn * c.h - c.on) * idn;
+            const V3 p{c.opx + t * dp.x, c.opy + t * dp.y, c.opz + t * dp.z};
+            if (t > 0.0f && (p.x * p.x + p.y * p.y + p.z * p.z) <= c.r2) best = fminf(best, t);
+        }
+    }
+    return best;
+}
+
+// same result as depth_pixel: cylinders whose conservative column interval [ulo, uhi] excludes column u are skipped
+AG_HD float depth_pixel_culled(const Camera& cam, V3 d, const CylView* cyl, const int* ulo, const int* uhi, int u, int n, V3 goal) {
+    float t = kInf;
+    for (int k = 0; k < n; ++k) {
+        if (u < ulo[k] || u > uhi[k]) continue;
+        t = fminf(t, ray_cyl_view(d, cyl[k]));
+    }
+    if (d.z < -1e-12f) {
+        const float tg = -cam.o.z * fast_rcp(d.z);
+        if (tg > 0.0f) t = fminf(t, tg);
+    }
+    const V3 oc{cam.o.x - goal.x, cam.o.y - goal.y, cam.o.z - goal.z};
+    const float a = d.x * d.x + d.y * d.y + d.z * d.z;
+    const float b = d.x * oc.x + d.y * oc.y + d.z * oc.z;
+    const float c = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - kGoalRadius * kGoalRadius;
+    const float disc = b * b - a * c;
+    if (disc >= 0.0f) {
+        const float ts = (-b - fast_sqrt(disc)) * fast_rcp(a);
         if (ts > 0.0f) t = fminf(t, ts);
     }
     return t <= kCamFar ? t : kInf;

@@ -177,8 +177,8 @@ class HipEnvHandle:
         N.check(self.lib.ag_planning_step_with_uniforms(self.h, actions.data_ptr(), ru.data_ptr(), self._stream()),
                 "ag_planning_step_with_uniforms")
 
-    def planning_render_next_step(self):
-        N.check(self.lib.ag_planning_render_now(self.h, None), "ag_planning_render_now")
+    def planning_render_next_step(self, debug_skip=0):
+        N.check(self.lib.ag_planning_render_now(self.h, ctypes.c_void_p(int(debug_skip))), "ag_planning_render_now")
 
     def planning_get_state(self):
         n = self.num_envs

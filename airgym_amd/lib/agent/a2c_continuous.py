@@ -540,7 +540,8 @@ class A2CAgent:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        # thread_local: RCCL's watchdog thread may issue HIP calls while we capture (multi-GPU runs)
+        with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
             out = fn()
         g.outputs = out
         return g

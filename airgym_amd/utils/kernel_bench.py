@@ -41,7 +41,7 @@ def measure_env_kernel(env, steps_per_graph=48, replays=20, warmup_replays=3, us
         graph = None
         if use_graph:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 for t in range(steps_per_graph):
                     env.step(actions[t])
 
