@@ -119,6 +119,7 @@ SYMBOLS = [
     ("ag_elu_bwd_bias_rows_per_block", ctypes.c_int, []),
     ("ag_elu_bwd_bias", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_adam_clip_step", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int] + [ctypes.c_float] * 8 + [_P]),
+    ("ag_adam_state_bytes", ctypes.c_int, []),
     ("ag_ppo_loss_num_sums", ctypes.c_int, []),
     ("ag_ppo_loss_max_blocks", ctypes.c_int, []),
     ("ag_ppo_loss", ctypes.c_int, [_P] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,

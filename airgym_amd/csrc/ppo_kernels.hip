@@ -234,44 +234,59 @@ __global__ __launch_bounds__(256) void elu_bwd_bias_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------
 struct AdamArgs {
     float* p; float* g; float* m; float* v;
-    double* state;
+    double* state;   // unused by the kernels (kept for symmetry with the C entry point)
     int n;
     float beta1, beta2, eps, weight_decay, max_grad_norm;   // max_grad_norm <= 0: no clipping
     float kl_threshold, min_lr, max_lr;                     // kl_threshold <= 0: LR not adapted
 };
 
-__global__ __launch_bounds__(1024) void adam_clip_step_kernel(const AdamArgs k) {
-    __shared__ float red[16];
-    __shared__ float s_coef, s_step_size, s_bc2_rsqrt;
-    const int tid = threadIdx.x;
+// Phase 1 of the optimizer step: per-block partial sums of g^2 (grid = kAdamBlocks).
+constexpr int kAdamBlocks = 64;
+constexpr int kAdamThreads = 256;
+
+__global__ __launch_bounds__(kAdamThreads) void adam_norm_kernel(const float* __restrict__ g, int n, float* __restrict__ partial) {
+    __shared__ float red[kAdamThreads / 64];
     float ss = 0.f;
-    for (int i = tid; i < k.n; i += 1024) { const float x = k.g[i]; ss += x * x; }
+    for (int i = blockIdx.x * kAdamThreads + threadIdx.x; i < n; i += kAdamBlocks * kAdamThreads) {
+        const float x = g[i];
+        ss += x * x;
+    }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
-    if (tid == 0) {
-        float tot = 0.f;
-        for (int w = 0; w < 16; ++w) tot += red[w];
-        const float norm = sqrtf(tot);
-        s_coef = (k.max_grad_norm > 0.f) ? fminf(k.max_grad_norm / (norm + 1e-6f), 1.0f) : 1.0f;
-        const double lr = k.state[0];
-        const double step = k.state[1] + 1.0;
-        const double bc1 = 1.0 - pow((double)k.beta1, step);
-        const double bc2 = 1.0 - pow((double)k.beta2, step);
-        s_step_size = (float)(lr / bc1);
-        s_bc2_rsqrt = (float)(1.0 / sqrt(bc2));
-        k.state[1] = step;
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kAdamThreads / 64; ++w) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// Phase 2: every block re-reduces the 64 partials (deterministic order), reads {lr, step} from state_in, updates its
+// slice; block 0 publishes {new lr, step + 1} to state_out (ping-pong: no block reads what block 0 writes).
+__global__ __launch_bounds__(kAdamThreads) void adam_clip_step_kernel(const AdamArgs k, const float* __restrict__ partial,
+                                                                       const double* __restrict__ state_in,
+                                                                       double* __restrict__ state_out) {
+    float tot = 0.f;
+    for (int w = 0; w < kAdamBlocks; ++w) tot += partial[w];
+    const float norm = sqrtf(tot);
+    const float coef = (k.max_grad_norm > 0.f) ? fminf(k.max_grad_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+    const double lr = state_in[0];
+    const double step = state_in[1] + 1.0;
+    const double bc1 = 1.0 - pow((double)k.beta1, step);
+    const double bc2 = 1.0 - pow((double)k.beta2, step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2r = (float)(1.0 / sqrt(bc2));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double nlr = lr;
         if (k.kl_threshold > 0.f) {      // legacy schedule: evaluated every minibatch, applies to the NEXT step
             const double kl = (double)k.g[k.n];
-            double nlr = lr;
             if (kl > 2.0 * k.kl_threshold) nlr = fmax(lr / 1.5, (double)k.min_lr);
             if (kl < 0.5 * k.kl_threshold) nlr = fmin(lr * 1.5, (double)k.max_lr);
-            k.state[0] = nlr;
         }
+        state_out[0] = nlr;
+        state_out[1] = step;
     }
-    __syncthreads();
-    const float coef = s_coef, step_size = s_step_size, bc2r = s_bc2_rsqrt;
-    for (int i = tid; i < k.n; i += 1024) {
+    for (int i = blockIdx.x * kAdamThreads + threadIdx.x; i < k.n; i += kAdamBlocks * kAdamThreads) {
         float g = k.g[i] * coef;
         k.g[i] = g;
         const float p = k.p[i];
@@ -303,6 +318,17 @@ extern "C" int ag_adam_clip_step(float* param, float* grad, float* exp_avg, floa
     if (!param || !grad || !exp_avg || !exp_avg_sq || !state || n <= 0) return AG_ERR_INVALID_ARG;
     AdamArgs k{param, grad, exp_avg, exp_avg_sq, state, n, beta1, beta2, eps, weight_decay, max_grad_norm,
                kl_threshold, min_lr, max_lr};
-    hipLaunchKernelGGL(adam_clip_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, k);
+    // state_dev layout: double[2 + 2 + 64 floats]: {lr, step} | scratch {lr, step} | 64 float partials
+    double* scratch = state + 2;
+    float* partial = reinterpret_cast<float*>(state + 4);
+    hipLaunchKernelGGL(adam_norm_kernel, dim3(kAdamBlocks), dim3(kAdamThreads), 0, (hipStream_t)stream, grad, n, partial);
+    hipLaunchKernelGGL(adam_clip_step_kernel, dim3(kAdamBlocks), dim3(kAdamThreads), 0, (hipStream_t)stream, k, partial,
+                       (const double*)state, scratch);
+    // publish {lr, step} back to the caller-visible slot (stream-ordered 16-byte copy)
+    if (hipMemcpyAsync(state, scratch, 2 * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return AG_ERR_HIP;
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
+
+extern "C" int ag_adam_state_bytes(void) { return (int)(4 * sizeof(double) + kAdamBlocks * sizeof(float)); }
+

@@ -77,7 +77,9 @@ class FlatAdam:
         self.b1, self.b2 = betas
         self.eps, self.wd = eps, weight_decay
         dev = flat_param.device
-        self.state = torch.tensor([float(lr), 0.0], dtype=torch.float64, device=dev)   # {lr, step}: one device buffer
+        # {lr, step} + scratch for the fused HIP step (ag_adam_state_bytes = 4 doubles + 64 floats = 36 doubles)
+        self.state = torch.zeros(36, dtype=torch.float64, device=dev)
+        self.state[0] = float(lr)
         self.lr = self.state[0]
         self.step_t = self.state[1]
         self.exp_avg = torch.zeros_like(flat_param)

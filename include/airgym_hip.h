@@ -198,8 +198,10 @@ int ag_elu_bwd_bias(const float* dh_dev, const float* h_dev, float* dz_dev, floa
 /* Clip-by-norm + Adam + KL-adaptive LR over a flat parameter buffer in one launch
  * (trancate_gradients_and_step, lib/agent/a2c_base.py:293-316; AdaptiveScheduler, lib/core/schedulers.py:19-32).
  * grad_dev has n + 1 elements: element n is the (already all-reduced) KL of this minibatch.
- * state_dev: double[2] = {learning rate, step count}, updated in place.  max_grad_norm <= 0 disables clipping,
- * kl_threshold <= 0 disables the LR adaptation. */
+ * state_dev: ag_adam_state_bytes() bytes whose first double[2] = {learning rate, step count}, updated in place (the rest
+ * is scratch).  max_grad_norm <= 0 disables clipping, kl_threshold <= 0 disables the LR adaptation. */
+int ag_adam_state_bytes(void);
+
 int ag_adam_clip_step(float* param_dev, float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, double* state_dev,
                       int n, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                       float kl_threshold, float min_lr, float max_lr, void* stream);
