@@ -82,6 +82,7 @@ class HipEnvHandle:
             self.image = self._view(pb.image_dev, torch.float32, (n, 1, 212, 120))
             self.collisions = self._view(pb.collisions_dev, torch.float32, (n,))
         self.reward_terms = None
+        self.reward_terms_stacked = None
         self.cmd_thrusts = None
         if reward_terms:
             self.reward_terms = {
@@ -90,6 +91,13 @@ class HipEnvHandle:
             }
             if b.cmd_thrusts_dev:
                 self.cmd_thrusts = self._view(b.cmd_thrusts_dev, torch.float32, (n, 4))
+            # the term arrays are consecutive padded slices of the arena: one [T, n_pad] view lets callers reduce all
+            # of them with a single kernel (padding lanes are never written and stay zero)
+            names = N.REWARD_TERM_NAMES[task]
+            p0, p1 = int(b.reward_terms_dev[0]), int(b.reward_terms_dev[1])
+            n_pad = (p1 - p0) // 4
+            if all(int(b.reward_terms_dev[i]) == p0 + i * n_pad * 4 for i in range(len(names))):
+                self.reward_terms_stacked = self._view(b.reward_terms_dev[0], torch.float32, (len(names), n_pad))
 
     # ------------------------------------------------------------------ helpers
     def _view(self, ptr, dtype, shape):

@@ -373,14 +373,16 @@ class A2CAgent:
         self.current_shaped_rewards += shaped
         self.current_lengths += 1
         done_f = self.dones_buf[n + 1].float()
-        st = self.ep_stats[n]
-        st[0] = done_f.sum()
-        st[1] = (self.current_rewards[:, 0] * done_f).sum()
-        st[2] = (self.current_shaped_rewards[:, 0] * done_f).sum()
-        st[3] = (self.current_lengths * done_f).sum()
+        # [count, sum reward, sum shaped reward, sum length] of the episodes that ended this step: one fused reduction
+        self.ep_stats[n] = (torch.stack((torch.ones_like(done_f), self.current_rewards[:, 0],
+                                         self.current_shaped_rewards[:, 0], self.current_lengths)) * done_f).sum(1)
         if self._term_names and self.config.get("log_reward_terms", True):
-            rt = self._hip_env.reward_terms
-            self._term_sums += torch.stack([rt[k].mean() for k in self._term_names]).double()
+            stacked = getattr(self._hip_env, "reward_terms_stacked", None)
+            if stacked is not None:       # one reduction for all terms
+                self._term_sums += stacked.sum(1).double() / self._hip_env.num_envs
+            else:
+                rt = self._hip_env.reward_terms
+                self._term_sums += torch.stack([rt[k].mean() for k in self._term_names]).double()
         not_done = 1.0 - done_f
         self.current_rewards *= not_done.unsqueeze(1)
         self.current_shaped_rewards *= not_done.unsqueeze(1)

@@ -332,3 +332,31 @@ def test_wave_specialised_kernel_matches_single_wave(Handle):
         for k_ in sa:
             assert torch.allclose(sa[k_].float(), sb[k_].float(), rtol=0, atol=2e-6), k_
         a.close(); b.close()
+
+
+def test_tracking_full_size_properties(Handle):
+    """BASELINE config 2 size: Tracking, 65 536 envs, LV control - size-independent properties."""
+    n = 65536
+    env = Handle("tracking", "vel", n, seed=0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    tot = 0
+    for t in range(120):
+        a = torch.randn(n, 4, generator=g, device="cuda").clamp(-1, 1)
+        env.step(a)
+        if t % 10 == 0:
+            assert torch.equal(env.compact_reset_ids().long(), env.reset_buf.nonzero().squeeze(-1))
+        tot += int(env.reset_buf.sum())
+    st = env.get_state()
+    assert env.obs_buf.shape == (n, 48) and torch.isfinite(env.obs_buf).all() and torch.isfinite(env.rew_buf).all()
+    assert torch.allclose(st["root_states"][:, 3:7].norm(dim=-1), torch.ones(n, device="cuda"), atol=1e-5)
+    # obs[18:21] = lemniscate(progress) - position (tracking.py:194-214), no noise on these columns
+    t0 = st["progress"].float() * 0.01 * 0.25
+    ref = torch.stack((3 * torch.sin(t0) / (1 + torch.cos(t0) ** 2), 3 * torch.sin(t0) * torch.cos(t0) / (1 + torch.cos(t0) ** 2),
+                       torch.ones_like(t0)), -1)
+    done = env.reset_buf.bool()
+    assert torch.allclose(env.obs_buf[~done, 18:21], (ref - st["root_states"][:, 0:3])[~done], atol=1e-4)
+    assert tot > 0 and (st["progress"] < 3600).all()
+    # dist_norm term == |ref0 - pos| for envs that did not reset this step; envs farther than 1 m are flagged done
+    dn = env.reward_terms["dist_norm"]
+    assert (dn[done] > 1.0).float().mean() > 0.9 or done.sum() == 0
+    env.close()
