@@ -116,6 +116,10 @@ SYMBOLS = [
     ("ag_planning_set_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),
     ("ag_planning_step_with_uniforms", ctypes.c_int, [_P, _P, _P, _P]),
     ("ag_planning_render_now", ctypes.c_int, [_P, _P]),
+    ("ag_ppo_loss_finalize", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),
+    ("ag_normalize_rows", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
+                                         ctypes.c_float, _P]),
     ("ag_elu_bwd_bias_rows_per_block", ctypes.c_int, []),
     ("ag_elu_bwd_bias", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_adam_clip_step", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int] + [ctypes.c_float] * 8 + [_P]),

@@ -6,7 +6,8 @@
 // lib/core/torch_ext.py:27-36 policy_kl):
 //   per row i:  neglogp, ratio, clipped surrogate a_i, value loss c_i, bound loss b_i, KL(new || old)
 //   d(total loss)/d(head outputs)  [M, A+1]  (mu columns then the value column), already scaled by 1/M
-//   per-block partial sums of {a, c, b, kl, d logstd_0..A-1}  (reduced deterministically by the caller)
+//   per-block partial sums of {a, c, b, kl, d logstd_0..A-1, column sums of d heads (= the head-bias gradient)}
+//   (reduced deterministically by the caller or by ag_ppo_loss_finalize)
 // and writes the new (mu, sigma) rows back to the dataset (PPODataset.update_mu_sigma, datasets.py:20-24).
 // Memory-bound: ~(A+1 + 3A + 4 + A+1 + 2A) floats per row.
 #include <hip/hip_runtime.h>
@@ -16,7 +17,9 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kNumSums = 4 + AG_MAX_ACTIONS;  // a, c, b, kl, dlogstd[<=5]
+constexpr int kDLogstd0 = 4;                              // a, c, b, kl, dlogstd[<=5], dbias_heads[<=6]
+constexpr int kDBias0 = 4 + AG_MAX_ACTIONS;
+constexpr int kNumSums = 4 + AG_MAX_ACTIONS + AG_MAX_ACTIONS + 1;
 
 struct LossArgs {
     const float* heads;      // [M, A+1]
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(const LossArgs k) {
         for (int a = 0; a < A; ++a) {
             // d nlp / d mu_a = -z_a / sigma_a ;  d nlp / d logstd_a = 1 - z_a^2
             float dmu = da_dnlp * (-z[a] * inv_sig[a]);
-            acc[4 + a] += da_dnlp * (1.0f - z[a] * z[a]);
+            acc[kDLogstd0 + a] += da_dnlp * (1.0f - z[a] * z[a]);
             if (k.bound_type == 1) {
                 const float hi_v = fmaxf(mu[a] - 1.1f, 0.0f), lo_v = fminf(mu[a] + 1.1f, 0.0f);
                 b_loss += lo_v * lo_v + hi_v * hi_v;
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(const LossArgs k) {
                 dmu += k.bounds_loss_coef * 2.0f * mu[a];
             }
             dh[a] = dmu * k.inv_m;
+            acc[kDBias0 + a] += dmu * k.inv_m;
             // KL(p0 = new || p1 = old), torch_ext.py:27-36
             const float s1 = k.old_sigma[(size_t)i * A + a], m1 = k.old_mu[(size_t)i * A + a];
             const float dm = m1 - mu[a];
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(const LossArgs k) {
             }
         }
         dh[A] = 0.5f * k.critic_coef * dc_dv * k.inv_m;
+        acc[kDBias0 + A] += dh[A];
         acc[0] += a_loss;
         acc[1] += c_loss;
         acc[2] += b_loss;
@@ -146,6 +151,70 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(const LossArgs k) {
     }
 }
 
+
+// Reduces the per-block partials of ppo_loss_kernel (fixed order -> deterministic) and writes everything the optimizer
+// step needs straight into the flat gradient buffer: d loss / d logstd, the fused-head bias gradient, the minibatch KL
+// (appended gradient element) and the logged scalars.  One workgroup; replaces ~15 tiny launches.
+struct FinalizeArgs {
+    const float* partials; int num_blocks; int M; int A;
+    const float* logstd; float entropy_coef, critic_coef, bounds_loss_coef;
+    float* grad_logstd; float* grad_head_bias; float* kl_out; float* stats;   // stats[6]: a, c, entropy, b, kl, loss
+};
+
+__global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const FinalizeArgs k) {
+    __shared__ float red[4][kNumSums];
+    __shared__ float tot[kNumSums];
+    float acc[kNumSums];
+#pragma unroll
+    for (int j = 0; j < kNumSums; ++j) acc[j] = 0.0f;
+    for (int b = threadIdx.x; b < k.num_blocks; b += 256) {
+#pragma unroll
+        for (int j = 0; j < kNumSums; ++j) acc[j] += k.partials[(size_t)b * kNumSums + j];
+    }
+#pragma unroll
+    for (int j = 0; j < kNumSums; ++j) {
+        float x = acc[j];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        acc[j] = x;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < kNumSums; ++j) red[wave][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumSums) tot[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float inv_m = 1.0f / (float)k.M;
+        const float a_loss = tot[0] * inv_m, c_loss = tot[1] * inv_m, b_loss = tot[2] * inv_m, kl = tot[3] * inv_m;
+        float entropy = 0.0f;
+        for (int a = 0; a < k.A; ++a) entropy += 0.5f + 0.5f * 1.8378770664093453f + k.logstd[a];
+        for (int a = 0; a < k.A; ++a) k.grad_logstd[a] = tot[kDLogstd0 + a] * inv_m - k.entropy_coef;
+        for (int a = 0; a <= k.A; ++a) k.grad_head_bias[a] = tot[kDBias0 + a];      // already scaled by 1/M
+        *k.kl_out = kl;
+        k.stats[0] = a_loss; k.stats[1] = c_loss; k.stats[2] = entropy; k.stats[3] = b_loss; k.stats[4] = kl;
+        k.stats[5] = a_loss + 0.5f * c_loss * k.critic_coef - entropy * k.entropy_coef + b_loss * k.bounds_loss_coef;
+    }
+}
+
+// Running-mean/std input normalisation (lib/core/running_mean_std.py:64-79): out = clamp((x - mean) / sqrt(var + eps),
+// -clip, clip) with the statistics read from the float64 running buffers.  One pass instead of seven eager kernels.
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, const double* __restrict__ mean,
+                                                             const double* __restrict__ var, float* __restrict__ out,
+                                                             size_t total, int D, float eps, float clip) {
+    extern __shared__ float stat[];      // mean[D] | std[D]
+    for (int c = threadIdx.x; c < D; c += 256) {
+        stat[c] = (float)mean[c];
+        stat[D + c] = sqrtf((float)var[c] + eps);
+    }
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (size_t)D);
+        const float y = (x[i] - stat[c]) / stat[D + c];
+        out[i] = fminf(fmaxf(y, -clip), clip);
+    }
+}
 }  // namespace
 
 extern "C" int ag_ppo_loss_num_sums(void) { return kNumSums; }
@@ -332,3 +401,27 @@ extern "C" int ag_adam_clip_step(float* param, float* grad, float* exp_avg, floa
 
 extern "C" int ag_adam_state_bytes(void) { return (int)(4 * sizeof(double) + kAdamBlocks * sizeof(float)); }
 
+
+extern "C" int ag_ppo_loss_finalize(const float* partials, int num_blocks, int M, int A, const float* logstd,
+                                    float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd,
+                                    float* grad_head_bias, float* kl_out, float* stats, void* stream) {
+    if (!partials || !logstd || !grad_logstd || !grad_head_bias || !kl_out || !stats || num_blocks <= 0 || M <= 0)
+        return AG_ERR_INVALID_ARG;
+    if (A < 1 || A > AG_MAX_ACTIONS) return AG_ERR_UNSUPPORTED;
+    FinalizeArgs k{partials, num_blocks, M, A, logstd, entropy_coef, critic_coef, bounds_loss_coef,
+                   grad_logstd, grad_head_bias, kl_out, stats};
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, k);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_normalize_rows(const float* x, const double* mean, const double* var, float* out, long long rows, int D,
+                                 float eps, float clip, void* stream) {
+    if (!x || !mean || !var || !out || rows <= 0 || D <= 0) return AG_ERR_INVALID_ARG;
+    if (D > 4096) return AG_ERR_UNSUPPORTED;
+    const size_t total = (size_t)rows * (size_t)D;
+    size_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)grid), dim3(256), 2 * D * sizeof(float), (hipStream_t)stream,
+                       x, mean, var, out, total, D, eps, clip);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}

@@ -253,6 +253,8 @@ class A2CAgent:
             os.makedirs(self.summaries_dir, exist_ok=True)
             from airgym_amd.lib.utils.summary import make_writer
             self.writer = make_writer(self.summaries_dir)
+        from airgym_amd.lib.agent.fused_update import FusedMLPStep
+        self._fused_step = FusedMLPStep(self) if FusedMLPStep.supported(self) else None
         self._graphs = {}
         self._rollouts_done = 0
         self.obs = None
@@ -262,6 +264,12 @@ class A2CAgent:
         """Re-home every parameter (and its .grad) as a view into one flat buffer.  The last element
         of the gradient buffer carries the KL scalar through the same all-reduce."""
         ps = [p for p in self.model.parameters() if p.requires_grad]
+        m = self.model
+        fused_heads = not m.separate and m.fixed_sigma
+        if fused_heads:
+            # mu and value heads adjacent (weights, then biases): the fused [A+1, H] head GEMM reads them as ONE view
+            head = [m.mu.weight, m.value_head.weight, m.mu.bias, m.value_head.bias]
+            ps = [p for p in ps if all(p is not q for q in head)] + head
         total = sum(p.numel() for p in ps)
         dev = self.ppo_device
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -274,6 +282,13 @@ class A2CAgent:
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
             off += n
         self._params = ps
+        self.heads_w = self.heads_b = self.heads_w_grad = self.heads_b_grad = None
+        if fused_heads:
+            A1, Hd = m.mu.weight.shape[0] + 1, m.mu.weight.shape[1]
+            o = total - A1 * Hd - A1
+            self.heads_w, self.heads_w_grad = (t[o:o + A1 * Hd].view(A1, Hd) for t in (self.flat_param, self.flat_grad))
+            self.heads_b, self.heads_b_grad = (t[o + A1 * Hd:o + A1 * Hd + A1] for t in (self.flat_param, self.flat_grad))
+            m.fused_heads = (self.heads_w, self.heads_b)      # no-grad inference reads the views (no cat per call)
 
     def broadcast_parameters(self):
         """Initial parameter / normaliser sync from rank 0 (reference: broadcast_object_list of the
@@ -498,13 +513,13 @@ class A2CAgent:
         return a_loss.detach(), c_loss.detach(), entropy.detach(), b_loss.detach(), mu.detach(), sigma.detach()
 
     @torch.no_grad()
-    def _reduce_clip_step(self):
+    def _reduce_clip_step(self, need_kl=True):
         """trancate_gradients_and_step (a2c_base.py:293-316) + the legacy per-minibatch KL schedule
         (a2c_continuous.py:111-118): one all-reduce, clip-by-norm, Adam, LR update - all on device."""
         if self.multi_gpu:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad /= self.world_size
-        kl = self.flat_grad[-1].double()
+        kl = self.flat_grad[-1].double() if need_kl else None
         adaptive = self.is_adaptive_lr and self.schedule_type == "legacy"
         if self.flat_grad.is_cuda and self.config.get("use_fused_adam", True):
             self.optimizer.fused_clip_step(
@@ -528,6 +543,10 @@ class A2CAgent:
     def train_actor_critic(self, idx):
         """One optimizer step on minibatch idx; returns device scalars (no sync)."""
         mb = self.dataset[idx]
+        if self._fused_step is not None and mb["obs"].shape[0] == self.minibatch_size:
+            st = self._fused_step.step(mb)
+            kl = self._reduce_clip_step(need_kl=self.multi_gpu)      # multi-GPU: the rank-averaged KL
+            return st[0], st[1], st[2], st[3], (kl if self.multi_gpu else st[4])
         a, c, e, b, mu, sigma = self._loss_and_backward(mb)
         kl = self._reduce_clip_step()
         if mu is not None:      # the fused kernel already wrote the new rows back in place
@@ -565,6 +584,8 @@ class A2CAgent:
         if self.normalize_input:
             self.model.running_mean_std.eval()   # statistics are merged explicitly (model.update_stats), never by .train()
         self.model.stats_group = self.group if (self.multi_gpu and self.sync_normalizers) else None
+        if self._fused_step is not None:
+            self._fused_step.begin_epoch()
         for mini_ep in range(self.mini_epochs_num):
             ep_kls = []
             # "don't need to update statistics more than one miniepoch", a2c_continuous.py:130-131

@@ -1,0 +1,135 @@
+"""Hand-scheduled forward + backward of ONE PPO minibatch for the shared-trunk ELU-MLP Gaussian policy
+(reference math: lib/agent/a2c_continuous.py:299-369 calc_gradients under autograd; lib/network/mlp.py:36-39;
+lib/model/a2c_continuous_logstd_model.py:130-198).
+
+Why not autograd: at the bench configuration (M = 196 608 rows, MLP 18-256-256-(4+1)) the minibatch is ~1.0 ms of
+GEMM / ELU / loss work that already runs at the fp32-MFMA or HBM rate, plus ~0.5 ms of tiny kernels autograd adds around
+it (gradient accumulation adds, zero fills, cat/split of the fused head, a [M,5] column sum, seven eager ops for the
+input normaliser, scalar bookkeeping).  Here every gradient is written straight into its slice of the flat gradient
+buffer and the schedule is exactly:
+
+    normalise (1 HIP kernel) -> per layer [GEMM+bias, ELU in place] -> head GEMM -> ag_ppo_loss -> ag_ppo_loss_finalize
+    -> head wgrad (split-K bmm + sum) -> dX GEMM -> per layer reversed [ag_elu_bwd_bias, bias sum, split-K wgrad, dX GEMM]
+
+The GEMMs stay hipBLASLt (MFMA); everything else is the HIP kernels of csrc/ppo_kernels.hip.  All buffers are
+preallocated once, so the step is allocation-free and capturable.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from airgym_amd import _native as N
+from airgym_amd.lib.core.fused_loss import BOUND_TYPES
+from airgym_amd.lib.network.splitk_linear import SPLIT_K
+
+
+class FusedMLPStep:
+    @staticmethod
+    def supported(agent):
+        m = agent.model
+        return (str(agent.ppo_device).startswith("cuda") and agent.config.get("use_fused_update", True)
+                and agent._fused_loss_ok() and not m.dict_obs and m.actor_mlp.activation_name == "elu"
+                and agent.minibatch_size % SPLIT_K == 0 and getattr(agent, "heads_w", None) is not None
+                and all(l.weight.shape[0] % 4 == 0 and l.weight.shape[0] <= 1024 and 256 % (l.weight.shape[0] // 4) == 0
+                        for l in m.actor_mlp.layers))
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.lib = N.load()
+        m, dev = agent.model, agent.ppo_device
+        M = self.M = agent.minibatch_size
+        self.A = agent.actions_num
+        self.layers = [(l.weight, l.bias, l.weight.grad, l.bias.grad) for l in m.actor_mlp.layers]
+        f = dict(dtype=torch.float32, device=dev)
+        D = self.layers[0][0].shape[1]
+        self.xn = torch.empty(M, D, **f)
+        self.h = [torch.empty(M, w.shape[0], **f) for w, _, _, _ in self.layers]
+        widest = max(w.shape[0] for w, _, _, _ in self.layers)
+        self.dh = torch.empty(M * widest, **f)          # d loss / d h_l   (reused by every layer)
+        self.dz = torch.empty(M * widest, **f)          # d loss / d z_l
+        self.heads = torch.empty(M, self.A + 1, **f)
+        self.d_heads = torch.empty(M, self.A + 1, **f)
+        self.nsums = self.lib.ag_ppo_loss_num_sums()
+        self.loss_partials = torch.empty(self.lib.ag_ppo_loss_max_blocks(), self.nsums, **f)
+        rows = self.lib.ag_elu_bwd_bias_rows_per_block()
+        self.bias_partials = torch.empty((M + rows - 1) // rows * widest, **f)
+        self.wgrad_partials = [torch.empty(SPLIT_K, w.shape[0], w.shape[1], **f) for w, _, _, _ in self.layers]
+        self.head_wgrad_partials = torch.empty(SPLIT_K, self.A + 1, self.layers[-1][0].shape[0], **f)
+        self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 6, **f)
+        self.k = 0
+
+    def begin_epoch(self):
+        self.k = 0
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.agent.ppo_device).cuda_stream)
+
+    @torch.no_grad()
+    def step(self, mb):
+        """Forward, loss, backward of minibatch `mb`; gradients (and the KL in the appended slot) are left in
+        agent.flat_grad.  Returns the stats row [a_loss, c_loss, entropy, b_loss, kl, loss] (device, no sync)."""
+        ag, lib, m = self.agent, self.lib, self.agent.model
+        M, A, S = self.M, self.A, SPLIT_K
+        obs = mb["obs"]
+        assert obs.shape[0] == M and obs.is_contiguous()
+        st = self._stream()
+        # ---- input normalisation (statistics merged during the first mini-epoch only, a2c_continuous.py:130-131)
+        if m.normalize_input:
+            rms = m.running_mean_std
+            if m.update_stats:
+                rms.update(obs, m.stats_group)
+            N.check(lib.ag_normalize_rows(obs.data_ptr(), rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
+                                          self.xn.data_ptr(), M, obs.shape[1], float(rms.epsilon), 5.0, st),
+                    "ag_normalize_rows")
+            x = self.xn
+        else:
+            x = obs
+        # ---- forward
+        inputs = []
+        for (w, b, _, _), h in zip(self.layers, self.h):
+            inputs.append(x)
+            torch.addmm(b, x, w.t(), out=h)
+            F.elu_(h)
+            x = h
+        torch.addmm(ag.heads_b, x, ag.heads_w.t(), out=self.heads)
+        # ---- loss, d loss / d heads, per-block partial sums
+        nb = ctypes.c_int(0)
+        bcoef = float(ag.bounds_loss_coef or 0.0)
+        bt = BOUND_TYPES[ag.bound_loss_type] if ag.bounds_loss_coef is not None else 0
+        logstd = m.logstd
+        N.check(lib.ag_ppo_loss(self.heads.data_ptr(), logstd.data_ptr(), mb["actions"].data_ptr(),
+                                mb["old_logp_actions"].data_ptr(), mb["advantages"].data_ptr(), mb["returns"].data_ptr(),
+                                mb["old_values"].data_ptr(), mb["mu"].data_ptr(), mb["sigma"].data_ptr(), M, A,
+                                float(ag.e_clip), float(ag.critic_coef), bcoef, int(bool(ag.clip_value)), int(bt),
+                                self.d_heads.data_ptr(), mb["mu"].data_ptr(), mb["sigma"].data_ptr(),
+                                self.loss_partials.data_ptr(), ctypes.byref(nb), st), "ag_ppo_loss")
+        stats = self.stats_ring[self.k % self.stats_ring.shape[0]]
+        self.k += 1
+        N.check(lib.ag_ppo_loss_finalize(self.loss_partials.data_ptr(), nb.value, M, A, logstd.data_ptr(),
+                                         float(ag.entropy_coef), float(ag.critic_coef), bcoef, logstd.grad.data_ptr(),
+                                         ag.heads_b_grad.data_ptr(), ag.flat_grad[-1:].data_ptr(), stats.data_ptr(), st),
+                "ag_ppo_loss_finalize")
+        # ---- backward: fused head
+        H = x.shape[1]
+        torch.bmm(self.d_heads.view(S, M // S, A + 1).transpose(1, 2), x.view(S, M // S, H), out=self.head_wgrad_partials)
+        torch.sum(self.head_wgrad_partials, 0, out=ag.heads_w_grad)
+        dh = self.dh[:M * H].view(M, H)
+        torch.mm(self.d_heads, ag.heads_w, out=dh)
+        # ---- backward: trunk
+        for li in range(len(self.layers) - 1, -1, -1):
+            w, _, gw, gb = self.layers[li]
+            h, xin = self.h[li], inputs[li]
+            C, K = w.shape
+            dz = self.dz[:M * C].view(M, C)
+            rows = lib.ag_elu_bwd_bias_rows_per_block()
+            parts = self.bias_partials[:(M + rows - 1) // rows * C].view(-1, C)
+            N.check(lib.ag_elu_bwd_bias(dh.data_ptr(), h.data_ptr(), dz.data_ptr(), parts.data_ptr(), M, C, st),
+                    "ag_elu_bwd_bias")
+            torch.sum(parts, 0, out=gb)
+            torch.bmm(dz.view(S, M // S, C).transpose(1, 2), xin.view(S, M // S, K), out=self.wgrad_partials[li])
+            torch.sum(self.wgrad_partials[li], 0, out=gw)
+            if li > 0:
+                dh = self.dh[:M * K].view(M, K)
+                torch.mm(dz, w, out=dh)
+        return stats

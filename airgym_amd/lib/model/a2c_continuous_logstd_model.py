@@ -74,6 +74,7 @@ class ModelA2CContinuousLogStd(nn.Module):
         self.update_stats = False     # set by the agent during the first mini-epoch
         self.stats_group = None       # torch.distributed group for synchronised moments (or None)
         self.last_heads = None
+        self.fused_heads = None       # (weight [A+1,H], bias [A+1]) views of the agent's flat parameter buffer
 
     def load(self, params):
         """Parse the YAML `network` block (a2c_continuous_logstd_model.py:200-227)."""
@@ -130,8 +131,11 @@ class ModelA2CContinuousLogStd(nn.Module):
             # mu and value heads read the same trunk output: one [*,H]x[H,A+1] GEMM instead of two
             # (parameters stay separate modules so the state-dict keys are the reference's)
             n_act = self.mu.weight.shape[0]
-            heads = linear(a_out, torch.cat((self.mu.weight, self.value_head.weight), 0),
-                           torch.cat((self.mu.bias, self.value_head.bias), 0))
+            if self.fused_heads is not None and not torch.is_grad_enabled():
+                heads = torch.addmm(self.fused_heads[1], a_out, self.fused_heads[0].t())
+            else:
+                heads = linear(a_out, torch.cat((self.mu.weight, self.value_head.weight), 0),
+                               torch.cat((self.mu.bias, self.value_head.bias), 0))
             self.last_heads = heads      # [*, A+1] GEMM output, consumed by the fused PPO-loss kernel
             if heads_only:
                 return heads

@@ -176,8 +176,9 @@ int ag_set_tick(ag_handle h, uint64_t tick);
  *   heads_dev [M, A+1]: mu columns then the value column (one GEMM output); logstd_dev [A].
  *   d_heads_dev [M, A+1]: d(a_loss.mean + 0.5*critic_coef*c_loss.mean + bounds_coef*b_loss.mean)/d heads.
  *   partials_dev [ag_ppo_loss_max_blocks(), ag_ppo_loss_num_sums()]: per-block sums of
- *       {a_loss, c_loss, b_loss, kl, d(sum_i a_i)/d logstd_0..A-1}; *num_blocks_out rows are valid; the caller
- *       reduces them (deterministic) and divides by M.  bound_type: 0 none, 1 'bound', 2 'regularisation'.
+ *       {a_loss, c_loss, b_loss, kl, d(sum_i a_i)/d logstd_0..AG_MAX_ACTIONS-1, column sums of d_heads 0..AG_MAX_ACTIONS};
+ *       *num_blocks_out rows are valid; the caller reduces them (deterministic) and divides by M, or hands them to
+ *       ag_ppo_loss_finalize.  bound_type: 0 none, 1 'bound', 2 'regularisation'.
  *   new_mu_dev / new_sigma_dev [M, A]: optional write-back of the current policy rows (both or neither). */
 int ag_ppo_loss_num_sums(void);
 int ag_ppo_loss_max_blocks(void);
@@ -187,6 +188,19 @@ int ag_ppo_loss(const float* heads_dev, const float* logstd_dev, const float* ac
                 float e_clip, float critic_coef, float bounds_loss_coef, int clip_value, int bound_type,
                 float* d_heads_dev, float* new_mu_dev, float* new_sigma_dev, float* partials_dev,
                 int* num_blocks_out, void* stream);
+
+/* Reduce the partials of ag_ppo_loss in one workgroup and write what the optimizer step consumes:
+ *   grad_logstd_dev [A] = d loss / d logstd (entropy term included), grad_head_bias_dev [A+1] = bias gradient of the fused
+ *   mu|value head, *kl_out_dev = minibatch KL, stats_dev [6] = {a_loss, c_loss, entropy, b_loss, kl, total loss}
+ *   (a2c_continuous.py:340-369). */
+int ag_ppo_loss_finalize(const float* partials_dev, int num_blocks, int M, int A, const float* logstd_dev,
+                         float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd_dev,
+                         float* grad_head_bias_dev, float* kl_out_dev, float* stats_dev, void* stream);
+
+/* out = clamp((x - mean) / sqrt(var + eps), -clip, clip) over [rows, D] with float64 running statistics
+ * (lib/core/running_mean_std.py:64-79, RunningMeanStd.forward in eval mode). */
+int ag_normalize_rows(const float* x_dev, const double* mean_dev, const double* var_dev, float* out_dev, long long rows,
+                      int D, float eps, float clip, void* stream);
 
 /* ELU backward fused with the bias gradient of the producing Linear (lib/network/mlp.py:36-39 under autograd):
  * dz = dh * ELU'(z) computed from h = ELU(z); db_partials_dev [ceil(M / rows_per_block), C] per-block column sums of dz
