@@ -120,6 +120,10 @@ SYMBOLS = [
                                             ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),
     ("ag_normalize_rows", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
                                          ctypes.c_float, _P]),
+    ("ag_mlp_input_layer", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_float, ctypes.c_float, _P]),
+    ("ag_elu_heads", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_heads_bwd_elu", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_elu_bwd_bias_rows_per_block", ctypes.c_int, []),
     ("ag_elu_bwd_bias", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_adam_clip_step", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int] + [ctypes.c_float] * 8 + [_P]),

@@ -425,3 +425,195 @@ extern "C" int ag_normalize_rows(const float* x, const double* mean, const doubl
                        x, mean, var, out, total, D, eps, clip);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Fused edges of the MLP trunk (lib/network/mlp.py:36-39; lib/model/a2c_continuous_logstd_model.py:126-146).
+// The 256x256 GEMMs stay with hipBLASLt; these kernels remove the HBM round trips AROUND them:
+//   input_layer : xn = clamp((obs-mean)/std), h1 = ELU(xn W1^T + b1)        one pass: read obs, write xn + h1
+//   elu_heads   : h = ELU(z) in place, heads = h Wh^T + bh                  the [M,C]x[C,A+1] GEMM rides along
+//   heads_bwd   : dz = (d_heads Wh) * ELU'(h), bias partial sums            the [M,A+1]x[A+1,C] GEMM + its [M,C] store/load vanish
+// All are HBM-bound streaming kernels: C/4 threads cover one row with float4 accesses.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float elu1(float z) { return z > 0.f ? z : expm1f(z); }
+
+constexpr int kInTileRows = 64;
+
+// grid: ceil(M / 64); block 256; dynamic LDS: Wt[D][C] + xs[64][D]
+__global__ __launch_bounds__(256) void input_layer_kernel(const float* __restrict__ obs, const double* __restrict__ mean,
+                                                          const double* __restrict__ var, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ xn,
+                                                          float* __restrict__ h, int M, int D, int C, float eps, float clip,
+                                                          int normalize) {
+    extern __shared__ float lds[];
+    float* Wt = lds;                    // [D][C]
+    float* xs = lds + (size_t)D * C;    // [64][D]
+    for (int i = threadIdx.x; i < D * C; i += 256) {
+        const int c = i / D, d = i - c * D;          // W is [C][D] row-major
+        Wt[d * C + c] = W[i];
+    }
+    const int row0 = blockIdx.x * kInTileRows;
+    const int rows = min(kInTileRows, M - row0);
+    for (int i = threadIdx.x; i < rows * D; i += 256) {
+        const int d = i % D;
+        float v = obs[(size_t)row0 * D + i];
+        if (normalize) {
+            v = (v - (float)mean[d]) / sqrtf((float)var[d] + eps);
+            v = fminf(fmaxf(v, -clip), clip);
+            xn[(size_t)row0 * D + i] = v;
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int tpr = C >> 2;
+    const int rgroups = 256 / tpr;                   // row groups working concurrently
+    const int col4 = threadIdx.x % tpr, rg = threadIdx.x / tpr;
+    if (rg >= rgroups) return;
+    const float4 b4 = reinterpret_cast<const float4*>(bias)[col4];
+    for (int r = rg * 4; r < rows; r += rgroups * 4) {
+        float4 acc[4] = {b4, b4, b4, b4};
+        const int nr = min(4, rows - r);
+        for (int d = 0; d < D; ++d) {
+            const float4 w = reinterpret_cast<const float4*>(Wt + (size_t)d * C)[col4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = xs[min(r + j, rows - 1) * D + d];
+                acc[j].x = fmaf(x, w.x, acc[j].x); acc[j].y = fmaf(x, w.y, acc[j].y);
+                acc[j].z = fmaf(x, w.z, acc[j].z); acc[j].w = fmaf(x, w.w, acc[j].w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < nr) {
+                float4 o;
+                o.x = elu1(acc[j].x); o.y = elu1(acc[j].y); o.z = elu1(acc[j].z); o.w = elu1(acc[j].w);
+                reinterpret_cast<float4*>(h + (size_t)(row0 + r + j) * C)[col4] = o;
+            }
+        }
+    }
+}
+
+// h = ELU(z) in place; heads[m, a] = sum_c h[m,c] Wh[a,c] + bh[a].  tpr = C/4 threads per row (power of two <= 64).
+template <int A1>
+__global__ __launch_bounds__(256) void elu_heads_kernel(float* __restrict__ zh, const float* __restrict__ Wh,
+                                                        const float* __restrict__ bh, float* __restrict__ heads, int M, int C,
+                                                        int rows_per_block) {
+    const int tpr = C >> 2;
+    const int rpp = 256 / tpr;
+    const int col4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    float4 w[A1];
+#pragma unroll
+    for (int a = 0; a < A1; ++a) w[a] = reinterpret_cast<const float4*>(Wh + (size_t)a * C)[col4];
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row_end = min(row0 + rows_per_block, M);
+    for (int r = row0 + rsub; r < row_end; r += rpp) {
+        float4* p = reinterpret_cast<float4*>(zh + (size_t)r * C) + col4;
+        float4 z = *p;
+        z.x = elu1(z.x); z.y = elu1(z.y); z.z = elu1(z.z); z.w = elu1(z.w);
+        *p = z;
+        float s[A1];
+#pragma unroll
+        for (int a = 0; a < A1; ++a) s[a] = (z.x * w[a].x + z.y * w[a].y) + (z.z * w[a].z + z.w * w[a].w);
+        for (int off = tpr >> 1; off > 0; off >>= 1) {
+#pragma unroll
+            for (int a = 0; a < A1; ++a) s[a] += __shfl_xor(s[a], off, 64);
+        }
+        if (col4 == 0) {
+#pragma unroll
+            for (int a = 0; a < A1; ++a) heads[(size_t)r * A1 + a] = s[a] + bh[a];
+        }
+    }
+}
+
+// dz = (d_heads Wh) * ELU'(h) with per-block column sums (same partial layout as elu_bwd_bias_kernel).
+template <int A1>
+__global__ __launch_bounds__(256) void heads_bwd_elu_kernel(const float* __restrict__ d_heads, const float* __restrict__ Wh,
+                                                            const float* __restrict__ h, float* __restrict__ dz,
+                                                            float* __restrict__ db_partials, int M, int C) {
+    __shared__ float4 red[256];
+    const int tpr = C >> 2;
+    const int rpp = 256 / tpr;
+    const int col4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    float4 w[A1];
+#pragma unroll
+    for (int a = 0; a < A1; ++a) w[a] = reinterpret_cast<const float4*>(Wh + (size_t)a * C)[col4];
+    const int row0 = blockIdx.x * kEluRowsPerBlock;
+    const int row_end = min(row0 + kEluRowsPerBlock, M);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rsub < rpp) {
+        for (int r = row0 + rsub; r < row_end; r += rpp) {
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < A1; ++a) {
+                const float d = d_heads[(size_t)r * A1 + a];
+                g.x = fmaf(d, w[a].x, g.x); g.y = fmaf(d, w[a].y, g.y); g.z = fmaf(d, w[a].z, g.z); g.w = fmaf(d, w[a].w, g.w);
+            }
+            const size_t idx = (size_t)r * tpr + col4;
+            const float4 y = reinterpret_cast<const float4*>(h)[idx];
+            float4 o;
+            o.x = g.x * (y.x > 0.f ? 1.f : y.x + 1.f);
+            o.y = g.y * (y.y > 0.f ? 1.f : y.y + 1.f);
+            o.z = g.z * (y.z > 0.f ? 1.f : y.z + 1.f);
+            o.w = g.w * (y.w > 0.f ? 1.f : y.w + 1.f);
+            reinterpret_cast<float4*>(dz)[idx] = o;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < tpr) {
+        float4 s = red[threadIdx.x];
+        for (int j = 1; j < rpp; ++j) {
+            const float4 t = red[threadIdx.x + j * tpr];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        reinterpret_cast<float4*>(db_partials)[(size_t)blockIdx.x * tpr + threadIdx.x] = s;
+    }
+}
+
+bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int ag_mlp_input_layer(const float* obs, const double* mean, const double* var, const float* W, const float* bias,
+                                  float* xn, float* h, int M, int D, int C, float eps, float clip, void* stream) {
+    if (!obs || !W || !bias || !h || M <= 0 || D <= 0) return AG_ERR_INVALID_ARG;
+    const int normalize = (mean && var && xn) ? 1 : 0;
+    if (!normalize && (mean || var || xn)) return AG_ERR_INVALID_ARG;
+    if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)D * C + (size_t)kInTileRows * D) * sizeof(float);
+    if (lds > 64 * 1024) return AG_ERR_UNSUPPORTED;
+    const int grid = (M + kInTileRows - 1) / kInTileRows;
+    hipLaunchKernelGGL(input_layer_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, obs, mean, var, W, bias, xn, h,
+                       M, D, C, eps, clip, normalize);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_elu_heads(float* zh, const float* Wh, const float* bh, float* heads, int M, int C, int A1, void* stream) {
+    if (!zh || !Wh || !bh || !heads || M <= 0) return AG_ERR_INVALID_ARG;
+    if (C < 16 || C > 256 || !pow2(C)) return AG_ERR_UNSUPPORTED;
+    const int rows_per_block = 64;
+    const int grid = (M + rows_per_block - 1) / rows_per_block;
+    if (A1 == 5)
+        hipLaunchKernelGGL(elu_heads_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, zh, Wh, bh, heads, M, C, rows_per_block);
+    else if (A1 == 6)
+        hipLaunchKernelGGL(elu_heads_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, zh, Wh, bh, heads, M, C, rows_per_block);
+    else
+        return AG_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_heads_bwd_elu(const float* d_heads, const float* Wh, const float* h, float* dz, float* db_partials, int M,
+                                int C, int A1, void* stream) {
+    if (!d_heads || !Wh || !h || !dz || !db_partials || M <= 0) return AG_ERR_INVALID_ARG;
+    if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
+    const int grid = (M + kEluRowsPerBlock - 1) / kEluRowsPerBlock;
+    if (A1 == 5)
+        hipLaunchKernelGGL(heads_bwd_elu_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz, db_partials, M, C);
+    else if (A1 == 6)
+        hipLaunchKernelGGL(heads_bwd_elu_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz, db_partials, M, C);
+    else
+        return AG_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}

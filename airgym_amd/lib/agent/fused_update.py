@@ -8,8 +8,10 @@ it (gradient accumulation adds, zero fills, cat/split of the fused head, a [M,5]
 input normaliser, scalar bookkeeping).  Here every gradient is written straight into its slice of the flat gradient
 buffer and the schedule is exactly:
 
-    normalise (1 HIP kernel) -> per layer [GEMM+bias, ELU in place] -> head GEMM -> ag_ppo_loss -> ag_ppo_loss_finalize
-    -> head wgrad (split-K bmm + sum) -> dX GEMM -> per layer reversed [ag_elu_bwd_bias, bias sum, split-K wgrad, dX GEMM]
+    ag_mlp_input_layer (normalise + Linear + ELU) -> middle layers [GEMM+bias, ELU in place] -> last layer GEMM+bias ->
+    ag_elu_heads (ELU + head product) -> ag_ppo_loss -> ag_ppo_loss_finalize -> head wgrad (split-K bmm + sum) ->
+    ag_heads_bwd_elu (dX of the head + ELU' + bias sums) -> per layer reversed [bias sum, split-K wgrad, dX GEMM,
+    ag_elu_bwd_bias]
 
 The GEMMs stay hipBLASLt (MFMA); everything else is the HIP kernels of csrc/ppo_kernels.hip.  All buffers are
 preallocated once, so the step is allocation-free and capturable.
@@ -56,6 +58,9 @@ class FusedMLPStep:
         self.bias_partials = torch.empty((M + rows - 1) // rows * widest, **f)
         self.wgrad_partials = [torch.empty(SPLIT_K, w.shape[0], w.shape[1], **f) for w, _, _, _ in self.layers]
         self.head_wgrad_partials = torch.empty(SPLIT_K, self.A + 1, self.layers[-1][0].shape[0], **f)
+        C0, Cl = self.layers[0][0].shape[0], self.layers[-1][0].shape[0]
+        self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
+        self.fuse_heads = len(self.layers) >= 2 and 16 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
         self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 6, **f)
         self.k = 0
 
@@ -74,25 +79,47 @@ class FusedMLPStep:
         obs = mb["obs"]
         assert obs.shape[0] == M and obs.is_contiguous()
         st = self._stream()
-        # ---- input normalisation (statistics merged during the first mini-epoch only, a2c_continuous.py:130-131)
-        if m.normalize_input:
-            rms = m.running_mean_std
-            if m.update_stats:
-                rms.update(obs, m.stats_group)
-            N.check(lib.ag_normalize_rows(obs.data_ptr(), rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
-                                          self.xn.data_ptr(), M, obs.shape[1], float(rms.epsilon), 5.0, st),
-                    "ag_normalize_rows")
-            x = self.xn
-        else:
-            x = obs
-        # ---- forward
+        # ---- forward.  Statistics are merged during the first mini-epoch only (a2c_continuous.py:130-131).
+        rms = m.running_mean_std if m.normalize_input else None
+        if rms is not None and m.update_stats:
+            rms.update(obs, m.stats_group)
+        w0, b0 = self.layers[0][0], self.layers[0][1]
+        D, C0 = obs.shape[1], w0.shape[0]
         inputs = []
-        for (w, b, _, _), h in zip(self.layers, self.h):
+        if self.fuse_input:       # normalise + Linear(D -> C0) + ELU in one pass
+            mean_p = rms.running_mean.data_ptr() if rms is not None else None
+            var_p = rms.running_var.data_ptr() if rms is not None else None
+            N.check(lib.ag_mlp_input_layer(obs.data_ptr(), mean_p, var_p, w0.data_ptr(), b0.data_ptr(),
+                                           self.xn.data_ptr() if rms is not None else None, self.h[0].data_ptr(), M, D, C0,
+                                           float(rms.epsilon) if rms is not None else 0.0, 5.0, st), "ag_mlp_input_layer")
+            x = self.xn if rms is not None else obs
+        else:
+            if rms is not None:
+                N.check(lib.ag_normalize_rows(obs.data_ptr(), rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
+                                              self.xn.data_ptr(), M, D, float(rms.epsilon), 5.0, st), "ag_normalize_rows")
+                x = self.xn
+            else:
+                x = obs
+            torch.addmm(b0, x, w0.t(), out=self.h[0])
+            F.elu_(self.h[0])
+        inputs.append(x)
+        x = self.h[0]
+        last = len(self.layers) - 1
+        heads_done = False
+        for li in range(1, len(self.layers)):
+            w, b = self.layers[li][0], self.layers[li][1]
             inputs.append(x)
+            h = self.h[li]
             torch.addmm(b, x, w.t(), out=h)
-            F.elu_(h)
+            if li == last and self.fuse_heads:      # ELU in place + the [M,C]x[C,A+1] head product in the same pass
+                N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
+                                         M, w.shape[0], A + 1, st), "ag_elu_heads")
+                heads_done = True
+            else:
+                F.elu_(h)
             x = h
-        torch.addmm(ag.heads_b, x, ag.heads_w.t(), out=self.heads)
+        if not heads_done:
+            torch.addmm(ag.heads_b, x, ag.heads_w.t(), out=self.heads)
         # ---- loss, d loss / d heads, per-block partial sums
         nb = ctypes.c_int(0)
         bcoef = float(ag.bounds_loss_coef or 0.0)
@@ -114,18 +141,21 @@ class FusedMLPStep:
         H = x.shape[1]
         torch.bmm(self.d_heads.view(S, M // S, A + 1).transpose(1, 2), x.view(S, M // S, H), out=self.head_wgrad_partials)
         torch.sum(self.head_wgrad_partials, 0, out=ag.heads_w_grad)
-        dh = self.dh[:M * H].view(M, H)
-        torch.mm(self.d_heads, ag.heads_w, out=dh)
-        # ---- backward: trunk
-        for li in range(len(self.layers) - 1, -1, -1):
+        # ---- backward: trunk.  The last layer's dX = d_heads Wh is formed inside the ELU' pass.
+        rows = lib.ag_elu_bwd_bias_rows_per_block()
+        dh = None
+        for li in range(last, -1, -1):
             w, _, gw, gb = self.layers[li]
             h, xin = self.h[li], inputs[li]
             C, K = w.shape
             dz = self.dz[:M * C].view(M, C)
-            rows = lib.ag_elu_bwd_bias_rows_per_block()
             parts = self.bias_partials[:(M + rows - 1) // rows * C].view(-1, C)
-            N.check(lib.ag_elu_bwd_bias(dh.data_ptr(), h.data_ptr(), dz.data_ptr(), parts.data_ptr(), M, C, st),
-                    "ag_elu_bwd_bias")
+            if li == last:
+                N.check(lib.ag_heads_bwd_elu(self.d_heads.data_ptr(), ag.heads_w.data_ptr(), h.data_ptr(), dz.data_ptr(),
+                                             parts.data_ptr(), M, C, A + 1, st), "ag_heads_bwd_elu")
+            else:
+                N.check(lib.ag_elu_bwd_bias(dh.data_ptr(), h.data_ptr(), dz.data_ptr(), parts.data_ptr(), M, C, st),
+                        "ag_elu_bwd_bias")
             torch.sum(parts, 0, out=gb)
             torch.bmm(dz.view(S, M // S, C).transpose(1, 2), xin.view(S, M // S, K), out=self.wgrad_partials[li])
             torch.sum(self.wgrad_partials[li], 0, out=gw)

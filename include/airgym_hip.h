@@ -202,6 +202,21 @@ int ag_ppo_loss_finalize(const float* partials_dev, int num_blocks, int M, int A
 int ag_normalize_rows(const float* x_dev, const double* mean_dev, const double* var_dev, float* out_dev, long long rows,
                       int D, float eps, float clip, void* stream);
 
+/* Fused edges of the MLP trunk (lib/network/mlp.py:36-39, a2c_continuous_logstd_model.py:126-146); the wide GEMMs in
+ * between stay with hipBLASLt.
+ *   ag_mlp_input_layer: xn = clamp((obs - mean)/sqrt(var + eps), +-clip) [M, D] (skipped when mean/var/xn are all NULL,
+ *       then obs is used as is), h = ELU(xn W^T + bias) [M, C]; W [C, D] row-major; D*C + 64*D floats must fit 64 KB.
+ *   ag_elu_heads: zh [M, C] <- ELU(zh) in place and heads [M, A1] = ELU(zh) Wh^T + bh; Wh [A1, C]; C a power of two
+ *       16..256, A1 = A + 1 in {5, 6}.
+ *   ag_heads_bwd_elu: dz = (d_heads Wh) * ELU'(h) and per-block column sums (layout of ag_elu_bwd_bias). */
+int ag_mlp_input_layer(const float* obs_dev, const double* mean_dev, const double* var_dev, const float* W_dev,
+                       const float* bias_dev, float* xn_dev, float* h_dev, int M, int D, int C, float eps, float clip,
+                       void* stream);
+int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float* heads_dev, int M, int C, int A1,
+                 void* stream);
+int ag_heads_bwd_elu(const float* d_heads_dev, const float* Wh_dev, const float* h_dev, float* dz_dev,
+                     float* db_partials_dev, int M, int C, int A1, void* stream);
+
 /* ELU backward fused with the bias gradient of the producing Linear (lib/network/mlp.py:36-39 under autograd):
  * dz = dh * ELU'(z) computed from h = ELU(z); db_partials_dev [ceil(M / rows_per_block), C] per-block column sums of dz
  * (caller reduces).  C % 4 == 0 and 256 % (C/4) == 0 (C = 64, 128, 256, 512, 1024 ...). */

@@ -362,7 +362,8 @@ def test_tracking_full_size_properties(Handle):
     env.close()
 
 
-def test_hand_scheduled_update_matches_autograd(Handle):
+@pytest.mark.parametrize("units", [[256, 256], [128, 64, 32], [512]])
+def test_hand_scheduled_update_matches_autograd(Handle, units):
     """FusedMLPStep (hand-scheduled forward/backward writing into the flat gradient buffer) == the autograd path on the
     same minibatch: every gradient, the KL slot, the logged scalars and the mu/sigma write-back."""
     import os
@@ -376,6 +377,7 @@ def test_hand_scheduled_update_matches_autograd(Handle):
         envs = 4096; minibatches = 4; graph = 0
     params = bench.build_params(Args, 1)
     params["config"]["bounds_loss_coef"] = 1e-4
+    params["network"]["mlp"]["units"] = units
     agent = A2CAgent("t", params)
     assert agent._fused_step is not None, "the bench configuration must take the hand-scheduled path"
     agent.init_tensors()
