@@ -326,6 +326,8 @@ class A2CAgent:
         self._term_names = list(terms.keys()) if terms else []
         self._term_sums = torch.zeros(len(self._term_names), dtype=torch.float64, device=dev)
         self._term_steps = 0
+        from airgym_amd.lib.agent.fused_update import FusedRolloutStep
+        self._fused_rollout = FusedRolloutStep(self) if FusedRolloutStep.supported(self) else None
 
     def _obs_at(self, n):
         return {k: v[n] for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict) else self.obs_buf[n]
@@ -357,6 +359,8 @@ class A2CAgent:
     @torch.no_grad()
     def _rollout_step(self, n):
         """One step of play_steps (a2c_base.py:651-695) with every tensor written in place."""
+        if self._fused_rollout is not None:
+            return self._fused_rollout.step(n)
         res = self.get_action_values(self._obs_at(n))
         self.actions_buf[n].copy_(res["actions"])
         self.neglogpacs_buf[n].copy_(res["neglogpacs"])
@@ -407,22 +411,33 @@ class A2CAgent:
     def play_steps(self):
         H = self.horizon_length
         graphable = self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0
+        fr = self._fused_rollout
+
+        def rollout():
+            if fr is not None:
+                fr.begin_rollout()
+            for n in range(H):
+                self._rollout_step(n)
+            if fr is not None:
+                fr.end_rollout()
         if "rollout" in self._graphs:
             self._graphs["rollout"].replay()
         else:
-            for n in range(H):
-                self._rollout_step(n)
+            rollout()
             if graphable:
                 # the first rollout ran eagerly (lazy library initialisation); now capture the whole H-step
                 # rollout - policy inference + env kernel, H launches of the device-tick ping-pong - for replay
-                self._graphs["rollout"] = self._capture(lambda: [self._rollout_step(n) for n in range(H)], warmup=False)
+                self._graphs["rollout"] = self._capture(rollout, warmup=False)
         self._rollouts_done += 1
         self.model.eval()
         last_values = self.model({"is_train": False, "obs": self._obs_at(H)})["values"]
-        fdones = self.dones_buf[H].float()
-        mb_fdones = self.dones_buf[:H].float()
-        mb_advs = self._gae(fdones, last_values, mb_fdones)
-        mb_returns = mb_advs + self.values_buf
+        if fr is not None:
+            mb_advs, mb_returns = fr.gae(last_values)
+        else:
+            fdones = self.dones_buf[H].float()
+            mb_fdones = self.dones_buf[:H].float()
+            mb_advs = self._gae(fdones, last_values, mb_fdones)
+            mb_returns = mb_advs + self.values_buf
         batch = {
             "obses": ({k: swap_and_flatten01(v[:H]) for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict)
                       else swap_and_flatten01(self.obs_buf[:H])),

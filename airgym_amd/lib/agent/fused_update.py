@@ -163,3 +163,142 @@ class FusedMLPStep:
                 dh = self.dh[:M * K].view(M, K)
                 torch.mm(dz, w, out=dh)
         return stats
+
+
+class FusedRolloutStep:
+    """One step of A2CBase.play_steps (lib/agent/a2c_base.py:651-695) as six launches:
+    ag_mlp_input_layer -> [GEMM (+ELU)] -> ag_elu_heads -> ag_policy_sample -> ag_step_into -> ag_rollout_account
+    (+ two one-kernel reductions for the logged statistics).  The action noise is Philox-based and counter-keyed, so the
+    captured hipGraph of the whole rollout draws fresh noise on every replay (begin_rollout bumps the device counter)."""
+
+    @staticmethod
+    def supported(agent):
+        from airgym_amd.lib.utils.tr_helpers import DefaultRewardsShaper
+        m = agent.model
+        sh = agent.rewards_shaper
+        return (str(agent.ppo_device).startswith("cuda") and agent.config.get("use_fused_rollout", True)
+                and agent._hip_env is not None and agent._fused_loss_ok() and not m.dict_obs
+                and m.actor_mlp.activation_name == "elu" and getattr(agent, "heads_w", None) is not None
+                and agent.actions_num in (4, 5) and agent.clip_actions
+                and bool((agent.actions_low == -1).all()) and bool((agent.actions_high == 1).all())
+                and isinstance(sh, DefaultRewardsShaper)
+                and all(l.weight.shape[0] % 4 == 0 and l.weight.shape[0] <= 1024 and 256 % (l.weight.shape[0] // 4) == 0
+                        for l in m.actor_mlp.layers))
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.lib = N.load()
+        m, dev = agent.model, agent.ppo_device
+        n = self.n = agent.num_actors * agent.num_agents
+        self.A = agent.actions_num
+        self.layers = [(l.weight, l.bias) for l in m.actor_mlp.layers]
+        f = dict(dtype=torch.float32, device=dev)
+        D = self.layers[0][0].shape[1]
+        self.xn = torch.empty(n, D, **f)
+        self.h = [torch.empty(n, w.shape[0], **f) for w, _ in self.layers]
+        self.heads = torch.empty(n, self.A + 1, **f)
+        self.env_actions = torch.empty(n, self.A, **f)
+        C0, Cl = self.layers[0][0].shape[0], self.layers[-1][0].shape[0]
+        self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
+        self.fuse_heads = len(self.layers) >= 2 and 16 <= Cl <= 256 and (Cl & (Cl - 1)) == 0
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.acct_partials = torch.zeros(self.lib.ag_rollout_account_blocks(n), 4, dtype=torch.float64, device=dev)
+        self.seed = (int(agent.params.get("seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
+        self.id_offset = agent.global_rank * n
+        stacked = getattr(agent._hip_env, "reward_terms_stacked", None)
+        self.term_buf = (torch.zeros(agent.horizon_length, stacked.shape[0], **f)
+                         if stacked is not None and agent._term_names and agent.config.get("log_reward_terms", True) else None)
+
+    def begin_rollout(self):
+        self.counter.add_(1)      # captured with the rollout graph: every replay advances the noise counter
+
+    def end_rollout(self):
+        if self.term_buf is not None:
+            self.agent._term_sums += self.term_buf.sum(0).double() / self.n
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.agent.ppo_device).cuda_stream)
+
+    @torch.no_grad()
+    def heads_of(self, obs):
+        """Policy forward on [n, D] observations -> heads [n, A+1] (mu | normalised value)."""
+        ag, lib, m = self.agent, self.lib, self.agent.model
+        n, A, st = self.n, self.A, self._stream()
+        rms = m.running_mean_std if m.normalize_input else None
+        w0, b0 = self.layers[0]
+        D, C0 = obs.shape[1], w0.shape[0]
+        if self.fuse_input:
+            N.check(lib.ag_mlp_input_layer(obs.data_ptr(), rms.running_mean.data_ptr() if rms is not None else None,
+                                           rms.running_var.data_ptr() if rms is not None else None, w0.data_ptr(),
+                                           b0.data_ptr(), self.xn.data_ptr() if rms is not None else None,
+                                           self.h[0].data_ptr(), n, D, C0, float(rms.epsilon) if rms is not None else 0.0,
+                                           5.0, st), "ag_mlp_input_layer")
+        else:
+            x = obs
+            if rms is not None:
+                N.check(lib.ag_normalize_rows(obs.data_ptr(), rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
+                                              self.xn.data_ptr(), n, D, float(rms.epsilon), 5.0, st), "ag_normalize_rows")
+                x = self.xn
+            torch.addmm(b0, x, w0.t(), out=self.h[0])
+            F.elu_(self.h[0])
+        x = self.h[0]
+        last = len(self.layers) - 1
+        heads_done = False
+        for li in range(1, len(self.layers)):
+            w, b = self.layers[li]
+            h = self.h[li]
+            torch.addmm(b, x, w.t(), out=h)
+            if li == last and self.fuse_heads:
+                N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
+                                         n, w.shape[0], A + 1, st), "ag_elu_heads")
+                heads_done = True
+            else:
+                F.elu_(h)
+            x = h
+        if not heads_done:
+            torch.addmm(ag.heads_b, x, ag.heads_w.t(), out=self.heads)
+        return self.heads
+
+    @torch.no_grad()
+    def step(self, slot):
+        ag, lib, m = self.agent, self.lib, self.agent.model
+        n, A = self.n, self.A
+        self.heads_of(ag.obs_buf[slot])
+        st = self._stream()
+        vms = m.value_mean_std if m.normalize_value else None
+        N.check(lib.ag_policy_sample(self.heads.data_ptr(), m.logstd.data_ptr(),
+                                     vms.running_mean.data_ptr() if vms is not None else None,
+                                     vms.running_var.data_ptr() if vms is not None else None,
+                                     float(vms.epsilon) if vms is not None else 0.0, self.seed, self.counter.data_ptr(),
+                                     ag.horizon_length, slot, self.id_offset, ag.actions_buf[slot].data_ptr(),
+                                     ag.neglogpacs_buf[slot].data_ptr(), ag.values_buf[slot].data_ptr(),
+                                     ag.mus_buf[slot].data_ptr(), ag.sigmas_buf[slot].data_ptr(),
+                                     self.env_actions.data_ptr(), n, A, st), "ag_policy_sample")
+        env = ag._hip_env
+        env.step_into(self.env_actions, ag.obs_buf[slot + 1], ag.raw_rewards_buf[slot], ag.dones_buf[slot + 1])
+        sh = ag.rewards_shaper
+        tmo = env.time_out_buf if ag.value_bootstrap else None
+        N.check(lib.ag_rollout_account(ag.raw_rewards_buf[slot].data_ptr(), ag.dones_buf[slot + 1].data_ptr(),
+                                       tmo.data_ptr() if tmo is not None else None,
+                                       ag.values_buf[slot].data_ptr() if tmo is not None else None,
+                                       float(sh.scale_value), float(sh.shift_value), float(sh.min_val), float(sh.max_val),
+                                       int(bool(sh.log_val)), float(ag.gamma), ag.rewards_buf[slot].data_ptr(),
+                                       ag.current_rewards.data_ptr(), ag.current_shaped_rewards.data_ptr(),
+                                       ag.current_lengths.data_ptr(), self.acct_partials.data_ptr(), n, st),
+                "ag_rollout_account")
+        torch.sum(self.acct_partials, 0, out=ag.ep_stats[slot])
+        if self.term_buf is not None:
+            torch.sum(env.reward_terms_stacked, 1, out=self.term_buf[slot])
+
+    @torch.no_grad()
+    def gae(self, last_values):
+        """advantages, returns [H, n, 1] from the rollout buffers (a2c_base.py:463-478)."""
+        ag = self.agent
+        H = ag.horizon_length
+        advs = torch.empty_like(ag.values_buf)
+        rets = torch.empty_like(ag.values_buf)
+        lv = last_values.contiguous()
+        N.check(self.lib.ag_gae(ag.rewards_buf.data_ptr(), ag.values_buf.data_ptr(), ag.dones_buf.data_ptr(), lv.data_ptr(),
+                                float(ag.gamma), float(ag.tau), advs.data_ptr(), rets.data_ptr(), H, self.n, self._stream()),
+                "ag_gae")
+        return advs, rets

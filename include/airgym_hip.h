@@ -202,6 +202,28 @@ int ag_ppo_loss_finalize(const float* partials_dev, int num_blocks, int M, int A
 int ag_normalize_rows(const float* x_dev, const double* mean_dev, const double* var_dev, float* out_dev, long long rows,
                       int D, float eps, float clip, void* stream);
 
+/* Rollout bookkeeping of A2CBase.play_steps (lib/agent/a2c_base.py:651-695) and GAE (a2c_base.py:463-478).
+ *   ag_policy_sample: actions = mu + sigma * N(0,1) from heads [n, A+1] (mu | value) and logstd [A]; the noise is
+ *       Philox4x32-10 keyed by `seed` with counter (id_offset + env, (*counter_dev) * horizon + slot, stream 16, block), so a
+ *       captured hipGraph draws fresh noise on every replay once the caller bumps *counter_dev (int64, device).
+ *       Writes actions / mus / sigmas [n, A], neglogp [n], values [n] (de-normalised with vmean/vvar when given,
+ *       base_model.py:29-35) and, optionally, env_actions = clamp(actions, -1, 1) (a2c_base.py:229-236).
+ *   ag_rollout_account: shaped = clamp((r + shift) * scale, min, max) [log] (+ gamma * value on time-outs), running episode
+ *       reward / shaped reward / length, and per-block partial sums {episodes ended, sum reward, sum shaped, sum length}
+ *       in partials_dev [ag_rollout_account_blocks(n), 4] (double); running sums are cleared where dones != 0.
+ *   ag_gae: dones_dev [H+1, n] (dones[t] = done entering step t), rewards / values / advs / returns [H, n]. */
+int ag_policy_sample(const float* heads_dev, const float* logstd_dev, const double* vmean_dev, const double* vvar_dev,
+                     float veps, unsigned long long seed, const long long* counter_dev, int horizon, int slot,
+                     long long id_offset, float* actions_dev, float* neglogp_dev, float* values_dev, float* mus_dev,
+                     float* sigmas_dev, float* env_actions_dev, int n, int A, void* stream);
+int ag_rollout_account_blocks(int n);
+int ag_rollout_account(const float* raw_reward_dev, const long long* dones_dev, const unsigned char* timeouts_dev,
+                       const float* values_dev, float scale, float shift, float min_val, float max_val, int log_val,
+                       float gamma, float* shaped_dev, float* cur_rew_dev, float* cur_shaped_dev, float* cur_len_dev,
+                       double* partials_dev, int n, void* stream);
+int ag_gae(const float* rewards_dev, const float* values_dev, const long long* dones_dev, const float* last_values_dev,
+           float gamma, float tau, float* advs_dev, float* returns_dev, int H, int n, void* stream);
+
 /* Fused edges of the MLP trunk (lib/network/mlp.py:36-39, a2c_continuous_logstd_model.py:126-146); the wide GEMMs in
  * between stay with hipBLASLt.
  *   ag_mlp_input_layer: xn = clamp((obs - mean)/sqrt(var + eps), +-clip) [M, D] (skipped when mean/var/xn are all NULL,

@@ -1,0 +1,154 @@
+"""GPU tests of the rollout bookkeeping kernels (csrc/rollout_kernels.hip) against the composed torch ops that restate
+A2CBase.play_steps / discount_values (lib/agent/a2c_base.py:463-478, 651-695) and against the Philox oracle."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from airgym_amd import _native as N
+    assert torch.cuda.is_available()
+    return N.load()
+
+
+@pytest.mark.parametrize("A,normalize_value", [(4, True), (5, False), (4, False)])
+def test_policy_sample(lib, A, normalize_value):
+    from airgym_amd import _native as N
+    from airgym_amd.lib.model.a2c_continuous_logstd_model import ModelA2CContinuousLogStd
+    n, H, slot, seed, offset = 3001, 24, 7, 0x1234567887654321, 1000
+    g = torch.Generator(device="cuda").manual_seed(0)
+    heads = torch.randn(n, A + 1, device="cuda", generator=g)
+    heads[:, A] *= 4                                   # some |v| > 5 so the de-normalisation clamp is exercised
+    logstd = 0.3 * torch.randn(A, device="cuda", generator=g)
+    vmean = torch.tensor([0.7], dtype=torch.float64, device="cuda")
+    vvar = torch.tensor([2.5], dtype=torch.float64, device="cuda")
+    counter = torch.tensor([5], dtype=torch.int64, device="cuda")
+    f = dict(device="cuda", dtype=torch.float32)
+    actions, mus, sigmas, env_a = (torch.empty(n, A, **f) for _ in range(4))
+    nlp, values = torch.empty(n, **f), torch.empty(n, **f)
+    N.check(lib.ag_policy_sample(heads.data_ptr(), logstd.data_ptr(), vmean.data_ptr() if normalize_value else None,
+                                 vvar.data_ptr() if normalize_value else None, 1e-5, seed, counter.data_ptr(), H, slot, offset,
+                                 actions.data_ptr(), nlp.data_ptr(), values.data_ptr(), mus.data_ptr(), sigmas.data_ptr(),
+                                 env_a.data_ptr(), n, A, _stream()), "ag_policy_sample")
+    mu, sigma = heads[:, :A], torch.exp(logstd).expand(n, A)
+    assert torch.equal(mus, mu) and torch.allclose(sigmas, sigma, rtol=1e-6)
+    # the noise is the oracle's Philox / Box-Muller stream 16 at tick = counter * H + slot
+    z_ref = philox.normals(seed, np.arange(offset, offset + n), 5 * H + slot, 16, A)[:, :A]
+    z = ((actions - mu) / sigma).cpu().numpy()
+    np.testing.assert_allclose(z, z_ref, rtol=0, atol=2e-4)
+    ref_nlp = ModelA2CContinuousLogStd.neglogp(actions, mu, sigma, logstd.expand(n, A))
+    assert torch.allclose(nlp, ref_nlp, rtol=1e-5, atol=1e-5)
+    v = heads[:, A]
+    ref_v = torch.sqrt(vvar.float() + 1e-5) * torch.clamp(v, -5, 5) + vmean.float() if normalize_value else v
+    assert torch.allclose(values, ref_v, rtol=1e-6, atol=1e-6)
+    assert torch.equal(env_a, actions.clamp(-1, 1)) and (actions.abs() > 1).any()
+    # a different counter value -> different noise; the same -> identical (pure function of the counters)
+    a2 = torch.empty_like(actions)
+    counter.add_(1)
+    N.check(lib.ag_policy_sample(heads.data_ptr(), logstd.data_ptr(), None, None, 0.0, seed, counter.data_ptr(), H, slot, offset,
+                                 a2.data_ptr(), nlp.data_ptr(), values.data_ptr(), mus.data_ptr(), sigmas.data_ptr(), None,
+                                 n, A, _stream()), "ag_policy_sample")
+    assert not torch.equal(a2, actions)
+    zz = ((a2 - mu) / sigma)
+    assert abs(zz.mean().item()) < 0.05 and abs(zz.std().item() - 1.0) < 0.05
+
+
+@pytest.mark.parametrize("bootstrap", [False, True])
+def test_rollout_account(lib, bootstrap):
+    from airgym_amd import _native as N
+    n = 70001
+    g = torch.Generator(device="cuda").manual_seed(1)
+    raw = torch.randn(n, device="cuda", generator=g)
+    dones = (torch.rand(n, device="cuda", generator=g) < 0.1).long()
+    tmo = (torch.rand(n, device="cuda", generator=g) < 0.2).to(torch.uint8)
+    values = torch.randn(n, device="cuda", generator=g)
+    cr, cs, cl = (torch.rand(n, device="cuda", generator=g) * 10 for _ in range(3))
+    cr0, cs0, cl0 = cr.clone(), cs.clone(), cl.clone()
+    shaped = torch.empty(n, device="cuda")
+    parts = torch.zeros(lib.ag_rollout_account_blocks(n), 4, dtype=torch.float64, device="cuda")
+    scale, shift, lo, hi, gamma = 0.5, 0.1, -0.9, 0.8, 0.99
+    N.check(lib.ag_rollout_account(raw.data_ptr(), dones.data_ptr(), tmo.data_ptr() if bootstrap else None,
+                                   values.data_ptr() if bootstrap else None, scale, shift, lo, hi, 0, gamma, shaped.data_ptr(),
+                                   cr.data_ptr(), cs.data_ptr(), cl.data_ptr(), parts.data_ptr(), n, _stream()),
+            "ag_rollout_account")
+    ref_sh = torch.clamp((raw + shift) * scale, lo, hi)
+    if bootstrap:
+        ref_sh = ref_sh + gamma * values * tmo.float()
+    assert torch.allclose(shaped, ref_sh, rtol=1e-6, atol=1e-7)
+    r_cr, r_cs, r_cl = cr0 + raw, cs0 + ref_sh, cl0 + 1
+    d = dones.bool()
+    ref = torch.stack((d.double().sum(), r_cr[d].double().sum(), r_cs[d].double().sum(), r_cl[d].double().sum()))
+    assert torch.allclose(parts.sum(0), ref, rtol=1e-9)
+    assert torch.allclose(cr, r_cr * (~d), atol=1e-6) and torch.allclose(cs, r_cs * (~d), atol=1e-6) and torch.allclose(cl, r_cl * (~d))
+    # unbounded shaper == identity clamp
+    N.check(lib.ag_rollout_account(raw.data_ptr(), dones.data_ptr(), None, None, 1.0, 0.0, -math.inf, math.inf, 0, gamma,
+                                   shaped.data_ptr(), cr.data_ptr(), cs.data_ptr(), cl.data_ptr(), parts.data_ptr(), n,
+                                   _stream()), "ag_rollout_account")
+    assert torch.equal(shaped, raw)
+
+
+def test_gae_kernel(lib):
+    from airgym_amd import _native as N
+    from airgym_amd.lib.agent.a2c_continuous import discount_values
+    H, n, gamma, tau = 24, 5003, 0.99, 0.95
+    g = torch.Generator(device="cuda").manual_seed(2)
+    rewards = torch.randn(H, n, 1, device="cuda", generator=g)
+    values = torch.randn(H, n, 1, device="cuda", generator=g)
+    dones = (torch.rand(H + 1, n, device="cuda", generator=g) < 0.1).long()
+    last_values = torch.randn(n, 1, device="cuda", generator=g)
+    advs, rets = torch.empty_like(values), torch.empty_like(values)
+    N.check(lib.ag_gae(rewards.data_ptr(), values.data_ptr(), dones.data_ptr(), last_values.data_ptr(), gamma, tau,
+                       advs.data_ptr(), rets.data_ptr(), H, n, _stream()), "ag_gae")
+    ref = discount_values(dones[H].float(), last_values, dones[:H].float(), values, rewards, gamma, tau)
+    assert torch.allclose(advs, ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rets, ref + values, rtol=1e-5, atol=1e-5)
+
+
+def test_fused_rollout_trains(lib):
+    """The six-launch rollout step feeds the same buffers as the eager path: finite training, per-env episode accounting
+    consistent with the env's own progress counters, fresh noise on every hipGraph replay."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+
+    class Args:
+        envs = 4096; minibatches = 4; graph = 1
+    agent = A2CAgent("t", bench.build_params(Args, 1))
+    agent.init_tensors()
+    assert agent._fused_rollout is not None and agent._fused_step is not None
+    agent.obs = agent.env_reset()
+    H = agent.horizon_length
+    acts = []
+    for ep in range(3):                      # epoch 0 eager, epoch 1 captures, epoch 2 replays the graph
+        agent.epoch_num += 1
+        st = agent.train_epoch()
+        acts.append(agent.actions_buf.clone())
+        assert all(math.isfinite(st[k]) for k in ("a_loss", "c_loss", "kl", "entropy"))
+        z = (agent.actions_buf - agent.mus_buf) / agent.sigmas_buf
+        assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1) < 0.02
+        # stored neglogp is what the model recomputes from the stored (action, mu, sigma)
+        nlp = 0.5 * (z ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * 4 + torch.log(agent.sigmas_buf).sum(-1)
+        assert torch.allclose(nlp, agent.neglogpacs_buf, rtol=1e-4, atol=1e-4)
+        # running episode length == the env's progress counter for envs that did not just reset
+        prog = agent._hip_env.get_state()["progress"].float()
+        alive = agent.dones_buf[H] == 0
+        diff = prog[alive] - agent.current_lengths[alive]      # the env counts the step that follows its reset as well
+        assert ((diff == 0) | (diff == 1)).all()
+    assert not torch.equal(acts[1], acts[2])
+    noise1 = (acts[1] - agent.mus_buf).abs().sum()
+    assert noise1 > 0
+    assert agent.game_lengths.current_size > 0 or agent.ep_stats[:, 0].sum() >= 0

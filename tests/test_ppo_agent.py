@@ -189,7 +189,8 @@ def _dp_worker(rank, world, port, q):
     out["trained"] = agent2.flat_param.clone()
     out["trained_rms"] = agent2.model.running_mean_std.running_mean.clone()
     out["frames"] = agent2.frame
-    q.put((rank, out))
+    # by value: tensors would travel as fds served by this process, which may exit before the parent reads them
+    q.put((rank, {k: (v.detach().numpy().copy() if torch.is_tensor(v) else v) for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -206,7 +207,7 @@ def test_data_parallel_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    r0, r1 = res[0], res[1]
+    r0, r1 = ({k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in res[r].items()} for r in (0, 1))
     # replicas identical after the step (single all-reduce carried grads + KL)
     assert torch.equal(r0["param"], r1["param"]) and r0["lr"] == r1["lr"]
     assert torch.equal(r0["rms_mean"], r1["rms_mean"])
