@@ -130,6 +130,9 @@ SYMBOLS = [
                                           ctypes.c_float, ctypes.c_float, _P]),
     ("ag_elu_heads", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_heads_bwd_elu", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_wgrad_rows_per_block", ctypes.c_int, []),
+    ("ag_heads_bwd_elu_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_elu_bwd_input_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_elu_bwd_bias_rows_per_block", ctypes.c_int, []),
     ("ag_elu_bwd_bias", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_adam_clip_step", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int] + [ctypes.c_float] * 8 + [_P]),

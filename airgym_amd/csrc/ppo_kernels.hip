@@ -436,7 +436,11 @@ extern "C" int ag_normalize_rows(const float* x, const double* mean, const doubl
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ float elu1(float z) { return z > 0.f ? z : expm1f(z); }
+// ELU(alpha = 1) as torch evaluates it, exp(z) - 1 on the negative side, with the hardware exp2 (v_exp_f32, ~1 ulp):
+// expm1f from the device library costs ~10x more VALU issue slots and made these streaming kernels compute-bound.
+__device__ __forceinline__ float elu1(float z) {
+    return z > 0.f ? z : __builtin_amdgcn_exp2f(z * 1.4426950408889634f) - 1.0f;
+}
 
 constexpr int kInTileRows = 64;
 
@@ -494,6 +498,60 @@ __global__ __launch_bounds__(256) void input_layer_kernel(const float* __restric
     }
 }
 
+// Same contract as input_layer_kernel with D known at compile time: each thread keeps its 4 x D slab of W in registers
+// (its column group never changes) and streams rows: per row D broadcast LDS reads, 4*D FMAs, one float4 store.
+constexpr int kInRegTileRows = 128;
+
+template <int D>
+__global__ __launch_bounds__(256) void input_layer_reg_kernel(const float* __restrict__ obs, const double* __restrict__ mean,
+                                                              const double* __restrict__ var, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ xn,
+                                                              float* __restrict__ h, int M, int C, float eps, float clip,
+                                                              int normalize) {
+    __shared__ float xs[kInRegTileRows * D];
+    const int row0 = blockIdx.x * kInRegTileRows;
+    const int rows = min(kInRegTileRows, M - row0);
+    for (int i = threadIdx.x; i < rows * D; i += 256) {
+        const int d = i % D;
+        float v = obs[(size_t)row0 * D + i];
+        if (normalize) {
+            v = (v - (float)mean[d]) / sqrtf((float)var[d] + eps);
+            v = fminf(fmaxf(v, -clip), clip);
+            xn[(size_t)row0 * D + i] = v;
+        }
+        xs[i] = v;
+    }
+    const int tpr = C >> 2;
+    const int rgroups = 256 / tpr;
+    const int col4 = threadIdx.x % tpr, rg = threadIdx.x / tpr;
+    float4 w[D];
+    if (rg < rgroups) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            w[d].x = W[(size_t)(col4 * 4 + 0) * D + d];
+            w[d].y = W[(size_t)(col4 * 4 + 1) * D + d];
+            w[d].z = W[(size_t)(col4 * 4 + 2) * D + d];
+            w[d].w = W[(size_t)(col4 * 4 + 3) * D + d];
+        }
+    }
+    __syncthreads();
+    if (rg >= rgroups) return;
+    const float4 b4 = reinterpret_cast<const float4*>(bias)[col4];
+    for (int r = rg; r < rows; r += rgroups) {
+        const float* xr = xs + r * D;
+        float4 acc = b4;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float x = xr[d];
+            acc.x = fmaf(x, w[d].x, acc.x); acc.y = fmaf(x, w[d].y, acc.y);
+            acc.z = fmaf(x, w[d].z, acc.z); acc.w = fmaf(x, w[d].w, acc.w);
+        }
+        float4 o;
+        o.x = elu1(acc.x); o.y = elu1(acc.y); o.z = elu1(acc.z); o.w = elu1(acc.w);
+        reinterpret_cast<float4*>(h + (size_t)(row0 + r) * C)[col4] = o;
+    }
+}
+
 // h = ELU(z) in place; heads[m, a] = sum_c h[m,c] Wh[a,c] + bh[a].  tpr = C/4 threads per row (power of two <= 64).
 template <int A1>
 __global__ __launch_bounds__(256) void elu_heads_kernel(float* __restrict__ zh, const float* __restrict__ Wh,
@@ -507,21 +565,37 @@ __global__ __launch_bounds__(256) void elu_heads_kernel(float* __restrict__ zh, 
     for (int a = 0; a < A1; ++a) w[a] = reinterpret_cast<const float4*>(Wh + (size_t)a * C)[col4];
     const int row0 = blockIdx.x * rows_per_block;
     const int row_end = min(row0 + rows_per_block, M);
-    for (int r = row0 + rsub; r < row_end; r += rpp) {
-        float4* p = reinterpret_cast<float4*>(zh + (size_t)r * C) + col4;
-        float4 z = *p;
-        z.x = elu1(z.x); z.y = elu1(z.y); z.z = elu1(z.z); z.w = elu1(z.w);
-        *p = z;
-        float s[A1];
+    for (int r = row0 + rsub; r < row_end; r += 2 * rpp) {
+        // two rows in flight per thread: both loads are issued before either row is finished
+        const int r2 = r + rpp;
+        const bool has2 = r2 < row_end;
+        float4* p0 = reinterpret_cast<float4*>(zh + (size_t)r * C) + col4;
+        float4* p1 = reinterpret_cast<float4*>(zh + (size_t)(has2 ? r2 : r) * C) + col4;
+        float4 z0 = *p0;
+        float4 z1 = *p1;
+        z0.x = elu1(z0.x); z0.y = elu1(z0.y); z0.z = elu1(z0.z); z0.w = elu1(z0.w);
+        z1.x = elu1(z1.x); z1.y = elu1(z1.y); z1.z = elu1(z1.z); z1.w = elu1(z1.w);
+        *p0 = z0;
+        if (has2) *p1 = z1;
+        float s0[A1], s1[A1];
 #pragma unroll
-        for (int a = 0; a < A1; ++a) s[a] = (z.x * w[a].x + z.y * w[a].y) + (z.z * w[a].z + z.w * w[a].w);
+        for (int a = 0; a < A1; ++a) {
+            s0[a] = (z0.x * w[a].x + z0.y * w[a].y) + (z0.z * w[a].z + z0.w * w[a].w);
+            s1[a] = (z1.x * w[a].x + z1.y * w[a].y) + (z1.z * w[a].z + z1.w * w[a].w);
+        }
         for (int off = tpr >> 1; off > 0; off >>= 1) {
 #pragma unroll
-            for (int a = 0; a < A1; ++a) s[a] += __shfl_xor(s[a], off, 64);
+            for (int a = 0; a < A1; ++a) {
+                s0[a] += __shfl_xor(s0[a], off, 64);
+                s1[a] += __shfl_xor(s1[a], off, 64);
+            }
         }
         if (col4 == 0) {
 #pragma unroll
-            for (int a = 0; a < A1; ++a) heads[(size_t)r * A1 + a] = s[a] + bh[a];
+            for (int a = 0; a < A1; ++a) {
+                heads[(size_t)r * A1 + a] = s0[a] + bh[a];
+                if (has2) heads[(size_t)r2 * A1 + a] = s1[a] + bh[a];
+            }
         }
     }
 }
@@ -582,6 +656,19 @@ extern "C" int ag_mlp_input_layer(const float* obs, const double* mean, const do
     const int normalize = (mean && var && xn) ? 1 : 0;
     if (!normalize && (mean || var || xn)) return AG_ERR_INVALID_ARG;
     if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
+    if (D == 16 || D == 18 || D == 20) {
+        const int g = (M + kInRegTileRows - 1) / kInRegTileRows;
+        if (D == 16)
+            hipLaunchKernelGGL(input_layer_reg_kernel<16>, dim3(g), dim3(256), 0, (hipStream_t)stream, obs, mean, var, W, bias,
+                               xn, h, M, C, eps, clip, normalize);
+        else if (D == 18)
+            hipLaunchKernelGGL(input_layer_reg_kernel<18>, dim3(g), dim3(256), 0, (hipStream_t)stream, obs, mean, var, W, bias,
+                               xn, h, M, C, eps, clip, normalize);
+        else
+            hipLaunchKernelGGL(input_layer_reg_kernel<20>, dim3(g), dim3(256), 0, (hipStream_t)stream, obs, mean, var, W, bias,
+                               xn, h, M, C, eps, clip, normalize);
+        return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+    }
     const size_t lds = ((size_t)D * C + (size_t)kInTileRows * D) * sizeof(float);
     if (lds > 64 * 1024) return AG_ERR_UNSUPPORTED;
     const int grid = (M + kInTileRows - 1) / kInTileRows;
@@ -615,5 +702,210 @@ extern "C" int ag_heads_bwd_elu(const float* d_heads, const float* Wh, const flo
         hipLaunchKernelGGL(heads_bwd_elu_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz, db_partials, M, C);
     else
         return AG_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward edges with the small weight gradients folded in (no [M,C] intermediate is written just to be re-read):
+//   heads_bwd_elu_wgrad : as heads_bwd_elu, plus per-block partials of dWh[a,c] = sum_m d_heads[m,a] h[m,c]
+//   elu_bwd_input_wgrad : FIRST layer.  dz = dh * ELU'(h) is consumed on the fly: per-block partials of
+//                         dW[c,d] = sum_m dz[m,c] x[m,d]  (D <= 24) and db[c] = sum_m dz[m,c]; dz itself is never stored
+//                         (nothing upstream of the first layer needs it).
+// Partials are [blocks, ...]; the caller reduces them with one sum over dim 0 (deterministic).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kWgRows = 128;      // rows per block
+
+template <int A1>
+__global__ __launch_bounds__(256) void heads_bwd_elu_wgrad_kernel(const float* __restrict__ d_heads, const float* __restrict__ Wh,
+                                                                  const float* __restrict__ h, float* __restrict__ dz,
+                                                                  float* __restrict__ db_partials, float* __restrict__ dwh_partials,
+                                                                  int M, int C) {
+    __shared__ float4 red[256];
+    const int tpr = C >> 2;
+    const int rpp = 256 / tpr;
+    const int col4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    float4 w[A1], gw[A1];
+#pragma unroll
+    for (int a = 0; a < A1; ++a) {
+        w[a] = reinterpret_cast<const float4*>(Wh + (size_t)a * C)[col4];
+        gw[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int row0 = blockIdx.x * kWgRows;
+    const int row_end = min(row0 + kWgRows, M);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rsub < rpp) {
+        for (int r = row0 + rsub; r < row_end; r += rpp) {
+            const size_t idx = (size_t)r * tpr + col4;
+            const float4 y = reinterpret_cast<const float4*>(h)[idx];
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a = 0; a < A1; ++a) {
+                const float d = d_heads[(size_t)r * A1 + a];
+                g.x = fmaf(d, w[a].x, g.x); g.y = fmaf(d, w[a].y, g.y); g.z = fmaf(d, w[a].z, g.z); g.w = fmaf(d, w[a].w, g.w);
+                gw[a].x = fmaf(d, y.x, gw[a].x); gw[a].y = fmaf(d, y.y, gw[a].y);
+                gw[a].z = fmaf(d, y.z, gw[a].z); gw[a].w = fmaf(d, y.w, gw[a].w);
+            }
+            float4 o;
+            o.x = g.x * (y.x > 0.f ? 1.f : y.x + 1.f);
+            o.y = g.y * (y.y > 0.f ? 1.f : y.y + 1.f);
+            o.z = g.z * (y.z > 0.f ? 1.f : y.z + 1.f);
+            o.w = g.w * (y.w > 0.f ? 1.f : y.w + 1.f);
+            reinterpret_cast<float4*>(dz)[idx] = o;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+    }
+    // reduce the rpp row groups: bias sums, then each head row
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < tpr) {
+        float4 s = red[threadIdx.x];
+        for (int j = 1; j < rpp; ++j) {
+            const float4 t = red[threadIdx.x + j * tpr];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        reinterpret_cast<float4*>(db_partials)[(size_t)blockIdx.x * tpr + threadIdx.x] = s;
+    }
+#pragma unroll
+    for (int a = 0; a < A1; ++a) {
+        __syncthreads();
+        red[threadIdx.x] = gw[a];
+        __syncthreads();
+        if (threadIdx.x < tpr) {
+            float4 s = red[threadIdx.x];
+            for (int j = 1; j < rpp; ++j) {
+                const float4 t = red[threadIdx.x + j * tpr];
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            reinterpret_cast<float4*>(dwh_partials)[((size_t)blockIdx.x * A1 + a) * tpr + threadIdx.x] = s;
+        }
+    }
+}
+
+// D is a template parameter so the [4][D] accumulator tile lives in registers.  Two rows are in flight per thread
+// (four 16-byte loads issued before use); the row groups then add their tiles into one [C][D+1] LDS buffer in turn.
+template <int D>
+__global__ __launch_bounds__(256) void elu_bwd_input_wgrad_kernel(const float* __restrict__ dh, const float* __restrict__ h,
+                                                                  const float* __restrict__ x, float* __restrict__ dw_partials,
+                                                                  float* __restrict__ db_partials, int M, int C) {
+    extern __shared__ float lds[];          // xs[kWgRows][D] | red[C][D+1]
+    float* xs = lds;
+    float* red = lds + kWgRows * D;
+    const int tpr = C >> 2;
+    const int rpp = 256 / tpr;
+    const int col4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int row0 = blockIdx.x * kWgRows;
+    const int rows = min(kWgRows, M - row0);
+    for (int i = threadIdx.x; i < rows * D; i += 256) xs[i] = x[(size_t)row0 * D + i];
+    __syncthreads();
+    float acc[4][D];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[j][d] = 0.f;
+    if (rsub < rpp) {
+        for (int r = rsub; r < rows; r += 2 * rpp) {
+            const int r2 = r + rpp;
+            const bool has2 = r2 < rows;
+            const size_t i0 = (size_t)(row0 + r) * tpr + col4;
+            const size_t i1 = (size_t)(row0 + (has2 ? r2 : r)) * tpr + col4;
+            const float4 g0 = reinterpret_cast<const float4*>(dh)[i0];
+            const float4 y0 = reinterpret_cast<const float4*>(h)[i0];
+            const float4 g1 = reinterpret_cast<const float4*>(dh)[i1];
+            const float4 y1 = reinterpret_cast<const float4*>(h)[i1];
+            float o[4], q[4];
+            o[0] = g0.x * (y0.x > 0.f ? 1.f : y0.x + 1.f);
+            o[1] = g0.y * (y0.y > 0.f ? 1.f : y0.y + 1.f);
+            o[2] = g0.z * (y0.z > 0.f ? 1.f : y0.z + 1.f);
+            o[3] = g0.w * (y0.w > 0.f ? 1.f : y0.w + 1.f);
+            const float m2 = has2 ? 1.f : 0.f;
+            q[0] = m2 * g1.x * (y1.x > 0.f ? 1.f : y1.x + 1.f);
+            q[1] = m2 * g1.y * (y1.y > 0.f ? 1.f : y1.y + 1.f);
+            q[2] = m2 * g1.z * (y1.z > 0.f ? 1.f : y1.z + 1.f);
+            q[3] = m2 * g1.w * (y1.w > 0.f ? 1.f : y1.w + 1.f);
+            const float* xr0 = xs + r * D;
+            const float* xr1 = xs + (has2 ? r2 : r) * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float xv0 = xr0[d], xv1 = xr1[d];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j][d] = fmaf(q[j], xv1, fmaf(o[j], xv0, acc[j][d]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bsum[j] += o[j] + q[j];
+        }
+    }
+    // the rpp row groups add their tiles into red[C][D+1] one after the other (fixed order -> deterministic)
+    for (int g2 = 0; g2 < rpp; ++g2) {
+        if (rsub == g2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* dst = red + (size_t)(col4 * 4 + j) * (D + 1);
+                if (g2 == 0) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) dst[d] = acc[j][d];
+                    dst[D] = bsum[j];
+                } else {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) dst[d] += acc[j][d];
+                    dst[D] += bsum[j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int per = C * (D + 1);
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const int c = i / (D + 1), d = i - c * (D + 1);
+        if (d < D) dw_partials[((size_t)blockIdx.x * C + c) * D + d] = red[i];
+        else db_partials[(size_t)blockIdx.x * C + c] = red[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int ag_wgrad_rows_per_block(void) { return kWgRows; }
+
+extern "C" int ag_heads_bwd_elu_wgrad(const float* d_heads, const float* Wh, const float* h, float* dz, float* db_partials,
+                                      float* dwh_partials, int M, int C, int A1, void* stream) {
+    if (!d_heads || !Wh || !h || !dz || !db_partials || !dwh_partials || M <= 0) return AG_ERR_INVALID_ARG;
+    if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
+    const int grid = (M + kWgRows - 1) / kWgRows;
+    if (A1 == 5)
+        hipLaunchKernelGGL(heads_bwd_elu_wgrad_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz,
+                           db_partials, dwh_partials, M, C);
+    else if (A1 == 6)
+        hipLaunchKernelGGL(heads_bwd_elu_wgrad_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz,
+                           db_partials, dwh_partials, M, C);
+    else
+        return AG_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_elu_bwd_input_wgrad(const float* dh, const float* h, const float* x, float* dw_partials, float* db_partials,
+                                      int M, int C, int D, void* stream) {
+    if (!dh || !h || !x || !dw_partials || !db_partials || M <= 0) return AG_ERR_INVALID_ARG;
+    if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)kWgRows * D + (size_t)C * (D + 1));
+    if (lds > 160 * 1024) return AG_ERR_UNSUPPORTED;
+    const int grid = (M + kWgRows - 1) / kWgRows;
+#define AG_LAUNCH_D(DV)                                                                                                       \
+    case DV: {                                                                                                                \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)elu_bwd_input_wgrad_kernel<DV>,                               \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
+            return AG_ERR_HIP;                                                                                                \
+        hipLaunchKernelGGL(elu_bwd_input_wgrad_kernel<DV>, dim3(grid), dim3(256), lds, (hipStream_t)stream, dh, h, x,         \
+                           dw_partials, db_partials, M, C);                                                                   \
+        break;                                                                                                                \
+    }
+    switch (D) {
+        AG_LAUNCH_D(16)
+        AG_LAUNCH_D(18)
+        AG_LAUNCH_D(20)
+        default: return AG_ERR_UNSUPPORTED;
+    }
+#undef AG_LAUNCH_D
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }

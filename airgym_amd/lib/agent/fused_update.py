@@ -58,6 +58,15 @@ class FusedMLPStep:
         self.bias_partials = torch.empty((M + rows - 1) // rows * widest, **f)
         self.wgrad_partials = [torch.empty(SPLIT_K, w.shape[0], w.shape[1], **f) for w, _, _, _ in self.layers]
         self.head_wgrad_partials = torch.empty(SPLIT_K, self.A + 1, self.layers[-1][0].shape[0], **f)
+        wrows = self.lib.ag_wgrad_rows_per_block()
+        self.wg_blocks = (M + wrows - 1) // wrows
+        # small weight gradients folded into the ELU' passes (head: always; first layer: D in {16,18,20}, >= 2 layers)
+        self.fuse_head_wgrad = True
+        self.head_wg_partials2 = torch.empty(self.wg_blocks, self.A + 1, self.layers[-1][0].shape[0], **f)
+        self.fuse_input_wgrad = len(self.layers) >= 2 and D in (16, 18, 20)
+        if self.fuse_input_wgrad:
+            self.in_wg_partials = torch.empty(self.wg_blocks, self.layers[0][0].shape[0], D, **f)
+        self.bias_partials2 = torch.empty(self.wg_blocks * widest, **f)
         C0, Cl = self.layers[0][0].shape[0], self.layers[-1][0].shape[0]
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
         self.fuse_heads = len(self.layers) >= 2 and 16 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
@@ -137,11 +146,9 @@ class FusedMLPStep:
                                          float(ag.entropy_coef), float(ag.critic_coef), bcoef, logstd.grad.data_ptr(),
                                          ag.heads_b_grad.data_ptr(), ag.flat_grad[-1:].data_ptr(), stats.data_ptr(), st),
                 "ag_ppo_loss_finalize")
-        # ---- backward: fused head
+        # ---- backward.  The head's dX = d_heads Wh and its weight gradient are formed inside the last layer's ELU' pass;
+        # the first layer's weight/bias gradients are formed inside ITS ELU' pass (dz of layer 0 is never stored).
         H = x.shape[1]
-        torch.bmm(self.d_heads.view(S, M // S, A + 1).transpose(1, 2), x.view(S, M // S, H), out=self.head_wgrad_partials)
-        torch.sum(self.head_wgrad_partials, 0, out=ag.heads_w_grad)
-        # ---- backward: trunk.  The last layer's dX = d_heads Wh is formed inside the ELU' pass.
         rows = lib.ag_elu_bwd_bias_rows_per_block()
         dh = None
         for li in range(last, -1, -1):
@@ -149,11 +156,21 @@ class FusedMLPStep:
             h, xin = self.h[li], inputs[li]
             C, K = w.shape
             dz = self.dz[:M * C].view(M, C)
-            parts = self.bias_partials[:(M + rows - 1) // rows * C].view(-1, C)
             if li == last:
-                N.check(lib.ag_heads_bwd_elu(self.d_heads.data_ptr(), ag.heads_w.data_ptr(), h.data_ptr(), dz.data_ptr(),
-                                             parts.data_ptr(), M, C, A + 1, st), "ag_heads_bwd_elu")
+                parts = self.bias_partials2[:self.wg_blocks * C].view(-1, C)
+                N.check(lib.ag_heads_bwd_elu_wgrad(self.d_heads.data_ptr(), ag.heads_w.data_ptr(), h.data_ptr(), dz.data_ptr(),
+                                                   parts.data_ptr(), self.head_wg_partials2.data_ptr(), M, C, A + 1, st),
+                        "ag_heads_bwd_elu_wgrad")
+                torch.sum(self.head_wg_partials2, 0, out=ag.heads_w_grad)
+            elif li == 0 and self.fuse_input_wgrad:
+                parts = self.bias_partials2[:self.wg_blocks * C].view(-1, C)
+                N.check(lib.ag_elu_bwd_input_wgrad(dh.data_ptr(), h.data_ptr(), xin.data_ptr(), self.in_wg_partials.data_ptr(),
+                                                   parts.data_ptr(), M, C, K, st), "ag_elu_bwd_input_wgrad")
+                torch.sum(parts, 0, out=gb)
+                torch.sum(self.in_wg_partials, 0, out=gw)
+                break
             else:
+                parts = self.bias_partials[:(M + rows - 1) // rows * C].view(-1, C)
                 N.check(lib.ag_elu_bwd_bias(dh.data_ptr(), h.data_ptr(), dz.data_ptr(), parts.data_ptr(), M, C, st),
                         "ag_elu_bwd_bias")
             torch.sum(parts, 0, out=gb)

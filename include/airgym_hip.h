@@ -239,6 +239,18 @@ int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float*
 int ag_heads_bwd_elu(const float* d_heads_dev, const float* Wh_dev, const float* h_dev, float* dz_dev,
                      float* db_partials_dev, int M, int C, int A1, void* stream);
 
+/* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block() rows
+ * (ceil(M / rows) blocks); the caller reduces them over dim 0.
+ *   ag_heads_bwd_elu_wgrad: ag_heads_bwd_elu plus dwh_partials_dev [blocks, A1, C] of dWh[a,c] = sum_m d_heads[m,a] h[m,c];
+ *       db_partials_dev [blocks, C].
+ *   ag_elu_bwd_input_wgrad: first layer; dz = dh * ELU'(h) is consumed on the fly and never stored:
+ *       dw_partials_dev [blocks, C, D] of dW[c,d] = sum_m dz[m,c] x[m,d], db_partials_dev [blocks, C].  D in {16, 18, 20}. */
+int ag_wgrad_rows_per_block(void);
+int ag_heads_bwd_elu_wgrad(const float* d_heads_dev, const float* Wh_dev, const float* h_dev, float* dz_dev,
+                           float* db_partials_dev, float* dwh_partials_dev, int M, int C, int A1, void* stream);
+int ag_elu_bwd_input_wgrad(const float* dh_dev, const float* h_dev, const float* x_dev, float* dw_partials_dev,
+                           float* db_partials_dev, int M, int C, int D, void* stream);
+
 /* ELU backward fused with the bias gradient of the producing Linear (lib/network/mlp.py:36-39 under autograd):
  * dz = dh * ELU'(z) computed from h = ELU(z); db_partials_dev [ceil(M / rows_per_block), C] per-block column sums of dz
  * (caller reduces).  C % 4 == 0 and 256 % (C/4) == 0 (C = 64, 128, 256, 512, 1024 ...). */
