@@ -71,3 +71,64 @@ def measure_env_kernel(env, steps_per_graph=48, replays=20, warmup_replays=3, us
         "graph": bool(use_graph),
         "steps_timed": total_steps,
     }
+
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate, 64 FLOP/clk/SIMD
+
+
+def _time_us(fn, iters=20, warmup=3):
+    s = torch.cuda.current_stream()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(warmup):
+        fn()
+    start.record(s)
+    for _ in range(iters):
+        fn()
+    stop.record(s)
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e3 / iters
+
+
+@torch.no_grad()
+def measure_update_kernels(agent, iters=20):
+    """Per-kernel roofline figures of the PPO minibatch (hand-scheduled path): the hipBLASLt fp32 GEMM against the f32-MFMA
+    peak and the HIP streaming kernels against HBM, timed with events on the launch stream, on the live activations."""
+    import ctypes
+
+    from airgym_amd import _native as N
+    fs = getattr(agent, "_fused_step", None)
+    if fs is None or len(fs.layers) < 2:
+        return []
+    lib = N.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream(agent.ppo_device).cuda_stream)
+    M, A1 = fs.M, fs.A + 1
+    w, b = fs.layers[-1][0], fs.layers[-1][1]
+    C, K = w.shape
+    x, h = fs.h[-2], fs.h[-1]
+    out = []
+    us = _time_us(lambda: torch.addmm(b, x, w.t(), out=fs.dz[:M * C].view(M, C)), iters)
+    flops = 2.0 * M * C * K
+    out.append({"kernel": f"hipBLASLt f32 GEMM [{M}x{K}]x[{K}x{C}] (+bias), update forward", "bound": "mfma",
+                "achieved": flops / us / 1e6, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "us_per_launch": us})
+    scratch = fs.dz[:M * C].view(M, C)
+    scratch.copy_(h)
+
+    def hbm(name, us, nbytes):
+        out.append({"kernel": name, "bound": "hbm", "achieved": nbytes / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": nbytes / us / 1e3 / HBM_PEAK_GBPS, "us_per_launch": us, "algo_bytes": nbytes})
+    us = _time_us(lambda: lib.ag_elu_heads(scratch.data_ptr(), agent.heads_w.data_ptr(), agent.heads_b.data_ptr(),
+                                            fs.heads.data_ptr(), M, C, A1, st), iters)
+    hbm("ag_elu_heads (ELU in place + head product)", us, 4.0 * M * (2 * C + A1))
+    parts = fs.bias_partials2[:fs.wg_blocks * C]
+    us = _time_us(lambda: lib.ag_heads_bwd_elu_wgrad(fs.d_heads.data_ptr(), agent.heads_w.data_ptr(), h.data_ptr(),
+                                                      scratch.data_ptr(), parts.data_ptr(), fs.head_wg_partials2.data_ptr(),
+                                                      M, C, A1, st), iters)
+    hbm("ag_heads_bwd_elu_wgrad (head dX + ELU' + head wgrad)", us, 4.0 * M * (2 * C + A1))
+    if fs.fuse_input_wgrad:
+        D = fs.layers[0][0].shape[1]
+        C0 = fs.layers[0][0].shape[0]
+        us = _time_us(lambda: lib.ag_elu_bwd_input_wgrad(fs.dh.data_ptr(), fs.h[0].data_ptr(), fs.xn.data_ptr(),
+                                                          fs.in_wg_partials.data_ptr(), parts.data_ptr(), M, C0, D, st), iters)
+        hbm("ag_elu_bwd_input_wgrad (ELU' + first-layer wgrad)", us, 4.0 * M * (2 * C0 + D))
+    return out

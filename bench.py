@@ -172,6 +172,8 @@ def main():
                 "kernel": "ag::step_kernel<hovering, rate>", "us_per_launch": r["us_per_step"],
                 "algo_bytes_per_env_step": r["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
             }
+            from airgym_amd.utils.kernel_bench import measure_update_kernels
+            out["update_kernels"] = measure_update_kernels(agent)      # where the epoch's time actually goes
             out["env_only"] = {"value": r["env_steps_per_s"], "unit": "env-steps/s",
                                "note": "env-step kernel only, synthetic N(0,1) clamped actions, hipGraph replay"}
         if world == 1 and not args.no_cpu_baseline:
