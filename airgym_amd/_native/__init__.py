@@ -88,6 +88,11 @@ class AgStateView(ctypes.Structure):
 
 # every symbol include/airgym_hip.h declares: (name, restype, argtypes)
 _P = ctypes.c_void_p
+class AgSumJob(ctypes.Structure):
+    """ag_sum_job (include/airgym_hip.h)"""
+    _fields_ = [("partials_dev", ctypes.c_void_p), ("out_dev", ctypes.c_void_p), ("rows", ctypes.c_int), ("n", ctypes.c_int)]
+
+
 SYMBOLS = [
     ("ag_version", ctypes.c_int, []),
     ("ag_last_error", ctypes.c_char_p, []),
@@ -130,7 +135,9 @@ SYMBOLS = [
                                           ctypes.c_float, ctypes.c_float, _P]),
     ("ag_elu_heads", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_heads_bwd_elu", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    ("ag_wgrad_rows_per_block", ctypes.c_int, []),
+    ("ag_wgrad_rows_per_block", ctypes.c_int, [ctypes.c_int]),
+    ("ag_sum_rows_groups", ctypes.c_int, []),
+    ("ag_sum_rows_multi", ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_longlong, _P]),
     ("ag_heads_bwd_elu_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_elu_bwd_input_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_elu_bwd_bias_rows_per_block", ctypes.c_int, []),

@@ -54,19 +54,43 @@ class FusedMLPStep:
         self.d_heads = torch.empty(M, self.A + 1, **f)
         self.nsums = self.lib.ag_ppo_loss_num_sums()
         self.loss_partials = torch.empty(self.lib.ag_ppo_loss_max_blocks(), self.nsums, **f)
-        rows = self.lib.ag_elu_bwd_bias_rows_per_block()
-        self.bias_partials = torch.empty((M + rows - 1) // rows * widest, **f)
-        self.wgrad_partials = [torch.empty(SPLIT_K, w.shape[0], w.shape[1], **f) for w, _, _, _ in self.layers]
-        self.head_wgrad_partials = torch.empty(SPLIT_K, self.A + 1, self.layers[-1][0].shape[0], **f)
-        wrows = self.lib.ag_wgrad_rows_per_block()
+        L = len(self.layers)
+        erows = self.lib.ag_elu_bwd_bias_rows_per_block()
+        wrows, irows = self.lib.ag_wgrad_rows_per_block(0), self.lib.ag_wgrad_rows_per_block(1)
         self.wg_blocks = (M + wrows - 1) // wrows
+        self.in_wg_blocks = (M + irows - 1) // irows
         # small weight gradients folded into the ELU' passes (head: always; first layer: D in {16,18,20}, >= 2 layers)
-        self.fuse_head_wgrad = True
-        self.head_wg_partials2 = torch.empty(self.wg_blocks, self.A + 1, self.layers[-1][0].shape[0], **f)
-        self.fuse_input_wgrad = len(self.layers) >= 2 and D in (16, 18, 20)
-        if self.fuse_input_wgrad:
-            self.in_wg_partials = torch.empty(self.wg_blocks, self.layers[0][0].shape[0], D, **f)
-        self.bias_partials2 = torch.empty(self.wg_blocks * widest, **f)
+        self.fuse_input_wgrad = L >= 2 and D in (16, 18, 20)
+        self.head_wg_partials = torch.empty(self.wg_blocks, self.A + 1, self.layers[-1][0].shape[0], **f)
+        self.bias_partials, self.wgrad_partials = [], []
+        for li, (w, _, _, _) in enumerate(self.layers):
+            C, K = w.shape
+            if li == L - 1:
+                nb = self.wg_blocks
+            elif li == 0 and self.fuse_input_wgrad:
+                nb = self.in_wg_blocks
+            else:
+                nb = (M + erows - 1) // erows
+            self.bias_partials.append(torch.empty(nb, C, **f))
+            if li == 0 and self.fuse_input_wgrad:
+                self.wgrad_partials.append(torch.empty(self.in_wg_blocks, C, K, **f))
+            else:
+                self.wgrad_partials.append(torch.empty(SPLIT_K, C, K, **f))
+        # every partial-sum reduction of the step runs in ONE ag_sum_rows_multi call (two launches) after the backward
+        jobs = [(self.head_wg_partials, agent.heads_w_grad)]
+        for li, (_, _, gw, gb) in enumerate(self.layers):
+            jobs.append((self.bias_partials[li], gb))
+            jobs.append((self.wgrad_partials[li], gw))
+        self._jobs = (N.AgSumJob * len(jobs))()
+        tot = 0
+        for j, (src, dst) in enumerate(jobs):
+            n = dst.numel()
+            assert src.numel() % n == 0 and dst.is_contiguous()
+            self._jobs[j] = N.AgSumJob(src.data_ptr(), dst.data_ptr(), src.numel() // n, n)
+            tot += n
+        self.use_sum_multi = len(jobs) <= 12 and all(d.numel() % 4 == 0 for _, d in jobs)
+        self._sum_pairs = jobs
+        self.sum_scratch = torch.empty(self.lib.ag_sum_rows_groups() * tot, **f)
         C0, Cl = self.layers[0][0].shape[0], self.layers[-1][0].shape[0]
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
         self.fuse_heads = len(self.layers) >= 2 and 16 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
@@ -148,37 +172,36 @@ class FusedMLPStep:
                 "ag_ppo_loss_finalize")
         # ---- backward.  The head's dX = d_heads Wh and its weight gradient are formed inside the last layer's ELU' pass;
         # the first layer's weight/bias gradients are formed inside ITS ELU' pass (dz of layer 0 is never stored).
-        H = x.shape[1]
-        rows = lib.ag_elu_bwd_bias_rows_per_block()
         dh = None
         for li in range(last, -1, -1):
-            w, _, gw, gb = self.layers[li]
+            w = self.layers[li][0]
             h, xin = self.h[li], inputs[li]
             C, K = w.shape
             dz = self.dz[:M * C].view(M, C)
+            parts = self.bias_partials[li]
             if li == last:
-                parts = self.bias_partials2[:self.wg_blocks * C].view(-1, C)
                 N.check(lib.ag_heads_bwd_elu_wgrad(self.d_heads.data_ptr(), ag.heads_w.data_ptr(), h.data_ptr(), dz.data_ptr(),
-                                                   parts.data_ptr(), self.head_wg_partials2.data_ptr(), M, C, A + 1, st),
+                                                   parts.data_ptr(), self.head_wg_partials.data_ptr(), M, C, A + 1, st),
                         "ag_heads_bwd_elu_wgrad")
-                torch.sum(self.head_wg_partials2, 0, out=ag.heads_w_grad)
             elif li == 0 and self.fuse_input_wgrad:
-                parts = self.bias_partials2[:self.wg_blocks * C].view(-1, C)
-                N.check(lib.ag_elu_bwd_input_wgrad(dh.data_ptr(), h.data_ptr(), xin.data_ptr(), self.in_wg_partials.data_ptr(),
-                                                   parts.data_ptr(), M, C, K, st), "ag_elu_bwd_input_wgrad")
-                torch.sum(parts, 0, out=gb)
-                torch.sum(self.in_wg_partials, 0, out=gw)
+                N.check(lib.ag_elu_bwd_input_wgrad(dh.data_ptr(), h.data_ptr(), xin.data_ptr(),
+                                                   self.wgrad_partials[0].data_ptr(), parts.data_ptr(), M, C, K, st),
+                        "ag_elu_bwd_input_wgrad")
                 break
             else:
-                parts = self.bias_partials[:(M + rows - 1) // rows * C].view(-1, C)
                 N.check(lib.ag_elu_bwd_bias(dh.data_ptr(), h.data_ptr(), dz.data_ptr(), parts.data_ptr(), M, C, st),
                         "ag_elu_bwd_bias")
-            torch.sum(parts, 0, out=gb)
             torch.bmm(dz.view(S, M // S, C).transpose(1, 2), xin.view(S, M // S, K), out=self.wgrad_partials[li])
-            torch.sum(self.wgrad_partials[li], 0, out=gw)
             if li > 0:
                 dh = self.dh[:M * K].view(M, K)
                 torch.mm(dz, w, out=dh)
+        # ---- every partial-sum reduction (bias / weight gradients of all layers + the head) in two launches
+        if self.use_sum_multi:
+            N.check(lib.ag_sum_rows_multi(self._jobs, len(self._jobs), self.sum_scratch.data_ptr(), self.sum_scratch.numel(), st),
+                    "ag_sum_rows_multi")
+        else:
+            for src, dst in self._sum_pairs:
+                torch.sum(src.view(-1, dst.numel()), 0, out=dst.view(-1))
         return stats
 
 

@@ -120,15 +120,16 @@ def measure_update_kernels(agent, iters=20):
     us = _time_us(lambda: lib.ag_elu_heads(scratch.data_ptr(), agent.heads_w.data_ptr(), agent.heads_b.data_ptr(),
                                             fs.heads.data_ptr(), M, C, A1, st), iters)
     hbm("ag_elu_heads (ELU in place + head product)", us, 4.0 * M * (2 * C + A1))
-    parts = fs.bias_partials2[:fs.wg_blocks * C]
+    parts = fs.bias_partials[-1]
     us = _time_us(lambda: lib.ag_heads_bwd_elu_wgrad(fs.d_heads.data_ptr(), agent.heads_w.data_ptr(), h.data_ptr(),
-                                                      scratch.data_ptr(), parts.data_ptr(), fs.head_wg_partials2.data_ptr(),
+                                                      scratch.data_ptr(), parts.data_ptr(), fs.head_wg_partials.data_ptr(),
                                                       M, C, A1, st), iters)
     hbm("ag_heads_bwd_elu_wgrad (head dX + ELU' + head wgrad)", us, 4.0 * M * (2 * C + A1))
     if fs.fuse_input_wgrad:
         D = fs.layers[0][0].shape[1]
         C0 = fs.layers[0][0].shape[0]
+        iparts = fs.bias_partials[0]
         us = _time_us(lambda: lib.ag_elu_bwd_input_wgrad(fs.dh.data_ptr(), fs.h[0].data_ptr(), fs.xn.data_ptr(),
-                                                          fs.in_wg_partials.data_ptr(), parts.data_ptr(), M, C0, D, st), iters)
+                                                          fs.wgrad_partials[0].data_ptr(), iparts.data_ptr(), M, C0, D, st), iters)
         hbm("ag_elu_bwd_input_wgrad (ELU' + first-layer wgrad)", us, 4.0 * M * (2 * C0 + D))
     return out

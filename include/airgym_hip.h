@@ -239,17 +239,30 @@ int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float*
 int ag_heads_bwd_elu(const float* d_heads_dev, const float* Wh_dev, const float* h_dev, float* dz_dev,
                      float* db_partials_dev, int M, int C, int A1, void* stream);
 
-/* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block() rows
+/* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block(which) rows
  * (ceil(M / rows) blocks); the caller reduces them over dim 0.
  *   ag_heads_bwd_elu_wgrad: ag_heads_bwd_elu plus dwh_partials_dev [blocks, A1, C] of dWh[a,c] = sum_m d_heads[m,a] h[m,c];
  *       db_partials_dev [blocks, C].
  *   ag_elu_bwd_input_wgrad: first layer; dz = dh * ELU'(h) is consumed on the fly and never stored:
  *       dw_partials_dev [blocks, C, D] of dW[c,d] = sum_m dz[m,c] x[m,d], db_partials_dev [blocks, C].  D in {16, 18, 20}. */
-int ag_wgrad_rows_per_block(void);
+int ag_wgrad_rows_per_block(int which);   /* which: 0 = ag_heads_bwd_elu_wgrad, 1 = ag_elu_bwd_input_wgrad */
 int ag_heads_bwd_elu_wgrad(const float* d_heads_dev, const float* Wh_dev, const float* h_dev, float* dz_dev,
                            float* db_partials_dev, float* dwh_partials_dev, int M, int C, int A1, void* stream);
 int ag_elu_bwd_input_wgrad(const float* dh_dev, const float* h_dev, const float* x_dev, float* dw_partials_dev,
                            float* db_partials_dev, int M, int C, int D, void* stream);
+
+/* Every partial-sum reduction of one minibatch in two launches.  Job j: out_dev[0..n) = sum over `rows` rows of
+ * partials_dev [rows, n] (n % 4 == 0, partials 16-byte aligned).  scratch_dev holds ag_sum_rows_groups() * sum_j n floats.
+ * Fixed summation order (deterministic); at most AG_MAX_SUM_JOBS jobs per call. */
+#define AG_MAX_SUM_JOBS 12
+typedef struct ag_sum_job {
+    const float* partials_dev;
+    float* out_dev;
+    int rows;
+    int n;
+} ag_sum_job;
+int ag_sum_rows_groups(void);
+int ag_sum_rows_multi(const ag_sum_job* jobs_host, int njobs, float* scratch_dev, long long scratch_floats, void* stream);
 
 /* ELU backward fused with the bias gradient of the producing Linear (lib/network/mlp.py:36-39 under autograd):
  * dz = dh * ELU'(z) computed from h = ELU(z); db_partials_dev [ceil(M / rows_per_block), C] per-block column sums of dz
