@@ -123,6 +123,8 @@ SYMBOLS = [
     ("ag_planning_render_now", ctypes.c_int, [_P, _P]),
     ("ag_ppo_loss_finalize", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),
+    ("ag_rms_scratch_doubles", ctypes.c_longlong, [ctypes.c_int]),
+    ("ag_rms_update", ctypes.c_int, [_P, ctypes.c_longlong, ctypes.c_int, _P, _P, _P, _P, _P]),
     ("ag_normalize_rows", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
                                          ctypes.c_float, _P]),
     ("ag_policy_sample", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_ulonglong, _P, ctypes.c_int, ctypes.c_int,

@@ -1004,3 +1004,76 @@ extern "C" int ag_sum_rows_multi(const ag_sum_job* jobs, int njobs, float* scrat
     hipLaunchKernelGGL(sum_rows_stage2_kernel, dim3((max_n4 + 255) / 256, 1, njobs), dim3(256), 0, (hipStream_t)stream, k);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// RunningMeanStd.update (lib/core/running_mean_std.py:31-62) for a [rows, D] batch in two launches: per-block column
+// sums / sums of squares in float64, then one workgroup forms the batch mean and unbiased variance and merges them into
+// the running statistics with the reference's parallel-variance formula.  Replaces ~20 eager kernels per call.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kRmsBlocks = 256;
+
+__global__ __launch_bounds__(256) void rms_moments_kernel(const float* __restrict__ x, long long rows, int D,
+                                                          double* __restrict__ partial) {   // [kRmsBlocks][2][D]
+    extern __shared__ double sh[];      // [groups][2][D]
+    const int groups = 256 / D;         // row groups per block (D <= 256)
+    const int c = threadIdx.x % D, g = threadIdx.x / D;
+    double s = 0.0, q = 0.0;
+    if (g < groups) {
+        for (long long r = (long long)blockIdx.x * groups + g; r < rows; r += (long long)kRmsBlocks * groups) {
+            const double v = (double)x[r * D + c];
+            s += v;
+            q += v * v;
+        }
+        sh[(g * 2 + 0) * D + c] = s;
+        sh[(g * 2 + 1) * D + c] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < D) {
+        double ts = 0.0, tq = 0.0;
+        for (int k = 0; k < groups; ++k) {
+            ts += sh[(k * 2 + 0) * D + threadIdx.x];
+            tq += sh[(k * 2 + 1) * D + threadIdx.x];
+        }
+        partial[((size_t)blockIdx.x * 2 + 0) * D + threadIdx.x] = ts;
+        partial[((size_t)blockIdx.x * 2 + 1) * D + threadIdx.x] = tq;
+    }
+}
+
+__global__ __launch_bounds__(256) void rms_merge_kernel(const double* __restrict__ partial, long long rows, int D,
+                                                        double* __restrict__ mean, double* __restrict__ var,
+                                                        double* __restrict__ count) {
+    const double cnt = *count;
+    __syncthreads();                     // everyone has read the old count before thread 0 overwrites it
+    for (int c = threadIdx.x; c < D; c += 256) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < kRmsBlocks; ++b) {
+            s += partial[((size_t)b * 2 + 0) * D + c];
+            q += partial[((size_t)b * 2 + 1) * D + c];
+        }
+        const double n = (double)rows;
+        const double bmean = s / n;
+        const double bvar = (q - s * bmean) / (n - 1.0);        // unbiased, as torch.var
+        const double delta = bmean - mean[c];
+        const double tot = cnt + n;
+        const double m2 = var[c] * cnt + bvar * n + delta * delta * cnt * n / tot;
+        mean[c] = mean[c] + delta * n / tot;
+        var[c] = m2 / tot;
+    }
+    if (threadIdx.x == 0) *count = cnt + (double)rows;
+}
+
+}  // namespace
+
+extern "C" long long ag_rms_scratch_doubles(int D) { return (long long)kRmsBlocks * 2 * D; }
+
+extern "C" int ag_rms_update(const float* x, long long rows, int D, double* mean, double* var, double* count, double* scratch,
+                             void* stream) {
+    if (!x || !mean || !var || !count || !scratch || rows < 2) return AG_ERR_INVALID_ARG;
+    if (D <= 0 || D > 256) return AG_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)(256 / D) * 2 * D * sizeof(double);
+    hipLaunchKernelGGL(rms_moments_kernel, dim3(kRmsBlocks), dim3(256), lds, (hipStream_t)stream, x, rows, D, scratch);
+    hipLaunchKernelGGL(rms_merge_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, rows, D, mean, var, count);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}

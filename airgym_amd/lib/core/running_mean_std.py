@@ -26,6 +26,9 @@ class RunningMeanStd(nn.Module):
         """Merge the moments of batch x ([B, ...]).  With `group` (torch.distributed) the batch moments
         are first combined across ranks so that every replica keeps identical statistics (the reference
         lets them drift)."""
+        if group is None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] >= 2 \
+                and 0 < x[0].numel() <= 256:
+            return self._update_hip(x)
         batch_count = float(x.size()[0])
         mean = x.mean(self.axis).double()
         var = x.var(self.axis).double()
@@ -47,6 +50,20 @@ class RunningMeanStd(nn.Module):
         self.running_mean.copy_(new_mean)
         self.running_var.copy_(m2 / tot_count)
         self.count.copy_(tot_count)
+
+    def _update_hip(self, x):
+        """Same merge in two HIP launches (`ag_rms_update`): float64 column moments, then the in-place merge."""
+        import ctypes
+
+        from airgym_amd import _native as N
+        lib = N.load()
+        D = x[0].numel()
+        if getattr(self, "_scratch", None) is None or self._scratch.device != x.device:
+            self._scratch = torch.empty(lib.ag_rms_scratch_doubles(D), dtype=torch.float64, device=x.device)
+        count = self.count.view(1)
+        N.check(lib.ag_rms_update(x.data_ptr(), x.shape[0], D, self.running_mean.data_ptr(), self.running_var.data_ptr(),
+                                  count.data_ptr(), self._scratch.data_ptr(),
+                                  ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "ag_rms_update")
 
     def forward(self, input, denorm=False, mask=None):
         if self.training:

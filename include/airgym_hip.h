@@ -197,6 +197,13 @@ int ag_ppo_loss_finalize(const float* partials_dev, int num_blocks, int M, int A
                          float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd_dev,
                          float* grad_head_bias_dev, float* kl_out_dev, float* stats_dev, void* stream);
 
+/* RunningMeanStd.update (lib/core/running_mean_std.py:31-62) on a [rows, D] float batch: batch mean / unbiased variance in
+ * float64, merged in place into mean_dev / var_dev [D] and *count_dev with the reference's parallel-variance formula.
+ * scratch_dev: ag_rms_scratch_doubles(D) doubles.  D <= 256, rows >= 2. */
+long long ag_rms_scratch_doubles(int D);
+int ag_rms_update(const float* x_dev, long long rows, int D, double* mean_dev, double* var_dev, double* count_dev,
+                  double* scratch_dev, void* stream);
+
 /* out = clamp((x - mean) / sqrt(var + eps), -clip, clip) over [rows, D] with float64 running statistics
  * (lib/core/running_mean_std.py:64-79, RunningMeanStd.forward in eval mode). */
 int ag_normalize_rows(const float* x_dev, const double* mean_dev, const double* var_dev, float* out_dev, long long rows,

@@ -152,3 +152,25 @@ def test_fused_rollout_trains(lib):
     noise1 = (acts[1] - agent.mus_buf).abs().sum()
     assert noise1 > 0
     assert agent.game_lengths.current_size > 0 or agent.ep_stats[:, 0].sum() >= 0
+
+
+@pytest.mark.parametrize("rows,D", [(196608, 18), (4097, 1), (70001, 48), (2, 18)])
+def test_rms_update_kernel(lib, rows, D):
+    """ag_rms_update == RunningMeanStd.update's torch formulas (running_mean_std.py:31-62), twice in a row."""
+    from airgym_amd.lib.core.running_mean_std import RunningMeanStd
+    g = torch.Generator(device="cuda").manual_seed(4)
+    hip, ref = RunningMeanStd((D,)).cuda(), RunningMeanStd((D,)).cuda()
+    for it in range(2):
+        x = (3 * torch.randn(rows, D, device="cuda", generator=g) + 7 * it).contiguous()
+        hip.update(x)                                      # HIP path (CUDA, contiguous f32, no group)
+        # reference formulas
+        mean, var, n = x.mean(0).double(), x.var(0).double(), float(rows)
+        delta = mean - ref.running_mean
+        tot = ref.count + n
+        m2 = ref.running_var * ref.count + var * n + delta ** 2 * ref.count * n / tot
+        ref.running_mean.copy_(ref.running_mean + delta * n / tot)
+        ref.running_var.copy_(m2 / tot)
+        ref.count.copy_(tot)
+        assert torch.allclose(hip.running_mean, ref.running_mean, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(hip.running_var, ref.running_var, rtol=2e-5, atol=1e-6)
+        assert hip.count.item() == ref.count.item()
