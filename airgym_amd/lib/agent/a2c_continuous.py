@@ -150,6 +150,9 @@ class A2CAgent:
         self.ppo_device = config.get("device", "cuda:0")
         if str(self.ppo_device).startswith("cuda"):
             torch.cuda.set_device(self.ppo_device)
+            if config.get("tuned_gemms", True):
+                from airgym_amd.utils.gemm_tuning import enable_tuned_gemms
+                self.tuned_gemms = enable_tuned_gemms()
 
         # ---- environment (sharded by rank: env ids are global)
         self.num_actors = config["num_actors"]

@@ -51,6 +51,7 @@ def build_params(args, world_size):
     c["save_frequency"] = 0
     c["save_best_after"] = 10 ** 9
     c["use_hip_graph"] = bool(args.graph)
+    c["tuned_gemms"] = bool(getattr(args, "tuned_gemms", 1))
     params["seed"] = 0
     return params
 
@@ -87,6 +88,7 @@ def main():
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (BASELINE: 65536)")
     ap.add_argument("--minibatches", type=int, default=8, help="optimizer steps per mini-epoch")
     ap.add_argument("--graph", type=int, default=1, help="capture the rollout in a hipGraph")
+    ap.add_argument("--tuned-gemms", type=int, default=1, help="apply the shipped TunableOp GEMM table (library kernel choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -150,7 +152,9 @@ def main():
                    "envs_per_gpu": args.envs, "global_envs": world * args.envs, "horizon_length": H,
                    "mini_epochs": agent.mini_epochs_num, "minibatch_size": agent.minibatch_size,
                    "policy": "MLP(256,256) actor-critic, fixed sigma", "parallelism": f"dp{world}",
-                   "hip_graph_rollout": bool(args.graph)},
+                   "hip_graph_rollout": bool(args.graph),
+                   "gemm_selection": ("TunableOp table airgym_amd/assets/tunableop_gfx950.csv (hipBLASLt / rocBLAS fp32)"
+                                      if getattr(agent, "tuned_gemms", False) else "hipBLASLt default heuristic (fp32)")},
         "phases": {"rollout_s": play, "update_s": update, "final_lr": agent.last_lr,
                    "last_kl": last_stats["kl"], "last_a_loss": last_stats["a_loss"], "last_c_loss": last_stats["c_loss"],
                    "finite": bool(all(map(lambda x: x == x and abs(x) != float("inf"),
