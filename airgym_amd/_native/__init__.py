@@ -115,6 +115,7 @@ SYMBOLS = [
     ("ag_set_tick", ctypes.c_int, [_P, ctypes.c_uint64]),
     ("ag_set_launch_params", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     ("ag_debug_touch", ctypes.c_int, [_P, _P, _P]),
+    ("ag_debug_touch_variant", ctypes.c_int, [_P, _P, ctypes.c_int, _P]),
     ("ag_planning_set_obstacle_table", ctypes.c_int, [_P, _P, ctypes.c_int]),
     ("ag_planning_get_buffers", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningBuffers)]),
     ("ag_planning_get_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),

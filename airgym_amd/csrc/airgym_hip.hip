@@ -236,6 +236,36 @@ __global__ __launch_bounds__(64) void touch_kernel(ag::KArgs k, const float* act
     }
 }
 
+// Diagnostic variants of touch_kernel: MODE 1 = non-temporal stores, 2 = non-temporal loads + stores, 3 = empty kernel
+// (pure dependent-launch boundary).  Used by tools/touch_probe.py to price the kernel boundary.
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ __launch_bounds__(64) void touch_variant_kernel(ag::KArgs k, const float* actions, int num_obs) {
+    if (MODE == 3) return;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    nt_f4 in[7];
+    const nt_f4* src[7] = {(const nt_f4*)k.S[0], (const nt_f4*)k.S[1], (const nt_f4*)k.S[2], (const nt_f4*)k.S[3],
+                           (const nt_f4*)k.C[0], (const nt_f4*)k.C[1], (const nt_f4*)k.PA};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) in[j] = (MODE == 2) ? __builtin_nontemporal_load(src[j] + i) : src[j][i];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < k.n) a = reinterpret_cast<const float4*>(actions)[i];
+    in[0].x += 1e-30f * (in[6].x + a.x);
+    in[6] = nt_f4{a.x, a.y, a.z, a.w};
+    nt_f4* dst[7] = {(nt_f4*)k.S[0], (nt_f4*)k.S[1], (nt_f4*)k.S[2], (nt_f4*)k.S[3], (nt_f4*)k.C[0], (nt_f4*)k.C[1], (nt_f4*)k.PA};
+#pragma unroll
+    for (int j = 0; j < 7; ++j) __builtin_nontemporal_store(in[j], dst[j] + i);
+    if (i < k.n) {
+        __builtin_nontemporal_store(in[0].x, k.rew + i);
+        k.reset[i] = 0;
+        k.timeout[i] = 0;
+        float* o = k.obs + (size_t)i * num_obs;
+        for (int j = 0; j < num_obs; j += 2) __builtin_nontemporal_store(nt_f2{in[0].y, in[0].z}, reinterpret_cast<nt_f2*>(o) + (j >> 1));
+    }
+}
+
 __global__ void planning_get_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_planning_state_view v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k.n) return;
@@ -630,6 +660,17 @@ int ag_planning_render_now(ag_handle h, void* stream) {
     if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
     h->force_render = 1 | ((int)(uintptr_t)stream << 1);
     return AG_OK;
+}
+
+int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void* stream) {
+    if (!h || !actions_dev) return AG_ERR_INVALID_ARG;
+    const dim3 grid((h->cfg.num_envs + 63) / 64), block(64);
+    const int nobs = h->num_obs;
+    if (mode == 1) hipLaunchKernelGGL(touch_variant_kernel<1>, grid, block, 0, (hipStream_t)stream, h->k, actions_dev, nobs);
+    else if (mode == 2) hipLaunchKernelGGL(touch_variant_kernel<2>, grid, block, 0, (hipStream_t)stream, h->k, actions_dev, nobs);
+    else if (mode == 3) hipLaunchKernelGGL(touch_variant_kernel<3>, grid, block, 0, (hipStream_t)stream, h->k, actions_dev, nobs);
+    else return AG_ERR_INVALID_ARG;
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
 int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream) {

@@ -33,12 +33,23 @@ class ModelA2CContinuousLogStd(nn.Module):
         self.normalize_input = params["config"].get("normalize_input", False)
         self.value_size = params["config"].get("value_size", 1)
         self.load(params["network"])
-        if self.has_resnet or self.has_vae:
-            raise NotImplementedError("ResNet / frozen-VAE encoders are not part of this build (CNN and MLP are)")
+        if self.has_resnet:
+            raise NotImplementedError("the ResNet18 encoder (torchvision weights download) is not part of this build; "
+                                      "CNN, frozen-VAE and MLP are")
         self.dict_obs = isinstance(input_shape, dict)
-        if self.has_cnn != self.dict_obs:
-            raise ValueError("a 'cnn' network block needs dict observations {image, observation} and vice versa")
-        if self.has_cnn:
+        if (self.has_cnn or self.has_vae) != self.dict_obs:
+            raise ValueError("a 'cnn' / 'vae' network block needs dict observations {image, observation} and vice versa")
+        self._frozen = []            # frozen encoders: NOT registered, so they stay out of parameters() / state_dict()
+        if self.has_vae:
+            # a2c_continuous_logstd_model.py:32-35,45-48,114-126: frozen VAE means take the CNN features' place
+            from airgym_amd.lib.network.vae import FrozenVAEEncoder
+            input_shape = dict(input_shape)
+            self._frozen.append(FrozenVAEEncoder(self.vae_cfg, device="cpu"))
+            mlp_in = input_shape["observation"][0] + self.feature_dim
+            self.actor_mlp = MLP(mlp_in, self.mlp_cfg["units"], self.mlp_cfg["activation"])
+            if self.separate:
+                self.critic_mlp = MLP(mlp_in, self.mlp_cfg["units"], self.mlp_cfg["activation"])
+        elif self.has_cnn:
             from airgym_amd.lib.network.cnn import CNNFeatureExtractor
             input_shape = dict(input_shape)
             self.actor_cnn = CNNFeatureExtractor(feature_dim=self.feature_dim)
@@ -85,6 +96,9 @@ class ModelA2CContinuousLogStd(nn.Module):
         self.has_vae = "vae" in params
         if self.has_cnn:
             self.feature_dim = params["cnn"]["output_dim"]
+        if self.has_vae:
+            self.vae_cfg = dict(params["vae"])
+            self.feature_dim = int(self.vae_cfg.get("latent_dims", 64))
         space = params.get("space", {}).get("continuous", {})
         self.fixed_sigma = space.get("fixed_sigma", True)
 
@@ -111,9 +125,20 @@ class ModelA2CContinuousLogStd(nn.Module):
     def denorm_value(self, value):
         return self.value_mean_std(value, denorm=True) if self.normalize_value else value
 
+    def _apply(self, fn, *a, **k):
+        for enc in self._frozen:      # follow .to(device) / .float() although the encoder is not a registered child
+            enc.encoder._apply(fn, *a, **k)
+        return super()._apply(fn, *a, **k)
+
     # ---- forward
     def trunk(self, obs, heads_only=False):
-        if self.dict_obs:
+        if self.dict_obs and self.has_vae:
+            normed_image = self.norm_image(obs["image"])
+            feat = self._frozen[0].encode(normed_image)       # one frozen encoder serves actor and critic (same weights)
+            a_in = self.norm_observation(torch.cat((obs["observation"], feat), dim=-1))
+            a_out = self.actor_mlp(a_in)
+            c_out = self.critic_mlp(a_in) if self.separate else a_out
+        elif self.dict_obs:
             normed_image = self.norm_image(obs["image"])
             a_feat = self.actor_cnn(normed_image)
             a_in = self.norm_observation(torch.cat((obs["observation"], a_feat), dim=-1))

@@ -325,6 +325,8 @@ int ag_planning_render_now(ag_handle h, void* stream);
 
 /* Diagnostic: a kernel with the step's loads/stores and no arithmetic (launch + memory-latency floor). */
 int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream);
+/* diagnostic variants: mode 1 = non-temporal stores, 2 = non-temporal loads + stores, 3 = empty kernel (launch boundary) */
+int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void* stream);
 
 /* Launch geometry knobs for benchmarking: block_size 0 = wave-specialised kernel (default: physics wave + noise wave
  * per 64 envs), 64/128/256 = one-wave-per-64-envs kernel with that workgroup size (obs staged through LDS or not). */

@@ -517,6 +517,50 @@ def gen_planning(out):
     out["planning_images"] = dict(cam=cam, add=add[:, 0], mul=mul[:, 0], kernel=ker / 256.0, image=s3.full_camera_array)
 
 
+
+def vae_fill_(module):
+    """Deterministic parameter fill shared with tests/test_oracle_golden.py (the 7 MB of encoder weights cannot be a
+    fixture): parameter i (sorted by name) <- cos(0.61803 * k + i) * 0.7 / sqrt(fan_in), biases 0.02 * sin(k + i)."""
+    import math
+    with torch.no_grad():
+        for i, (name, p) in enumerate(sorted(module.named_parameters())):
+            k = torch.arange(p.numel(), dtype=torch.float64)
+            if p.dim() > 1:
+                fan_in = p[0].numel()
+                v = torch.cos(0.61803 * k + i) * (0.7 / math.sqrt(fan_in))
+            else:
+                v = 0.02 * torch.sin(k + i)
+            p.copy_(v.reshape(p.shape).float())
+
+
+def vae_test_image():
+    i = torch.arange(212, dtype=torch.float32).view(1, 1, 212, 1)
+    j = torch.arange(120, dtype=torch.float32).view(1, 1, 1, 120)
+    b = torch.arange(3, dtype=torch.float32).view(3, 1, 1, 1)
+    return 0.5 + 0.5 * torch.sin(0.05 * i + 0.11 * j + b)
+
+
+def gen_vae(out):
+    """lib/network/VAE.py ImgEncoder + VAE.encode through the VAEImageEncoder.encode recipe (bilinear resize to 120x212,
+    means returned), with deterministic weights."""
+    import contextlib
+    import io
+    from lib.network.VAE import VAE
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae = VAE(input_dim=1, latent_dim=64)
+    vae.eval()
+    vae_fill_(vae.encoder)
+    img = vae_test_image()
+    with torch.no_grad():
+        resized = torch.nn.functional.interpolate(img, [120, 212], mode="bilinear")
+        z = vae.encoder(resized)
+        _, means, std = vae.encode(resized)
+    np.savez_compressed(os.path.join(out, "vae_encoder.npz"), z=z.numpy(), means=means.numpy(), std=std.numpy(),
+                        resized_probe=resized[:, 0, ::17, ::23].numpy(),
+                        param_names=np.array(sorted(n for n, _ in vae.encoder.named_parameters())))
+    print("vae_encoder.npz", z.shape, float(z.abs().mean()))
+
+
 def main():
     install_stubs()
     import airgym.envs.base.hovering as H
@@ -535,6 +579,7 @@ def main():
     gen_ppo(out)
     gen_gae(out)
     gen_planning(out)
+    gen_vae(out)
     for name, d in out.items():
         arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
         path = os.path.join(HERE, f"{name}.npz")
