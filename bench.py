@@ -35,13 +35,14 @@ HBM_PEAK_GBPS = 8000.0
 
 
 def build_params(args, world_size):
-    with open(os.path.join(REPO, "scripts", "config", "ppo_hovering.yaml")) as f:
+    task, ctl = getattr(args, "task", "hovering"), getattr(args, "ctl", "rate")
+    with open(os.path.join(REPO, "scripts", "config", f"ppo_{task}.yaml")) as f:
         params = yaml.safe_load(f)["params"]
     c = params["config"]
     params["network"]["mlp"]["units"] = [256, 256]          # BASELINE.json config 1: MLP(256,256)
     c["num_actors"] = args.envs
     c["minibatch_size"] = args.envs * c["horizon_length"] // args.minibatches
-    c["env_config"] = {"use_image": False, "num_envs": args.envs, "ctl_mode": "rate", "seed": 0,
+    c["env_config"] = {"use_image": False, "num_envs": args.envs, "ctl_mode": ctl, "seed": 0,
                        "sim_device": f"cuda:{int(os.getenv('LOCAL_RANK', '0'))}", "headless": True}
     c["device"] = f"cuda:{int(os.getenv('LOCAL_RANK', '0'))}"
     c["multi_gpu"] = world_size > 1
@@ -89,6 +90,9 @@ def main():
     ap.add_argument("--minibatches", type=int, default=8, help="optimizer steps per mini-epoch")
     ap.add_argument("--graph", type=int, default=1, help="capture the rollout in a hipGraph")
     ap.add_argument("--tuned-gemms", type=int, default=1, help="apply the shipped TunableOp GEMM table (library kernel choice)")
+    ap.add_argument("--task", default="hovering", choices=["hovering", "tracking"],
+                    help="default = BASELINE config 1; 'tracking --ctl vel' = config 2 (side measurement, not the headline)")
+    ap.add_argument("--ctl", default="rate", choices=["pos", "vel", "atti", "rate", "prop"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -136,7 +140,7 @@ def main():
     H = agent.horizon_length
     total_env_steps = world * args.envs * H * args.steps
     out = {
-        "metric": "env_steps_per_sec_hovering_65536_envs_per_gpu",
+        "metric": f"env_steps_per_sec_{args.task}_{args.envs}_envs_per_gpu",
         "value": total_env_steps / elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -148,7 +152,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "hovering_ctbr_ppo_epoch", "task": "hovering", "ctl_mode": "rate",
+        "config": {"workload": f"{args.task}_{ {'rate': 'ctbr', 'vel': 'lv', 'pos': 'py', 'atti': 'cta', 'prop': 'srt'}[args.ctl] }_ppo_epoch",
+                   "task": args.task, "ctl_mode": args.ctl,
                    "envs_per_gpu": args.envs, "global_envs": world * args.envs, "horizon_length": H,
                    "mini_epochs": agent.mini_epochs_num, "minibatch_size": agent.minibatch_size,
                    "policy": "MLP(256,256) actor-critic, fixed sigma", "parallelism": f"dp{world}",
@@ -167,20 +172,20 @@ def main():
             r = measure_env_kernel(hip, steps_per_graph=48, replays=20)
             traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (cannot be read live)
             pmc = os.path.join(REPO, "profiles", "r01_env_kernel_pmc.json")
-            if os.path.exists(pmc) and args.envs == ENVS_PER_GPU:
+            if os.path.exists(pmc) and args.envs == ENVS_PER_GPU and (args.task, args.ctl) == ("hovering", "rate"):
                 traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": r["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": "profiles/r01_env_kernel_pmc.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
-                "kernel": "ag::step_kernel<hovering, rate>", "us_per_launch": r["us_per_step"],
+                "kernel": f"ag::step_kernel<{args.task}, {args.ctl}>", "us_per_launch": r["us_per_step"],
                 "algo_bytes_per_env_step": r["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
             }
             from airgym_amd.utils.kernel_bench import measure_update_kernels
             out["update_kernels"] = measure_update_kernels(agent)      # where the epoch's time actually goes
             out["env_only"] = {"value": r["env_steps_per_s"], "unit": "env-steps/s",
                                "note": "env-step kernel only, synthetic N(0,1) clamped actions, hipGraph replay"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and (args.task, args.ctl) == ("hovering", "rate"):
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

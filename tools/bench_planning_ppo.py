@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""End-to-end Planning PPO epoch (BASELINE config 4 shape: depth-image obs + CNN policy, CTBR) on one GPU.
+Side measurement for DESIGN.md; the headline bench stays bench.py."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=16384)
+    ap.add_argument("--horizon", type=int, default=24)
+    ap.add_argument("--minibatches", type=int, default=24)
+    ap.add_argument("--mini-epochs", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--encoder", default="cnn", choices=["cnn", "vae"])
+    ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen find mode)")
+    ap.add_argument("--channels-last", type=int, default=0)
+    args = ap.parse_args()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
+    c = params["config"]
+    c.update(num_actors=args.envs, horizon_length=args.horizon, mini_epochs=args.mini_epochs,
+             minibatch_size=args.envs * args.horizon // args.minibatches, device="cuda:0", max_epochs=-1,
+             write_summaries=False, print_stats=False, save_frequency=0, save_best_after=10 ** 9)
+    c["env_config"] = {"use_image": True, "num_envs": args.envs, "ctl_mode": "rate", "seed": 0, "sim_device": "cuda:0",
+                       "headless": True}
+    if args.encoder == "vae":
+        params["network"].pop("cnn", None)
+        params["network"]["vae"] = {"latent_dims": 64, "allow_random_init": True, "image_res": [120, 212],
+                                    "interpolation_mode": "bilinear", "return_sampled_latent": False}
+    params["seed"] = 0
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    agent = A2CAgent("planning_bench", params)
+    if args.channels_last:
+        agent.model.actor_cnn.to(memory_format=torch.channels_last)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    for _ in range(args.warmup):
+        agent.epoch_num += 1
+        agent.train_epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    play = upd = 0.0
+    for _ in range(args.steps):
+        agent.epoch_num += 1
+        st = agent.train_epoch()
+        play += st["play_time"]; upd += st["update_time"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": f"env_steps_per_sec_planning_{args.envs}_envs_per_gpu", "encoder": args.encoder,
+                      "value": args.envs * args.horizon * args.steps / dt, "ms_per_epoch": dt / args.steps * 1e3,
+                      "rollout_ms": play / args.steps * 1e3, "update_ms": upd / args.steps * 1e3,
+                      "minibatch": c["minibatch_size"], "mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                      "kl": st["kl"], "a_loss": st["a_loss"]}))
+
+
+if __name__ == "__main__":
+    main()
