@@ -8,6 +8,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# MIOpen's default find mode benchmarks every solver (including the naive reference convolutions: ~100 s of kernel time at
+# 4096-image minibatches, profiles/r01_planning_ppo_kernel_trace.md) the first time a shape is seen; FAST = immediate mode
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 import torch  # noqa: E402
 import yaml  # noqa: E402
 
@@ -22,7 +25,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--encoder", default="cnn", choices=["cnn", "vae"])
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen find mode)")
-    ap.add_argument("--channels-last", type=int, default=0)
     args = ap.parse_args()
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
@@ -40,8 +42,7 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
     agent = A2CAgent("planning_bench", params)
-    if args.channels_last:
-        agent.model.actor_cnn.to(memory_format=torch.channels_last)
+    # (channels_last was tried: MIOpen falls back to its naive kernels for these shapes, 137 s per epoch instead of 5.7 s)
     agent.init_tensors()
     agent.obs = agent.env_reset()
     for _ in range(args.warmup):
