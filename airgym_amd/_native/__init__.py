@@ -137,7 +137,6 @@ SYMBOLS = [
     ("ag_mlp_input_layer", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, _P]),
     ("ag_elu_heads", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    ("ag_heads_bwd_elu", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_wgrad_rows_per_block", ctypes.c_int, [ctypes.c_int]),
     ("ag_sum_rows_groups", ctypes.c_int, []),
     ("ag_sum_rows_multi", ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_longlong, _P]),

@@ -431,7 +431,7 @@ extern "C" int ag_normalize_rows(const float* x, const double* mean, const doubl
 // The 256x256 GEMMs stay with hipBLASLt; these kernels remove the HBM round trips AROUND them:
 //   input_layer : xn = clamp((obs-mean)/std), h1 = ELU(xn W1^T + b1)        one pass: read obs, write xn + h1
 //   elu_heads   : h = ELU(z) in place, heads = h Wh^T + bh                  the [M,C]x[C,A+1] GEMM rides along
-//   heads_bwd   : dz = (d_heads Wh) * ELU'(h), bias partial sums            the [M,A+1]x[A+1,C] GEMM + its [M,C] store/load vanish
+//   (the backward counterpart, heads_bwd_elu_wgrad, is further down with the folded weight gradients)
 // All are HBM-bound streaming kernels: C/4 threads cover one row with float4 accesses.
 // ---------------------------------------------------------------------------------------------------
 namespace {
@@ -600,52 +600,6 @@ __global__ __launch_bounds__(256) void elu_heads_kernel(float* __restrict__ zh, 
     }
 }
 
-// dz = (d_heads Wh) * ELU'(h) with per-block column sums (same partial layout as elu_bwd_bias_kernel).
-template <int A1>
-__global__ __launch_bounds__(256) void heads_bwd_elu_kernel(const float* __restrict__ d_heads, const float* __restrict__ Wh,
-                                                            const float* __restrict__ h, float* __restrict__ dz,
-                                                            float* __restrict__ db_partials, int M, int C) {
-    __shared__ float4 red[256];
-    const int tpr = C >> 2;
-    const int rpp = 256 / tpr;
-    const int col4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
-    float4 w[A1];
-#pragma unroll
-    for (int a = 0; a < A1; ++a) w[a] = reinterpret_cast<const float4*>(Wh + (size_t)a * C)[col4];
-    const int row0 = blockIdx.x * kEluRowsPerBlock;
-    const int row_end = min(row0 + kEluRowsPerBlock, M);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rsub < rpp) {
-        for (int r = row0 + rsub; r < row_end; r += rpp) {
-            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int a = 0; a < A1; ++a) {
-                const float d = d_heads[(size_t)r * A1 + a];
-                g.x = fmaf(d, w[a].x, g.x); g.y = fmaf(d, w[a].y, g.y); g.z = fmaf(d, w[a].z, g.z); g.w = fmaf(d, w[a].w, g.w);
-            }
-            const size_t idx = (size_t)r * tpr + col4;
-            const float4 y = reinterpret_cast<const float4*>(h)[idx];
-            float4 o;
-            o.x = g.x * (y.x > 0.f ? 1.f : y.x + 1.f);
-            o.y = g.y * (y.y > 0.f ? 1.f : y.y + 1.f);
-            o.z = g.z * (y.z > 0.f ? 1.f : y.z + 1.f);
-            o.w = g.w * (y.w > 0.f ? 1.f : y.w + 1.f);
-            reinterpret_cast<float4*>(dz)[idx] = o;
-            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
-        }
-    }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x < tpr) {
-        float4 s = red[threadIdx.x];
-        for (int j = 1; j < rpp; ++j) {
-            const float4 t = red[threadIdx.x + j * tpr];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-        reinterpret_cast<float4*>(db_partials)[(size_t)blockIdx.x * tpr + threadIdx.x] = s;
-    }
-}
-
 bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 }  // namespace
@@ -686,20 +640,6 @@ extern "C" int ag_elu_heads(float* zh, const float* Wh, const float* bh, float* 
         hipLaunchKernelGGL(elu_heads_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, zh, Wh, bh, heads, M, C, rows_per_block);
     else if (A1 == 6)
         hipLaunchKernelGGL(elu_heads_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, zh, Wh, bh, heads, M, C, rows_per_block);
-    else
-        return AG_ERR_UNSUPPORTED;
-    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
-}
-
-extern "C" int ag_heads_bwd_elu(const float* d_heads, const float* Wh, const float* h, float* dz, float* db_partials, int M,
-                                int C, int A1, void* stream) {
-    if (!d_heads || !Wh || !h || !dz || !db_partials || M <= 0) return AG_ERR_INVALID_ARG;
-    if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
-    const int grid = (M + kEluRowsPerBlock - 1) / kEluRowsPerBlock;
-    if (A1 == 5)
-        hipLaunchKernelGGL(heads_bwd_elu_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz, db_partials, M, C);
-    else if (A1 == 6)
-        hipLaunchKernelGGL(heads_bwd_elu_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz, db_partials, M, C);
     else
         return AG_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;

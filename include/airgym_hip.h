@@ -237,18 +237,16 @@ int ag_gae(const float* rewards_dev, const float* values_dev, const long long* d
  *       then obs is used as is), h = ELU(xn W^T + bias) [M, C]; W [C, D] row-major; D*C + 64*D floats must fit 64 KB.
  *   ag_elu_heads: zh [M, C] <- ELU(zh) in place and heads [M, A1] = ELU(zh) Wh^T + bh; Wh [A1, C]; C a power of two
  *       16..256, A1 = A + 1 in {5, 6}.
- *   ag_heads_bwd_elu: dz = (d_heads Wh) * ELU'(h) and per-block column sums (layout of ag_elu_bwd_bias). */
+ */
 int ag_mlp_input_layer(const float* obs_dev, const double* mean_dev, const double* var_dev, const float* W_dev,
                        const float* bias_dev, float* xn_dev, float* h_dev, int M, int D, int C, float eps, float clip,
                        void* stream);
 int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float* heads_dev, int M, int C, int A1,
                  void* stream);
-int ag_heads_bwd_elu(const float* d_heads_dev, const float* Wh_dev, const float* h_dev, float* dz_dev,
-                     float* db_partials_dev, int M, int C, int A1, void* stream);
 
 /* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block(which) rows
  * (ceil(M / rows) blocks); the caller reduces them over dim 0.
- *   ag_heads_bwd_elu_wgrad: ag_heads_bwd_elu plus dwh_partials_dev [blocks, A1, C] of dWh[a,c] = sum_m d_heads[m,a] h[m,c];
+ *   ag_heads_bwd_elu_wgrad: dz = (d_heads Wh) * ELU'(h) (the head's dX formed inside the ELU' pass), plus dwh_partials_dev [blocks, A1, C] of dWh[a,c] = sum_m d_heads[m,a] h[m,c];
  *       db_partials_dev [blocks, C].
  *   ag_elu_bwd_input_wgrad: first layer; dz = dh * ELU'(h) is consumed on the fly and never stored:
  *       dw_partials_dev [blocks, C, D] of dW[c,d] = sum_m dz[m,c] x[m,d], db_partials_dev [blocks, C].  D in {16, 18, 20}. */

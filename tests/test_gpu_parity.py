@@ -362,8 +362,9 @@ def test_tracking_full_size_properties(Handle):
     env.close()
 
 
-@pytest.mark.parametrize("units", [[256, 256], [128, 64, 32], [512]])
-def test_hand_scheduled_update_matches_autograd(Handle, units):
+@pytest.mark.parametrize("task,ctl,units", [("hovering", "rate", [256, 256]), ("hovering", "rate", [128, 64, 32]),
+                                            ("hovering", "rate", [512]), ("tracking", "vel", [256, 256])])
+def test_hand_scheduled_update_matches_autograd(Handle, task, ctl, units):
     """FusedMLPStep (hand-scheduled forward/backward writing into the flat gradient buffer) == the autograd path on the
     same minibatch: every gradient, the KL slot, the logged scalars and the mu/sigma write-back."""
     import os
@@ -375,6 +376,7 @@ def test_hand_scheduled_update_matches_autograd(Handle, units):
 
     class Args:
         envs = 4096; minibatches = 4; graph = 0
+    Args.task, Args.ctl = task, ctl
     params = bench.build_params(Args, 1)
     params["config"]["bounds_loss_coef"] = 1e-4
     params["network"]["mlp"]["units"] = units
