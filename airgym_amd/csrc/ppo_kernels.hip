@@ -552,8 +552,27 @@ __global__ __launch_bounds__(256) void input_layer_reg_kernel(const float* __res
     }
 }
 
+// Sum over groups of `width` consecutive lanes (width = 16, 32 or 64) with DPP row operations - pure VALU, no LDS round
+// trips (six dependent ds_bpermute per value made elu_heads latency-bound).  The group total is valid in the LAST lane of
+// each group (lane % width == width - 1).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(moved);
+}
+
+__device__ __forceinline__ float group_sum_last_lane(float v, int width) {
+    v = dpp_add<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);       // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);       // row_mirror: every lane of a 16-lane row holds the row sum
+    if (width >= 32) v = dpp_add<0x142, 0xA>(v);   // row_bcast15: rows 1,3 += lane 15 of rows 0,2
+    if (width >= 64) v = dpp_add<0x143, 0xC>(v);   // row_bcast31: rows 2,3 += lane 31
+    return v;
+}
+
 // h = ELU(z) in place; heads[m, a] = sum_c h[m,c] Wh[a,c] + bh[a].  tpr = C/4 threads per row (power of two <= 64).
-template <int A1>
+template <int A1, bool WRITE_BACK>
 __global__ __launch_bounds__(256) void elu_heads_kernel(float* __restrict__ zh, const float* __restrict__ Wh,
                                                         const float* __restrict__ bh, float* __restrict__ heads, int M, int C,
                                                         int rows_per_block) {
@@ -575,22 +594,22 @@ __global__ __launch_bounds__(256) void elu_heads_kernel(float* __restrict__ zh, 
         float4 z1 = *p1;
         z0.x = elu1(z0.x); z0.y = elu1(z0.y); z0.z = elu1(z0.z); z0.w = elu1(z0.w);
         z1.x = elu1(z1.x); z1.y = elu1(z1.y); z1.z = elu1(z1.z); z1.w = elu1(z1.w);
-        *p0 = z0;
-        if (has2) *p1 = z1;
+        if (WRITE_BACK) {      // without it the buffer keeps the pre-activation z (HBM writes cost ~2x reads on this part)
+            *p0 = z0;
+            if (has2) *p1 = z1;
+        }
         float s0[A1], s1[A1];
 #pragma unroll
         for (int a = 0; a < A1; ++a) {
             s0[a] = (z0.x * w[a].x + z0.y * w[a].y) + (z0.z * w[a].z + z0.w * w[a].w);
             s1[a] = (z1.x * w[a].x + z1.y * w[a].y) + (z1.z * w[a].z + z1.w * w[a].w);
         }
-        for (int off = tpr >> 1; off > 0; off >>= 1) {
 #pragma unroll
-            for (int a = 0; a < A1; ++a) {
-                s0[a] += __shfl_xor(s0[a], off, 64);
-                s1[a] += __shfl_xor(s1[a], off, 64);
-            }
+        for (int a = 0; a < A1; ++a) {
+            s0[a] = group_sum_last_lane(s0[a], tpr);
+            s1[a] = group_sum_last_lane(s1[a], tpr);
         }
-        if (col4 == 0) {
+        if (col4 == tpr - 1) {
 #pragma unroll
             for (int a = 0; a < A1; ++a) {
                 heads[(size_t)r * A1 + a] = s0[a] + bh[a];
@@ -631,17 +650,18 @@ extern "C" int ag_mlp_input_layer(const float* obs, const double* mean, const do
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
-extern "C" int ag_elu_heads(float* zh, const float* Wh, const float* bh, float* heads, int M, int C, int A1, void* stream) {
+extern "C" int ag_elu_heads(float* zh, const float* Wh, const float* bh, float* heads, int M, int C, int A1, int write_back,
+                            void* stream) {
     if (!zh || !Wh || !bh || !heads || M <= 0) return AG_ERR_INVALID_ARG;
-    if (C < 16 || C > 256 || !pow2(C)) return AG_ERR_UNSUPPORTED;
+    if (C < 64 || C > 256 || !pow2(C)) return AG_ERR_UNSUPPORTED;      // C/4 lanes per row: one, two or four DPP rows
     const int rows_per_block = 64;
     const int grid = (M + rows_per_block - 1) / rows_per_block;
-    if (A1 == 5)
-        hipLaunchKernelGGL(elu_heads_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, zh, Wh, bh, heads, M, C, rows_per_block);
-    else if (A1 == 6)
-        hipLaunchKernelGGL(elu_heads_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, zh, Wh, bh, heads, M, C, rows_per_block);
-    else
-        return AG_ERR_UNSUPPORTED;
+#define AG_EH(A1V, WB) hipLaunchKernelGGL((elu_heads_kernel<A1V, WB>), dim3(grid), dim3(256), 0, (hipStream_t)stream, zh, Wh, bh, \
+                                         heads, M, C, rows_per_block)
+    if (A1 == 5) { if (write_back) AG_EH(5, true); else AG_EH(5, false); }
+    else if (A1 == 6) { if (write_back) AG_EH(6, true); else AG_EH(6, false); }
+    else return AG_ERR_UNSUPPORTED;
+#undef AG_EH
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
@@ -658,7 +678,7 @@ namespace {
 constexpr int kWgRows = 128;      // rows per block, head kernel (measured: 82 us at 128, 109 us at 256)
 constexpr int kInWgRows = 256;    // rows per block, first-layer kernel (measured: 106 us at 128, 95 us at 256)
 
-template <int A1>
+template <int A1, bool PREACT>
 __global__ __launch_bounds__(256) void heads_bwd_elu_wgrad_kernel(const float* __restrict__ d_heads, const float* __restrict__ Wh,
                                                                   const float* __restrict__ h, float* __restrict__ dz,
                                                                   float* __restrict__ db_partials, float* __restrict__ dwh_partials,
@@ -679,7 +699,10 @@ __global__ __launch_bounds__(256) void heads_bwd_elu_wgrad_kernel(const float* _
     if (rsub < rpp) {
         for (int r = row0 + rsub; r < row_end; r += rpp) {
             const size_t idx = (size_t)r * tpr + col4;
-            const float4 y = reinterpret_cast<const float4*>(h)[idx];
+            float4 y = reinterpret_cast<const float4*>(h)[idx];
+            if (PREACT) {        // the buffer holds z, not ELU(z): rebuild h here (ELU'(z) = h + 1 on the negative side)
+                y.x = elu1(y.x); y.y = elu1(y.y); y.z = elu1(y.z); y.w = elu1(y.w);
+            }
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int a = 0; a < A1; ++a) {
@@ -810,18 +833,16 @@ __global__ __launch_bounds__(256) void elu_bwd_input_wgrad_kernel(const float* _
 extern "C" int ag_wgrad_rows_per_block(int which) { return which == 0 ? kWgRows : kInWgRows; }
 
 extern "C" int ag_heads_bwd_elu_wgrad(const float* d_heads, const float* Wh, const float* h, float* dz, float* db_partials,
-                                      float* dwh_partials, int M, int C, int A1, void* stream) {
+                                      float* dwh_partials, int M, int C, int A1, int h_is_preactivation, void* stream) {
     if (!d_heads || !Wh || !h || !dz || !db_partials || !dwh_partials || M <= 0) return AG_ERR_INVALID_ARG;
     if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
     const int grid = (M + kWgRows - 1) / kWgRows;
-    if (A1 == 5)
-        hipLaunchKernelGGL(heads_bwd_elu_wgrad_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz,
-                           db_partials, dwh_partials, M, C);
-    else if (A1 == 6)
-        hipLaunchKernelGGL(heads_bwd_elu_wgrad_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_heads, Wh, h, dz,
-                           db_partials, dwh_partials, M, C);
-    else
-        return AG_ERR_UNSUPPORTED;
+#define AG_HB(A1V, PA) hipLaunchKernelGGL((heads_bwd_elu_wgrad_kernel<A1V, PA>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                                         d_heads, Wh, h, dz, db_partials, dwh_partials, M, C)
+    if (A1 == 5) { if (h_is_preactivation) AG_HB(5, true); else AG_HB(5, false); }
+    else if (A1 == 6) { if (h_is_preactivation) AG_HB(6, true); else AG_HB(6, false); }
+    else return AG_ERR_UNSUPPORTED;
+#undef AG_HB
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 

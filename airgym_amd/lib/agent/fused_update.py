@@ -93,7 +93,7 @@ class FusedMLPStep:
         self.sum_scratch = torch.empty(self.lib.ag_sum_rows_groups() * tot, **f)
         C0, Cl = self.layers[0][0].shape[0], self.layers[-1][0].shape[0]
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
-        self.fuse_heads = len(self.layers) >= 2 and 16 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
+        self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
         self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 6, **f)
         self.k = 0
 
@@ -145,8 +145,9 @@ class FusedMLPStep:
             h = self.h[li]
             torch.addmm(b, x, w.t(), out=h)
             if li == last and self.fuse_heads:      # ELU in place + the [M,C]x[C,A+1] head product in the same pass
+                # no write-back: the buffer keeps the pre-activation z, the backward pass rebuilds ELU(z) on the fly
                 N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
-                                         M, w.shape[0], A + 1, st), "ag_elu_heads")
+                                         M, w.shape[0], A + 1, 0, st), "ag_elu_heads")
                 heads_done = True
             else:
                 F.elu_(h)
@@ -181,8 +182,8 @@ class FusedMLPStep:
             parts = self.bias_partials[li]
             if li == last:
                 N.check(lib.ag_heads_bwd_elu_wgrad(self.d_heads.data_ptr(), ag.heads_w.data_ptr(), h.data_ptr(), dz.data_ptr(),
-                                                   parts.data_ptr(), self.head_wg_partials.data_ptr(), M, C, A + 1, st),
-                        "ag_heads_bwd_elu_wgrad")
+                                                   parts.data_ptr(), self.head_wg_partials.data_ptr(), M, C, A + 1,
+                                                   int(heads_done), st), "ag_heads_bwd_elu_wgrad")
             elif li == 0 and self.fuse_input_wgrad:
                 N.check(lib.ag_elu_bwd_input_wgrad(dh.data_ptr(), h.data_ptr(), xin.data_ptr(),
                                                    self.wgrad_partials[0].data_ptr(), parts.data_ptr(), M, C, K, st),
@@ -240,7 +241,7 @@ class FusedRolloutStep:
         self.env_actions = torch.empty(n, self.A, **f)
         C0, Cl = self.layers[0][0].shape[0], self.layers[-1][0].shape[0]
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
-        self.fuse_heads = len(self.layers) >= 2 and 16 <= Cl <= 256 and (Cl & (Cl - 1)) == 0
+        self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.acct_partials = torch.zeros(self.lib.ag_rollout_account_blocks(n), 4, dtype=torch.float64, device=dev)
         self.seed = (int(agent.params.get("seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
@@ -290,7 +291,7 @@ class FusedRolloutStep:
             torch.addmm(b, x, w.t(), out=h)
             if li == last and self.fuse_heads:
                 N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
-                                         n, w.shape[0], A + 1, st), "ag_elu_heads")
+                                         n, w.shape[0], A + 1, 0, st), "ag_elu_heads")
                 heads_done = True
             else:
                 F.elu_(h)

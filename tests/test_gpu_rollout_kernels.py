@@ -174,3 +174,26 @@ def test_rms_update_kernel(lib, rows, D):
         assert torch.allclose(hip.running_mean, ref.running_mean, rtol=1e-6, atol=1e-6)
         assert torch.allclose(hip.running_var, ref.running_var, rtol=2e-5, atol=1e-6)
         assert hip.count.item() == ref.count.item()
+
+
+@pytest.mark.parametrize("C", [64, 128, 256])
+@pytest.mark.parametrize("A1,write_back", [(5, 1), (6, 0)])
+def test_elu_heads_kernel(lib, C, A1, write_back):
+    """ag_elu_heads == ELU then the [M,C]x[C,A1] head product (DPP row reduction over 16 / 32 / 64 lanes)."""
+    import torch.nn.functional as F
+    from airgym_amd import _native as N
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M in (1, 63, 5001):
+        z = torch.randn(M, C, device="cuda", generator=g) * 2
+        Wh = torch.randn(A1, C, device="cuda", generator=g) * 0.1
+        bh = torch.randn(A1, device="cuda", generator=g)
+        heads = torch.empty(M, A1, device="cuda")
+        buf = z.clone()
+        N.check(lib.ag_elu_heads(buf.data_ptr(), Wh.data_ptr(), bh.data_ptr(), heads.data_ptr(), M, C, A1, write_back, _stream()),
+                "ag_elu_heads")
+        h = F.elu(z)
+        assert torch.allclose(heads, h @ Wh.t() + bh, rtol=1e-5, atol=1e-5)
+        if write_back:
+            assert torch.allclose(buf, h, rtol=1e-6, atol=1e-6)
+        else:
+            assert torch.equal(buf, z)
