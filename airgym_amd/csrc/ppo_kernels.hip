@@ -874,13 +874,13 @@ extern "C" int ag_elu_bwd_input_wgrad(const float* dh, const float* h, const flo
 
 // ---------------------------------------------------------------------------------------------------
 // All partial-sum reductions of one minibatch in TWO launches (instead of a fill + reduce pair per gradient):
-// stage 1 sums each job's S partial rows in kSumGroups groups (grid.z = job, grid.y = group), stage 2 sums the groups
+// stage 1 sums each job's S partial rows in up to 64 groups (a flat grid over all jobs' column-blocks x groups), stage 2 sums the groups
 // into the gradient slice.  Fixed summation order -> deterministic.  n % 4 == 0 and 16-byte aligned partials; the
 // destination only needs 4-byte alignment.
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int kSumGroups = 16;
+constexpr int kSumMaxGroups = 64;        // partial rows are first summed in up to 64 groups per job (>= 8 rows per group)
 constexpr int kMaxSumJobs = AG_MAX_SUM_JOBS;
 
 struct SumJobs {
@@ -888,19 +888,30 @@ struct SumJobs {
     float* out[kMaxSumJobs];
     int S[kMaxSumJobs];
     int n4[kMaxSumJobs];
-    long long scratch_off[kMaxSumJobs];   // in floats, into scratch [sum over jobs of kSumGroups * n]
+    int groups[kMaxSumJobs];
+    int block0_s1[kMaxSumJobs + 1];       // first flat block of each job in stage 1 (blocks = ceil(n4/64) * groups)
+    int block0_s2[kMaxSumJobs + 1];       // ... and in stage 2 (blocks = ceil(n4/64))
+    long long scratch_off[kMaxSumJobs];   // in floats, into scratch [sum over jobs of groups * n]
     float* scratch;
+    int njobs;
 };
 
+__device__ __forceinline__ int find_job(const int* block0, int njobs, int b) {
+    int j = 0;
+    while (j + 1 < njobs && b >= block0[j + 1]) ++j;
+    return j;
+}
+
+// block = 64 float4 columns x 4 row lanes
 __global__ __launch_bounds__(256) void sum_rows_stage1_kernel(const SumJobs k) {
     __shared__ float4 red[256];
-    const int j = blockIdx.z, g = blockIdx.y;
-    const int n4 = k.n4[j];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    if (blockIdx.x * 64 >= n4) return;
+    const int j = find_job(k.block0_s1, k.njobs, blockIdx.x);
+    const int local = blockIdx.x - k.block0_s1[j];
+    const int n4 = k.n4[j], G = k.groups[j], S = k.S[j];
+    const int g = local % G, bx = local / G;
+    const int col = bx * 64 + (threadIdx.x & 63);
     const int lane = threadIdx.x >> 6;
-    const int S = k.S[j];
-    const int rpg = (S + kSumGroups - 1) / kSumGroups;
+    const int rpg = (S + G - 1) / G;
     const int s_end = min((g + 1) * rpg, S);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < n4) {
@@ -923,32 +934,43 @@ __global__ __launch_bounds__(256) void sum_rows_stage1_kernel(const SumJobs k) {
 }
 
 __global__ __launch_bounds__(256) void sum_rows_stage2_kernel(const SumJobs k) {
-    const int j = blockIdx.z;
-    const int n4 = k.n4[j];
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= n4) return;
-    const float4* src = reinterpret_cast<const float4*>(k.scratch + k.scratch_off[j]);
+    __shared__ float4 red[256];
+    const int j = find_job(k.block0_s2, k.njobs, blockIdx.x);
+    const int bx = blockIdx.x - k.block0_s2[j];
+    const int n4 = k.n4[j], G = k.groups[j];
+    const int col = bx * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x >> 6;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int g = 0; g < kSumGroups; ++g) {
-        const float4 v = src[(size_t)g * n4 + col];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    if (col < n4) {
+        const float4* src = reinterpret_cast<const float4*>(k.scratch + k.scratch_off[j]);
+#pragma unroll 4
+        for (int g = lane; g < G; g += 4) {
+            const float4 v = src[(size_t)g * n4 + col];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
-    float* dst = k.out[j] + (size_t)col * 4;
-    dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z; dst[3] = acc.w;
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && col < n4) {
+        const float4 s0 = red[threadIdx.x], s1 = red[threadIdx.x + 64], s2 = red[threadIdx.x + 128], s3 = red[threadIdx.x + 192];
+        float* dst = k.out[j] + (size_t)col * 4;
+        dst[0] = (s0.x + s1.x) + (s2.x + s3.x); dst[1] = (s0.y + s1.y) + (s2.y + s3.y);
+        dst[2] = (s0.z + s1.z) + (s2.z + s3.z); dst[3] = (s0.w + s1.w) + (s2.w + s3.w);
+    }
 }
 
 }  // namespace
 
-extern "C" int ag_sum_rows_groups(void) { return kSumGroups; }
+extern "C" int ag_sum_rows_groups(void) { return kSumMaxGroups; }
 
 extern "C" int ag_sum_rows_multi(const ag_sum_job* jobs, int njobs, float* scratch, long long scratch_floats, void* stream) {
     if (!jobs || !scratch || njobs <= 0) return AG_ERR_INVALID_ARG;
     if (njobs > kMaxSumJobs) return AG_ERR_UNSUPPORTED;
     SumJobs k{};
     k.scratch = scratch;
+    k.njobs = njobs;
     long long off = 0;
-    int max_n4 = 0;
+    int b1 = 0, b2 = 0;
     for (int j = 0; j < njobs; ++j) {
         if (!jobs[j].partials_dev || !jobs[j].out_dev || jobs[j].rows <= 0 || jobs[j].n <= 0) return AG_ERR_INVALID_ARG;
         if (jobs[j].n % 4 != 0 || (reinterpret_cast<uintptr_t>(jobs[j].partials_dev) & 15)) return AG_ERR_UNSUPPORTED;
@@ -956,13 +978,22 @@ extern "C" int ag_sum_rows_multi(const ag_sum_job* jobs, int njobs, float* scrat
         k.out[j] = jobs[j].out_dev;
         k.S[j] = jobs[j].rows;
         k.n4[j] = jobs[j].n / 4;
+        int G = jobs[j].rows / 8;
+        G = G < 1 ? 1 : (G > kSumMaxGroups ? kSumMaxGroups : G);
+        k.groups[j] = G;
         k.scratch_off[j] = off;
-        off += (long long)kSumGroups * jobs[j].n;
-        if (k.n4[j] > max_n4) max_n4 = k.n4[j];
+        off += (long long)G * jobs[j].n;
+        const int nbx = (k.n4[j] + 63) / 64;
+        k.block0_s1[j] = b1;
+        k.block0_s2[j] = b2;
+        b1 += nbx * G;
+        b2 += nbx;
     }
+    k.block0_s1[njobs] = b1;
+    k.block0_s2[njobs] = b2;
     if (off > scratch_floats || (reinterpret_cast<uintptr_t>(scratch) & 15)) return AG_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(sum_rows_stage1_kernel, dim3((max_n4 + 63) / 64, kSumGroups, njobs), dim3(256), 0, (hipStream_t)stream, k);
-    hipLaunchKernelGGL(sum_rows_stage2_kernel, dim3((max_n4 + 255) / 256, 1, njobs), dim3(256), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(sum_rows_stage1_kernel, dim3(b1), dim3(256), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(sum_rows_stage2_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, k);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 

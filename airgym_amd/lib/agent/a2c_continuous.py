@@ -220,6 +220,7 @@ class A2CAgent:
         self.last_lr = float(config["learning_rate"])
         self.use_hip_graph = config.get("use_hip_graph", False)
         self.sync_normalizers = config.get("sync_normalizers", True)
+        self.sync_timers = config.get("sync_timers", False)
         self.frame = 0
         self.epoch_num = 0
         self.curr_frames = 0
@@ -591,7 +592,9 @@ class A2CAgent:
         """a2c_continuous.py:78-138"""
         play_time_start = time.time()
         batch_dict = self.play_steps()
-        if str(self.ppo_device).startswith("cuda"):
+        # without sync_timers the host keeps enqueueing the update while the rollout graph still runs; play_time is then
+        # the host-side enqueue time only (the epoch total stays exact: one sync at the end)
+        if self.sync_timers and str(self.ppo_device).startswith("cuda"):
             torch.cuda.synchronize()
         play_time_end = time.time()
         update_time_start = play_time_end
@@ -627,17 +630,20 @@ class A2CAgent:
             self.last_lr, self.entropy_coef = self.scheduler.update(self.last_lr, self.entropy_coef, self.epoch_num,
                                                                     self.frame, 0.0)
             self.optimizer.lr.fill_(self.last_lr)
-        if str(self.ppo_device).startswith("cuda"):
-            torch.cuda.synchronize()
+        # one device->host transfer for every logged scalar (it is also the epoch's only synchronisation point)
+        dev_stats = torch.stack([torch_ext.mean_list(a_losses).float().reshape(()), torch_ext.mean_list(c_losses).float().reshape(()),
+                                 torch_ext.mean_list(entropies).float().reshape(()), torch_ext.mean_list(kls).float().reshape(()),
+                                 (torch_ext.mean_list(b_losses).float().reshape(()) if b_losses
+                                  else torch.zeros((), device=self.ppo_device)),
+                                 self.optimizer.lr.float().reshape(())]).tolist()
         update_time_end = time.time()
-        self.last_lr = float(self.optimizer.lr.item())
+        self.last_lr = float(dev_stats[5])
         self._flush_episode_stats()
         return {
             "play_time": play_time_end - play_time_start, "update_time": update_time_end - update_time_start,
             "total_time": update_time_end - play_time_start,
-            "a_loss": torch_ext.mean_list(a_losses).item(), "c_loss": torch_ext.mean_list(c_losses).item(),
-            "entropy": torch_ext.mean_list(entropies).item(), "kl": torch_ext.mean_list(kls).item(),
-            "b_loss": torch_ext.mean_list(b_losses).item() if b_losses else 0.0, "last_lr": self.last_lr,
+            "a_loss": dev_stats[0], "c_loss": dev_stats[1], "entropy": dev_stats[2], "kl": dev_stats[3],
+            "b_loss": dev_stats[4], "last_lr": self.last_lr,
         }
 
     def _flush_episode_stats(self):

@@ -160,7 +160,7 @@ def main():
                    "hip_graph_rollout": bool(args.graph),
                    "gemm_selection": ("TunableOp table airgym_amd/assets/tunableop_gfx950.csv (hipBLASLt / rocBLAS fp32)"
                                       if getattr(agent, "tuned_gemms", False) else "hipBLASLt default heuristic (fp32)")},
-        "phases": {"rollout_s": play, "update_s": update, "final_lr": agent.last_lr,
+        "phases": {"rollout_host_enqueue_s": play, "update_s": update, "final_lr": agent.last_lr,
                    "last_kl": last_stats["kl"], "last_a_loss": last_stats["a_loss"], "last_c_loss": last_stats["c_loss"],
                    "finite": bool(all(map(lambda x: x == x and abs(x) != float("inf"),
                                           (last_stats["kl"], last_stats["a_loss"], last_stats["c_loss"]))))},

@@ -259,7 +259,7 @@ int ag_elu_bwd_input_wgrad(const float* dh_dev, const float* h_dev, const float*
                            float* db_partials_dev, int M, int C, int D, void* stream);
 
 /* Every partial-sum reduction of one minibatch in two launches.  Job j: out_dev[0..n) = sum over `rows` rows of
- * partials_dev [rows, n] (n % 4 == 0, partials 16-byte aligned).  scratch_dev holds ag_sum_rows_groups() * sum_j n floats.
+ * partials_dev [rows, n] (n % 4 == 0, partials 16-byte aligned).  scratch_dev holds up to ag_sum_rows_groups() * sum_j n floats.
  * Fixed summation order (deterministic); at most AG_MAX_SUM_JOBS jobs per call. */
 #define AG_MAX_SUM_JOBS 12
 typedef struct ag_sum_job {

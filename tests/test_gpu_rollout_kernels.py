@@ -197,3 +197,28 @@ def test_elu_heads_kernel(lib, C, A1, write_back):
             assert torch.allclose(buf, h, rtol=1e-6, atol=1e-6)
         else:
             assert torch.equal(buf, z)
+
+
+def test_sum_rows_multi(lib):
+    """ag_sum_rows_multi: several [rows, n] partial tables reduced over rows in two launches, into unaligned outputs."""
+    from airgym_amd import _native as N
+    g = torch.Generator(device="cuda").manual_seed(6)
+    shapes = [(1536, 1280), (1536, 256), (64, 65536), (768, 256), (768, 4608), (1, 8), (7, 12), (3000, 4)]
+    flat = torch.zeros(sum(n for _, n in shapes) + 1, device="cuda")
+    parts, outs, off = [], [], 1                     # offset 1: destinations only 4-byte aligned
+    for rows, n in shapes:
+        parts.append(torch.randn(rows, n, device="cuda", generator=g))
+        outs.append(flat[off:off + n]); off += n
+    jobs = (N.AgSumJob * len(shapes))()
+    for j, (p, o) in enumerate(zip(parts, outs)):
+        jobs[j] = N.AgSumJob(p.data_ptr(), o.data_ptr(), p.shape[0], p.shape[1])
+    scratch = torch.empty(lib.ag_sum_rows_groups() * sum(n for _, n in shapes), device="cuda")
+    for _ in range(2):
+        N.check(lib.ag_sum_rows_multi(jobs, len(shapes), scratch.data_ptr(), scratch.numel(), _stream()), "ag_sum_rows_multi")
+    for p, o in zip(parts, outs):
+        ref = p.double().sum(0)
+        assert torch.allclose(o.double(), ref, rtol=1e-5, atol=1e-4 * max(1.0, p.shape[0] ** 0.5))
+    assert flat[0] == 0
+    first = flat.clone()
+    N.check(lib.ag_sum_rows_multi(jobs, len(shapes), scratch.data_ptr(), scratch.numel(), _stream()), "ag_sum_rows_multi")
+    assert torch.equal(first, flat), "fixed summation order: bit-identical on repeat"
