@@ -1,4 +1,5 @@
-"""Correctness + timing of ag_mlp_hidden_heads against addmm + ag_elu_heads."""
+"""Correctness + timing of ag_mlp_hidden_heads (airgym_amd/csrc/experimental/mlp_gemm.hip) against addmm + ag_elu_heads.
+The kernel is not in the default build: add it to csrc/build.py units() and bind it in _native/__init__.py to re-run."""
 import ctypes
 import os
 import sys
@@ -22,7 +23,7 @@ def run(M, K=256, A1=5, check=True):
     bh = torch.randn(A1, device="cuda", generator=g)
     Z = torch.empty(M, 256, device="cuda")
     heads = torch.empty(M, A1, device="cuda")
-    N.check(lib.ag_mlp_hidden_heads  # needs a build with experimental/mlp_gemm.hip linked in(X.data_ptr(), W.data_ptr(), b.data_ptr(), Wh.data_ptr(), bh.data_ptr(), Z.data_ptr(),
+    N.check(lib.ag_mlp_hidden_heads(X.data_ptr(), W.data_ptr(), b.data_ptr(), Wh.data_ptr(), bh.data_ptr(), Z.data_ptr(),
                                     heads.data_ptr(), M, K, 256, A1, st), "ag_mlp_hidden_heads")
     torch.cuda.synchronize()
     if check:
@@ -39,7 +40,7 @@ for M in (65536, 196608):
     X, W, b, Wh, bh, Z, heads = run(M, check=False)
 
     def mine():
-        lib.ag_mlp_hidden_heads  # needs a build with experimental/mlp_gemm.hip linked in(X.data_ptr(), W.data_ptr(), b.data_ptr(), Wh.data_ptr(), bh.data_ptr(), Z.data_ptr(),
+        lib.ag_mlp_hidden_heads(X.data_ptr(), W.data_ptr(), b.data_ptr(), Wh.data_ptr(), bh.data_ptr(), Z.data_ptr(),
                                 heads.data_ptr(), M, 256, 256, 5, st)
 
     def ref():
