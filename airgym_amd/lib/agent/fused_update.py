@@ -100,13 +100,19 @@ class FusedMLPStep:
     def begin_epoch(self):
         self.k = 0
 
+    def next_stats_row(self):
+        row = self.stats_ring[self.k % self.stats_ring.shape[0]]
+        self.k += 1
+        return row
+
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.agent.ppo_device).cuda_stream)
 
     @torch.no_grad()
-    def step(self, mb):
+    def step(self, mb, stats_out=None):
         """Forward, loss, backward of minibatch `mb`; gradients (and the KL in the appended slot) are left in
-        agent.flat_grad.  Returns the stats row [a_loss, c_loss, entropy, b_loss, kl, loss] (device, no sync)."""
+        agent.flat_grad.  Returns the stats row [a_loss, c_loss, entropy, b_loss, kl, loss] (device, no sync);
+        `stats_out` overrides where that row is written (hipGraph capture needs a fixed address)."""
         ag, lib, m = self.agent, self.lib, self.agent.model
         M, A, S = self.M, self.A, SPLIT_K
         obs = mb["obs"]
@@ -165,8 +171,11 @@ class FusedMLPStep:
                                 float(ag.e_clip), float(ag.critic_coef), bcoef, int(bool(ag.clip_value)), int(bt),
                                 self.d_heads.data_ptr(), mb["mu"].data_ptr(), mb["sigma"].data_ptr(),
                                 self.loss_partials.data_ptr(), ctypes.byref(nb), st), "ag_ppo_loss")
-        stats = self.stats_ring[self.k % self.stats_ring.shape[0]]
-        self.k += 1
+        if stats_out is not None:
+            stats = stats_out
+        else:
+            stats = self.stats_ring[self.k % self.stats_ring.shape[0]]
+            self.k += 1
         N.check(lib.ag_ppo_loss_finalize(self.loss_partials.data_ptr(), nb.value, M, A, logstd.data_ptr(),
                                          float(ag.entropy_coef), float(ag.critic_coef), bcoef, logstd.grad.data_ptr(),
                                          ag.heads_b_grad.data_ptr(), ag.flat_grad[-1:].data_ptr(), stats.data_ptr(), st),

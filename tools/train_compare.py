@@ -12,10 +12,10 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 
-def run(fused, envs, epochs, every):
+def run(fused, envs, epochs, every, minibatches=4, graph=None):
     class A:
         pass
-    A.envs, A.minibatches, A.graph, A.task, A.ctl, A.tuned_gemms = envs, 4, int(fused), "hovering", "rate", 1
+    A.envs, A.minibatches, A.graph, A.task, A.ctl, A.tuned_gemms = envs, minibatches, int(fused if graph is None else graph), "hovering", "rate", 1
     params = bench.build_params(A, 1)
     c = params["config"]
     c["use_fused_update"] = c["use_fused_rollout"] = c["use_fused_loss"] = c["use_fused_adam"] = bool(fused)
@@ -41,6 +41,8 @@ if __name__ == "__main__":
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--epochs", type=int, default=60)
     ap.add_argument("--every", type=int, default=10)
+    ap.add_argument("--minibatches", type=int, default=4)
     a = ap.parse_args()
-    for fused in (1, 0):
-        print(json.dumps({"fused": bool(fused), "curve": run(fused, a.envs, a.epochs, a.every)}))
+    for fused, graph in ((1, 1), (1, 0), (0, 0)):
+        print(json.dumps({"fused": bool(fused), "hip_graphs": bool(graph),
+                          "curve": run(fused, a.envs, a.epochs, a.every, a.minibatches, graph)}))
