@@ -222,3 +222,32 @@ def test_sum_rows_multi(lib):
     first = flat.clone()
     N.check(lib.ag_sum_rows_multi(jobs, len(shapes), scratch.data_ptr(), scratch.numel(), _stream()), "ag_sum_rows_multi")
     assert torch.equal(first, flat), "fixed summation order: bit-identical on repeat"
+
+
+def test_minibatch_graphs_are_bit_identical_to_eager(lib):
+    """use_hip_graph: rollout graph + one captured graph per minibatch step == the eager launch sequence, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    results = []
+    for graph in (1, 0):
+        class Args:
+            envs = 2048; minibatches = 8; task = "hovering"; ctl = "rate"; tuned_gemms = 1
+        Args.graph = graph
+        torch.manual_seed(0)
+        agent = A2CAgent("g", bench.build_params(Args, 1))
+        assert agent._graph_update == bool(graph)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()
+        for ep in range(1, 5):
+            agent.epoch_num = ep
+            st = agent.train_epoch()
+        if graph:
+            assert len(agent._upd_graphs) == 16 and "rollout" in agent._graphs      # 8 minibatches x {stats on, off}
+        results.append((agent.flat_param.clone(), agent.optimizer.lr.item(), st["kl"],
+                        agent.model.running_mean_std.running_mean.clone()))
+        agent.vec_env.env.hip.close()
+    (p1, lr1, kl1, m1), (p0, lr0, kl0, m0) = results
+    assert torch.equal(p1, p0) and lr1 == lr0 and kl1 == kl0 and torch.equal(m1, m0)
