@@ -502,12 +502,19 @@ __global__ __launch_bounds__(256) void input_layer_kernel(const float* __restric
 // (its column group never changes) and streams rows: per row D broadcast LDS reads, 4*D FMAs, one float4 store.
 constexpr int kInRegTileRows = 128;
 
-template <int D>
+template <int CPT> struct VecN;
+template <> struct VecN<4> { typedef float4 type; };
+template <> struct VecN<2> { typedef float2 type; };
+
+// CPT = output columns per thread (4: float4 stores, D <= 20; 2: float2 stores, wider inputs such as Tracking's D = 48,
+// so that the D x CPT slab of W still fits in registers).
+template <int D, int CPT>
 __global__ __launch_bounds__(256) void input_layer_reg_kernel(const float* __restrict__ obs, const double* __restrict__ mean,
                                                               const double* __restrict__ var, const float* __restrict__ W,
                                                               const float* __restrict__ bias, float* __restrict__ xn,
                                                               float* __restrict__ h, int M, int C, float eps, float clip,
                                                               int normalize) {
+    typedef typename VecN<CPT>::type vec_t;
     __shared__ float xs[kInRegTileRows * D];
     const int row0 = blockIdx.x * kInRegTileRows;
     const int rows = min(kInRegTileRows, M - row0);
@@ -521,34 +528,36 @@ __global__ __launch_bounds__(256) void input_layer_reg_kernel(const float* __res
         }
         xs[i] = v;
     }
-    const int tpr = C >> 2;
+    const int tpr = C / CPT;
     const int rgroups = 256 / tpr;
-    const int col4 = threadIdx.x % tpr, rg = threadIdx.x / tpr;
-    float4 w[D];
+    const int colg = threadIdx.x % tpr, rg = threadIdx.x / tpr;
+    float w[D][CPT];
+    float b[CPT];
     if (rg < rgroups) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            w[d].x = W[(size_t)(col4 * 4 + 0) * D + d];
-            w[d].y = W[(size_t)(col4 * 4 + 1) * D + d];
-            w[d].z = W[(size_t)(col4 * 4 + 2) * D + d];
-            w[d].w = W[(size_t)(col4 * 4 + 3) * D + d];
+        for (int j = 0; j < CPT; ++j) {
+            b[j] = bias[colg * CPT + j];
+#pragma unroll
+            for (int d = 0; d < D; ++d) w[d][j] = W[(size_t)(colg * CPT + j) * D + d];
         }
     }
     __syncthreads();
     if (rg >= rgroups) return;
-    const float4 b4 = reinterpret_cast<const float4*>(bias)[col4];
     for (int r = rg; r < rows; r += rgroups) {
         const float* xr = xs + r * D;
-        float4 acc = b4;
+        float acc[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] = b[j];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const float x = xr[d];
-            acc.x = fmaf(x, w[d].x, acc.x); acc.y = fmaf(x, w[d].y, acc.y);
-            acc.z = fmaf(x, w[d].z, acc.z); acc.w = fmaf(x, w[d].w, acc.w);
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) acc[j] = fmaf(x, w[d][j], acc[j]);
         }
-        float4 o;
-        o.x = elu1(acc.x); o.y = elu1(acc.y); o.z = elu1(acc.z); o.w = elu1(acc.w);
-        reinterpret_cast<float4*>(h + (size_t)(row0 + r) * C)[col4] = o;
+        float o[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) o[j] = elu1(acc[j]);
+        reinterpret_cast<vec_t*>(h + (size_t)(row0 + r) * C)[colg] = *reinterpret_cast<const vec_t*>(o);
     }
 }
 
@@ -629,19 +638,18 @@ extern "C" int ag_mlp_input_layer(const float* obs, const double* mean, const do
     const int normalize = (mean && var && xn) ? 1 : 0;
     if (!normalize && (mean || var || xn)) return AG_ERR_INVALID_ARG;
     if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
+#define AG_IN(DV, CPTV)                                                                                                    \
+    hipLaunchKernelGGL((input_layer_reg_kernel<DV, CPTV>), dim3((M + kInRegTileRows - 1) / kInRegTileRows), dim3(256), 0,     \
+                       (hipStream_t)stream, obs, mean, var, W, bias, xn, h, M, C, eps, clip, normalize)
     if (D == 16 || D == 18 || D == 20) {
-        const int g = (M + kInRegTileRows - 1) / kInRegTileRows;
-        if (D == 16)
-            hipLaunchKernelGGL(input_layer_reg_kernel<16>, dim3(g), dim3(256), 0, (hipStream_t)stream, obs, mean, var, W, bias,
-                               xn, h, M, C, eps, clip, normalize);
-        else if (D == 18)
-            hipLaunchKernelGGL(input_layer_reg_kernel<18>, dim3(g), dim3(256), 0, (hipStream_t)stream, obs, mean, var, W, bias,
-                               xn, h, M, C, eps, clip, normalize);
-        else
-            hipLaunchKernelGGL(input_layer_reg_kernel<20>, dim3(g), dim3(256), 0, (hipStream_t)stream, obs, mean, var, W, bias,
-                               xn, h, M, C, eps, clip, normalize);
+        if (D == 16) AG_IN(16, 4); else if (D == 18) AG_IN(18, 4); else AG_IN(20, 4);
         return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
     }
+    if (D == 48 && C <= 512 && (C & 1) == 0 && 256 % (C / 2) == 0) {      // Tracking: 48 observations
+        AG_IN(48, 2);
+        return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+    }
+#undef AG_IN
     const size_t lds = ((size_t)D * C + (size_t)kInTileRows * D) * sizeof(float);
     if (lds > 64 * 1024) return AG_ERR_UNSUPPORTED;
     const int grid = (M + kInTileRows - 1) / kInTileRows;
@@ -747,66 +755,70 @@ __global__ __launch_bounds__(256) void heads_bwd_elu_wgrad_kernel(const float* _
     }
 }
 
-// D is a template parameter so the [4][D] accumulator tile lives in registers.  Two rows are in flight per thread
-// (four 16-byte loads issued before use); the row groups then add their tiles into one [C][D+1] LDS buffer in turn.
-template <int D>
+// D is a template parameter so the [CPT][D] accumulator tile lives in registers (CPT columns per thread).  Two rows are in flight per thread (loads issued before use); the row groups then add their
+// tiles into one [C][D+1] LDS buffer in turn.
+template <int D, int CPT, int ROWS>
 __global__ __launch_bounds__(256) void elu_bwd_input_wgrad_kernel(const float* __restrict__ dh, const float* __restrict__ h,
                                                                   const float* __restrict__ x, float* __restrict__ dw_partials,
                                                                   float* __restrict__ db_partials, int M, int C) {
-    extern __shared__ float lds[];          // xs[kInWgRows][D] | red[C][D+1]
+    typedef typename VecN<CPT>::type vec_t;
+    extern __shared__ float lds[];          // xs[ROWS][D] | red[C][D+1]
     float* xs = lds;
-    float* red = lds + kInWgRows * D;
-    const int tpr = C >> 2;
+    float* red = lds + ROWS * D;
+    const int tpr = C / CPT;
     const int rpp = 256 / tpr;
-    const int col4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
-    const int row0 = blockIdx.x * kInWgRows;
-    const int rows = min(kInWgRows, M - row0);
+    const int colg = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int row0 = blockIdx.x * ROWS;
+    const int rows = min(ROWS, M - row0);
     for (int i = threadIdx.x; i < rows * D; i += 256) xs[i] = x[(size_t)row0 * D + i];
     __syncthreads();
-    float acc[4][D];
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[CPT][D];
+    float bsum[CPT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < CPT; ++j) {
+        bsum[j] = 0.f;
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[j][d] = 0.f;
+    }
     if (rsub < rpp) {
         for (int r = rsub; r < rows; r += 2 * rpp) {
             const int r2 = r + rpp;
             const bool has2 = r2 < rows;
-            const size_t i0 = (size_t)(row0 + r) * tpr + col4;
-            const size_t i1 = (size_t)(row0 + (has2 ? r2 : r)) * tpr + col4;
-            const float4 g0 = reinterpret_cast<const float4*>(dh)[i0];
-            const float4 y0 = reinterpret_cast<const float4*>(h)[i0];
-            const float4 g1 = reinterpret_cast<const float4*>(dh)[i1];
-            const float4 y1 = reinterpret_cast<const float4*>(h)[i1];
-            float o[4], q[4];
-            o[0] = g0.x * (y0.x > 0.f ? 1.f : y0.x + 1.f);
-            o[1] = g0.y * (y0.y > 0.f ? 1.f : y0.y + 1.f);
-            o[2] = g0.z * (y0.z > 0.f ? 1.f : y0.z + 1.f);
-            o[3] = g0.w * (y0.w > 0.f ? 1.f : y0.w + 1.f);
+            const size_t i0 = (size_t)(row0 + r) * tpr + colg;
+            const size_t i1 = (size_t)(row0 + (has2 ? r2 : r)) * tpr + colg;
+            const vec_t g0v = reinterpret_cast<const vec_t*>(dh)[i0];
+            const vec_t y0v = reinterpret_cast<const vec_t*>(h)[i0];
+            const vec_t g1v = reinterpret_cast<const vec_t*>(dh)[i1];
+            const vec_t y1v = reinterpret_cast<const vec_t*>(h)[i1];
+            const float* g0 = reinterpret_cast<const float*>(&g0v);
+            const float* y0 = reinterpret_cast<const float*>(&y0v);
+            const float* g1 = reinterpret_cast<const float*>(&g1v);
+            const float* y1 = reinterpret_cast<const float*>(&y1v);
             const float m2 = has2 ? 1.f : 0.f;
-            q[0] = m2 * g1.x * (y1.x > 0.f ? 1.f : y1.x + 1.f);
-            q[1] = m2 * g1.y * (y1.y > 0.f ? 1.f : y1.y + 1.f);
-            q[2] = m2 * g1.z * (y1.z > 0.f ? 1.f : y1.z + 1.f);
-            q[3] = m2 * g1.w * (y1.w > 0.f ? 1.f : y1.w + 1.f);
+            float o[CPT], q[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                o[j] = g0[j] * (y0[j] > 0.f ? 1.f : y0[j] + 1.f);
+                q[j] = m2 * g1[j] * (y1[j] > 0.f ? 1.f : y1[j] + 1.f);
+            }
             const float* xr0 = xs + r * D;
             const float* xr1 = xs + (has2 ? r2 : r) * D;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const float xv0 = xr0[d], xv1 = xr1[d];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j][d] = fmaf(q[j], xv1, fmaf(o[j], xv0, acc[j][d]));
+                for (int j = 0; j < CPT; ++j) acc[j][d] = fmaf(q[j], xv1, fmaf(o[j], xv0, acc[j][d]));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bsum[j] += o[j] + q[j];
+            for (int j = 0; j < CPT; ++j) bsum[j] += o[j] + q[j];
         }
     }
     // the rpp row groups add their tiles into red[C][D+1] one after the other (fixed order -> deterministic)
     for (int g2 = 0; g2 < rpp; ++g2) {
         if (rsub == g2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float* dst = red + (size_t)(col4 * 4 + j) * (D + 1);
+            for (int j = 0; j < CPT; ++j) {
+                float* dst = red + (size_t)(colg * CPT + j) * (D + 1);
                 if (g2 == 0) {
 #pragma unroll
                     for (int d = 0; d < D; ++d) dst[d] = acc[j][d];
@@ -832,6 +844,10 @@ __global__ __launch_bounds__(256) void elu_bwd_input_wgrad_kernel(const float* _
 
 extern "C" int ag_wgrad_rows_per_block(int which) { return which == 0 ? kWgRows : kInWgRows; }
 
+// D = 48 (Tracking) was tried with 2 columns per thread: 194 us vs 168 us for ag_elu_bwd_bias + the split-K bmm, so wide
+// inputs keep the unfused path.
+extern "C" int ag_input_wgrad_rows(int D) { return (D == 16 || D == 18 || D == 20) ? kInWgRows : 0; }
+
 extern "C" int ag_heads_bwd_elu_wgrad(const float* d_heads, const float* Wh, const float* h, float* dz, float* db_partials,
                                       float* dwh_partials, int M, int C, int A1, int h_is_preactivation, void* stream) {
     if (!d_heads || !Wh || !h || !dz || !db_partials || !dwh_partials || M <= 0) return AG_ERR_INVALID_ARG;
@@ -849,23 +865,25 @@ extern "C" int ag_heads_bwd_elu_wgrad(const float* d_heads, const float* Wh, con
 extern "C" int ag_elu_bwd_input_wgrad(const float* dh, const float* h, const float* x, float* dw_partials, float* db_partials,
                                       int M, int C, int D, void* stream) {
     if (!dh || !h || !x || !dw_partials || !db_partials || M <= 0) return AG_ERR_INVALID_ARG;
-    if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)kInWgRows * D + (size_t)C * (D + 1));
+    const int cpt = 4;
+    const int rows = ag_input_wgrad_rows(D);
+    if (rows == 0 || C <= 0 || C > 256 * cpt || (C % cpt) != 0 || (256 % (C / cpt)) != 0) return AG_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)rows * D + (size_t)C * (D + 1));
     if (lds > 160 * 1024) return AG_ERR_UNSUPPORTED;
-    const int grid = (M + kInWgRows - 1) / kInWgRows;
-#define AG_LAUNCH_D(DV)                                                                                                       \
+    const int grid = (M + rows - 1) / rows;
+#define AG_LAUNCH_D(DV, CPTV, ROWSV)                                                                                          \
     case DV: {                                                                                                                \
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)elu_bwd_input_wgrad_kernel<DV>,                               \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)elu_bwd_input_wgrad_kernel<DV, CPTV, ROWSV>,                  \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
             return AG_ERR_HIP;                                                                                                \
-        hipLaunchKernelGGL(elu_bwd_input_wgrad_kernel<DV>, dim3(grid), dim3(256), lds, (hipStream_t)stream, dh, h, x,         \
-                           dw_partials, db_partials, M, C);                                                                   \
+        hipLaunchKernelGGL((elu_bwd_input_wgrad_kernel<DV, CPTV, ROWSV>), dim3(grid), dim3(256), lds, (hipStream_t)stream,    \
+                           dh, h, x, dw_partials, db_partials, M, C);                                                         \
         break;                                                                                                                \
     }
     switch (D) {
-        AG_LAUNCH_D(16)
-        AG_LAUNCH_D(18)
-        AG_LAUNCH_D(20)
+        AG_LAUNCH_D(16, 4, kInWgRows)
+        AG_LAUNCH_D(18, 4, kInWgRows)
+        AG_LAUNCH_D(20, 4, kInWgRows)
         default: return AG_ERR_UNSUPPORTED;
     }
 #undef AG_LAUNCH_D

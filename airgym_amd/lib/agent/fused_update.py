@@ -56,11 +56,11 @@ class FusedMLPStep:
         self.loss_partials = torch.empty(self.lib.ag_ppo_loss_max_blocks(), self.nsums, **f)
         L = len(self.layers)
         erows = self.lib.ag_elu_bwd_bias_rows_per_block()
-        wrows, irows = self.lib.ag_wgrad_rows_per_block(0), self.lib.ag_wgrad_rows_per_block(1)
+        wrows, irows = self.lib.ag_wgrad_rows_per_block(0), max(1, self.lib.ag_input_wgrad_rows(D))
         self.wg_blocks = (M + wrows - 1) // wrows
         self.in_wg_blocks = (M + irows - 1) // irows
         # small weight gradients folded into the ELU' passes (head: always; first layer: D in {16,18,20}, >= 2 layers)
-        self.fuse_input_wgrad = L >= 2 and D in (16, 18, 20)
+        self.fuse_input_wgrad = L >= 2 and self.lib.ag_input_wgrad_rows(D) > 0
         self.head_wg_partials = torch.empty(self.wg_blocks, self.A + 1, self.layers[-1][0].shape[0], **f)
         self.bias_partials, self.wgrad_partials = [], []
         for li, (w, _, _, _) in enumerate(self.layers):

@@ -250,8 +250,10 @@ int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float*
  *   ag_heads_bwd_elu_wgrad: dz = (d_heads Wh) * ELU'(h) (the head's dX formed inside the ELU' pass), plus dwh_partials_dev [blocks, A1, C] of dWh[a,c] = sum_m d_heads[m,a] h[m,c];
  *       db_partials_dev [blocks, C].
  *   ag_elu_bwd_input_wgrad: first layer; dz = dh * ELU'(h) is consumed on the fly and never stored:
- *       dw_partials_dev [blocks, C, D] of dW[c,d] = sum_m dz[m,c] x[m,d], db_partials_dev [blocks, C].  D in {16, 18, 20}. */
-int ag_wgrad_rows_per_block(int which);   /* which: 0 = ag_heads_bwd_elu_wgrad, 1 = ag_elu_bwd_input_wgrad */
+ *       dw_partials_dev [blocks, C, D] of dW[c,d] = sum_m dz[m,c] x[m,d], db_partials_dev [blocks, C].
+ *       D in {16, 18, 20}; blocks = ceil(M / ag_input_wgrad_rows(D)). */
+int ag_wgrad_rows_per_block(int which);   /* which: 0 = ag_heads_bwd_elu_wgrad, 1 = ag_elu_bwd_input_wgrad (D <= 20) */
+int ag_input_wgrad_rows(int D);           /* rows per block of ag_elu_bwd_input_wgrad for input width D; 0 = unsupported */
 int ag_heads_bwd_elu_wgrad(const float* d_heads_dev, const float* Wh_dev, const float* h_dev, float* dz_dev,
                            float* db_partials_dev, float* dwh_partials_dev, int M, int C, int A1, int h_is_preactivation,
                            void* stream);

@@ -23,6 +23,8 @@ def main():
     import bench
     from tools.phase_times import A
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    A.task = os.getenv("PROFILE_TASK", "hovering")
+    A.ctl = os.getenv("PROFILE_CTL", "rate")
     agent = A2CAgent("phase", bench.build_params(A, 1))
     agent.init_tensors()
     agent.obs = agent.env_reset()
