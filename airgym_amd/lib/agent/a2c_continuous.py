@@ -439,10 +439,13 @@ class A2CAgent:
                 self._graphs["rollout"] = self._capture(rollout, warmup=False)
         self._rollouts_done += 1
         self.model.eval()
-        last_values = self.model({"is_train": False, "obs": self._obs_at(H)})["values"]
         if fr is not None:
+            # bootstrap value of the last observation through the same fused forward as the rollout steps
+            heads = fr.heads_of(self.obs_buf[H])
+            last_values = self.model.denorm_value(heads[:, self.actions_num:self.actions_num + 1])
             mb_advs, mb_returns = fr.gae(last_values)
         else:
+            last_values = self.model({"is_train": False, "obs": self._obs_at(H)})["values"]
             fdones = self.dones_buf[H].float()
             mb_fdones = self.dones_buf[:H].float()
             mb_advs = self._gae(fdones, last_values, mb_fdones)
