@@ -19,7 +19,6 @@ Math restated from: play_steps a2c_base.py:651-711; discount_values (GAE) :463-4
 a2c_continuous.py:140-177; calc_gradients :299-369; trancate_gradients_and_step a2c_base.py:293-316;
 train_epoch a2c_continuous.py:78-138.  Pinned by tests/golden/ppo.npz, gae.npz (reference outputs).
 """
-import math
 import os
 import time
 from datetime import datetime
