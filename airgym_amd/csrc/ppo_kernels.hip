@@ -584,10 +584,12 @@ __device__ __forceinline__ float group_sum_last_lane(float v, int width) {
 template <int A1, bool WRITE_BACK>
 __global__ __launch_bounds__(256) void elu_heads_kernel(float* __restrict__ zh, const float* __restrict__ Wh,
                                                         const float* __restrict__ bh, float* __restrict__ heads, int M, int C,
-                                                        int rows_per_block) {
+                                                        int rows_per_block, const float* __restrict__ zbias) {
     const int tpr = C >> 2;
     const int rpp = 256 / tpr;
     const int col4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    // zbias: the producing Linear's bias when the GEMM ran without its bias epilogue (zh then holds x W^T only)
+    const float4 zb = zbias ? reinterpret_cast<const float4*>(zbias)[col4] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 w[A1];
 #pragma unroll
     for (int a = 0; a < A1; ++a) w[a] = reinterpret_cast<const float4*>(Wh + (size_t)a * C)[col4];
@@ -601,8 +603,8 @@ __global__ __launch_bounds__(256) void elu_heads_kernel(float* __restrict__ zh, 
         float4* p1 = reinterpret_cast<float4*>(zh + (size_t)(has2 ? r2 : r) * C) + col4;
         float4 z0 = *p0;
         float4 z1 = *p1;
-        z0.x = elu1(z0.x); z0.y = elu1(z0.y); z0.z = elu1(z0.z); z0.w = elu1(z0.w);
-        z1.x = elu1(z1.x); z1.y = elu1(z1.y); z1.z = elu1(z1.z); z1.w = elu1(z1.w);
+        z0.x = elu1(z0.x + zb.x); z0.y = elu1(z0.y + zb.y); z0.z = elu1(z0.z + zb.z); z0.w = elu1(z0.w + zb.w);
+        z1.x = elu1(z1.x + zb.x); z1.y = elu1(z1.y + zb.y); z1.z = elu1(z1.z + zb.z); z1.w = elu1(z1.w + zb.w);
         if (WRITE_BACK) {      // without it the buffer keeps the pre-activation z (HBM writes cost ~2x reads on this part)
             *p0 = z0;
             if (has2) *p1 = z1;
@@ -659,13 +661,13 @@ extern "C" int ag_mlp_input_layer(const float* obs, const double* mean, const do
 }
 
 extern "C" int ag_elu_heads(float* zh, const float* Wh, const float* bh, float* heads, int M, int C, int A1, int write_back,
-                            void* stream) {
+                            const float* zbias, void* stream) {
     if (!zh || !Wh || !bh || !heads || M <= 0) return AG_ERR_INVALID_ARG;
     if (C < 64 || C > 256 || !pow2(C)) return AG_ERR_UNSUPPORTED;      // C/4 lanes per row: one, two or four DPP rows
     const int rows_per_block = 64;
     const int grid = (M + rows_per_block - 1) / rows_per_block;
 #define AG_EH(A1V, WB) hipLaunchKernelGGL((elu_heads_kernel<A1V, WB>), dim3(grid), dim3(256), 0, (hipStream_t)stream, zh, Wh, bh, \
-                                         heads, M, C, rows_per_block)
+                                         heads, M, C, rows_per_block, zbias)
     if (A1 == 5) { if (write_back) AG_EH(5, true); else AG_EH(5, false); }
     else if (A1 == 6) { if (write_back) AG_EH(6, true); else AG_EH(6, false); }
     else return AG_ERR_UNSUPPORTED;
@@ -690,11 +692,12 @@ template <int A1, bool PREACT>
 __global__ __launch_bounds__(256) void heads_bwd_elu_wgrad_kernel(const float* __restrict__ d_heads, const float* __restrict__ Wh,
                                                                   const float* __restrict__ h, float* __restrict__ dz,
                                                                   float* __restrict__ db_partials, float* __restrict__ dwh_partials,
-                                                                  int M, int C) {
+                                                                  int M, int C, const float* __restrict__ zbias) {
     __shared__ float4 red[256];
     const int tpr = C >> 2;
     const int rpp = 256 / tpr;
     const int col4 = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const float4 zb = (PREACT && zbias) ? reinterpret_cast<const float4*>(zbias)[col4] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 w[A1], gw[A1];
 #pragma unroll
     for (int a = 0; a < A1; ++a) {
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(256) void heads_bwd_elu_wgrad_kernel(const float* _
             const size_t idx = (size_t)r * tpr + col4;
             float4 y = reinterpret_cast<const float4*>(h)[idx];
             if (PREACT) {        // the buffer holds z, not ELU(z): rebuild h here (ELU'(z) = h + 1 on the negative side)
-                y.x = elu1(y.x); y.y = elu1(y.y); y.z = elu1(y.z); y.w = elu1(y.w);
+                y.x = elu1(y.x + zb.x); y.y = elu1(y.y + zb.y); y.z = elu1(y.z + zb.z); y.w = elu1(y.w + zb.w);
             }
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -849,12 +852,13 @@ extern "C" int ag_wgrad_rows_per_block(int which) { return which == 0 ? kWgRows 
 extern "C" int ag_input_wgrad_rows(int D) { return (D == 16 || D == 18 || D == 20) ? kInWgRows : 0; }
 
 extern "C" int ag_heads_bwd_elu_wgrad(const float* d_heads, const float* Wh, const float* h, float* dz, float* db_partials,
-                                      float* dwh_partials, int M, int C, int A1, int h_is_preactivation, void* stream) {
+                                      float* dwh_partials, int M, int C, int A1, int h_is_preactivation, const float* zbias,
+                                      void* stream) {
     if (!d_heads || !Wh || !h || !dz || !db_partials || !dwh_partials || M <= 0) return AG_ERR_INVALID_ARG;
     if (C <= 0 || C > 1024 || (C & 3) || (256 % (C >> 2)) != 0) return AG_ERR_UNSUPPORTED;
     const int grid = (M + kWgRows - 1) / kWgRows;
 #define AG_HB(A1V, PA) hipLaunchKernelGGL((heads_bwd_elu_wgrad_kernel<A1V, PA>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
-                                         d_heads, Wh, h, dz, db_partials, dwh_partials, M, C)
+                                         d_heads, Wh, h, dz, db_partials, dwh_partials, M, C, zbias)
     if (A1 == 5) { if (h_is_preactivation) AG_HB(5, true); else AG_HB(5, false); }
     else if (A1 == 6) { if (h_is_preactivation) AG_HB(6, true); else AG_HB(6, false); }
     else return AG_ERR_UNSUPPORTED;

@@ -440,6 +440,7 @@ class A2CAgent:
         self.model.eval()
         if fr is not None:
             # bootstrap value of the last observation through the same fused forward as the rollout steps
+            fr.refresh_weights()
             heads = fr.heads_of(self.obs_buf[H])
             last_values = self.model.denorm_value(heads[:, self.actions_num:self.actions_num + 1])
             mb_advs, mb_returns = fr.gae(last_values)

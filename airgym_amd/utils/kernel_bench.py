@@ -118,12 +118,12 @@ def measure_update_kernels(agent, iters=20):
         out.append({"kernel": name, "bound": "hbm", "achieved": nbytes / us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": nbytes / us / 1e3 / HBM_PEAK_GBPS, "us_per_launch": us, "algo_bytes": nbytes})
     us = _time_us(lambda: lib.ag_elu_heads(scratch.data_ptr(), agent.heads_w.data_ptr(), agent.heads_b.data_ptr(),
-                                            fs.heads.data_ptr(), M, C, A1, 0, st), iters)
+                                            fs.heads.data_ptr(), M, C, A1, 0, None, st), iters)
     hbm("ag_elu_heads (ELU + head product, pre-activation kept)", us, 4.0 * M * (C + A1))
     parts = fs.bias_partials[-1]
     us = _time_us(lambda: lib.ag_heads_bwd_elu_wgrad(fs.d_heads.data_ptr(), agent.heads_w.data_ptr(), h.data_ptr(),
                                                       scratch.data_ptr(), parts.data_ptr(), fs.head_wg_partials.data_ptr(),
-                                                      M, C, A1, 1, st), iters)
+                                                      M, C, A1, 1, None, st), iters)
     hbm("ag_heads_bwd_elu_wgrad (head dX + ELU' + head wgrad)", us, 4.0 * M * (2 * C + A1))
     if fs.fuse_input_wgrad:
         D = fs.layers[0][0].shape[1]

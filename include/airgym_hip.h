@@ -236,14 +236,15 @@ int ag_gae(const float* rewards_dev, const float* values_dev, const long long* d
  *   ag_mlp_input_layer: xn = clamp((obs - mean)/sqrt(var + eps), +-clip) [M, D] (skipped when mean/var/xn are all NULL,
  *       then obs is used as is), h = ELU(xn W^T + bias) [M, C]; W [C, D] row-major; D*C + 64*D floats must fit 64 KB.
  *   ag_elu_heads: heads [M, A1] = ELU(zh) Wh^T + bh; with write_back zh [M, C] <- ELU(zh) in place, without it zh keeps
- *       the pre-activation (then pass h_is_preactivation = 1 to ag_heads_bwd_elu_wgrad); Wh [A1, C]; C a power of two
+ *       the pre-activation (then pass h_is_preactivation = 1 to ag_heads_bwd_elu_wgrad); zbias_dev [C] (optional) is added
+ *       to zh before the ELU - for a producing GEMM run WITHOUT its bias epilogue (pass the same pointer to the backward); Wh [A1, C]; C a power of two
  *       64..256, A1 = A + 1 in {5, 6}.
  */
 int ag_mlp_input_layer(const float* obs_dev, const double* mean_dev, const double* var_dev, const float* W_dev,
                        const float* bias_dev, float* xn_dev, float* h_dev, int M, int D, int C, float eps, float clip,
                        void* stream);
 int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float* heads_dev, int M, int C, int A1,
-                 int write_back, void* stream);
+                 int write_back, const float* zbias_dev, void* stream);
 
 /* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block(which) rows
  * (ceil(M / rows) blocks); the caller reduces them over dim 0.
@@ -256,7 +257,7 @@ int ag_wgrad_rows_per_block(int which);   /* which: 0 = ag_heads_bwd_elu_wgrad, 
 int ag_input_wgrad_rows(int D);           /* rows per block of ag_elu_bwd_input_wgrad for input width D; 0 = unsupported */
 int ag_heads_bwd_elu_wgrad(const float* d_heads_dev, const float* Wh_dev, const float* h_dev, float* dz_dev,
                            float* db_partials_dev, float* dwh_partials_dev, int M, int C, int A1, int h_is_preactivation,
-                           void* stream);
+                           const float* zbias_dev, void* stream);
 int ag_elu_bwd_input_wgrad(const float* dh_dev, const float* h_dev, const float* x_dev, float* dw_partials_dev,
                            float* db_partials_dev, int M, int C, int D, void* stream);
 

@@ -189,9 +189,11 @@ def test_elu_heads_kernel(lib, C, A1, write_back):
         bh = torch.randn(A1, device="cuda", generator=g)
         heads = torch.empty(M, A1, device="cuda")
         buf = z.clone()
-        N.check(lib.ag_elu_heads(buf.data_ptr(), Wh.data_ptr(), bh.data_ptr(), heads.data_ptr(), M, C, A1, write_back, _stream()),
+        zb = torch.randn(C, device="cuda", generator=g) if write_back == 0 else None
+        N.check(lib.ag_elu_heads(buf.data_ptr(), Wh.data_ptr(), bh.data_ptr(), heads.data_ptr(), M, C, A1, write_back,
+                                 zb.data_ptr() if zb is not None else None, _stream()),
                 "ag_elu_heads")
-        h = F.elu(z)
+        h = F.elu(z + zb) if zb is not None else F.elu(z)
         assert torch.allclose(heads, h @ Wh.t() + bh, rtol=1e-5, atol=1e-5)
         if write_back:
             assert torch.allclose(buf, h, rtol=1e-6, atol=1e-6)
