@@ -253,3 +253,73 @@ def test_minibatch_graphs_are_bit_identical_to_eager(lib):
         agent.vec_env.env.hip.close()
     (p1, lr1, kl1, m1), (p0, lr0, kl0, m0) = results
     assert torch.equal(p1, p0) and lr1 == lr0 and kl1 == kl0 and torch.equal(m1, m0)
+
+
+def _dp_gpu_worker(rank, world, port, q):
+    try:
+        _dp_gpu_worker_body(rank, world, port, q)
+    except BaseException:          # report instead of leaving the parent to wait for its timeout
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def _dp_gpu_worker_body(rank, world, port, q):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import bench
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+
+    class Args:
+        envs = 1024; minibatches = 4; graph = 1; task = "hovering"; ctl = "rate"; tuned_gemms = 1
+    params = bench.build_params(Args, world)
+    c = params["config"]
+    c["dist_backend"] = "gloo"            # both ranks share the one GPU of the test box; the collective goes through gloo
+    c["device"] = "cuda:0"
+    torch.manual_seed(100 + rank)         # different initialisation per rank: broadcast_parameters must repair it
+    agent = A2CAgent("dp", params)
+    agent.init_tensors()
+    assert agent.multi_gpu and agent._fused_step is not None and agent._fused_rollout is not None
+    assert agent.env_config["env_id_offset"] == rank * 1024 and not agent._graph_update
+    agent.obs = agent.env_reset()
+    agent.broadcast_parameters()
+    for ep in range(1, 4):
+        agent.epoch_num = ep
+        st = agent.train_epoch()
+    q.put((rank, agent.flat_param.cpu().numpy().copy(), float(agent.optimizer.lr.item()), st["kl"],
+           agent.model.running_mean_std.running_mean.cpu().numpy().copy(), agent.actions_buf[0, :4].cpu().numpy().copy()))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_fused_path_two_ranks_one_gpu(lib):
+    """The multi-GPU code path with the fused rollout / hand-scheduled update: two ranks (sharing this box's one GPU, gloo
+    for the gradient all-reduce) stay bit-identical replicas while rolling out different env shards."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in range(2):
+            got.append(q.get(timeout=150))
+            assert not isinstance(got[-1][1], str), got[-1][2]
+    except BaseException:
+        for p in procs:
+            p.terminate()
+        raise
+    res = dict((r[0], r[1:]) for r in got)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (p0, lr0, kl0, m0, a0), (p1, lr1, kl1, m1, a1) = res[0], res[1]
+    assert np.array_equal(p0, p1) and lr0 == lr1 and kl0 == kl1 and np.array_equal(m0, m1)
+    assert np.isfinite(p0).all() and not np.array_equal(a0, a1)      # same policy, different env shards / noise streams
