@@ -259,7 +259,9 @@ class FusedRolloutStep:
         self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0
         self.wt_last = torch.empty(self.layers[-1][0].shape[1], Cl, **f)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.acct_partials = torch.zeros(self.lib.ag_rollout_account_blocks(n), 4, dtype=torch.float64, device=dev)
+        # per-step, per-block episode sums; reduced over blocks ONCE per rollout (end_rollout)
+        self.acct_partials = torch.zeros(agent.horizon_length, self.lib.ag_rollout_account_blocks(n), 4,
+                                         dtype=torch.float64, device=dev)
         self.seed = (int(agent.params.get("seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
         self.id_offset = agent.global_rank * n
         stacked = getattr(agent._hip_env, "reward_terms_stacked", None)
@@ -276,6 +278,7 @@ class FusedRolloutStep:
             self.wt_last.copy_(self.layers[-1][0].t())
 
     def end_rollout(self):
+        torch.sum(self.acct_partials, 1, out=self.agent.ep_stats)
         if self.term_buf is not None:
             self.agent._term_sums += self.term_buf.sum(0).double() / self.n
 
@@ -348,9 +351,8 @@ class FusedRolloutStep:
                                        float(sh.scale_value), float(sh.shift_value), float(sh.min_val), float(sh.max_val),
                                        int(bool(sh.log_val)), float(ag.gamma), ag.rewards_buf[slot].data_ptr(),
                                        ag.current_rewards.data_ptr(), ag.current_shaped_rewards.data_ptr(),
-                                       ag.current_lengths.data_ptr(), self.acct_partials.data_ptr(), n, st),
+                                       ag.current_lengths.data_ptr(), self.acct_partials[slot].data_ptr(), n, st),
                 "ag_rollout_account")
-        torch.sum(self.acct_partials, 0, out=ag.ep_stats[slot])
         if self.term_buf is not None:
             torch.sum(env.reward_terms_stacked, 1, out=self.term_buf[slot])
 
