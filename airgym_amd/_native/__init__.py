@@ -132,7 +132,7 @@ SYMBOLS = [
                                         ctypes.c_longlong, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_rollout_account_blocks", ctypes.c_int, [ctypes.c_int]),
     ("ag_rollout_account", ctypes.c_int, [_P, _P, _P, _P] + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_float,
-                                          _P, _P, _P, _P, _P, ctypes.c_int, _P]),
+                                          _P, _P, _P, _P, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_longlong, _P, _P]),
     ("ag_gae", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_mlp_input_layer", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, _P]),

@@ -218,6 +218,8 @@ int ag_normalize_rows(const float* x_dev, const double* mean_dev, const double* 
  *   ag_rollout_account: shaped = clamp((r + shift) * scale, min, max) [log] (+ gamma * value on time-outs), running episode
  *       reward / shaped reward / length, and per-block partial sums {episodes ended, sum reward, sum shaped, sum length}
  *       in partials_dev [ag_rollout_account_blocks(n), 4] (double); running sums are cleared where dones != 0.
+ *       Optional: terms_dev [num_terms][terms_stride] per-env reward-term arrays -> term_partials_dev [blocks, num_terms]
+ *       per-block sums (Episode/<term> logging, lib/utils/isaacgym_utils.py:66-99).
  *   ag_gae: dones_dev [H+1, n] (dones[t] = done entering step t), rewards / values / advs / returns [H, n]. */
 int ag_policy_sample(const float* heads_dev, const float* logstd_dev, const double* vmean_dev, const double* vvar_dev,
                      float veps, unsigned long long seed, const long long* counter_dev, int horizon, int slot,
@@ -227,7 +229,8 @@ int ag_rollout_account_blocks(int n);
 int ag_rollout_account(const float* raw_reward_dev, const long long* dones_dev, const unsigned char* timeouts_dev,
                        const float* values_dev, float scale, float shift, float min_val, float max_val, int log_val,
                        float gamma, float* shaped_dev, float* cur_rew_dev, float* cur_shaped_dev, float* cur_len_dev,
-                       double* partials_dev, int n, void* stream);
+                       double* partials_dev, int n, const float* terms_dev, int num_terms, long long terms_stride,
+                       double* term_partials_dev, void* stream);
 int ag_gae(const float* rewards_dev, const float* values_dev, const long long* dones_dev, const float* last_values_dev,
            float gamma, float tau, float* advs_dev, float* returns_dev, int H, int n, void* stream);
 
