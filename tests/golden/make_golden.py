@@ -561,6 +561,59 @@ def gen_vae(out):
     print("vae_encoder.npz", z.shape, float(z.abs().mean()))
 
 
+def planning_probe_inputs(n=6):
+    """Deterministic policy inputs (formula shared with tests/test_reference_checkpoint.py)."""
+    i = torch.arange(212, dtype=torch.float32).view(1, 1, 212, 1)
+    j = torch.arange(120, dtype=torch.float32).view(1, 1, 1, 120)
+    b = torch.arange(n, dtype=torch.float32).view(n, 1, 1, 1)
+    image = 0.5 + 0.5 * torch.sin(0.031 * i + 0.057 * j + 0.7 * b)
+    observation = torch.sin(torch.arange(n * 16, dtype=torch.float32).view(n, 16) * 0.37) * 1.5
+    return image, observation
+
+
+def gen_planning_checkpoint(out):
+    """trained/planning_cnn_rate.pth (the reference's shipped Planning policy) through the reference's OWN sub-modules
+    (lib.network.cnn / mlp, lib.core.running_mean_std), wired as a2c_continuous_logstd_model.py:140-170 wires them (the model
+    class itself needs torchvision): golden mu / value for deterministic inputs + a manifest of the checkpoint's tensors."""
+    import contextlib
+    import io
+    import json
+    from lib.core.running_mean_std import RunningMeanStd, RunningMeanStdObs
+    from lib.network.cnn import CNNFeatureExtractor
+    from lib.network.mlp import MLP
+    ck = torch.load(os.path.join(REF, "trained", "planning_cnn_rate.pth"), map_location="cpu", weights_only=False)
+    sd = ck["model"]
+    manifest = {k: {"shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""),
+                    "sum": float(v.double().sum()), "abs_sum": float(v.double().abs().sum())} for k, v in sd.items()}
+
+    def sub(prefix):
+        return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    with contextlib.redirect_stdout(io.StringIO()):
+        cnn = CNNFeatureExtractor(feature_dim=30)
+        mlp = MLP(46, [64, 128, 64], "elu")
+    cnn.load_state_dict(sub("actor_cnn."))
+    mlp.load_state_dict(sub("actor_mlp."))
+    rms = RunningMeanStdObs({"image": (1, 212, 120), "observation": (46,)})
+    rms.load_state_dict(sub("running_mean_std."))
+    vms = RunningMeanStd((1,))
+    vms.load_state_dict(sub("value_mean_std."))
+    mu_l, v_l = torch.nn.Linear(64, 4), torch.nn.Linear(64, 1)
+    mu_l.load_state_dict(sub("mu."))
+    v_l.load_state_dict(sub("value_head."))
+    for m in (cnn, mlp, rms, vms):
+        m.eval()
+    image, observation = planning_probe_inputs()
+    with torch.no_grad():
+        feat = cnn(rms.running_mean_std["image"](image))
+        trunk = mlp(rms.running_mean_std["observation"](torch.cat((observation, feat), dim=-1)))
+        mu, value = mu_l(trunk), v_l(trunk)
+        value_denorm = vms(value, denorm=True)
+    np.savez_compressed(os.path.join(out, "planning_checkpoint.npz"), mu=mu.numpy(), value=value.numpy(),
+                        value_denorm=value_denorm.numpy(), features=feat.numpy(), logstd=sd["logstd"].numpy(),
+                        manifest=np.array(json.dumps(manifest)), epoch=int(ck["epoch"]), frame=int(ck["frame"]))
+    print("planning_checkpoint.npz", mu.shape, float(mu.abs().mean()), float(value_denorm.mean()))
+
+
 def main():
     install_stubs()
     import airgym.envs.base.hovering as H
@@ -580,6 +633,7 @@ def main():
     gen_gae(out)
     gen_planning(out)
     gen_vae(out)
+    gen_planning_checkpoint(out)
     for name, d in out.items():
         arrs = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
         path = os.path.join(HERE, f"{name}.npz")

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Behavioural cross-check of the parts of the env that cannot be pinned (integrator, PX4-style cascades, depth renderer):
+fly the reference's own trained Planning policy (trained/planning_cnn_rate.pth, trained in IsaacGym + rlPx4Controller) in THIS
+env and compare it with a random and a zero-action policy.  The checkpoint is not part of the repo: pass --checkpoint."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--checkpoint", required=True)
+    ap.add_argument("--envs", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=1500)
+    args = ap.parse_args()
+    from airgym_amd.lib.model.a2c_continuous_logstd_model import ModelA2CContinuousLogStd
+    from airgym_amd.lib.utils import vecenv
+    import airgym_amd.envs  # noqa: F401  (registers the tasks)
+    params = {"network": {"separate": False, "mlp": {"units": [64, 128, 64], "activation": "elu"},
+                          "space": {"continuous": {"fixed_sigma": True}}, "cnn": {"output_dim": 30}},
+              "config": {"normalize_input": True, "normalize_value": True}}
+    keys = {"actions_num": 4, "input_shape": {"image": (1, 212, 120), "observation": (16,)}}
+    model = ModelA2CContinuousLogStd(params, keys)
+    model.load_state_dict(torch.load(args.checkpoint, map_location="cpu", weights_only=False)["model"], strict=True)
+    model = model.cuda().eval()
+    out = {}
+    for name in ("reference_policy", "random", "zero"):
+        env = vecenv.create_vec_env("planning", args.envs, use_image=True, num_envs=args.envs, ctl_mode="rate", seed=0,
+                                    sim_device="cuda:0", headless=True)
+        obs = env.reset()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        ep_len = torch.zeros(args.envs, device="cuda")
+        ep_rew = torch.zeros(args.envs, device="cuda")
+        done_len, done_rew, n_done, rew_sum = 0.0, 0.0, 0, 0.0
+        for t in range(args.steps):
+            with torch.no_grad():
+                if name == "reference_policy":
+                    mu, _, _ = model.trunk({"image": obs["image"], "observation": obs["observation"]})
+                    act = mu.clamp(-1, 1)                                  # deterministic play (players.py:372-388)
+                elif name == "random":
+                    act = torch.randn(args.envs, 4, device="cuda", generator=g).clamp(-1, 1)
+                else:
+                    act = torch.zeros(args.envs, 4, device="cuda")
+            obs, rew, dones, _ = env.step(act)
+            ep_len += 1
+            ep_rew += rew
+            rew_sum += float(rew.mean())
+            d = dones.bool()
+            if d.any():
+                done_len += float(ep_len[d].sum()); done_rew += float(ep_rew[d].sum()); n_done += int(d.sum())
+                ep_len[d] = 0; ep_rew[d] = 0
+        out[name] = {"episodes": n_done, "mean_episode_length": round(done_len / max(n_done, 1), 1),
+                     "mean_episode_reward": round(done_rew / max(n_done, 1), 2), "mean_reward_per_step": round(rew_sum / args.steps, 4)}
+        env.env.hip.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
