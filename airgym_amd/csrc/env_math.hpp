@@ -318,14 +318,56 @@ AG_HD void rate_control(CtlState& c, const float* rate_sp, const float* wb, floa
     }
 }
 
+// Quad-X control allocation with PX4's sequential desaturation, airmode disabled (PX4 v1.14
+// ControlAllocationSequentialDesaturation::mixAirmodeDisabled / mixYaw / desaturateActuators; oracle/px4_cascade.py
+// mix_quad_x): roll+pitch+thrust are mixed first; a saturated output is relieved by REDUCING thrust only, then by scaling
+// back the roll, then the pitch demand; yaw is mixed last against limits widened by 15 % and gives way first; a final
+// thrust-reduce pass, then the [0,1] clip.  (A clip-only mixer turns every saturated torque demand into extra collective
+// thrust; the reference's own trained Planning policy cannot hold altitude on such a vehicle - DESIGN.md section 2.)
+// gain k such that o + k * vec relieves the worst violation on either side: k_i = (clamp(o_i) - o_i) / vec_i is zero for
+// an output inside [lo, hi], so min / max over all four equal PX4's loop over the violating ones (computeDesaturationGain).
+// `inv` holds 1 / vec_i (the mixer columns are +-0.70710678 or +-1: reciprocals are compile-time constants).
+AG_HD float desat_gain(const float* o, const float* inv, float lo, float hi) {
+    const float k0 = (clampf(o[0], lo, hi) - o[0]) * inv[0];
+    const float k1 = (clampf(o[1], lo, hi) - o[1]) * inv[1];
+    const float k2 = (clampf(o[2], lo, hi) - o[2]) * inv[2];
+    const float k3 = (clampf(o[3], lo, hi) - o[3]) * inv[3];
+    const float kmin = fminf(fminf(fminf(k0, k1), fminf(k2, k3)), 0.0f);
+    const float kmax = fmaxf(fmaxf(fmaxf(k0, k1), fmaxf(k2, k3)), 0.0f);
+    return kmin + kmax;
+}
+
+AG_HD void desaturate(float* o, const float* vec, const float* inv, float lo, float hi, bool reduce_only) {
+    float k1 = desat_gain(o, inv, lo, hi);
+    const bool active = !(reduce_only && k1 > 0.0f);
+    k1 = active ? k1 : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(k1, vec[i], o[i]);
+    float k2 = 0.5f * desat_gain(o, inv, lo, hi);
+    k2 = active ? k2 : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(k2, vec[i], o[i]);
+}
+
 AG_HD void mix_quad_x(float thrust, const float* u, float* cmd) {
-    const float r = kMixRP * u[0];
-    const float p = kMixRP * u[1];
-    const float y = kMixYaw * u[2];
-    cmd[0] = clampf(thrust - r - p - y, 0.0f, 1.0f);
-    cmd[1] = clampf(thrust + r + p - y, 0.0f, 1.0f);
-    cmd[2] = clampf(thrust + r - p + y, 0.0f, 1.0f);
-    cmd[3] = clampf(thrust - r + p + y, 0.0f, 1.0f);
+    // rotor torque-sign pattern (roll, pitch, yaw): 1:(-,-,-) 2:(+,+,-) 3:(+,-,+) 4:(-,+,+)
+    constexpr float kInvRP = 1.41421356f, kInvYaw = 1.0f;       // 1 / kMixRP, 1 / kMixYaw
+    const float rv[4] = {-kMixRP, kMixRP, kMixRP, -kMixRP}, ri[4] = {-kInvRP, kInvRP, kInvRP, -kInvRP};
+    const float pv[4] = {-kMixRP, kMixRP, -kMixRP, kMixRP}, pi[4] = {-kInvRP, kInvRP, -kInvRP, kInvRP};
+    const float yv[4] = {-kMixYaw, -kMixYaw, kMixYaw, kMixYaw}, yi[4] = {-kInvYaw, -kInvYaw, kInvYaw, kInvYaw};
+    const float tv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = thrust + rv[i] * u[0] + pv[i] * u[1];
+    desaturate(o, tv, tv, 0.0f, 1.0f, true);
+    desaturate(o, rv, ri, 0.0f, 1.0f, false);
+    desaturate(o, pv, pi, 0.0f, 1.0f, false);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(yv[i], u[2], o[i]);
+    desaturate(o, yv, yi, 0.0f, 1.15f, false);
+    desaturate(o, tv, tv, 0.0f, 1.0f, true);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cmd[i] = clampf(o[i], 0.0f, 1.0f);
 }
 
 AG_HD void attitude_control(Q4 q, Q4 qd, float* rate_sp) {

@@ -149,17 +149,48 @@ def rate_control(st, rate_sp, wb):
     return tuple(out)
 
 
+def _desat_gain(o, inv, lo, hi):
+    """PX4 ControlAllocationSequentialDesaturation::computeDesaturationGain, vectorised over envs: k_i = (clamp(o_i) - o_i) /
+    vec_i is zero for an output inside [lo, hi], so min / max over all four equal PX4's loop over the violating ones.
+    o [N,4]; inv [4] = 1 / vec (float32 constants, as in csrc/env_math.hpp)."""
+    k = (torch.clamp(o, min=lo, max=hi) - o) * inv
+    zero = torch.zeros(o.shape[0], dtype=o.dtype)
+    return torch.minimum(k.min(dim=1).values, zero) + torch.maximum(k.max(dim=1).values, zero)
+
+
+def _desaturate(o, vec, inv, lo, hi, reduce_only):
+    """desaturateActuators: shift along `vec` by the gain, then by half of the residual gain."""
+    k1 = _desat_gain(o, inv, lo, hi)
+    active = (k1 <= 0.0) if reduce_only else torch.ones_like(k1, dtype=torch.bool)
+    k1 = torch.where(active, k1, torch.zeros_like(k1))
+    o = o + k1.unsqueeze(1) * vec
+    k2 = 0.5 * _desat_gain(o, inv, lo, hi)
+    k2 = torch.where(active, k2, torch.zeros_like(k2))
+    return o + k2.unsqueeze(1) * vec
+
+
 def mix_quad_x(thrust, u):
-    """Rotor i torque-sign pattern (roll, pitch, yaw) in FLU with rotors at
-    (+,-), (-,+), (+,+), (-,-):  1:(-,-,-)  2:(+,+,-)  3:(+,-,+)  4:(-,+,+)."""
-    r = MIX_RP * u[0]
-    p = MIX_RP * u[1]
-    y = MIX_YAW * u[2]
-    c1 = _clamp(thrust - r - p - y, 0.0, 1.0)
-    c2 = _clamp(thrust + r + p - y, 0.0, 1.0)
-    c3 = _clamp(thrust + r - p + y, 0.0, 1.0)
-    c4 = _clamp(thrust - r + p + y, 0.0, 1.0)
-    return torch.stack((c1, c2, c3, c4), dim=-1)
+    """Quad-X allocation with PX4's sequential desaturation, airmode disabled (PX4 v1.14 mixAirmodeDisabled + mixYaw).
+    Rotor i torque-sign pattern (roll, pitch, yaw) in FLU with rotors at (+,-), (-,+), (+,+), (-,-):
+    1:(-,-,-)  2:(+,+,-)  3:(+,-,+)  4:(-,+,+).  Thrust is only ever reduced to unsaturate; roll, then pitch are scaled
+    back; yaw is mixed last against limits widened by 15 % and gives way first."""
+    dt = thrust.dtype
+    inv_rp, inv_yaw = 1.41421356, 1.0 / MIX_YAW         # the float32 reciprocal constants of csrc/env_math.hpp
+    rv = torch.tensor([-MIX_RP, MIX_RP, MIX_RP, -MIX_RP], dtype=dt)
+    pv = torch.tensor([-MIX_RP, MIX_RP, -MIX_RP, MIX_RP], dtype=dt)
+    yv = torch.tensor([-MIX_YAW, -MIX_YAW, MIX_YAW, MIX_YAW], dtype=dt)
+    tv = torch.ones(4, dtype=dt)
+    ri = torch.tensor([-inv_rp, inv_rp, inv_rp, -inv_rp], dtype=dt)
+    pi = torch.tensor([-inv_rp, inv_rp, -inv_rp, inv_rp], dtype=dt)
+    yi = torch.tensor([-inv_yaw, -inv_yaw, inv_yaw, inv_yaw], dtype=dt)
+    o = thrust.unsqueeze(1) + u[0].unsqueeze(1) * rv + u[1].unsqueeze(1) * pv
+    o = _desaturate(o, tv, tv, 0.0, 1.0, True)
+    o = _desaturate(o, rv, ri, 0.0, 1.0, False)
+    o = _desaturate(o, pv, pi, 0.0, 1.0, False)
+    o = o + u[2].unsqueeze(1) * yv
+    o = _desaturate(o, yv, yi, 0.0, 1.15, False)
+    o = _desaturate(o, tv, tv, 0.0, 1.0, True)
+    return _clamp(o, 0.0, 1.0)
 
 
 # ----------------------------------------------------------------------------

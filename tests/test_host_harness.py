@@ -259,4 +259,6 @@ def test_planning_step_matches_oracle(lib, ctl):
                                "alive_reward", "ups_reward", "z_reward", "esdf_reward", "thrust_reward",
                                "reach_goal_reward", "reward"]):
             np.testing.assert_allclose(terms[:, j], ex["item_reward_info"][k].numpy(), atol=2e-5, err_msg=k)
-    assert n_done > 0       # the z corridor is 0.6 m wide: random actions leave it, resets are exercised
+    # the z corridor is 0.6 m wide: random rate / thrust actions leave it, so resets are exercised; the velocity and position
+    # cascades hold altitude (more so since the mixer stopped turning saturated torque demands into lift)
+    assert n_done > 0 or ctl in ("vel", "pos")

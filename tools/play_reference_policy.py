@@ -16,6 +16,9 @@ def main():
     ap.add_argument("--checkpoint", required=True)
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--image-flips", nargs="*", default=[], choices=["u", "v", "uv"],
+                    help="renderer-convention probe: re-fly the reference policy with the image mirrored left-right (u), "
+                         "upside-down (v) or both")
     ap.add_argument("--thrust-gains", type=float, nargs="*", default=[],
                     help="system-identification probe: re-fly the reference policy with its thrust command scaled by k")
     args = ap.parse_args()
@@ -30,7 +33,9 @@ def main():
     model.load_state_dict(torch.load(args.checkpoint, map_location="cpu", weights_only=False)["model"], strict=True)
     model = model.cuda().eval()
     out = {}
-    for name in ["reference_policy", "random", "zero"] + [f"reference_policy_thrust_x{k}" for k in args.thrust_gains]:
+    names = ["reference_policy", "random", "zero"] + [f"reference_policy_thrust_x{k}" for k in args.thrust_gains] \
+        + [f"reference_policy_flip_{f}" for f in args.image_flips]
+    for name in names:
         env = vecenv.create_vec_env("planning", args.envs, use_image=True, num_envs=args.envs, ctl_mode="rate", seed=0,
                                     sim_device="cuda:0", headless=True)
         obs = env.reset()
@@ -43,7 +48,11 @@ def main():
         for t in range(args.steps):
             with torch.no_grad():
                 if name.startswith("reference_policy"):
-                    mu, _, _ = model.trunk({"image": obs["image"], "observation": obs["observation"]})
+                    image = obs["image"]
+                    if "_flip_" in name:
+                        f = name.split("_flip_")[1]
+                        image = image.flip(dims=[d for d, c in ((2, "u"), (3, "v")) if c in f])
+                    mu, _, _ = model.trunk({"image": image, "observation": obs["observation"]})
                     act = mu.clamp(-1, 1)                                  # deterministic play (players.py:372-388)
                     if "_thrust_x" in name:                                # T = 0.5 + 0.5 a  ->  k T
                         k = float(name.split("_thrust_x")[1])
