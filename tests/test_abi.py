@@ -93,3 +93,39 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(root, f)
+
+
+def test_ppo_kernel_entry_points_validate_arguments_before_any_launch(lib):
+    """Argument validation of the PPO-loop entry points happens on the host, before anything is launched: callable here.
+    (error codes: include/airgym_hip.h - AG_ERR_INVALID_ARG = -1, AG_ERR_UNSUPPORTED = -2 ...)"""
+    from airgym_amd import _native as N
+    inval = lib.ag_ppo_loss_finalize(None, 1, 1, 4, None, 0.0, 0.0, 0.0, None, None, None, None, None)
+    assert inval != 0
+    unsupported = None
+    buf = (ctypes.c_float * 64)()
+    dbl = (ctypes.c_double * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    pd = ctypes.cast(dbl, ctypes.c_void_p)
+    # host-side pure queries
+    assert lib.ag_ppo_loss_num_sums() == 4 + 5 + 6 and lib.ag_ppo_loss_max_blocks() >= 256
+    assert lib.ag_wgrad_rows_per_block(0) > 0 and lib.ag_input_wgrad_rows(18) > 0 and lib.ag_input_wgrad_rows(48) == 0
+    assert lib.ag_sum_rows_groups() >= 16 and lib.ag_rollout_account_blocks(65536) == 256
+    assert lib.ag_rms_scratch_doubles(18) > 0 and lib.ag_adam_state_bytes() >= 32
+    # shape / pointer errors are return codes, not crashes
+    assert lib.ag_normalize_rows(None, pd, pd, p, 4, 18, 1e-5, 5.0, None) == inval
+    assert lib.ag_normalize_rows(p, pd, pd, p, 4, 100000, 1e-5, 5.0, None) not in (0, inval)          # D too large
+    unsupported = lib.ag_normalize_rows(p, pd, pd, p, 4, 100000, 1e-5, 5.0, None)
+    assert lib.ag_elu_heads(p, p, p, p, 8, 48, 5, 0, None, None) == unsupported                     # C not a power of two >= 64
+    assert lib.ag_elu_heads(p, p, p, p, 8, 256, 7, 0, None, None) == unsupported                    # A1 not in {5, 6}
+    assert lib.ag_elu_bwd_input_wgrad(p, p, p, p, p, 8, 256, 48, None) == unsupported               # D = 48 keeps the unfused path
+    assert lib.ag_mlp_input_layer(p, pd, None, p, p, p, p, 8, 18, 256, 1e-5, 5.0, None) == inval    # mean without var
+    assert lib.ag_policy_sample(p, p, pd, None, 1e-5, 0, p, 24, 0, 0, p, p, p, p, p, None, 8, 4, None) == inval
+    assert lib.ag_gae(p, p, p, p, 0.99, 0.95, p, p, 0, 8, None) == inval
+    jobs = (N.AgSumJob * 13)()
+    for j in range(13):
+        jobs[j] = N.AgSumJob(p.value, p.value, 4, 8)
+    assert lib.ag_sum_rows_multi(jobs, 13, p, 1 << 20, None) == unsupported                          # more than AG_MAX_SUM_JOBS
+    jobs[0] = N.AgSumJob(p.value, p.value, 4, 6)
+    assert lib.ag_sum_rows_multi(jobs, 1, p, 1 << 20, None) == unsupported                           # n % 4 != 0
+    jobs[0] = N.AgSumJob(p.value, p.value, 4, 8)
+    assert lib.ag_sum_rows_multi(jobs, 1, p, 4, None) == inval                                       # scratch too small
