@@ -755,8 +755,12 @@ class A2CAgent:
             return
         w.add_scalar("performance/step_inference_rl_update_fps", curr_frames / max(stats["total_time"], 1e-9), frame)
         w.add_scalar("performance/step_inference_fps", curr_frames / max(stats["play_time"], 1e-9), frame)
+        # the env step is one kernel inside the rollout, not separately timed: the step_* tags the reference's dashboards
+        # expect (a2c_base.py:323,326) carry the rollout figures
+        w.add_scalar("performance/step_fps", curr_frames / max(stats["play_time"], 1e-9), frame)
         w.add_scalar("performance/rl_update_time", stats["update_time"], frame)
         w.add_scalar("performance/step_inference_time", stats["play_time"], frame)
+        w.add_scalar("performance/step_time", stats["play_time"], frame)
         w.add_scalar("losses/a_loss", stats["a_loss"], frame)
         w.add_scalar("losses/c_loss", stats["c_loss"], frame)
         w.add_scalar("losses/entropy", stats["entropy"], frame)
