@@ -159,7 +159,8 @@ class A2CAgent:
         self.env_config = dict(config.get("env_config", {}))
         if self.multi_gpu:
             self.env_config.setdefault("env_id_offset", self.global_rank * self.num_actors)
-            self.env_config.setdefault("sim_device", self.ppo_device)
+            if str(self.ppo_device).startswith("cuda"):
+                self.env_config["sim_device"] = self.ppo_device   # env and learner share the rank's GPU
         self.vec_env = config.get("vec_env") or vecenv.create_vec_env(self.env_name, self.num_actors, **self.env_config)
         self.env_info = self.vec_env.get_env_info()
         self.value_size = self.env_info.get("value_size", 1)

@@ -34,7 +34,11 @@ class A2CPlayer:
         self.actions_num = action_space.shape[0]
         self.actions_low = torch.from_numpy(action_space.low.copy()).float().to(self.device)
         self.actions_high = torch.from_numpy(action_space.high.copy()).float().to(self.device)
-        self.obs_shape = self.env_info["observation_space"].shape
+        space = self.env_info["observation_space"]
+        if hasattr(space, "spaces"):        # Dict{image, observation} of the camera tasks (players.py:63-69)
+            self.obs_shape = {k: v.shape for k, v in space.spaces.items()}
+        else:
+            self.obs_shape = space.shape
         keys = {"actions_num": self.actions_num, "input_shape": self.obs_shape, "num_seqs": self.num_actors,
                 "value_size": 1, "normalize_value": config.get("normalize_value", False),
                 "normalize_input": config.get("normalize_input", False)}
@@ -43,9 +47,45 @@ class A2CPlayer:
 
     def restore(self, fn):
         checkpoint = torch_ext.load_checkpoint(fn)
-        self.model.load_state_dict(checkpoint["model"])
-        if "env_state" in checkpoint:
+        self.set_full_state_weights(checkpoint)
+        if checkpoint.get("env_state") is not None:
             self.env.set_env_state(checkpoint["env_state"])
+
+    def set_full_state_weights(self, checkpoint):
+        """players.py:376-429: a full checkpoint loads strictly; an MLP-only checkpoint (pretrained without
+        the image encoder) fills logstd, both normalisers, the MLP trunk, mu and value_head of a CNN model and
+        leaves the encoder at its initialisation.  Unlike the reference's bare `except:` the fallback is taken
+        only for the case it was written for (encoder keys missing); any other mismatch still raises."""
+        weights = checkpoint["model"]
+        try:
+            self.model.load_state_dict(weights)
+            return
+        except RuntimeError as e:
+            model_keys = set(self.model.state_dict().keys())
+            missing = model_keys - set(weights.keys())
+            encoder_only = missing and all(k.startswith(("actor_cnn.", "actor_enc.", "running_mean_std.running_mean_std.image"))
+                                           or k.startswith("running_mean_std.running_mean_std.") for k in missing)
+            if not (encoder_only and hasattr(self.model.running_mean_std, "running_mean_std")):
+                raise e
+        print("Missing CNN part. Loading Pretrained MLP Model......")
+        with torch.no_grad():
+            self.model.logstd.copy_(weights["logstd"])
+        if self.model.normalize_input and "running_mean_std.running_mean" in weights:
+            self.model.running_mean_std.running_mean_std["observation"].load_state_dict(
+                {k: weights["running_mean_std." + k] for k in ("running_mean", "running_var", "count")})
+        if self.model.normalize_value and "value_mean_std.running_mean" in weights:
+            self.model.value_mean_std.load_state_dict(
+                {k: weights["value_mean_std." + k] for k in ("running_mean", "running_var", "count")})
+        mlp = {k[len("actor_mlp."):]: v for k, v in weights.items() if k.startswith("actor_mlp.")}
+        own = self.model.actor_mlp.state_dict()
+        # strict=False in the reference; shapes that do not fit (first layer: obs+features wide here) are skipped loudly
+        fit = {k: v for k, v in mlp.items() if k in own and own[k].shape == v.shape}
+        skipped = sorted(set(mlp) - set(fit))
+        if skipped:
+            print("  actor_mlp tensors not loaded (shape differs with the encoder features appended):", skipped)
+        self.model.actor_mlp.load_state_dict(fit, strict=False)
+        self.model.mu.load_state_dict({"weight": weights["mu.weight"], "bias": weights["mu.bias"]})
+        self.model.value_head.load_state_dict({"weight": weights["value_head.weight"], "bias": weights["value_head.bias"]})
 
     @torch.no_grad()
     def get_action(self, obs, is_deterministic=True):

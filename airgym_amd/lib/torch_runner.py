@@ -69,6 +69,10 @@ class Runner:
         return player.run()
 
     def run(self, args):
-        if args.get("train", True) and not args.get("play", False):
+        """torch_runner.py:95-101: --train trains, --play plays, NEITHER flag trains (both are store_true
+        flags, so the documented `runner.py --task hovering --ctl_mode rate --headless` has train=False)."""
+        if args.get("train"):
             return self.run_train(args)
-        return self.run_play(args)
+        if args.get("play"):
+            return self.run_play(args)
+        return self.run_train(args)

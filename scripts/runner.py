@@ -41,7 +41,12 @@ def update_config(config, args):
         ec["seed"] = args["seed"]
     c["device"] = args["rl_device"]
     if args.get("multi_gpu"):
+        # one process per GPU: every rank simulates and learns on ITS device (the CLI default cuda:0 would put
+        # every rank's env on GPU 0 while the agent lives on cuda:LOCAL_RANK)
         c["multi_gpu"] = True
+        dev = "cuda:" + os.getenv("LOCAL_RANK", "0")
+        ec["sim_device"] = dev
+        c["device"] = dev
     return config
 
 

@@ -265,3 +265,74 @@ def test_dict_observation_cnn_agent_cpu(tmp_path):
     fn = str(tmp_path / "ck"); agent.save(fn)
     b = A2CAgent("run", params); b.restore(fn + ".pth")
     assert torch.equal(agent.flat_param, b.flat_param)
+
+
+def test_dict_observation_player_and_mlp_only_fallback(tmp_path):
+    """players.py:63-69,376-429: the player builds a CNN model from a Dict observation space, loads a full checkpoint
+    strictly, and falls back to filling logstd / normalisers / trunk / heads from an MLP-only checkpoint."""
+    from airgym_amd.lib.agent.players import A2CPlayer
+    _stub_env.register_dict()
+    torch.manual_seed(1)
+    params = _stub_env.ppo_params(num_actors=16, horizon=4, mini_epochs=1, max_epochs=1, env_name="oracle_dict")
+    params["network"]["cnn"] = {"output_dim": 8}
+    agent = A2CAgent("run", params)
+    agent.train()
+    fn = str(tmp_path / "ck"); agent.save(fn)
+    params["config"]["player"] = {"deterministic": True, "games_num": 1, "max_steps": 6, "print_stats": False}
+    p = A2CPlayer(params)
+    assert isinstance(p.obs_shape, dict) and p.obs_shape["image"] == (1, 24, 16)
+    p.restore(fn + ".pth")
+    assert torch.equal(p.model.actor_cnn.fc.weight, agent.model.actor_cnn.fc.weight)
+    obs = {"image": torch.rand(16, 1, 24, 16), "observation": torch.randn(16, 18)}
+    act = p.get_action(obs)
+    assert act.shape == (16, 4) and torch.equal(act, p.get_action(obs))
+    assert np.isfinite(p.run(print_every=3)["av_reward"])
+    # MLP-only checkpoint (no actor_cnn.* / per-key normalisers) whose trunk already has the CNN model's width
+    full = agent.model.state_dict()
+    mlp_only = {k: v.clone() for k, v in full.items() if k.startswith(("actor_mlp.", "mu.", "value_head.", "value_mean_std."))}
+    mlp_only["logstd"] = torch.full_like(full["logstd"], -0.3)
+    for k in ("running_mean", "running_var", "count"):
+        mlp_only["running_mean_std." + k] = full["running_mean_std.running_mean_std.observation." + k].clone() + 1.0
+    torch.save({"model": mlp_only}, str(tmp_path / "mlp.pth"))
+    q = A2CPlayer(params)
+    cnn_before = q.model.actor_cnn.fc.weight.clone()
+    q.restore(str(tmp_path / "mlp.pth"))
+    assert torch.equal(q.model.actor_cnn.fc.weight, cnn_before)                  # encoder untouched
+    assert torch.equal(q.model.logstd, mlp_only["logstd"])
+    assert torch.equal(q.model.running_mean_std.running_mean_std["observation"].running_mean,
+                       mlp_only["running_mean_std.running_mean"])
+    assert torch.equal(q.model.mu.weight, full["mu.weight"]) and torch.equal(q.model.actor_mlp.layers[0].weight,
+                                                                              full["actor_mlp.layers.0.weight"])
+    # a checkpoint that is wrong for another reason still raises
+    bad = dict(full); bad["mu.weight"] = torch.zeros(3, 3)
+    torch.save({"model": bad}, str(tmp_path / "bad.pth"))
+    with pytest.raises(RuntimeError):
+        A2CPlayer(params).restore(str(tmp_path / "bad.pth"))
+
+
+def test_runner_dispatch_and_multi_gpu_device(monkeypatch):
+    """torch_runner.py:95-101: neither --train nor --play given -> TRAIN (both are store_true flags).
+    scripts/runner.py update_config: under --multi_gpu every rank simulates on cuda:LOCAL_RANK, not the CLI default."""
+    import importlib.util
+    import os
+    from airgym_amd.lib.torch_runner import Runner
+    from airgym_amd.utils.helpers import get_args
+    args = vars(get_args(["--task", "hovering", "--ctl_mode", "rate", "--headless"]))
+    assert args["train"] is False and args["play"] is False
+    calls = []
+    r = Runner()
+    monkeypatch.setattr(r, "run_train", lambda a: calls.append("train"))
+    monkeypatch.setattr(r, "run_play", lambda a: calls.append("play"))
+    r.run(args)
+    r.run(dict(args, play=True))
+    r.run(dict(args, train=True, play=True))
+    assert calls == ["train", "play", "train"]
+    spec = importlib.util.spec_from_file_location(
+        "ag_runner_script", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "runner.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    cfg = {"params": {"config": {"env_config": {}}}}
+    out = mod.update_config(cfg, dict(args, multi_gpu=True))["params"]["config"]
+    assert out["env_config"]["sim_device"] == "cuda:3" and out["device"] == "cuda:3" and out["multi_gpu"] is True
+    out1 = mod.update_config({"params": {"config": {"env_config": {}}}}, dict(args, multi_gpu=False))["params"]["config"]
+    assert out1["env_config"]["sim_device"] == args["sim_device"]
