@@ -106,6 +106,9 @@ SYMBOLS = [
     ("ag_step", ctypes.c_int, [_P, _P, _P]),
     ("ag_step_into", ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     ("ag_step_with_inputs", ctypes.c_int, [_P, _P, _P, _P, _P]),
+    ("ag_term_sum_tiles", ctypes.c_int, [ctypes.c_int]),
+    ("ag_step_rollout", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ("ag_eval_obs_reward", ctypes.c_int, [_P, _P, _P, _P, _P]),
     ("ag_get_buffers", ctypes.c_int, [_P, ctypes.POINTER(AgBuffers)]),
     ("ag_get_state", ctypes.c_int, [_P, ctypes.POINTER(AgStateView), _P]),
     ("ag_set_state", ctypes.c_int, [_P, ctypes.POINTER(AgStateView), _P]),
@@ -115,13 +118,16 @@ SYMBOLS = [
     ("ag_set_tick", ctypes.c_int, [_P, ctypes.c_uint64]),
     ("ag_set_launch_params", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     ("ag_debug_touch", ctypes.c_int, [_P, _P, _P]),
+    ("ag_debug_wave_placement", ctypes.c_int, [_P, _P, _P]),
     ("ag_debug_touch_variant", ctypes.c_int, [_P, _P, ctypes.c_int, _P]),
     ("ag_planning_set_obstacle_table", ctypes.c_int, [_P, _P, ctypes.c_int]),
     ("ag_planning_get_buffers", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningBuffers)]),
     ("ag_planning_get_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),
     ("ag_planning_set_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),
     ("ag_planning_step_with_uniforms", ctypes.c_int, [_P, _P, _P, _P]),
-    ("ag_planning_render_now", ctypes.c_int, [_P, _P]),
+    ("ag_planning_eval_post", ctypes.c_int, [_P, _P, _P, _P]),
+    ("ag_planning_render_now", ctypes.c_int, [_P]),
+    ("ag_debug_planning_render_parts", ctypes.c_int, [_P, ctypes.c_int]),
     ("ag_ppo_loss_finalize", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),
     ("ag_rms_scratch_doubles", ctypes.c_longlong, [ctypes.c_int]),
@@ -132,7 +138,7 @@ SYMBOLS = [
                                         ctypes.c_longlong, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_rollout_account_blocks", ctypes.c_int, [ctypes.c_int]),
     ("ag_rollout_account", ctypes.c_int, [_P, _P, _P, _P] + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_float,
-                                          _P, _P, _P, _P, _P, ctypes.c_int, _P, ctypes.c_int, ctypes.c_longlong, _P, _P]),
+                                          _P, _P, _P, _P, _P, ctypes.c_int, _P]),
     ("ag_gae", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_mlp_input_layer", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, _P]),

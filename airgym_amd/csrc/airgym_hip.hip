@@ -12,6 +12,7 @@
 #include <string>
 
 #include "../../include/airgym_hip.h"
+#include "../../include/airgym_hip_debug.h"
 #include "kernel_args.hpp"
 #include "planning_math.hpp"
 
@@ -72,6 +73,11 @@ Layout make_layout(int n, int num_obs, bool terms, int task = 0) {
     L.total = off;
     return L;
 }
+
+const ag::EvalLauncher kEvalLaunchers[2][5] = {
+    {ag::launch_eval_0_0, ag::launch_eval_0_1, ag::launch_eval_0_2, ag::launch_eval_0_3, ag::launch_eval_0_4},
+    {ag::launch_eval_1_0, ag::launch_eval_1_1, ag::launch_eval_1_2, ag::launch_eval_1_3, ag::launch_eval_1_4},
+};
 
 const ag::StepLauncher kLaunchers[2][5] = {
     {ag::launch_step_0_0, ag::launch_step_0_1, ag::launch_step_0_2, ag::launch_step_0_3, ag::launch_step_0_4},
@@ -266,6 +272,14 @@ __global__ __launch_bounds__(64) void touch_variant_kernel(ag::KArgs k, const fl
     }
 }
 
+// Diagnostic: where does the hardware put the waves of the step kernel's launch geometry (grid n/64 x 128 threads)?
+// One uint2 per wave: HW_ID (wave / SIMD / CU / SE fields) and XCC_ID.
+__global__ __launch_bounds__(128) void wave_placement_kernel(uint2* out) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID (gfx940+)
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 2 + (threadIdx.x >> 6)] = make_uint2(hw, xcc);
+}
+
 __global__ void planning_get_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_planning_state_view v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k.n) return;
@@ -334,7 +348,8 @@ void bind_tick(ag_env* h, ag::KArgs& k) {
 }
 
 int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int64_t* reset_out,
-            const float* noise, const float* uniforms, void* stream) {
+            const float* noise, const float* uniforms, void* stream, uint8_t* done_u8 = nullptr,
+            float* term_sums = nullptr, bool rollout_form = false) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
     if (!actions) return fail(AG_ERR_INVALID_ARG, "actions_dev is NULL");
     if (h->num_actions == 4 && ((uintptr_t)actions & 15)) return fail(AG_ERR_INVALID_ARG, "actions_dev must be 16-byte aligned");
@@ -376,8 +391,15 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
     }
     k.ext_noise = noise;
     k.ext_uniforms = uniforms;
+    int block = h->block;
+    if (rollout_form) {   // u8 done flags, per-tile reward-term sums, no per-env term / cmd arrays
+        k.reset_u8 = done_u8;
+        k.term_sums = term_sums;
+        k.cmd = nullptr;
+        if (block == 1 || block >= 64) block = 0;   // the rollout form exists for the default kernel family only
+    }
     bind_tick(h, k);
-    hipError_t e = kLaunchers[h->cfg.task][h->cfg.ctl_mode](k, h->block, h->obs_via_lds, (hipStream_t)stream);
+    hipError_t e = kLaunchers[h->cfg.task][h->cfg.ctl_mode](k, block, h->obs_via_lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
     return AG_OK;
 }
@@ -536,6 +558,33 @@ int ag_step_into(ag_handle h, const float* actions_dev, float* obs_out_dev, floa
     return do_step(h, actions_dev, obs_out_dev, rew_out_dev, reset_out_dev, nullptr, nullptr, stream);
 }
 
+int ag_term_sum_tiles(int num_envs) { return num_envs > 0 ? (num_envs + 63) / 64 : 0; }
+
+int ag_step_rollout(ag_handle h, const float* actions_dev, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,
+                    float* term_sums_dev, void* stream) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    if (h->cfg.task == AG_TASK_PLANNING) return fail(AG_ERR_UNSUPPORTED, "ag_step_rollout: hovering / tracking handles only");
+    if (!done_out_dev) return fail(AG_ERR_INVALID_ARG, "done_out_dev is NULL");
+    if (term_sums_dev && ((uintptr_t)term_sums_dev & 3)) return fail(AG_ERR_INVALID_ARG, "term_sums_dev must be 4-byte aligned");
+    return do_step(h, actions_dev, obs_out_dev, rew_out_dev, nullptr, nullptr, nullptr, stream, done_out_dev, term_sums_dev, true);
+}
+
+int ag_eval_obs_reward(ag_handle h, const float* processed_actions_dev, const float* cmd_thrusts_dev, const float* noise_dev,
+                       void* stream) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    if (!processed_actions_dev || !cmd_thrusts_dev) return fail(AG_ERR_INVALID_ARG, "processed_actions_dev / cmd_thrusts_dev is NULL");
+    if (h->cfg.task == AG_TASK_PLANNING) return fail(AG_ERR_UNSUPPORTED, "ag_eval_obs_reward: hovering / tracking handles only");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    ag::KArgs k = h->k;
+    k.eval_actions = processed_actions_dev;
+    k.eval_cmd = cmd_thrusts_dev;
+    k.ext_noise = noise_dev;
+    hipError_t e = kEvalLaunchers[h->cfg.task][h->cfg.ctl_mode](k, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("eval kernel launch: ") + hipGetErrorString(e));
+    return AG_OK;
+}
+
 int ag_step_with_inputs(ag_handle h, const float* actions_dev, const float* noise_dev, const float* reset_uniforms_dev,
                         void* stream) {
     if (!noise_dev || !reset_uniforms_dev) return fail(AG_ERR_INVALID_ARG, "noise_dev / reset_uniforms_dev is NULL");
@@ -655,10 +704,32 @@ int ag_planning_step_with_uniforms(ag_handle h, const float* actions_dev, const 
     return do_step(h, actions_dev, nullptr, nullptr, nullptr, nullptr, reset_uniforms_dev, stream);
 }
 
-int ag_planning_render_now(ag_handle h, void* stream) {
-    // `stream` doubles as a diagnostics mask (0 in normal use): bit0 skip ray-cast, bit1 skip noise, bit2 skip 5x5 pass
+int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* collisions_dev, void* stream) {
     if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
-    h->force_render = 1 | ((int)(uintptr_t)stream << 1);
+    if (!actions_dev || !collisions_dev) return fail(AG_ERR_INVALID_ARG, "actions_dev / collisions_dev is NULL");
+    if (!h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    ag::KArgs k = h->k;
+    k.actions = actions_dev;
+    ag::PlanArgs pa = h->pa;
+    pa.ext_collisions = collisions_dev;
+    bind_tick(h, k);
+    hipError_t e = ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 2, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("planning post-phase launch: ") + hipGetErrorString(e));
+    return AG_OK;
+}
+
+int ag_planning_render_now(ag_handle h) {
+    if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    h->force_render = 1;
+    return AG_OK;
+}
+
+int ag_debug_planning_render_parts(ag_handle h, int skip_mask) {
+    if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    if (skip_mask < 0 || skip_mask > 7) return fail(AG_ERR_INVALID_ARG, "skip_mask: bit0 ray-cast, bit1 noise passes, bit2 5x5 pass");
+    h->force_render = 1 | (skip_mask << 1);
     return AG_OK;
 }
 
@@ -673,6 +744,14 @@ int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
+int ag_debug_wave_placement(ag_handle h, unsigned int* out_dev, void* stream) {
+    if (!h || !out_dev) return fail(AG_ERR_INVALID_ARG, "NULL argument");
+    hipLaunchKernelGGL(wave_placement_kernel, dim3((h->cfg.num_envs + 63) / 64), dim3(128), 0, (hipStream_t)stream,
+                       (uint2*)out_dev);
+    AG_HIP_CHECK(hipGetLastError());
+    return AG_OK;
+}
+
 int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream) {
     if (!h || !actions_dev) return fail(AG_ERR_INVALID_ARG, "NULL argument");
     hipLaunchKernelGGL(touch_kernel, dim3((h->cfg.num_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->k,
@@ -683,8 +762,8 @@ int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream) {
 
 int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
-    if (block_size != 0 && block_size != 64 && block_size != 128 && block_size != 256)
-        return fail(AG_ERR_INVALID_ARG, "block_size must be 0 (wave-specialised), 64, 128 or 256");
+    if (!(block_size >= 0 && block_size <= 4) && block_size != 64 && block_size != 128 && block_size != 256)
+        return fail(AG_ERR_INVALID_ARG, "block_size must be 0 (wave-specialised, default), 1..4 (its A/B variants), 64, 128 or 256");
     h->block = block_size;
     h->obs_via_lds = obs_via_lds ? 1 : 0;
     return AG_OK;

@@ -764,18 +764,20 @@ AG_HD void compute_reward(const EnvState& s, const float* R, const float* a, con
 }
 
 // ---------------------------------------------------------------------------
-// One full env step (Hovering.step, hovering.py:286-308).
-//   raw_action : what the agent passed (A floats)
+// One full env step (Hovering.step, hovering.py:286-308), in two halves so that a kernel can put the state stores
+// between them (the state is final after the physics unless the env terminates):
+//   env_step_physics : action map -> canonicalise -> controller -> wrench -> RK4 -> progress++
+//   env_step_outputs : observation (+noise) -> reward / termination -> pre_actions -> in-place reset
+//   raw_action : what the agent passed (A floats);  a[] : the processed action (out of the first half)
 //   pre_a      : in: previous processed action; out: this step's (zeroed if the env reset)
 //   EXT = parity mode: ext_noise[18] / ext_uniforms[12] supplied by the caller instead of Philox
 //   CLEAN_OBS = obs[] is returned WITHOUT noise and target subtraction (added by the noise wave's data later)
 // ---------------------------------------------------------------------------
-template <int TASK, int CTL, bool EXT, bool CLEAN_OBS = false>
-AG_HD void env_step(EnvState& s, CtlState& c, float* pre_a, const float* raw_action, const StepParams& P,
-                    uint32_t env_global, const float* ext_noise, const float* ext_uniforms, float* obs, StepOut& o) {
+template <int TASK, int CTL>
+AG_HD void env_step_physics(EnvState& s, CtlState& c, const float* raw_action, const StepParams& P, float* a, float* cmd) {
     constexpr int A = CtlTraits<CTL>::kNumActions;
     // ---- pre_physics_step, hovering.py:212-216
-    float a[A], lo[A], hi[A];
+    float lo[A], hi[A];
     action_limits<TASK, CTL>(lo, hi);
 #pragma unroll
     for (int i = 0; i < A; ++i) a[i] = raw_action[i];
@@ -785,15 +787,22 @@ AG_HD void env_step(EnvState& s, CtlState& c, float* pre_a, const float* raw_act
     // quaternion canonicalisation w >= 0, hovering.py:224-226
     if (s.q.w < 0.0f) { s.q.x = -s.q.x; s.q.y = -s.q.y; s.q.z = -s.q.z; s.q.w = -s.q.w; }
     // controller, hovering.py:234-254
-    controller_update<CTL>(c, s, a, o.cmd);
+    controller_update<CTL>(c, s, a, cmd);
     // wrench, hovering.py:256-277 (thrust zeroed for envs reset last step, reaction torque kept)
     float fz;
     V3 tau;
-    body_wrench_from_cmd(o.cmd, s.was_reset ? 0.0f : 1.0f, fz, tau);
+    body_wrench_from_cmd(cmd, s.was_reset ? 0.0f : 1.0f, fz, tau);
     // ---- gym.simulate
     rk4_step(s, fz, tau, P);
-    // ---- progress, obs, reward   hovering.py:297-299
+    // ---- progress, hovering.py:297
     s.progress += 1;
+    s.was_reset = 0;
+}
+
+// compute_observations + compute_reward on the post-physics state (hovering.py:298-299,337-459); no state change.
+template <int TASK, int CTL, bool EXT, bool CLEAN_OBS>
+AG_HD void env_observe_reward(const EnvState& s, const float* a, const float* pre_a, const float* cmd, const StepParams& P,
+                              uint32_t env_global, const float* ext_noise, float* obs, StepOut& o) {
     float R[9];
     quat_to_matrix(s.q, R);
     fill_clean_observations<TASK>(s, R, P, obs);
@@ -810,24 +819,38 @@ AG_HD void env_step(EnvState& s, CtlState& c, float* pre_a, const float* raw_act
         }
         apply_noise_and_target<TASK>(obs, z, P);
     }
-    compute_reward<TASK, CTL>(s, R, a, pre_a, o.cmd, P, o);
+    compute_reward<TASK, CTL>(s, R, a, pre_a, cmd, P, o);
+}
+
+// reset_idx for a done env, hovering.py:300-302,310-335 (+ controller memory, pre_actions)
+template <int CTL, bool EXT>
+AG_HD void env_reset_done(EnvState& s, CtlState& c, float* pre_a, const StepParams& P, uint32_t env_global,
+                          const float* ext_uniforms) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    float u[12];
+    if (EXT) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) u[i] = ext_uniforms[i];
+    } else {
+        reset_uniforms(P, env_global, u);
+    }
+    reset_state_from_uniforms(s, u, P);
+    ctl_reset(c, s);
+#pragma unroll
+    for (int i = 0; i < A; ++i) pre_a[i] = 0.0f;
+}
+
+template <int TASK, int CTL, bool EXT, bool CLEAN_OBS = false>
+AG_HD void env_step(EnvState& s, CtlState& c, float* pre_a, const float* raw_action, const StepParams& P,
+                    uint32_t env_global, const float* ext_noise, const float* ext_uniforms, float* obs, StepOut& o) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    float a[A];
+    env_step_physics<TASK, CTL>(s, c, raw_action, P, a, o.cmd);
+    env_observe_reward<TASK, CTL, EXT, CLEAN_OBS>(s, a, pre_a, o.cmd, P, env_global, ext_noise, obs, o);
 #pragma unroll
     for (int i = 0; i < A; ++i) pre_a[i] = a[i];  // hovering.py:369
-    // ---- reset_idx for done envs, hovering.py:300-302,310-335
     s.was_reset = o.done;
-    if (o.done) {
-        float u[12];
-        if (EXT) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) u[i] = ext_uniforms[i];
-        } else {
-            reset_uniforms(P, env_global, u);
-        }
-        reset_state_from_uniforms(s, u, P);
-        ctl_reset(c, s);
-#pragma unroll
-        for (int i = 0; i < A; ++i) pre_a[i] = 0.0f;
-    }
+    if (o.done) env_reset_done<CTL, EXT>(s, c, pre_a, P, env_global, ext_uniforms);
     o.timeout = (s.progress > P.max_episode_length) ? 1 : 0;  // hovering.py:304 (never true, Q3)
 }
 

@@ -32,6 +32,13 @@ struct KArgs {
     float4* cmd;                 // [n] or null
     const float* ext_noise;      // [n,18] or null
     const float* ext_uniforms;   // [n,12] or null
+    // rollout form (ag_step_rollout): done flags as u8 (the width the rollout buffer stores, experience.py:329) and
+    // per-64-env-tile sums of the reward terms instead of nine per-env arrays (Episode/<term> logging only needs means)
+    uint8_t* reset_u8;           // [n] or null; when set, `reset` (int64) is not written
+    float* term_sums;            // [ceil(n/64), 12] or null: sums over the tile's envs of terms[0..8]
+    // parity / inspection mode (ag_eval_obs_reward): processed actions + controller output supplied by the caller
+    const float* eval_actions;   // [n, A]
+    const float* eval_cmd;       // [n, 4]
     // RNG tick lives in device memory so that a captured hipGraph of env steps replays with fresh
     // counters: each launch reads tick_in and thread 0 publishes tick+1 to tick_out (the two slots
     // alternate launch to launch; stream order between launches makes the hand-off race-free).
@@ -51,6 +58,7 @@ struct PlanArgs {
     float* terms[11];            // item_reward_info arrays or null
     const float* table;          // [100, 8] obstacle variants (centre3, axis3, radius, half length)
     const float* ext_uniforms;   // [n, 121] or null (parity mode)
+    const float* ext_collisions; // [n] or null (parity mode: collision flags supplied instead of the geometric test)
     int n_pad;
     int debug_skip;              // diagnostics only: bit0 skip ray-cast, bit1 skip noise passes, bit2 skip the 5x5 pass
 };
@@ -60,12 +68,17 @@ hipError_t launch_planning_render(const KArgs& k, const PlanArgs& pa, hipStream_
 hipError_t launch_planning_reset_all(const KArgs& k, const PlanArgs& pa, int num_actions, hipStream_t st);
 
 typedef hipError_t (*StepLauncher)(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
+typedef hipError_t (*EvalLauncher)(const KArgs& k, hipStream_t stream);
 
 // defined in step_kernel.hip compiled with -DAG_TASK=<t> -DAG_CTL=<c>
 #define AG_DECL_LAUNCHER(t, c) hipError_t launch_step_##t##_##c(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
 AG_DECL_LAUNCHER(0, 0) AG_DECL_LAUNCHER(0, 1) AG_DECL_LAUNCHER(0, 2) AG_DECL_LAUNCHER(0, 3) AG_DECL_LAUNCHER(0, 4)
 AG_DECL_LAUNCHER(1, 0) AG_DECL_LAUNCHER(1, 1) AG_DECL_LAUNCHER(1, 2) AG_DECL_LAUNCHER(1, 3) AG_DECL_LAUNCHER(1, 4)
 #undef AG_DECL_LAUNCHER
+#define AG_DECL_EVAL(t, c) hipError_t launch_eval_##t##_##c(const KArgs& k, hipStream_t stream);
+AG_DECL_EVAL(0, 0) AG_DECL_EVAL(0, 1) AG_DECL_EVAL(0, 2) AG_DECL_EVAL(0, 3) AG_DECL_EVAL(0, 4)
+AG_DECL_EVAL(1, 0) AG_DECL_EVAL(1, 1) AG_DECL_EVAL(1, 2) AG_DECL_EVAL(1, 3) AG_DECL_EVAL(1, 4)
+#undef AG_DECL_EVAL
 
 __device__ __forceinline__ void load_env(const KArgs& k, int i, EnvState& s) {
     const float4 a = k.S[0][i], b = k.S[1][i], c = k.S[2][i], d = k.S[3][i];

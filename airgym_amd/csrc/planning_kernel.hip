@@ -79,7 +79,8 @@ __global__ __launch_bounds__(64) void planning_step_kernel(const KArgs k, const 
     }
     // check_collisions (customized.py:393-397 -> analytic): robot sphere vs the 40 capped cylinders and the ground
     int collided = (s.p.z <= kRobotRadius) ? 1 : 0;
-    for (int j = 0; j < kNumObst; ++j) {
+    if (pa.ext_collisions != nullptr) collided = (active && pa.ext_collisions[i] != 0.0f) ? 1 : 0;
+    for (int j = 0; pa.ext_collisions == nullptr && j < kNumObst; ++j) {
         const float4 ob = pa.OB[(size_t)j * pa.n_pad + i];
         const float dx = s.p.x - ob.x, dy = s.p.y - ob.y;
         if (dx * dx + dy * dy < 9.0f) {   // every cylinder stays within 2.7 m (xy) of its root: farther ones cannot touch

@@ -63,10 +63,9 @@ __global__ __launch_bounds__(256) void policy_sample_kernel(const SampleArgs k) 
 }
 
 struct AccountArgs {
-    const float* raw_reward; const long long* dones; const unsigned char* timeouts; const float* values;
+    const float* raw_reward; const unsigned char* dones; const unsigned char* timeouts; const float* values;
     float scale, shift, min_val, max_val; int log_val; float gamma;
     float* shaped; float* cur_rew; float* cur_shaped; float* cur_len; double* partials; int n;
-    const float* terms; int num_terms; long long terms_stride; double* term_partials;   // optional: [num_terms][stride] -> [blocks][num_terms]
 };
 
 __global__ __launch_bounds__(256) void rollout_account_kernel(const AccountArgs k) {
@@ -99,24 +98,10 @@ __global__ __launch_bounds__(256) void rollout_account_kernel(const AccountArgs 
     if (threadIdx.x < 4)
         k.partials[(size_t)blockIdx.x * 4 + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    // per-block sums of the per-env reward-term arrays (Episode/<term> logging): one reduction per rollout instead of one
-    // [T, n] reduction per step
-    if (k.terms) {
-        __shared__ double tred[4][AG_NUM_REWARD_TERMS];
-        for (int t = 0; t < k.num_terms; ++t) {
-            double v = (i < k.n) ? (double)k.terms[(size_t)t * k.terms_stride + i] : 0.0;
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if ((threadIdx.x & 63) == 0) tred[wave][t] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < k.num_terms)
-            k.term_partials[(size_t)blockIdx.x * k.num_terms + threadIdx.x] =
-                (tred[0][threadIdx.x] + tred[1][threadIdx.x]) + (tred[2][threadIdx.x] + tred[3][threadIdx.x]);
-    }
 }
 
 __global__ __launch_bounds__(256) void gae_kernel(const float* __restrict__ rewards, const float* __restrict__ values,
-                                                  const long long* __restrict__ dones, const float* __restrict__ last_values,
+                                                  const unsigned char* __restrict__ dones, const float* __restrict__ last_values,
                                                   float gamma, float tau, float* __restrict__ advs, float* __restrict__ returns,
                                                   int H, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -158,22 +143,20 @@ extern "C" int ag_policy_sample(const float* heads, const float* logstd, const d
 
 extern "C" int ag_rollout_account_blocks(int n) { return (n + 255) / 256; }
 
-extern "C" int ag_rollout_account(const float* raw_reward, const long long* dones, const unsigned char* timeouts,
+extern "C" int ag_rollout_account(const float* raw_reward, const unsigned char* dones, const unsigned char* timeouts,
                                   const float* values, float scale, float shift, float min_val, float max_val, int log_val,
                                   float gamma, float* shaped, float* cur_rew, float* cur_shaped, float* cur_len,
-                                  double* partials, int n, const float* terms, int num_terms, long long terms_stride,
-                                  double* term_partials, void* stream) {
+                                  double* partials, int n, void* stream) {
     if (!raw_reward || !dones || !shaped || !cur_rew || !cur_shaped || !cur_len || !partials || n <= 0)
         return AG_ERR_INVALID_ARG;
     if (timeouts && !values) return AG_ERR_INVALID_ARG;
-    if (terms && (!term_partials || num_terms <= 0 || num_terms > AG_NUM_REWARD_TERMS || terms_stride < n)) return AG_ERR_INVALID_ARG;
     AccountArgs k{raw_reward, dones, timeouts, values, scale, shift, min_val, max_val, log_val, gamma,
-                  shaped, cur_rew, cur_shaped, cur_len, partials, n, terms, num_terms, terms_stride, term_partials};
+                  shaped, cur_rew, cur_shaped, cur_len, partials, n};
     hipLaunchKernelGGL(rollout_account_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, k);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
-extern "C" int ag_gae(const float* rewards, const float* values, const long long* dones, const float* last_values, float gamma,
+extern "C" int ag_gae(const float* rewards, const float* values, const unsigned char* dones, const float* last_values, float gamma,
                       float tau, float* advs, float* returns, int H, int n, void* stream) {
     if (!rewards || !values || !dones || !last_values || !advs || !returns || H <= 0 || n <= 0) return AG_ERR_INVALID_ARG;
     hipLaunchKernelGGL(gae_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rewards, values, dones,

@@ -251,6 +251,210 @@ __global__ __launch_bounds__(128) void step_kernel_ws(const KArgs k) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-specialised kernel, second form (the default).  Same 2-wave split per 64 envs; differences to step_kernel_ws:
+//   * the physics wave STORES THE STATE RIGHT AFTER THE RK4 (it is final unless the env terminates; a terminating lane
+//     stores again after its reset), so the 112 B/env of state writes drain under the reward / observation arithmetic
+//     instead of behind it;
+//   * after the noise is ready (barrier 1) the physics wave forms (clean + sigma*z) - target in registers (target lives in
+//     SGPRs) and writes FINAL rows into an LDS tile laid out exactly like the HBM rows, so the copy-out (after barrier 2)
+//     is ds_read_b128 -> global_store_dwordx4 with no per-element index arithmetic (the first form spent ~450
+//     instructions per wave on row/column div-mod and three LDS reads per element);
+//   * rollout form: done flags as u8 and per-tile sums of the nine reward terms (summed by the noise wave, which has
+//     slack) instead of nine f32[N] arrays + cmd -> 59 B/env less HBM traffic;
+//   * FLIP: workgroups alternate which hardware wave plays which role so that a SIMD is not handed two physics waves.
+// Arithmetic and its order are those of env_step(): results are bit-identical to step_kernel<...>.
+// ---------------------------------------------------------------------------------------------------
+template <int TASK, int CTL, bool EARLY_STORE, bool FLIP>
+__global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k) {
+    constexpr int NOBS = TaskTraits<TASK>::kNumObs;
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    constexpr int SB = 19;                       // odd stride: conflict-free row access of the noise tile
+    constexpr int ST = 9;
+    __shared__ __attribute__((aligned(16))) float tileO[64 * NOBS];   // final observation rows, HBM order
+    __shared__ float tileB[64 * SB];
+    __shared__ float tileT[64 * ST];
+
+    const int hw_wave = threadIdx.x >> 6;
+    const int wave = FLIP ? (hw_wave ^ ((blockIdx.x >> 1) & 1)) : hw_wave;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 64 + lane;
+    const bool active = i < k.n;
+    StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *k.tick_out = P.tick + 1u;
+    const uint32_t env_global = P.env_id_offset + (uint32_t)i;
+    const bool want_terms = (k.term_sums != nullptr);
+
+    if (wave == 0) {
+        EnvState s;
+        CtlState c;
+        load_env(k, i, s);
+        load_ctl<CTL>(k, i, c);
+        float pre_a[A], raw_a[A], a[A];
+        {
+            const float4 pa = k.PA[i];
+            pre_a[0] = pa.x; pre_a[1] = pa.y; pre_a[2] = pa.z; pre_a[3] = pa.w;
+            if (A == 5) pre_a[A - 1] = k.PA4[i];
+        }
+        if (active) {
+            if (A == 4) {
+                const float4 av = reinterpret_cast<const float4*>(k.actions)[i];
+                raw_a[0] = av.x; raw_a[1] = av.y; raw_a[2] = av.z; raw_a[3] = av.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < A; ++j) raw_a[j] = k.actions[(size_t)i * A + j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A; ++j) raw_a[j] = 0.0f;
+        }
+        StepOut o;
+        env_step_physics<TASK, CTL>(s, c, raw_a, P, a, o.cmd);
+        if (EARLY_STORE) {          // final for every lane that does not terminate this step
+            store_env(k, i, s);
+            store_ctl<CTL>(k, i, c);
+            k.PA[i] = make_float4(a[0], a[1], a[2], a[3]);
+            if (A == 5) k.PA4[i] = a[A - 1];
+        }
+        float obs[NOBS];
+        env_observe_reward<TASK, CTL, false, true>(s, a, pre_a, o.cmd, P, env_global, nullptr, obs, o);
+#pragma unroll
+        for (int j = 0; j < A; ++j) pre_a[j] = a[j];
+        s.was_reset = o.done;
+        if (o.done) {
+            env_reset_done<CTL, false>(s, c, pre_a, P, env_global, nullptr);
+            if (EARLY_STORE) {
+                store_env(k, i, s);
+                store_ctl<CTL>(k, i, c);
+                k.PA[i] = make_float4(pre_a[0], pre_a[1], pre_a[2], pre_a[3]);
+                if (A == 5) k.PA4[i] = pre_a[A - 1];
+            }
+        }
+        o.timeout = (s.progress > P.max_episode_length) ? 1 : 0;
+        if (!EARLY_STORE) {
+            store_env(k, i, s);
+            store_ctl<CTL>(k, i, c);
+            k.PA[i] = make_float4(pre_a[0], pre_a[1], pre_a[2], pre_a[3]);
+            if (A == 5) k.PA4[i] = pre_a[A - 1];
+        }
+        const unsigned long long ballot = __ballot(active && o.done);
+        if (active) {
+            k.rew[i] = o.rew;
+            if (k.reset_u8 != nullptr) k.reset_u8[i] = (uint8_t)o.done;
+            else k.reset[i] = (long long)o.done;
+            k.timeout[i] = (uint8_t)o.timeout;
+            if (lane == 0) k.mask[i >> 6] = ballot;
+            if (k.cmd != nullptr) {
+                k.cmd[i] = make_float4(o.cmd[0], o.cmd[1], o.cmd[2], o.cmd[3]);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) k.terms[t][i] = o.terms[t];
+            }
+        }
+        if (want_terms) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) tileT[lane * ST + t] = active ? o.terms[t] : 0.0f;
+        }
+        __syncthreads();   // barrier 1: sigma*z rows are in tileB
+        // obs = (clean + sigma*z) - target for the 18 noisy columns (hovering.py:343-345), clean elsewhere
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            float v = obs[j] + tileB[lane * SB + j];
+            if (TASK == TASK_HOVERING) v -= P.target[j];
+            obs[j] = v;
+        }
+        if (NOBS % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < NOBS / 4; ++j)
+                reinterpret_cast<float4*>(tileO)[lane * (NOBS / 4) + j] = make_float4(obs[4 * j], obs[4 * j + 1], obs[4 * j + 2], obs[4 * j + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NOBS / 2; ++j)
+                reinterpret_cast<float2*>(tileO)[lane * (NOBS / 2) + j] = make_float2(obs[2 * j], obs[2 * j + 1]);
+        }
+    } else {
+        float z[18];
+        if (!P.noise_off) {
+            obs_noise_normals(P, env_global, z);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) z[j] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 18; ++j) tileB[lane * SB + j] = noise_sigma(j) * z[j];
+        __syncthreads();   // barrier 1
+    }
+    __syncthreads();       // barrier 2: final rows are in tileO
+
+    const int block_env0 = blockIdx.x * 64;
+    const int valid = min(64, k.n - block_env0) * NOBS;    // floats of this tile that exist
+    float* out = k.obs + (size_t)block_env0 * NOBS;
+    constexpr int NV4 = 64 * NOBS / 4;
+    constexpr int ITERS = (NV4 + 127) / 128;
+    const int t2 = wave * 64 + lane;     // role-relative thread index (any bijection onto 0..127 works)
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int m = t2 + it * 128;
+        if (m < NV4) {
+            const int e = 4 * m;
+            if (e + 3 < valid) {
+                reinterpret_cast<float4*>(out)[m] = reinterpret_cast<const float4*>(tileO)[m];
+            } else {
+                for (int q = e; q < e + 4 && q < valid; ++q) out[q] = tileO[q];
+            }
+        }
+    }
+    if (want_terms && wave == 1 && lane < 9) {     // per-tile sums of the reward terms, fixed order
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) acc += tileT[r * ST + lane];
+        k.term_sums[(size_t)blockIdx.x * 12 + lane] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Parity / inspection kernel (ag_eval_obs_reward): compute_observations + compute_quadcopter_reward of the reference
+// (hovering.py:337-459, tracking.py:202-296) on the handle's CURRENT state, with the processed actions and the
+// controller output supplied by the caller - the exact inputs the golden fixtures recorded from the reference's own
+// methods.  Same device functions (and therefore the same v_rcp / v_rsq / v_sqrt / v_exp code) as the step kernel.
+// Writes obs / reward / done / reward terms; the state is not modified.
+// ---------------------------------------------------------------------------------------------------
+template <int TASK, int CTL>
+__global__ __launch_bounds__(64) void eval_obs_reward_kernel(const KArgs k) {
+    constexpr int NOBS = TaskTraits<TASK>::kNumObs;
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= k.n) return;
+    EnvState s;
+    load_env(k, i, s);
+    float pre_a[A], a[A], cmd[4], z[18];
+    {
+        const float4 pa = k.PA[i];
+        pre_a[0] = pa.x; pre_a[1] = pa.y; pre_a[2] = pa.z; pre_a[3] = pa.w;
+        if (A == 5) pre_a[A - 1] = k.PA4[i];
+    }
+#pragma unroll
+    for (int j = 0; j < A; ++j) a[j] = k.eval_actions[(size_t)i * A + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cmd[j] = k.eval_cmd[(size_t)i * 4 + j];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) z[j] = (k.ext_noise != nullptr) ? k.ext_noise[(size_t)i * 18 + j] : 0.0f;
+    StepParams P = k.P;
+    P.noise_off = 0;
+    float obs[NOBS];
+    StepOut o;
+    env_observe_reward<TASK, CTL, true, false>(s, a, pre_a, cmd, P, 0u, z, obs, o);
+#pragma unroll
+    for (int j = 0; j < NOBS; ++j) k.obs[(size_t)i * NOBS + j] = obs[j];
+    k.rew[i] = o.rew;
+    k.reset[i] = (long long)o.done;
+    if (k.cmd != nullptr) {
+        k.cmd[i] = make_float4(cmd[0], cmd[1], cmd[2], cmd[3]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) k.terms[t][i] = o.terms[t];
+    }
+}
+
 template <int TASK, int CTL>
 static hipError_t launch_step(const KArgs& k, int block, int obs_via_lds, hipStream_t stream) {
     const int n = k.n;
@@ -264,8 +468,18 @@ static hipError_t launch_step(const KArgs& k, int block, int obs_via_lds, hipStr
         hipLaunchKernelGGL((step_kernel<TASK, CTL, 64, true, true>), dim3((n + 63) / 64), dim3(64), 0, stream, k);
         return hipGetLastError();
     }
-    if (block == 0) {   // wave-specialised geometry (default)
-        hipLaunchKernelGGL((step_kernel_ws<TASK, CTL>), dim3((n + 63) / 64), dim3(128), 0, stream, k);
+    const dim3 g64((n + 63) / 64);
+    if (block == 0) {   // wave-specialised geometry, second form (default)
+        hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, true, false>), g64, dim3(128), 0, stream, k);
+        return hipGetLastError();
+    }
+    // A/B variants of the wave-specialised kernel (ag_set_launch_params block_size 1..4; tools/sweep_env_kernel.py)
+    if (block == 2) { hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, false, false>), g64, dim3(128), 0, stream, k); return hipGetLastError(); }
+    if (block == 3) { hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, true, true>), g64, dim3(128), 0, stream, k); return hipGetLastError(); }
+    if (block == 4) { hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, false, true>), g64, dim3(128), 0, stream, k); return hipGetLastError(); }
+    if (k.reset_u8 != nullptr || k.term_sums != nullptr) return hipErrorInvalidValue;   // rollout form: ws2 only
+    if (block == 1) {   // first wave-specialised form, kept for A/B measurements
+        hipLaunchKernelGGL((step_kernel_ws<TASK, CTL>), g64, dim3(128), 0, stream, k);
         return hipGetLastError();
     }
     if (block == 64) { if (obs_via_lds) AG_LAUNCH(64, true); else AG_LAUNCH(64, false); }
@@ -273,6 +487,13 @@ static hipError_t launch_step(const KArgs& k, int block, int obs_via_lds, hipStr
     if (block == 256) { if (obs_via_lds) AG_LAUNCH(256, true); else AG_LAUNCH(256, false); }
 #undef AG_LAUNCH
     return hipErrorInvalidValue;
+}
+
+#define AG_ECAT_(a, b, c) launch_eval_##a##_##b
+#define AG_ECAT(a, b) AG_ECAT_(a, b, 0)
+hipError_t AG_ECAT(AG_TASK, AG_CTL)(const KArgs& k, hipStream_t stream) {
+    hipLaunchKernelGGL((eval_obs_reward_kernel<AG_TASK, AG_CTL>), dim3((k.n + 63) / 64), dim3(64), 0, stream, k);
+    return hipGetLastError();
 }
 
 #define AG_CAT_(a, b, c) launch_step_##a##_##b

@@ -138,6 +138,38 @@ class HipEnvHandle:
                                       ptr(rew_out, torch.float32, self.num_envs),
                                       ptr(reset_out, torch.int64, self.num_envs), self._stream()), "ag_step_into")
 
+    def step_rollout(self, actions, obs_out, rew_out, done_out, term_sums=None):
+        """Rollout form: obs / reward into rollout slots, done flags as uint8, per-tile reward-term sums
+        [ceil(n/64), 12] instead of the per-env term arrays (ag_step_rollout)."""
+        actions = self._check_actions(actions)
+        n = self.num_envs
+        assert obs_out.is_contiguous() and obs_out.dtype == torch.float32 and obs_out.numel() == n * self.num_obs
+        assert rew_out.is_contiguous() and rew_out.dtype == torch.float32 and rew_out.numel() == n
+        assert done_out.is_contiguous() and done_out.dtype == torch.uint8 and done_out.numel() == n
+        assert obs_out.device == self.device and rew_out.device == self.device and done_out.device == self.device
+        tp = None
+        if term_sums is not None:
+            assert term_sums.is_contiguous() and term_sums.dtype == torch.float32 and term_sums.device == self.device
+            assert term_sums.numel() == self.lib.ag_term_sum_tiles(n) * 12
+            tp = term_sums.data_ptr()
+        N.check(self.lib.ag_step_rollout(self.h, actions.data_ptr(), obs_out.data_ptr(), rew_out.data_ptr(),
+                                         done_out.data_ptr(), tp, self._stream()), "ag_step_rollout")
+
+    def eval_obs_reward(self, processed_actions, cmd_thrusts, noise=None):
+        """compute_observations + compute_quadcopter_reward on the CURRENT state with the reference-recorded inputs
+        (ag_eval_obs_reward; parity tests).  Results land in obs_buf / rew_buf / reset_buf / reward_terms."""
+        n = self.num_envs
+        a = processed_actions.to(device=self.device, dtype=torch.float32).contiguous()
+        c = cmd_thrusts.to(device=self.device, dtype=torch.float32).contiguous()
+        assert a.shape == (n, self.num_actions) and c.shape == (n, 4)
+        z = None
+        if noise is not None:
+            z = noise.to(device=self.device, dtype=torch.float32).contiguous()
+            assert z.shape == (n, 18)
+        N.check(self.lib.ag_eval_obs_reward(self.h, a.data_ptr(), c.data_ptr(), z.data_ptr() if z is not None else None,
+                                            self._stream()), "ag_eval_obs_reward")
+        torch.cuda.current_stream(self.device).synchronize()
+
     def step_with_inputs(self, actions, noise, reset_uniforms):
         actions = self._check_actions(actions)
         noise = noise.to(device=self.device, dtype=torch.float32).contiguous()
@@ -185,8 +217,20 @@ class HipEnvHandle:
         N.check(self.lib.ag_planning_step_with_uniforms(self.h, actions.data_ptr(), ru.data_ptr(), self._stream()),
                 "ag_planning_step_with_uniforms")
 
+    def planning_eval_post(self, actions, collisions):
+        """Post-physics half of Planning.step on the current state with supplied collision flags (parity tests)."""
+        actions = self._check_actions(actions)
+        c = collisions.to(device=self.device, dtype=torch.float32).contiguous()
+        assert c.shape == (self.num_envs,)
+        N.check(self.lib.ag_planning_eval_post(self.h, actions.data_ptr(), c.data_ptr(), self._stream()),
+                "ag_planning_eval_post")
+        torch.cuda.current_stream(self.device).synchronize()
+
     def planning_render_next_step(self, debug_skip=0):
-        N.check(self.lib.ag_planning_render_now(self.h, ctypes.c_void_p(int(debug_skip))), "ag_planning_render_now")
+        if debug_skip:
+            N.check(self.lib.ag_debug_planning_render_parts(self.h, int(debug_skip)), "ag_debug_planning_render_parts")
+        else:
+            N.check(self.lib.ag_planning_render_now(self.h), "ag_planning_render_now")
 
     def planning_get_state(self):
         n = self.num_envs

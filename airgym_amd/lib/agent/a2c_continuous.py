@@ -323,7 +323,8 @@ class A2CAgent:
         self.values_buf = torch.zeros(H, N, self.value_size, **f)
         self.rewards_buf = torch.zeros(H, N, self.value_size, **f)
         self.raw_rewards_buf = torch.zeros(H, N, **f)
-        self.dones_buf = torch.ones(H + 1, N, dtype=torch.int64, device=dev)   # dones[t] = done entering step t
+        # dones[t] = done entering step t; uint8 like the reference's rollout buffer (lib/core/experience.py:329)
+        self.dones_buf = torch.ones(H + 1, N, dtype=torch.uint8, device=dev)
         self.current_rewards = torch.zeros(N, self.value_size, **f)
         self.current_shaped_rewards = torch.zeros(N, self.value_size, **f)
         self.current_lengths = torch.zeros(N, **f)
@@ -335,6 +336,12 @@ class A2CAgent:
         self._term_names = list(terms.keys()) if terms else []
         self._term_sums = torch.zeros(len(self._term_names), dtype=torch.float64, device=dev)
         self._term_steps = 0
+        # Hovering / Tracking: the env kernel emits per-64-env-tile sums of the nine terms straight into this buffer
+        # (ag_step_rollout) instead of nine f32[N] arrays per step; one reduction per rollout (end of play_steps)
+        self._term_tiles = None
+        if (self._hip_env is not None and self._term_names and self.config.get("log_reward_terms", True)
+                and self._hip_env.task in ("hovering", "tracking")):
+            self._term_tiles = torch.zeros(H, (N + 63) // 64, 12, **f)
         from airgym_amd.lib.agent.fused_update import FusedRolloutStep
         self._fused_rollout = FusedRolloutStep(self) if FusedRolloutStep.supported(self) else None
 
@@ -379,11 +386,15 @@ class A2CAgent:
         env_actions = self.preprocess_actions(res["actions"])
         if self._hip_env is not None:
             if isinstance(self.obs_buf, dict):     # Planning: state vector into the slot, image copied from the camera buffer
-                self._hip_env.step_into(env_actions, self.obs_buf["observation"][n + 1], self.raw_rewards_buf[n],
-                                        self.dones_buf[n + 1])
+                self._hip_env.step_into(env_actions, self.obs_buf["observation"][n + 1], self.raw_rewards_buf[n], None)
+                self.dones_buf[n + 1].copy_(self._hip_env.reset_buf)
                 self.obs_buf["image"][n + 1].copy_(self._hip_env.image)
+            elif self._hip_env.task in ("hovering", "tracking"):
+                self._hip_env.step_rollout(env_actions, self.obs_buf[n + 1], self.raw_rewards_buf[n], self.dones_buf[n + 1],
+                                           self._term_tiles[n] if self._term_tiles is not None else None)
             else:
-                self._hip_env.step_into(env_actions, self.obs_buf[n + 1], self.raw_rewards_buf[n], self.dones_buf[n + 1])
+                self._hip_env.step_into(env_actions, self.obs_buf[n + 1], self.raw_rewards_buf[n], None)
+                self.dones_buf[n + 1].copy_(self._hip_env.reset_buf)
             time_outs = self._hip_env.time_out_buf
         else:
             obs, rewards, dones, infos = self.vec_env.step(env_actions)
@@ -404,7 +415,9 @@ class A2CAgent:
         # [count, sum reward, sum shaped reward, sum length] of the episodes that ended this step: one fused reduction
         self.ep_stats[n] = (torch.stack((torch.ones_like(done_f), self.current_rewards[:, 0],
                                          self.current_shaped_rewards[:, 0], self.current_lengths)) * done_f).sum(1)
-        if self._term_names and self.config.get("log_reward_terms", True):
+        if self._term_tiles is not None:
+            pass                              # per-tile sums were written by the env kernel; reduced once per rollout
+        elif self._term_names and self.config.get("log_reward_terms", True):
             stacked = getattr(self._hip_env, "reward_terms_stacked", None)
             if stacked is not None:       # one reduction for all terms
                 self._term_sums += stacked.sum(1).double() / self._hip_env.num_envs
@@ -419,7 +432,11 @@ class A2CAgent:
     @torch.no_grad()
     def play_steps(self):
         H = self.horizon_length
-        graphable = self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0
+        # capture needs an even horizon (device tick ping-pong); Planning decides on the HOST, at capture time, which steps
+        # render the camera (every 4th, planning.py:153-156), so its cadence survives replay only if H % 4 == 0
+        planning = getattr(self._hip_env, "task", None) == "planning"
+        graphable = (self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0
+                     and (not planning or H % 4 == 0))
         fr = self._fused_rollout
 
         def rollout():
@@ -429,6 +446,9 @@ class A2CAgent:
                 self._rollout_step(n)
             if fr is not None:
                 fr.end_rollout()
+            if self._term_tiles is not None:
+                self._term_sums += self._term_tiles.sum((0, 1), dtype=torch.float64)[:len(self._term_names)] / (
+                    self.num_actors * self.num_agents)
         if "rollout" in self._graphs:
             self._graphs["rollout"].replay()
         else:
@@ -555,9 +575,10 @@ class A2CAgent:
         if self.multi_gpu:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.flat_grad /= self.world_size
-        kl = self.flat_grad[-1].double() if need_kl else None
         adaptive = self.is_adaptive_lr and self.schedule_type == "legacy"
-        if self.flat_grad.is_cuda and self.config.get("use_fused_adam", True):
+        fused_adam = self.flat_grad.is_cuda and self.config.get("use_fused_adam", True)
+        kl = self.flat_grad[-1].double() if (need_kl or (adaptive and not fused_adam)) else None   # the torch schedule reads it
+        if fused_adam:
             self.optimizer.fused_clip_step(
                 self.flat_grad, self.grad_norm if self.truncate_grads else 0.0,
                 self.kl_threshold if adaptive else 0.0, getattr(self.scheduler, "min_lr", 0.0),

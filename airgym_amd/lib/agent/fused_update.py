@@ -223,7 +223,7 @@ class FusedMLPStep:
 
 class FusedRolloutStep:
     """One step of A2CBase.play_steps (lib/agent/a2c_base.py:651-695) as six launches:
-    ag_mlp_input_layer -> [GEMM (+ELU)] -> ag_elu_heads -> ag_policy_sample -> ag_step_into -> ag_rollout_account
+    ag_mlp_input_layer -> [GEMM (+ELU)] -> ag_elu_heads -> ag_policy_sample -> ag_step_rollout -> ag_rollout_account
     (+ two one-kernel reductions for the logged statistics).  The action noise is Philox-based and counter-keyed, so the
     captured hipGraph of the whole rollout draws fresh noise on every replay (begin_rollout bumps the device counter)."""
 
@@ -264,11 +264,6 @@ class FusedRolloutStep:
                                          dtype=torch.float64, device=dev)
         self.seed = (int(agent.params.get("seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
         self.id_offset = agent.global_rank * n
-        stacked = getattr(agent._hip_env, "reward_terms_stacked", None)
-        # per-step, per-block sums of the reward-term arrays (written by ag_rollout_account, reduced once per rollout)
-        self.term_partials = (torch.zeros(agent.horizon_length, self.acct_partials.shape[1], stacked.shape[0],
-                                          dtype=torch.float64, device=dev)
-                              if stacked is not None and agent._term_names and agent.config.get("log_reward_terms", True) else None)
 
     def begin_rollout(self):
         self.counter.add_(1)      # captured with the rollout graph: every replay advances the noise counter
@@ -281,8 +276,6 @@ class FusedRolloutStep:
 
     def end_rollout(self):
         torch.sum(self.acct_partials, 1, out=self.agent.ep_stats)
-        if self.term_partials is not None:
-            self.agent._term_sums += self.term_partials.sum((0, 1)) / self.n
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.agent.ppo_device).cuda_stream)
@@ -344,10 +337,10 @@ class FusedRolloutStep:
                                      ag.mus_buf[slot].data_ptr(), ag.sigmas_buf[slot].data_ptr(),
                                      self.env_actions.data_ptr(), n, A, st), "ag_policy_sample")
         env = ag._hip_env
-        env.step_into(self.env_actions, ag.obs_buf[slot + 1], ag.raw_rewards_buf[slot], ag.dones_buf[slot + 1])
+        # env kernel in its rollout form: u8 done flags and per-tile reward-term sums straight into the rollout buffers
+        env.step_rollout(self.env_actions, ag.obs_buf[slot + 1], ag.raw_rewards_buf[slot], ag.dones_buf[slot + 1],
+                         ag._term_tiles[slot] if ag._term_tiles is not None else None)
         sh = ag.rewards_shaper
-        tp = self.term_partials
-        stacked = env.reward_terms_stacked if tp is not None else None
         tmo = env.time_out_buf if ag.value_bootstrap else None
         N.check(lib.ag_rollout_account(ag.raw_rewards_buf[slot].data_ptr(), ag.dones_buf[slot + 1].data_ptr(),
                                        tmo.data_ptr() if tmo is not None else None,
@@ -355,10 +348,7 @@ class FusedRolloutStep:
                                        float(sh.scale_value), float(sh.shift_value), float(sh.min_val), float(sh.max_val),
                                        int(bool(sh.log_val)), float(ag.gamma), ag.rewards_buf[slot].data_ptr(),
                                        ag.current_rewards.data_ptr(), ag.current_shaped_rewards.data_ptr(),
-                                       ag.current_lengths.data_ptr(), self.acct_partials[slot].data_ptr(), n,
-                                       stacked.data_ptr() if tp is not None else None, stacked.shape[0] if tp is not None else 0,
-                                       stacked.shape[1] if tp is not None else 0,
-                                       tp[slot].data_ptr() if tp is not None else None, st),
+                                       ag.current_lengths.data_ptr(), self.acct_partials[slot].data_ptr(), n, st),
                 "ag_rollout_account")
 
     @torch.no_grad()

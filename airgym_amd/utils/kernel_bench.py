@@ -24,33 +24,63 @@ def algo_bytes(task, ctl_mode, num_obs, num_actions):
     return reads + writes
 
 
-def measure_env_kernel(env, steps_per_graph=48, replays=20, warmup_replays=3, use_graph=True, seed=1):
-    """Returns dict(us_per_step, env_steps_per_s, gbps_algorithmic).  `env` is a HipEnvHandle."""
+KERNEL_VARIANTS = {0: "step_kernel_ws2<{t},{c},true,false>", 1: "step_kernel_ws<{t},{c}>", 2: "step_kernel_ws2<{t},{c},false,false>",
+                   3: "step_kernel_ws2<{t},{c},true,true>", 4: "step_kernel_ws2<{t},{c},false,true>"}
+_TASK_ID = {"hovering": 0, "tracking": 1}
+_CTL_ID = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
+
+
+def kernel_name(task, ctl_mode, variant=0):
+    """Symbol (as rocprofv3 prints it) of the env-step kernel a handle launches for launch-params variant `variant`."""
+    fmt = KERNEL_VARIANTS.get(variant, "step_kernel<{t},{c}," + str(variant) + ",...>")
+    return "ag::" + fmt.format(t=_TASK_ID[task], c=_CTL_ID[ctl_mode])
+
+
+def measure_env_kernel(env, steps_per_graph=48, replays=52, warmup_replays=3, use_graph=True, seed=1, rollout_form=True):
+    """Returns dict(us_per_step, env_steps_per_s, gbps_algorithmic, ...).  `env` is a HipEnvHandle.
+
+    rollout_form=True times the kernel exactly as the PPO rollout launches it (ag_step_rollout: obs / reward / u8 done
+    flags into rollout slots, per-tile reward-term sums); False times the drop-in ag_step (int64 reset_buf, per-env
+    item_reward_info arrays).  Default 48 x 52 = 2 496 steps, so the 2 400-step time limit fires inside the timed
+    region."""
     assert steps_per_graph % 2 == 0, "capture an even number of steps (device tick ping-pong)"
     dev = env.device
     n, A = env.num_envs, env.num_actions
     g = torch.Generator(device=dev).manual_seed(seed)
     # what a freshly initialised policy emits: N(0,1) clamped to [-1,1] (SURVEY 8(d) config 1)
     actions = torch.randn(steps_per_graph, n, A, generator=g, device=dev).clamp_(-1.0, 1.0)
+    H = 24
+    if rollout_form:
+        obs = torch.zeros(H + 1, n, env.num_obs, device=dev)
+        rew = torch.zeros(H, n, device=dev)
+        done = torch.zeros(H + 1, n, dtype=torch.uint8, device=dev)
+        tiles = torch.zeros(H, (n + 63) // 64, 12, device=dev)
+
+    def one(t):
+        if rollout_form:
+            s = t % H
+            env.step_rollout(actions[t % steps_per_graph], obs[s + 1], rew[s], done[s + 1], tiles[s])
+        else:
+            env.step(actions[t % steps_per_graph])
     stream = torch.cuda.Stream(device=dev)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(stream):
         for t in range(4):
-            env.step(actions[t])
+            one(t)
         stream.synchronize()
         graph = None
         if use_graph:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 for t in range(steps_per_graph):
-                    env.step(actions[t])
+                    one(t)
 
         def run():
             if graph is not None:
                 graph.replay()
             else:
                 for t in range(steps_per_graph):
-                    env.step(actions[t])
+                    one(t)
         for _ in range(warmup_replays):
             run()
         stream.synchronize()
@@ -70,7 +100,17 @@ def measure_env_kernel(env, steps_per_graph=48, replays=20, warmup_replays=3, us
         "algo_bytes_per_env_step": b,
         "graph": bool(use_graph),
         "steps_timed": total_steps,
+        "form": "ag_step_rollout" if rollout_form else "ag_step",
     }
+
+
+def measure_copy_ceiling(device, nbytes=1 << 30, iters=20):
+    """Achievable HBM bandwidth of this device: a device-to-device copy of `nbytes` (read + write counted), GB/s."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    src.fill_(1)
+    us = _time_us(lambda: dst.copy_(src), iters=iters, warmup=3)
+    return 2.0 * nbytes / us / 1e3
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate, 64 FLOP/clk/SIMD

@@ -156,9 +156,27 @@ int ag_step(ag_handle h, const float* actions_dev, void* stream);
  * rollout buffer) instead of the handle's own; any of the three may be NULL = use the handle's. */
 int ag_step_into(ag_handle h, const float* actions_dev, float* obs_out_dev, float* rew_out_dev,
                  int64_t* reset_out_dev, void* stream);
+/* Rollout form of ag_step_into, what A2CBase.play_steps needs from Hovering.step (lib/agent/a2c_base.py:662-695):
+ * obs / reward written into rollout slots, done flags as u8 (the width ExperienceBuffer stores dones in,
+ * lib/core/experience.py:329) and - instead of the nine per-env item_reward_info arrays - per-tile sums of the reward
+ * terms for the Episode/<term> means (lib/utils/isaacgym_utils.py:66-99): term_sums_dev [ag_term_sum_tiles(num_envs), 12]
+ * f32 (NULL = none), row b = sums over envs 64b .. 64b+63 of reward_terms[0..8].  The handle's int64 reset buffer, term
+ * arrays and cmd_thrusts are NOT written by this call; reset_mask / timeout are.  Hovering / Tracking handles. */
+int ag_term_sum_tiles(int num_envs);
+int ag_step_rollout(ag_handle h, const float* actions_dev, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,
+                    float* term_sums_dev, void* stream);
 /* Parity mode: noise_dev [num_envs,18] standard normals, reset_uniforms_dev [num_envs,12] U[0,1). */
 int ag_step_with_inputs(ag_handle h, const float* actions_dev, const float* noise_dev,
                         const float* reset_uniforms_dev, void* stream);
+
+/* Parity / inspection mode: compute_observations + compute_quadcopter_reward (hovering.py:337-459, tracking.py:202-296)
+ * evaluated on the handle's CURRENT state (as left by ag_set_state: root state, progress, pre_actions), with the
+ * processed action (self.actions after hovering.py:212-216) and the controller output (self.cmd_thrusts, :235-254)
+ * supplied by the caller; noise_dev [num_envs,18] standard normals or NULL (no noise).  No integration, no reset, the
+ * state is untouched; obs / reward / reset(int64) / reward terms land in the handle's own buffers.  This is how the
+ * golden vectors recorded from the reference's own methods are replayed on the HIP code object (tests/test_gpu_golden.py). */
+int ag_eval_obs_reward(ag_handle h, const float* processed_actions_dev, const float* cmd_thrusts_dev, const float* noise_dev,
+                       void* stream);
 
 int ag_get_buffers(ag_handle h, ag_buffers* out);
 int ag_get_state(ag_handle h, const ag_state_view* view, void* stream);
@@ -218,20 +236,18 @@ int ag_normalize_rows(const float* x_dev, const double* mean_dev, const double* 
  *   ag_rollout_account: shaped = clamp((r + shift) * scale, min, max) [log] (+ gamma * value on time-outs), running episode
  *       reward / shaped reward / length, and per-block partial sums {episodes ended, sum reward, sum shaped, sum length}
  *       in partials_dev [ag_rollout_account_blocks(n), 4] (double); running sums are cleared where dones != 0.
- *       Optional: terms_dev [num_terms][terms_stride] per-env reward-term arrays -> term_partials_dev [blocks, num_terms]
- *       per-block sums (Episode/<term> logging, lib/utils/isaacgym_utils.py:66-99).
- *   ag_gae: dones_dev [H+1, n] (dones[t] = done entering step t), rewards / values / advs / returns [H, n]. */
+ *       dones_dev is u8 [n], the width the rollout buffer stores (lib/core/experience.py:329) and ag_step_rollout writes.
+ *   ag_gae: dones_dev u8 [H+1, n] (dones[t] = done entering step t), rewards / values / advs / returns [H, n]. */
 int ag_policy_sample(const float* heads_dev, const float* logstd_dev, const double* vmean_dev, const double* vvar_dev,
                      float veps, unsigned long long seed, const long long* counter_dev, int horizon, int slot,
                      long long id_offset, float* actions_dev, float* neglogp_dev, float* values_dev, float* mus_dev,
                      float* sigmas_dev, float* env_actions_dev, int n, int A, void* stream);
 int ag_rollout_account_blocks(int n);
-int ag_rollout_account(const float* raw_reward_dev, const long long* dones_dev, const unsigned char* timeouts_dev,
+int ag_rollout_account(const float* raw_reward_dev, const unsigned char* dones_dev, const unsigned char* timeouts_dev,
                        const float* values_dev, float scale, float shift, float min_val, float max_val, int log_val,
                        float gamma, float* shaped_dev, float* cur_rew_dev, float* cur_shaped_dev, float* cur_len_dev,
-                       double* partials_dev, int n, const float* terms_dev, int num_terms, long long terms_stride,
-                       double* term_partials_dev, void* stream);
-int ag_gae(const float* rewards_dev, const float* values_dev, const long long* dones_dev, const float* last_values_dev,
+                       double* partials_dev, int n, void* stream);
+int ag_gae(const float* rewards_dev, const float* values_dev, const unsigned char* dones_dev, const float* last_values_dev,
            float gamma, float tau, float* advs_dev, float* returns_dev, int H, int n, void* stream);
 
 /* Fused edges of the MLP trunk (lib/network/mlp.py:36-39, a2c_continuous_logstd_model.py:126-146); the wide GEMMs in
@@ -326,17 +342,16 @@ int ag_planning_get_state(ag_handle h, const ag_planning_state_view* view, void*
 int ag_planning_set_state(ag_handle h, const ag_planning_state_view* view, void* stream);
 /* Parity mode: per-env reset uniforms [num_envs, 121] supplied by the caller (NULL = counter RNG). */
 int ag_planning_step_with_uniforms(ag_handle h, const float* actions_dev, const float* reset_uniforms_dev, void* stream);
-/* Force / suppress the camera render of the NEXT step (tests); -1 restores the every-4th-step schedule. */
-int ag_planning_render_now(ag_handle h, void* stream);
+/* Parity / inspection mode: the post-physics half of Planning.step (planning.py:158-183: progress++, compute_observations,
+ * compute_quadcopter_reward, reset of done envs) on the handle's CURRENT state, with the collision flags
+ * (Customized.check_collisions, customized.py:393-397) supplied by the caller [num_envs] f32 0/1 instead of the geometric
+ * test - how the vectors recorded from the reference's own Planning methods are replayed on the HIP kernel.  actions_dev is
+ * the RAW action (the thrust channel is remapped in rate mode exactly as in a step). */
+int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* collisions_dev, void* stream);
+/* Render the camera on the NEXT step regardless of the every-4th-step schedule (planning.py:153-156). */
+int ag_planning_render_now(ag_handle h);
 
-/* Diagnostic: a kernel with the step's loads/stores and no arithmetic (launch + memory-latency floor). */
-int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream);
-/* diagnostic variants: mode 1 = non-temporal stores, 2 = non-temporal loads + stores, 3 = empty kernel (launch boundary) */
-int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void* stream);
-
-/* Launch geometry knobs for benchmarking: block_size 0 = wave-specialised kernel (default: physics wave + noise wave
- * per 64 envs), 64/128/256 = one-wave-per-64-envs kernel with that workgroup size (obs staged through LDS or not). */
-int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
+/* Benchmark / diagnostic knobs are not part of this interface: see airgym_hip_debug.h. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,38 @@
+/*
+ * airgym_hip_debug.h - benchmark and diagnostic entry points of libairgym_hip.so.
+ *
+ * NOT part of the drop-in interface (include/airgym_hip.h): nothing here replaces reference behaviour.  These exist so
+ * that bench.py / tools/ can price the launch floor and A/B the launch geometry of the env-step kernel on the same
+ * handle, and so that the Planning render kernel's phases can be timed separately.
+ */
+#ifndef AIRGYM_HIP_DEBUG_H
+#define AIRGYM_HIP_DEBUG_H
+
+#include "airgym_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A kernel with the Hovering/CTBR step's loads and stores and no arithmetic (launch + memory-latency floor). */
+int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream);
+/* mode 1 = non-temporal stores, 2 = non-temporal loads + stores, 3 = empty kernel (pure dependent-launch boundary) */
+int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void* stream);
+
+/* Launch geometry of the Hovering/Tracking step kernel: block_size 0 = wave-specialised kernel (default: physics wave +
+ * noise wave per 64 envs, state stored right after the integration), 2 = same with late state stores, 3 / 4 = 0 / 2 with
+ * alternating wave roles per workgroup, 1 = the first wave-specialised form (round 1), 64 / 128 / 256 = one wave per
+ * 64 envs with that workgroup size (obs staged through LDS or not). */
+int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
+
+/* Where the hardware places the step kernel's waves: launches its geometry (ceil(n/64) workgroups x 2 waves) and writes, per
+ * wave, {HW_REG_HW_ID, HW_REG_XCC_ID} into out_dev [ceil(n/64) * 2, 2] u32 (tools/wave_placement.py decodes SIMD / CU / XCC). */
+int ag_debug_wave_placement(ag_handle h, unsigned int* out_dev, void* stream);
+
+/* Next Planning step renders with parts of the render kernel skipped: bit0 ray-cast, bit1 noise passes, bit2 5x5 pass. */
+int ag_debug_planning_render_parts(ag_handle h, int skip_mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRGYM_HIP_DEBUG_H */

@@ -7,7 +7,7 @@ import re
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(REPO, "include", "airgym_hip.h")
+HEADERS = [os.path.join(REPO, "include", "airgym_hip.h"), os.path.join(REPO, "include", "airgym_hip_debug.h")]
 
 
 @pytest.fixture(scope="module")
@@ -17,7 +17,7 @@ def lib():
 
 
 def declared_symbols():
-    src = open(HEADER).read()
+    src = "\n".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(ag_[a-z_0-9]+)\s*\(", src)))
 

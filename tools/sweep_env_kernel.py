@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Sweep launch geometry of the env-step kernel on the GPU box (dev tool; prints one JSON line per config)."""
+"""A/B the launch geometry / variants of the env-step kernel on the GPU box (dev tool; one JSON line per config).
+
+    python tools/sweep_env_kernel.py --blocks 0 1 2 3 4 64 --forms rollout api --envs 65536 131072
+"""
 import argparse
 import json
 import os
@@ -9,25 +12,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from airgym_amd.hip_env import HipEnvHandle  # noqa: E402
-from airgym_amd.utils.kernel_bench import measure_env_kernel  # noqa: E402
+from airgym_amd.utils.kernel_bench import kernel_name, measure_env_kernel  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--task", default="hovering")
 ap.add_argument("--ctl", default="rate")
 ap.add_argument("--envs", type=int, nargs="+", default=[65536])
-ap.add_argument("--blocks", type=int, nargs="+", default=[0, 64, 256])
-ap.add_argument("--terms", type=int, default=1)
-ap.add_argument("--nograph", action="store_true")
+ap.add_argument("--blocks", type=int, nargs="+", default=[0, 1, 2, 3, 4, 64])
+ap.add_argument("--forms", nargs="+", default=["rollout", "api"])
+ap.add_argument("--replays", type=int, default=20)
 a = ap.parse_args()
 print(torch.cuda.get_device_name(0), file=sys.stderr)
 for n in a.envs:
-    for terms in ([a.terms] if a.terms in (0, 1) else [0, 1]):
-        env = HipEnvHandle(a.task, a.ctl, n, seed=0, reward_terms=bool(terms))
-        for block in a.blocks:
-            for lds in (1, 0):
-                env.set_launch_params(block, lds)
-                for graph in ([False] if a.nograph else [True, False]):
-                    r = measure_env_kernel(env, use_graph=graph)
-                    r.update(task=a.task, ctl=a.ctl, envs=n, block=block, obs_via_lds=lds, reward_terms=terms)
-                    print(json.dumps(r))
-        env.close()
+    env = HipEnvHandle(a.task, a.ctl, n, seed=0, reward_terms=True)
+    for block in a.blocks:
+        env.set_launch_params(block, 1)
+        for form in a.forms:
+            if form == "rollout" and (block == 1 or block >= 64):
+                continue        # the rollout form exists for the ws2 family only
+            r = measure_env_kernel(env, replays=a.replays, rollout_form=(form == "rollout"))
+            r.update(task=a.task, ctl=a.ctl, envs=n, block=block, kernel=kernel_name(a.task, a.ctl, block),
+                     frac=r["gbps_algorithmic"] / 8000.0)
+            print(json.dumps(r), flush=True)
+    env.close()
