@@ -19,7 +19,8 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kDLogstd0 = 4;                              // a, c, b, kl, dlogstd[<=5], dbias_heads[<=6]
 constexpr int kDBias0 = 4 + AG_MAX_ACTIONS;
-constexpr int kNumSums = 4 + AG_MAX_ACTIONS + AG_MAX_ACTIONS + 1;
+constexpr int kClipCount = 4 + AG_MAX_ACTIONS + AG_MAX_ACTIONS + 1;   // rows whose ratio left [1 - e_clip, 1 + e_clip]
+constexpr int kNumSums = kClipCount + 1;
 
 struct LossArgs {
     const float* heads;      // [M, A+1]
@@ -56,6 +57,8 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(const LossArgs k) {
         logstd_sum += ls[a];
     }
     const float half_log_2pi_a = 0.5f * 1.8378770664093453f * (float)A;
+    // policy_clip_fraction (lib/core/torch_ext.py:168-178): logratio outside [log(1 - e), log(1 + e)]
+    const float log_lo = logf(1.0f - k.e_clip), log_hi = logf(1.0f + k.e_clip);
 
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < k.M; i += gridDim.x * kBlock) {
         const float* h = k.heads + (size_t)i * (A + 1);
@@ -70,7 +73,9 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(const LossArgs k) {
         const float v = h[A];
         const float nlp = 0.5f * q + half_log_2pi_a + logstd_sum;
         const float adv = k.advantages[i];
-        const float ratio = expf(k.old_neglogp[i] - nlp);
+        const float logratio = k.old_neglogp[i] - nlp;
+        const float ratio = expf(logratio);
+        acc[kClipCount] += (logratio < log_lo || logratio > log_hi) ? 1.0f : 0.0f;
         const float lo = 1.0f - k.e_clip, hi = 1.0f + k.e_clip;
         const float rc = fminf(fmaxf(ratio, lo), hi);
         const float l1 = -adv * ratio, l2 = -adv * rc;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(const LossArgs k) {
 struct FinalizeArgs {
     const float* partials; int num_blocks; int M; int A;
     const float* logstd; float entropy_coef, critic_coef, bounds_loss_coef;
-    float* grad_logstd; float* grad_head_bias; float* kl_out; float* stats;   // stats[6]: a, c, entropy, b, kl, loss
+    float* grad_logstd; float* grad_head_bias; float* kl_out; float* stats;   // stats[8]: a, c, entropy, b, kl, loss, clip_frac, -
 };
 
 __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const FinalizeArgs k) {
@@ -195,6 +200,8 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const FinalizeAr
         *k.kl_out = kl;
         k.stats[0] = a_loss; k.stats[1] = c_loss; k.stats[2] = entropy; k.stats[3] = b_loss; k.stats[4] = kl;
         k.stats[5] = a_loss + 0.5f * c_loss * k.critic_coef - entropy * k.entropy_coef + b_loss * k.bounds_loss_coef;
+        k.stats[6] = tot[kClipCount] * inv_m;      // diagnostics/clip_frac (lib/core/dignostics.py:55-59)
+        k.stats[7] = 0.0f;
     }
 }
 

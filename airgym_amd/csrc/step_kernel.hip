@@ -404,11 +404,22 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k) {
             }
         }
     }
-    if (want_terms && wave == 1 && lane < 9) {     // per-tile sums of the reward terms, fixed order
+    if (want_terms && wave == 1) {     // per-tile sums of the reward terms, fixed order: 7 row groups x 9 terms, then 7 -> 1
+        const int term = lane % 9, part = lane / 9;          // lanes 0..62
+        const int r0 = (part == 0) ? 0 : 9 * part + 1, r1 = 9 * part + 10;   // row groups of 10,9,9,9,9,9,9
         float acc = 0.0f;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) acc += tileT[r * ST + lane];
-        k.term_sums[(size_t)blockIdx.x * 12 + lane] = acc;
+        if (lane < 63) {
+            for (int r = r0; r < r1; ++r) acc += tileT[r * ST + term];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 63) tileB[lane] = acc;                    // tileB is free after barrier 2 (same wave wrote it)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 9) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int p = 0; p < 7; ++p) tot += tileB[p * 9 + lane];
+            k.term_sums[(size_t)blockIdx.x * 12 + lane] = tot;
+        }
     }
 }
 
@@ -469,12 +480,12 @@ static hipError_t launch_step(const KArgs& k, int block, int obs_via_lds, hipStr
         return hipGetLastError();
     }
     const dim3 g64((n + 63) / 64);
-    if (block == 0) {   // wave-specialised geometry, second form (default)
-        hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, true, false>), g64, dim3(128), 0, stream, k);
+    if (block == 0) {   // wave-specialised geometry, second form (default: state stored after the reward, measured faster)
+        hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, false, false>), g64, dim3(128), 0, stream, k);
         return hipGetLastError();
     }
     // A/B variants of the wave-specialised kernel (ag_set_launch_params block_size 1..4; tools/sweep_env_kernel.py)
-    if (block == 2) { hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, false, false>), g64, dim3(128), 0, stream, k); return hipGetLastError(); }
+    if (block == 2) { hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, true, false>), g64, dim3(128), 0, stream, k); return hipGetLastError(); }
     if (block == 3) { hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, true, true>), g64, dim3(128), 0, stream, k); return hipGetLastError(); }
     if (block == 4) { hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, false, true>), g64, dim3(128), 0, stream, k); return hipGetLastError(); }
     if (k.reset_u8 != nullptr || k.term_sums != nullptr) return hipErrorInvalidValue;   // rollout form: ws2 only

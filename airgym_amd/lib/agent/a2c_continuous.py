@@ -199,6 +199,11 @@ class A2CAgent:
             self.scheduler = schedulers.IdentityScheduler()
         self.e_clip = config["e_clip"]
         self.clip_value = config["clip_value"]
+        # PpoDiagnostics (lib/core/dignostics.py:17-60; on in every shipped YAML): diagnostics/exp_var, clip_frac/<mini-epoch>,
+        # rms_value/{mean,var}; rank 0 only like a2c_base.py:127-130
+        self.use_diagnostics = bool(config.get("use_diagnostics", False)) and getattr(self, "global_rank", 0) == 0
+        self.diag_dict = {}
+        self._last_clip = None
         self.horizon_length = config["horizon_length"]
         self.normalize_advantage = config["normalize_advantage"]
         self.normalize_input = config.get("normalize_input", False)
@@ -547,6 +552,9 @@ class A2CAgent:
             return self._loss_and_backward_fused(mb)
         res = self.model({"is_train": True, "prev_actions": mb["actions"], "obs": mb["obs"]})
         a_loss = common_losses.actor_loss(mb["old_logp_actions"], res["prev_neglogp"], mb["advantages"], self.ppo, self.e_clip)
+        if self.use_diagnostics:
+            with torch.no_grad():
+                self._last_clip = torch_ext.policy_clip_fraction(res["prev_neglogp"].detach(), mb["old_logp_actions"], self.e_clip)
         if self.has_value_loss:
             c_loss = common_losses.critic_loss(mb["old_values"], res["values"], self.e_clip, mb["returns"], self.clip_value)
         else:
@@ -607,7 +615,7 @@ class A2CAgent:
                 key = (idx, bool(self.model.update_stats))
                 entry = self._upd_graphs.get(key)
                 if entry is None:
-                    row = torch.zeros(6, dtype=torch.float32, device=self.ppo_device)
+                    row = torch.zeros(8, dtype=torch.float32, device=self.ppo_device)
 
                     def body():
                         self._fused_step.step(mb, stats_out=row)
@@ -617,8 +625,10 @@ class A2CAgent:
                 entry[0].replay()
                 st = self._fused_step.next_stats_row()
                 st.copy_(entry[1])
+                self._last_clip = st[6]
                 return st[0], st[1], st[2], st[3], st[4]
             st = self._fused_step.step(mb)
+            self._last_clip = st[6]
             kl = self._reduce_clip_step(need_kl=self.multi_gpu)      # multi-GPU: the rank-averaged KL
             return st[0], st[1], st[2], st[3], (kl if self.multi_gpu else st[4])
         a, c, e, b, mu, sigma = self._loss_and_backward(mb)
@@ -662,13 +672,19 @@ class A2CAgent:
         self.model.stats_group = self.group if (self.multi_gpu and self.sync_normalizers) else None
         if self._fused_step is not None:
             self._fused_step.begin_epoch()
+        if self.use_diagnostics:
+            self._diag_epoch_begin()
         for mini_ep in range(self.mini_epochs_num):
             ep_kls = []
+            clip_fracs = []
             # "don't need to update statistics more than one miniepoch", a2c_continuous.py:130-131
             self.model.update_stats = self.normalize_input and mini_ep == 0
             for i in range(len(self.dataset)):
+                self._last_clip = None
                 a, c, e, b, kl = self.train_actor_critic(i)
                 a_losses.append(a); c_losses.append(c); entropies.append(e); ep_kls.append(kl)
+                if self.use_diagnostics and self._last_clip is not None:
+                    clip_fracs.append(self._last_clip)
                 if self.bounds_loss_coef is not None:
                     b_losses.append(b)
             av_kls = torch_ext.mean_list(ep_kls)
@@ -680,6 +696,8 @@ class A2CAgent:
                                                                         self.epoch_num, 0, av_kls.item())
                 self.optimizer.lr.fill_(self.last_lr)
             kls.append(av_kls)
+            if self.use_diagnostics and clip_fracs:     # PpoDiagnostics.mini_epoch, dignostics.py:43-46
+                self.diag_dict[f"diagnostics/clip_frac/{mini_ep}"] = torch.stack([c.float().reshape(()) for c in clip_fracs]).mean()
         self.model.update_stats = False
         if self.linear_lr:
             self.last_lr, self.entropy_coef = self.scheduler.update(self.last_lr, self.entropy_coef, self.epoch_num,
@@ -770,6 +788,20 @@ class A2CAgent:
             if should_exit:
                 return self.last_mean_rewards, epoch_num
 
+    @torch.no_grad()
+    def _diag_epoch_begin(self):
+        """PpoDiagnostics.epoch + the exp_var part of .mini_batch (dignostics.py:28-41,49-57).  explained_variance is a
+        function of the dataset's (old values, returns) only, so the per-minibatch values the reference averages over every
+        minibatch of every mini-epoch are computed here once per epoch from the contiguous minibatch slices."""
+        vd = self.dataset.values_dict
+        v, r = vd["old_values"].reshape(-1), vd["returns"].reshape(-1)
+        nmb = max(1, v.numel() // self.minibatch_size)
+        v, r = v[:nmb * self.minibatch_size].view(nmb, -1), r[:nmb * self.minibatch_size].view(nmb, -1)
+        self.diag_dict["diagnostics/exp_var"] = (1.0 - torch.var(r - v, dim=1) / torch.var(r, dim=1)).mean()
+        if self.normalize_value:
+            self.diag_dict["diagnostics/rms_value/mean"] = self.model.value_mean_std.running_mean.clone()
+            self.diag_dict["diagnostics/rms_value/var"] = self.model.value_mean_std.running_var.clone()
+
     def write_stats(self, total_time, epoch_num, stats, frame, curr_frames):
         """Same TensorBoard tags as a2c_base.py:318-336 and a2c_continuous.py:225-242."""
         w = self.writer
@@ -792,6 +824,8 @@ class A2CAgent:
         w.add_scalar("info/e_clip", self.e_clip, frame)
         w.add_scalar("info/kl", stats["kl"], frame)
         w.add_scalar("info/epochs", epoch_num, frame)
+        for k, v in self.diag_dict.items():      # PpoDiagnostics.send_info: x axis = epoch (dignostics.py:23-27)
+            w.add_scalar(k, float(v.reshape(-1)[0]), epoch_num)
         for k, v in getattr(self, "episode_term_means", {}).items():
             w.add_scalar("Episode/" + k, v, epoch_num)
         if self.game_rewards.current_size > 0:

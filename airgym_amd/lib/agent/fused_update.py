@@ -95,7 +95,7 @@ class FusedMLPStep:
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
         self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
         self.wt_last = torch.empty(self.layers[-1][0].shape[1], Cl, **f)      # W_last^T, refreshed before every forward
-        self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 6, **f)
+        self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 8, **f)
         self.k = 0
 
     def begin_epoch(self):
@@ -112,7 +112,7 @@ class FusedMLPStep:
     @torch.no_grad()
     def step(self, mb, stats_out=None):
         """Forward, loss, backward of minibatch `mb`; gradients (and the KL in the appended slot) are left in
-        agent.flat_grad.  Returns the stats row [a_loss, c_loss, entropy, b_loss, kl, loss] (device, no sync);
+        agent.flat_grad.  Returns the stats row [a_loss, c_loss, entropy, b_loss, kl, loss, clip_frac, 0] (device, no sync);
         `stats_out` overrides where that row is written (hipGraph capture needs a fixed address)."""
         ag, lib, m = self.agent, self.lib, self.agent.model
         M, A, S = self.M, self.A, SPLIT_K

@@ -75,3 +75,15 @@ class AverageMeter:
 
     def get_mean(self):
         return self.mean
+
+
+def explained_variance(y_pred, y):
+    """1 - Var[y - y_pred] / Var[y] (lib/core/torch_ext.py:149-166, masks=None branch; unbiased variances)."""
+    return 1.0 - torch.var(y - y_pred) / torch.var(y)
+
+
+def policy_clip_fraction(new_neglogp, old_neglogp, clip_param):
+    """Fraction of samples whose probability ratio left [1 - clip, 1 + clip] (lib/core/torch_ext.py:168-178)."""
+    import math
+    logratio = old_neglogp - new_neglogp
+    return torch.logical_or(logratio < math.log(1.0 - clip_param), logratio > math.log(1.0 + clip_param)).float().mean()

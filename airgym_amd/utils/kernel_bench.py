@@ -24,7 +24,7 @@ def algo_bytes(task, ctl_mode, num_obs, num_actions):
     return reads + writes
 
 
-KERNEL_VARIANTS = {0: "step_kernel_ws2<{t},{c},true,false>", 1: "step_kernel_ws<{t},{c}>", 2: "step_kernel_ws2<{t},{c},false,false>",
+KERNEL_VARIANTS = {0: "step_kernel_ws2<{t},{c},false,false>", 1: "step_kernel_ws<{t},{c}>", 2: "step_kernel_ws2<{t},{c},true,false>",
                    3: "step_kernel_ws2<{t},{c},true,true>", 4: "step_kernel_ws2<{t},{c},false,true>"}
 _TASK_ID = {"hovering": 0, "tracking": 1}
 _CTL_ID = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}

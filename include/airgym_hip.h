@@ -194,7 +194,8 @@ int ag_set_tick(ag_handle h, uint64_t tick);
  *   heads_dev [M, A+1]: mu columns then the value column (one GEMM output); logstd_dev [A].
  *   d_heads_dev [M, A+1]: d(a_loss.mean + 0.5*critic_coef*c_loss.mean + bounds_coef*b_loss.mean)/d heads.
  *   partials_dev [ag_ppo_loss_max_blocks(), ag_ppo_loss_num_sums()]: per-block sums of
- *       {a_loss, c_loss, b_loss, kl, d(sum_i a_i)/d logstd_0..AG_MAX_ACTIONS-1, column sums of d_heads 0..AG_MAX_ACTIONS};
+ *       {a_loss, c_loss, b_loss, kl, d(sum_i a_i)/d logstd_0..AG_MAX_ACTIONS-1, column sums of d_heads 0..AG_MAX_ACTIONS,
+ *        number of rows whose probability ratio left [1 - e_clip, 1 + e_clip]};
  *       *num_blocks_out rows are valid; the caller reduces them (deterministic) and divides by M, or hands them to
  *       ag_ppo_loss_finalize.  bound_type: 0 none, 1 'bound', 2 'regularisation'.
  *   new_mu_dev / new_sigma_dev [M, A]: optional write-back of the current policy rows (both or neither). */
@@ -209,7 +210,8 @@ int ag_ppo_loss(const float* heads_dev, const float* logstd_dev, const float* ac
 
 /* Reduce the partials of ag_ppo_loss in one workgroup and write what the optimizer step consumes:
  *   grad_logstd_dev [A] = d loss / d logstd (entropy term included), grad_head_bias_dev [A+1] = bias gradient of the fused
- *   mu|value head, *kl_out_dev = minibatch KL, stats_dev [6] = {a_loss, c_loss, entropy, b_loss, kl, total loss}
+ *   mu|value head, *kl_out_dev = minibatch KL, stats_dev [8] = {a_loss, c_loss, entropy, b_loss, kl, total loss,
+ *   clip fraction (PpoDiagnostics, lib/core/dignostics.py:49-59; torch_ext.policy_clip_fraction :168-178), 0}
  *   (a2c_continuous.py:340-369). */
 int ag_ppo_loss_finalize(const float* partials_dev, int num_blocks, int M, int A, const float* logstd_dev,
                          float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd_dev,

@@ -20,8 +20,8 @@ int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream);
 int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void* stream);
 
 /* Launch geometry of the Hovering/Tracking step kernel: block_size 0 = wave-specialised kernel (default: physics wave +
- * noise wave per 64 envs, state stored right after the integration), 2 = same with late state stores, 3 / 4 = 0 / 2 with
- * alternating wave roles per workgroup, 1 = the first wave-specialised form (round 1), 64 / 128 / 256 = one wave per
+ * noise wave per 64 envs, state stored after the reward), 2 = same with the state stored right after the integration,
+ * 3 / 4 = 2 / 0 with alternating wave roles per workgroup, 1 = the first wave-specialised form (round 1), 64 / 128 / 256 = one wave per
  * 64 envs with that workgroup size (obs staged through LDS or not). */
 int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
 

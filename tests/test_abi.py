@@ -107,7 +107,7 @@ def test_ppo_kernel_entry_points_validate_arguments_before_any_launch(lib):
     p = ctypes.cast(buf, ctypes.c_void_p)
     pd = ctypes.cast(dbl, ctypes.c_void_p)
     # host-side pure queries
-    assert lib.ag_ppo_loss_num_sums() == 4 + 5 + 6 and lib.ag_ppo_loss_max_blocks() >= 256
+    assert lib.ag_ppo_loss_num_sums() == 4 + 5 + 6 + 1 and lib.ag_ppo_loss_max_blocks() >= 256
     assert lib.ag_wgrad_rows_per_block(0) > 0 and lib.ag_input_wgrad_rows(18) > 0 and lib.ag_input_wgrad_rows(48) == 0
     assert lib.ag_sum_rows_groups() >= 16 and lib.ag_rollout_account_blocks(65536) == 256
     assert lib.ag_rms_scratch_doubles(18) > 0 and lib.ag_adam_state_bytes() >= 32

@@ -76,9 +76,10 @@ def test_golden_reward_and_done(Handle, golden, task, ctl):
         if key in g.files:      # thrust_reward is only emitted by the rate / atti branches of the reference
             np.testing.assert_allclose(buf.cpu().numpy(), g[key], rtol=0, atol=1e-5, equal_nan=True, err_msg=name)
     if task == "hovering":
-        # rows 4..11: |rel| = 3.999 / 4.001, rel_z = +-1.999 / +-2.001, roll just below / above 90 deg
-        assert list(reset[4:12]) == [0, 1, 0, 1, 0, 1, 0, 1]
-        assert list(g["reset"][4:12]) == [0, 1, 0, 1, 0, 1, 0, 1]
+        # rows 4..11: |rel| = 3.999 / 4.001, rel_z = +-1.999 / +-2.001, roll just below / above 90 deg; in atti mode a row
+        # also ends when its (random) a0 is negative (hovering.py:445-446)
+        a0_neg = (g["actions"][4:12, 0] < 0) if ctl == "atti" else np.zeros(8, bool)
+        assert list(reset[4:12]) == list(np.array([0, 1, 0, 1, 0, 1, 0, 1]) | a0_neg)
     env.close()
 
 
@@ -413,7 +414,7 @@ def test_golden_ppo_loss_kernel(golden):
                                 d_heads.data_ptr(), new_mu.data_ptr(), new_sigma.data_ptr(), parts.data_ptr(),
                                 ctypes.byref(nb), _stream()), "ag_ppo_loss")
         g_ls, g_hb = torch.empty(A, **f), torch.empty(A + 1, **f)
-        kl_out, stats = torch.empty(1, **f), torch.empty(6, **f)
+        kl_out, stats = torch.empty(1, **f), torch.empty(8, **f)
         N.check(lib.ag_ppo_loss_finalize(parts.data_ptr(), nb.value, M, A, dev[1].data_ptr(), ent_coef, critic_coef, b_coef,
                                          g_ls.data_ptr(), g_hb.data_ptr(), kl_out.data_ptr(), stats.data_ptr(), _stream()),
                 "ag_ppo_loss_finalize")
@@ -423,6 +424,9 @@ def test_golden_ppo_loss_kernel(golden):
         assert abs(s[0].item() - a_l.mean().item()) < 1e-5 and abs(s[2].item() - ent.item()) < 1e-6
         assert abs(s[4].item() - kl.item()) < 1e-5 * max(1.0, abs(kl.item())) and abs(kl_out.item() - kl.item()) < 1e-5 * max(1.0, abs(kl.item()))
         assert abs(s[5].item() - loss.item()) < 2e-5 * max(1.0, abs(loss.item()))
+        lr_ = old_nlp - nlp.detach()       # policy_clip_fraction, lib/core/torch_ext.py:168-178
+        clip_ref = ((lr_ < np.log(1.0 - e_clip)) | (lr_ > np.log(1.0 + e_clip))).float().mean().item()
+        assert abs(s[6].item() - clip_ref) <= 1.0 / M + 1e-7 and clip_ref > 0.05
         np.testing.assert_allclose(d_heads.cpu().numpy(), hq.grad.numpy(), rtol=1e-4, atol=1e-8)
         np.testing.assert_allclose(g_ls.cpu().numpy(), lq.grad.numpy(), rtol=1e-4, atol=1e-7)
         np.testing.assert_allclose(g_hb.cpu().numpy(), hq.grad.sum(0).numpy(), rtol=1e-4, atol=1e-7)

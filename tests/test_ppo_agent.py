@@ -336,3 +336,38 @@ def test_runner_dispatch_and_multi_gpu_device(monkeypatch):
     assert out["env_config"]["sim_device"] == "cuda:3" and out["device"] == "cuda:3" and out["multi_gpu"] is True
     out1 = mod.update_config({"params": {"config": {"env_config": {}}}}, dict(args, multi_gpu=False))["params"]["config"]
     assert out1["env_config"]["sim_device"] == args["sim_device"]
+
+
+def test_ppo_diagnostics_tags(tmp_path):
+    """PpoDiagnostics parity (lib/core/dignostics.py:17-60, on in every shipped YAML): diagnostics/exp_var,
+    diagnostics/clip_frac/<mini-epoch>, diagnostics/rms_value/{mean,var} reach the summary writer with the epoch as x."""
+    from airgym_amd.lib.core import torch_ext
+    torch.manual_seed(2)
+    params = _stub_env.ppo_params(num_actors=32, horizon=8, mini_epochs=3, max_epochs=1, use_diagnostics=True)
+    agent = A2CAgent("run", params)
+    logged = []
+
+    class W:
+        def add_scalar(self, tag, v, x):
+            logged.append((tag, float(v), x))
+    agent.writer = W()
+    agent.init_tensors(); agent.obs = agent.env_reset()
+    agent.epoch_num = 1
+    st = agent.train_epoch()
+    d = agent.diag_dict
+    assert {"diagnostics/exp_var", "diagnostics/clip_frac/0", "diagnostics/clip_frac/1", "diagnostics/clip_frac/2",
+            "diagnostics/rms_value/mean", "diagnostics/rms_value/var"} <= set(d)
+    vd = agent.dataset.values_dict
+    mbs = agent.minibatch_size
+    ev = [torch_ext.explained_variance(vd["old_values"][i:i + mbs], vd["returns"][i:i + mbs])
+          for i in range(0, agent.batch_size, mbs)]
+    assert torch.allclose(d["diagnostics/exp_var"], torch.stack(ev).mean(), atol=1e-6)
+    assert all(0.0 <= float(d[f"diagnostics/clip_frac/{m}"]) <= 1.0 for m in range(3))
+    assert torch.equal(d["diagnostics/rms_value/mean"], agent.model.value_mean_std.running_mean)
+    # the reference's own formula on a hand-made case: ratios exp(0), exp(0.3), exp(-0.3), exp(0.1) -> 2 of 4 clipped at 0.2
+    old = torch.tensor([1.0, 1.3, 0.7, 1.1]); new = torch.ones(4)
+    assert torch_ext.policy_clip_fraction(new, old, 0.2).item() == 0.5
+    agent.write_stats(1.0, 1, st, 256, 256)
+    tags = {t for t, _, _ in logged}
+    assert "diagnostics/exp_var" in tags and "diagnostics/clip_frac/2" in tags and "losses/a_loss" in tags
+    assert all(x == 1 for t, _, x in logged if t.startswith("diagnostics/"))

@@ -21,6 +21,7 @@ ap.add_argument("--envs", type=int, nargs="+", default=[65536])
 ap.add_argument("--blocks", type=int, nargs="+", default=[0, 1, 2, 3, 4, 64])
 ap.add_argument("--forms", nargs="+", default=["rollout", "api"])
 ap.add_argument("--replays", type=int, default=20)
+ap.add_argument("--nograph", action="store_true", help="eager launches (rocprofv3 counter passes)")
 a = ap.parse_args()
 print(torch.cuda.get_device_name(0), file=sys.stderr)
 for n in a.envs:
@@ -30,7 +31,7 @@ for n in a.envs:
         for form in a.forms:
             if form == "rollout" and (block == 1 or block >= 64):
                 continue        # the rollout form exists for the ws2 family only
-            r = measure_env_kernel(env, replays=a.replays, rollout_form=(form == "rollout"))
+            r = measure_env_kernel(env, replays=a.replays, rollout_form=(form == "rollout"), use_graph=not a.nograph)
             r.update(task=a.task, ctl=a.ctl, envs=n, block=block, kernel=kernel_name(a.task, a.ctl, block),
                      frac=r["gbps_algorithmic"] / 8000.0)
             print(json.dumps(r), flush=True)
