@@ -723,7 +723,9 @@ AG_HD void compute_reward(const EnvState& s, const float* R, const float* a, con
         const float ipd = fast_rsq(pd2);
         const float ivn = fast_rsq(s.v.x * s.v.x + s.v.y * s.v.y + s.v.z * s.v.z);
         const float dotp = (rx * ipd) * (s.v.x * ivn) + (ry * ipd) * (s.v.y * ivn) + (rz * ipd) * (s.v.z * ivn);
-        const float angle = fabsf(acosf(clampf(dotp, -1.0f, 1.0f)));
+        // torch.clamp propagates NaN (the 0/0 of a zero velocity, quirk Q8); fminf/fmaxf would swallow it
+        const float cdot = (dotp < -1.0f) ? -1.0f : ((dotp > 1.0f) ? 1.0f : dotp);
+        const float angle = fabsf(acosf(cdot));
         const float vel_dir = 0.1f * fast_exp(-angle * (1.0f / kPi));
         const float y3 = 3.0f * yd;
         const float yaw_reward = fast_rcp(1.0f + y3 * y3);

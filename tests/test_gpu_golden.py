@@ -180,6 +180,10 @@ def test_saturating_actions_match_oracle(Handle, task, ctl):
     env = Handle(task, ctl, n, seed=seed)
     # flip the sign of every other quaternion: same attitude, exercises the canonicalisation inside the step
     rs = ora.root_states.clone(); rs[0::2, 3:7] *= -1.0
+    if task == "hovering":      # a quarter of the envs close to the altitude bound and climbing: they terminate within the run
+        rs[0::4, 2] = 1.93; rs[0::4, 9] = 2.0
+    else:                       # ... or drifting out of the 1 m tube around the reference curve (tracking.py:275)
+        rs[0::4, 0] = 0.96; rs[0::4, 7] = 1.0
     ora.root_states = rs.clone()
     env.set_state(root_states=rs)
     rng = np.random.default_rng(11)
@@ -194,7 +198,8 @@ def test_saturating_actions_match_oracle(Handle, task, ctl):
         assert np.array_equal(env.reset_buf.cpu().numpy(), reset.numpy())
         np.testing.assert_allclose(st["root_states"].cpu().numpy(), ora.root_states.numpy(), rtol=0, atol=2e-5,
                                    err_msg=f"state step {t_}")
-        np.testing.assert_allclose(env.cmd_thrusts.cpu().numpy(), ora.cmd_thrusts.numpy(), rtol=0, atol=1e-5)
+        # saturated set-points put 1-ulp differences of v_rcp / v_rsq through gains of 10^2 and the desaturation branches
+        np.testing.assert_allclose(env.cmd_thrusts.cpu().numpy(), ora.cmd_thrusts.numpy(), rtol=0, atol=1e-4)
         np.testing.assert_allclose(env.rew_buf.cpu().numpy(), rew.numpy(), rtol=0, atol=2e-5, equal_nan=True)
         np.testing.assert_allclose(st["pre_actions"].cpu().numpy(), ora.pre_actions.numpy(), rtol=0, atol=0)
         np.testing.assert_allclose(env.obs_buf.cpu().numpy(), obs.numpy(), rtol=0, atol=5e-5)
@@ -359,8 +364,10 @@ def test_golden_running_mean_std_kernels(golden):
         N.check(lib.ag_normalize_rows(x.data_ptr(), mean.data_ptr(), var.data_ptr(), y.data_ptr(), x.shape[0], D, 1e-5, 5.0,
                                       _stream()), "ag_normalize_rows")
         np.testing.assert_allclose(y.cpu().numpy(), g[f"rms_y{i}"], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(mean.cpu().numpy(), g["rms_mean"], rtol=1e-12, atol=1e-14)
-    np.testing.assert_allclose(var.cpu().numpy(), g["rms_var"], rtol=1e-12, atol=1e-14)
+    # the reference forms the BATCH moments in float32 (input.mean / input.var) and merges them in float64; the kernel forms
+    # them in float64 from the same float32 data: agreement to float32 rounding of the batch moments
+    np.testing.assert_allclose(mean.cpu().numpy(), g["rms_mean"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(var.cpu().numpy(), g["rms_var"], rtol=1e-6, atol=0)
     assert count.item() == float(g["rms_count"])
     x0 = t(g["rms_x0"]).cuda().contiguous(); y = torch.empty_like(x0)
     N.check(lib.ag_normalize_rows(x0.data_ptr(), mean.data_ptr(), var.data_ptr(), y.data_ptr(), x0.shape[0], D, 1e-5, 5.0,
@@ -381,12 +388,12 @@ def test_golden_ppo_loss_kernel(golden):
     gen = torch.Generator().manual_seed(9)
     mu = t(g["mu_big"]).clone()                                   # |mu| > 1.1 in places: the bound loss is active
     actions = mu + sigma * torch.randn(M, A, generator=gen)
-    vp, v, ret = t(g["vp"]), t(g["v"]), t(g["ret"])
+    vp, v, ret = t(g["vp"]), t(g["v"]), t(g["ret"])      # vp = value_preds_batch (OLD values), v = the model's new values
     adv, old_nlp = t(g["adv"]), t(g["old_nlp"])
     old_mu, old_sigma = t(g["mu0"]), t(g["s0"])
     e_clip, critic_coef, ent_coef, b_coef = 0.2, 2.0, 0.01, 1e-4
     for clip_value, c_key in ((False, "c_loss"), (True, "c_loss_clip")):
-        heads = torch.cat((mu, vp), 1).contiguous()
+        heads = torch.cat((mu, v), 1).contiguous()
         # ---- oracle composition (a2c_continuous.py:299-350), autograd for the gradients
         hq = heads.clone().requires_grad_(True)
         lq = logstd.clone().requires_grad_(True)
@@ -395,7 +402,7 @@ def test_golden_ppo_loss_kernel(golden):
         sg = torch.exp(ls)
         nlp = ppo_ref.neglogp(actions, mu_q, sg, ls)
         a_l = ppo_ref.actor_loss(old_nlp, nlp, adv, e_clip)
-        c_l = ppo_ref.critic_loss(val_q, v, e_clip, ret, clip_value)
+        c_l = ppo_ref.critic_loss(vp, val_q, e_clip, ret, clip_value)
         b_l = ppo_ref.bound_loss(mu_q)
         ent = (0.5 + 0.5 * np.log(2 * np.pi) + ls).sum(-1).mean()
         loss = a_l.mean() + 0.5 * c_l.mean() * critic_coef - ent * ent_coef + b_l.mean() * b_coef
@@ -409,7 +416,7 @@ def test_golden_ppo_loss_kernel(golden):
         new_mu, new_sigma = torch.empty(M, A, **f), torch.empty(M, A, **f)
         parts = torch.zeros(lib.ag_ppo_loss_max_blocks(), lib.ag_ppo_loss_num_sums(), **f)
         nb = ctypes.c_int(0)
-        dev = [x.cuda().contiguous() for x in (heads, logstd, actions, old_nlp, adv, ret, v, old_mu, old_sigma)]
+        dev = [x.cuda().contiguous() for x in (heads, logstd, actions, old_nlp, adv, ret, vp, old_mu, old_sigma)]
         N.check(lib.ag_ppo_loss(*[x.data_ptr() for x in dev], M, A, e_clip, critic_coef, b_coef, int(clip_value), 1,
                                 d_heads.data_ptr(), new_mu.data_ptr(), new_sigma.data_ptr(), parts.data_ptr(),
                                 ctypes.byref(nb), _stream()), "ag_ppo_loss")
@@ -489,9 +496,10 @@ def test_golden_adaptive_lr_in_adam_kernel(golden):
             for grp in opt.param_groups:
                 grp["lr"] = lr
             opt.step()
-            lr = ppo_ref.adaptive_lr(lr, float(np.float32(kl)))
+            assert ppo_ref.adaptive_lr(lr, float(kl)) == lrs[k]                    # oracle == recorded (float64 KL)
+            # the kernel sees the KL as float32 (it lives in the gradient buffer) and compares it with the float32 threshold:
+            # kl = 2 * thr and kl = thr / 2 exactly stay "inside" on both sides, like the reference's float64 comparison
             assert abs(state[0].item() - lrs[k]) <= 1e-12 * max(1.0, lrs[k]) + 1e-18, (start, kl, state[0].item(), lrs[k])
-            assert lr == lrs[k]
             k += 1
             np.testing.assert_allclose(pd.cpu().numpy(), ref_p.detach().numpy(), rtol=0, atol=3e-6)
     assert k == len(lrs)

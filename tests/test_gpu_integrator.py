@@ -65,7 +65,7 @@ def test_free_fall_is_a_parabola(Handle):
     np.testing.assert_allclose(tr[:, :, 9], rs[:, 9] - G * t, rtol=0, atol=1e-5)
     for k in (0, 1):
         np.testing.assert_allclose(tr[:, :, k], rs[:, k] + rs[:, 7 + k] * t, rtol=0, atol=2e-6)
-        np.testing.assert_allclose(tr[:, :, 7 + k], np.broadcast_to(rs[:, 7 + k], tr[:, :, 0].shape), rtol=0, atol=0)
+        np.testing.assert_allclose(tr[:, :, 7 + k], np.broadcast_to(rs[:, 7 + k], tr[:, :, 0].shape), rtol=0, atol=1e-7)
     np.testing.assert_allclose(tr[:, :, 3:7], np.broadcast_to(rs[:, 3:7], tr[:, :, 3:7].shape), rtol=0, atol=1e-7)
     assert np.abs(tr[:, :, 10:13]).max() == 0.0
 
@@ -124,7 +124,7 @@ def test_torque_free_tumbling_conserves_momentum_and_energy(Handle):
     assert (np.abs(E - E[0]) / E[0]).max() < 8e-6
     np.testing.assert_allclose(np.linalg.norm(q, axis=-1), 1.0, rtol=0, atol=3e-7)
     t = (np.arange(31) * DT)[:, None]
-    np.testing.assert_allclose(tr[:, :, 2], 1.9 - 0.5 * G * t ** 2, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(tr[:, :, 2], np.broadcast_to(1.9 - 0.5 * G * t ** 2, tr[:, :, 2].shape), rtol=0, atol=3e-6)
     assert (1 - 2 * (q[..., 0] ** 2 + q[..., 1] ** 2)).min() > 0.3          # the body really tilted
 
 

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Does the HEADLINE configuration learn?  
+
+Trains Hovering / CTBR with the bench's configuration - 65 536 envs, 196 608-sample minibatches (8 per mini-epoch), MLP(256,256)
+- and, next to it, (b) the same 65 536 envs at the reference's minibatch RATIO (48 per mini-epoch, 32 768 samples) and (c) the
+shipped small configuration (4 096 envs, 2 048-sample minibatches, scripts/config/ppo_hovering.yaml:54-61), all from seed 0.
+Prints one JSON object per run: mean episode reward / length (the AverageMeter over the last `games_to_track` episodes, as the
+reference logs them), KL and learning rate every `--every` epochs, plus frames consumed.
+
+    python tools/learning_curves.py --epochs 120 --small-epochs 480 > profiles/r02_learning_curves.jsonl
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def run(name, envs, minibatches, epochs, every, units=(256, 256)):
+    class A:
+        pass
+    A.envs, A.minibatches, A.graph, A.task, A.ctl, A.tuned_gemms = envs, minibatches, 1, "hovering", "rate", 1
+    params = bench.build_params(A, 1)
+    params["network"]["mlp"]["units"] = list(units)
+    torch.manual_seed(0)
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    agent = A2CAgent("curve", params)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    curve = []
+    t0 = time.time()
+    for ep in range(1, epochs + 1):
+        agent.epoch_num = ep
+        st = agent.train_epoch()
+        if ep % every == 0 or ep == 1:
+            have = agent.game_rewards.current_size > 0
+            curve.append({"epoch": ep, "frames": ep * envs * agent.horizon_length,
+                          "reward": round(float(agent.game_rewards.get_mean()[0]), 2) if have else None,
+                          "length": round(float(agent.game_lengths.get_mean()[0]), 1) if have else None,
+                          "kl": round(st["kl"], 5), "lr": round(st["last_lr"], 7), "a_loss": round(st["a_loss"], 5),
+                          "c_loss": round(st["c_loss"], 5),
+                          "exp_var": round(float(agent.diag_dict.get("diagnostics/exp_var", float("nan"))), 4)})
+    wall = time.time() - t0
+    out = {"run": name, "envs": envs, "minibatch_size": agent.minibatch_size,
+           "optimizer_steps_per_epoch": agent.mini_epochs_num * agent.num_minibatches, "mlp": list(units), "epochs": epochs,
+           "wall_s": round(wall, 2), "env_steps_per_s": round(epochs * envs * agent.horizon_length / wall), "curve": curve}
+    agent.vec_env.env.hip.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=120)
+    ap.add_argument("--small-epochs", type=int, default=480)
+    ap.add_argument("--every", type=int, default=10)
+    a = ap.parse_args()
+    print(json.dumps(run("headline: 65536 envs, 8 minibatches/mini-epoch (196608 samples)", 65536, 8, a.epochs, a.every)), flush=True)
+    print(json.dumps(run("65536 envs, reference ratio: 48 minibatches/mini-epoch (32768 samples)", 65536, 48, a.epochs, a.every)), flush=True)
+    print(json.dumps(run("shipped small config: 4096 envs, 48 minibatches/mini-epoch (2048 samples), MLP(256,256)", 4096, 48,
+                         a.small_epochs, a.every * 4)), flush=True)
+    print(json.dumps(run("shipped small config with the shipped network [64,128,64]", 4096, 48, a.small_epochs, a.every * 4,
+                         units=(64, 128, 64))), flush=True)
