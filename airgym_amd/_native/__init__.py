@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libairgym_hip.so")
 
-AG_TASKS = {"hovering": 0, "tracking": 1, "planning": 2}
+AG_TASKS = {"hovering": 0, "tracking": 1, "planning": 2, "balloon": 3, "avoid": 4}
 AG_CTL_MODES = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
 AG_FLAG_REWARD_TERMS = 1 << 0
 AG_FLAG_OBS_NOISE_OFF = 1 << 1
@@ -31,6 +31,9 @@ REWARD_TERM_NAMES = {
                  "effort_reward", "ups_reward", "reward"],
     "planning": ["continous_action_reward", "heading_reward", "speed_reward", "forward_reward", "alive_reward",
                  "ups_reward", "z_reward", "esdf_reward", "thrust_reward", "reach_goal_reward", "reward"],
+    "balloon": ["guidance_reward", "hit_reward", "action_smoothness_reward", "effort_reward", "ups_reward", "reward"],
+    "avoid": ["pose_reward", "ups_reward", "spin_reward", "effort_reward", "action_smoothness_reward", "thrust_reward",
+              "alive_reward", "reward"],
 }
 
 
@@ -73,7 +76,8 @@ class AgPlanningBuffers(ctypes.Structure):
 
 
 class AgPlanningStateView(ctypes.Structure):
-    _fields_ = [("obstacles_dev", ctypes.c_void_p), ("goal_dev", ctypes.c_void_p), ("extra_dev", ctypes.c_void_p)]
+    _fields_ = [("obstacles_dev", ctypes.c_void_p), ("goal_dev", ctypes.c_void_p), ("extra_dev", ctypes.c_void_p),
+                ("object_vel_dev", ctypes.c_void_p)]
 
 
 class AgStateView(ctypes.Structure):
@@ -125,7 +129,7 @@ SYMBOLS = [
     ("ag_planning_get_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),
     ("ag_planning_set_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),
     ("ag_planning_step_with_uniforms", ctypes.c_int, [_P, _P, _P, _P]),
-    ("ag_planning_eval_post", ctypes.c_int, [_P, _P, _P, _P]),
+    ("ag_planning_eval_post", ctypes.c_int, [_P, _P, _P, _P, _P]),
     ("ag_planning_render_now", ctypes.c_int, [_P]),
     ("ag_debug_planning_render_parts", ctypes.c_int, [_P, ctypes.c_int]),
     ("ag_ppo_loss_finalize", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_float,

@@ -58,17 +58,17 @@ Layout make_layout(int n, int num_obs, bool terms, int task = 0) {
     L.reset_ids = take(np * 4);
     L.reset_count = take(256);
     L.tick = take(256);
-    const int nterms = (task == AG_TASK_PLANNING) ? 11 : 9;
+    const int nterms = (task == AG_TASK_PLANNING) ? 11 : (task == AG_TASK_AVOID ? 8 : (task == AG_TASK_BALLOON ? 6 : 9));
     for (int t = 0; t < 11; ++t) L.terms[t] = (terms && t < nterms) ? take(np * 4) : 0;
-    L.cmd = (terms && task != AG_TASK_PLANNING) ? take(np * 16) : 0;
+    L.cmd = (terms && task < AG_TASK_PLANNING) ? take(np * 16) : 0;
     L.OB = L.GOAL = L.PRP = L.image = L.collisions = L.table = 0;
-    if (task == AG_TASK_PLANNING) {
-        L.OB = take((size_t)ag::kNumObst * np * 16);
+    if (task >= AG_TASK_PLANNING) {      // the Customized family: Planning, Balloon, Avoid
+        L.OB = take((size_t)(task == AG_TASK_PLANNING ? ag::kNumObst : 1) * np * 16);
         L.GOAL = take(np * 16);
         L.PRP = take(np * 16);
         L.collisions = take(np * 4);
         L.table = take((size_t)ag::kNumVariants * 8 * 4);
-        L.image = take((size_t)n * ag::kCamPix * 4);
+        if (task != AG_TASK_BALLOON) L.image = take((size_t)n * ag::kCamPix * 4);      // Balloon has no camera
     }
     L.total = off;
     return L;
@@ -293,6 +293,7 @@ __global__ void planning_get_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_plann
     const float4 g = pa.GOAL[i], e = pa.PRP[i];
     if (v.goal_dev) { float* o = v.goal_dev + (size_t)i * 3; o[0] = g.x; o[1] = g.y; o[2] = g.z; }
     if (v.extra_dev) { float* o = v.extra_dev + (size_t)i * 5; o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = e.w; o[4] = g.w; }
+    if (v.object_vel_dev) { const float4 w = pa.OB[i]; float* o = v.object_vel_dev + (size_t)i * 3; o[0] = w.x; o[1] = w.y; o[2] = w.z; }
 }
 
 __global__ void planning_set_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_planning_state_view v) {
@@ -309,6 +310,7 @@ __global__ void planning_set_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_plann
     if (v.extra_dev) { const float* o = v.extra_dev + (size_t)i * 5; e = make_float4(o[0], o[1], o[2], o[3]); g.w = o[4]; }
     pa.GOAL[i] = g;
     pa.PRP[i] = e;
+    if (v.object_vel_dev) { const float* o = v.object_vel_dev + (size_t)i * 3; pa.OB[i] = make_float4(o[0], o[1], o[2], 0.f); }
 }
 
 void fill_params(ag_env* h) {
@@ -321,12 +323,14 @@ int validate(const ag_config* cfg) {
     if (cfg->struct_size != sizeof(ag_config))
         return fail(AG_ERR_INVALID_ARG, "ag_config.struct_size mismatch (ABI): got " + std::to_string(cfg->struct_size) +
                                             ", expected " + std::to_string(sizeof(ag_config)));
-    if (cfg->task != AG_TASK_HOVERING && cfg->task != AG_TASK_TRACKING && cfg->task != AG_TASK_PLANNING)
+    if (cfg->task < AG_TASK_HOVERING || cfg->task > AG_TASK_AVOID)
         return fail(AG_ERR_UNKNOWN_TASK, "Task with id " + std::to_string(cfg->task) + " was not registered");
     if (cfg->ctl_mode < AG_CTL_POS || cfg->ctl_mode > AG_CTL_PROP)
         return fail(AG_ERR_UNKNOWN_CTL, "unknown ctl_mode " + std::to_string(cfg->ctl_mode) + " (expected pos|vel|atti|rate|prop)");
-    if (cfg->task == AG_TASK_PLANNING && cfg->ctl_mode == AG_CTL_ATTI)
-        return fail(AG_ERR_UNSUPPORTED, "planning has 4-dim action observations (planning.py:214): ctl_mode atti (5 actions) is not supported");
+    if ((cfg->task == AG_TASK_PLANNING || cfg->task == AG_TASK_AVOID) && cfg->ctl_mode == AG_CTL_ATTI)
+        return fail(AG_ERR_UNSUPPORTED, "planning / avoid observations hold 4 action values (planning.py:214, avoid.py:232: the "
+                                        "reference's `obs_buf[..., 12:16] = actions_local` raises on atti's [N,5] actions): "
+                                        "ctl_mode atti is not supported for these tasks");
     if (cfg->num_envs <= 0) return fail(AG_ERR_INVALID_ARG, "num_envs must be > 0");
     if (!(cfg->dt > 0.0)) return fail(AG_ERR_INVALID_ARG, "dt must be > 0");
     return AG_OK;
@@ -354,7 +358,7 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
     if (!actions) return fail(AG_ERR_INVALID_ARG, "actions_dev is NULL");
     if (h->num_actions == 4 && ((uintptr_t)actions & 15)) return fail(AG_ERR_INVALID_ARG, "actions_dev must be 16-byte aligned");
     if (obs_out && ((uintptr_t)obs_out & 15)) return fail(AG_ERR_INVALID_ARG, "obs_out_dev must be 16-byte aligned");
-    if (h->cfg.task != AG_TASK_PLANNING && (noise == nullptr) != (uniforms == nullptr))
+    if (h->cfg.task < AG_TASK_PLANNING && (noise == nullptr) != (uniforms == nullptr))
         return fail(AG_ERR_INVALID_ARG, "noise_dev and reset_uniforms_dev must be given together");
     int rc = ensure_device(h);
     if (rc) return rc;
@@ -363,28 +367,36 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
     if (obs_out) k.obs = obs_out;
     if (rew_out) k.rew = rew_out;
     if (reset_out) k.reset = (long long*)reset_out;
-    if (h->cfg.task == AG_TASK_PLANNING) {
-        if (!h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
-        if (noise != nullptr) return fail(AG_ERR_UNSUPPORTED, "planning: use ag_planning_step_with_uniforms");
+    if (h->cfg.task >= AG_TASK_PLANNING) {
+        const int task = h->cfg.task;
+        if (task == AG_TASK_PLANNING && !h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
+        if (noise != nullptr && task != AG_TASK_BALLOON) return fail(AG_ERR_UNSUPPORTED, "planning / avoid: use ag_planning_step_with_uniforms");
         ag::PlanArgs pa = h->pa;
         pa.ext_uniforms = uniforms;
+        k.ext_noise = noise;            // Balloon parity mode: [n,18] observation noise
         pa.debug_skip = h->force_render >> 1;
         h->counter += 1;
-        const bool render = h->force_render || (h->counter % 4 == 0);   // cam_dt / dt = 4, planning.py:153-156
+        // cam_dt / dt = 4 (planning.py:153-156, avoid.py:181-185); Balloon has no onboard camera (balloon_config.py:52)
+        const bool render = (task != AG_TASK_BALLOON) && (h->force_render || (h->counter % 4 == 0));
         h->force_render = 0;
         // every kernel of this step reads the same tick; only the last one publishes tick + 1
         uint32_t* slots = (uint32_t*)(h->arena + h->L.tick);
         k.tick_in = slots + h->parity;
         k.tick_out = slots + (h->parity ^ 1);
+        const hipStream_t st = (hipStream_t)stream;
+        auto phase = [&](int ph) {
+            return task == AG_TASK_PLANNING ? ag::launch_planning_step(k, pa, h->cfg.ctl_mode, ph, st)
+                                            : ag::launch_custom_step(k, pa, task, h->cfg.ctl_mode, ph, st);
+        };
         hipError_t e;
         if (render) {
-            e = ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 1, (hipStream_t)stream);
-            if (e == hipSuccess) e = ag::launch_planning_render(k, pa, (hipStream_t)stream);
-            if (e == hipSuccess) e = ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 2, (hipStream_t)stream);
+            e = phase(1);
+            if (e == hipSuccess) e = (task == AG_TASK_PLANNING) ? ag::launch_planning_render(k, pa, st) : ag::launch_avoid_render(k, pa, st);
+            if (e == hipSuccess) e = phase(2);
         } else {
-            e = ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 0, (hipStream_t)stream);
+            e = phase(0);
         }
-        if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("planning step launch: ") + hipGetErrorString(e));
+        if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("planning / balloon / avoid step launch: ") + hipGetErrorString(e));
         h->parity ^= 1;
         h->tick += 1;
         return AG_OK;
@@ -416,6 +428,8 @@ int ag_num_obs(int task) {
     if (task == AG_TASK_HOVERING) return 18;  // hovering_config.py:14
     if (task == AG_TASK_TRACKING) return 48;  // tracking_config.py:13
     if (task == AG_TASK_PLANNING) return 16;  // planning_config.py:13
+    if (task == AG_TASK_BALLOON) return 18;   // balloon_config.py:13
+    if (task == AG_TASK_AVOID) return 16;     // avoid_config.py:13
     return fail(AG_ERR_UNKNOWN_TASK, "unknown task");
 }
 
@@ -427,8 +441,10 @@ int ag_num_actions(int ctl_mode) {
 int ag_default_episode_length(int task, double dt) {
     if (!(dt > 0.0)) return fail(AG_ERR_INVALID_ARG, "dt must be > 0");
     // tracking_config.py:17, hovering_config.py:17, planning_config.py:17
-    const double secs = (task == AG_TASK_TRACKING) ? 36.0 : ((task == AG_TASK_PLANNING) ? 16.0 : 24.0);
-    if (task < AG_TASK_HOVERING || task > AG_TASK_PLANNING) return fail(AG_ERR_UNKNOWN_TASK, "unknown task");
+    // tracking_config.py:17, hovering_config.py:17, planning_config.py:17, balloon_config.py:17, avoid_config.py:17
+    const double table[5] = {24.0, 36.0, 16.0, 8.0, 6.0};
+    if (task < AG_TASK_HOVERING || task > AG_TASK_AVOID) return fail(AG_ERR_UNKNOWN_TASK, "unknown task");
+    const double secs = table[task];
     return (int)(secs / dt);  // int(episode_length_s / dt), hovering.py:48
 }
 
@@ -480,7 +496,7 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     k.reset = (long long*)(h->arena + h->L.reset);
     k.timeout = (uint8_t*)(h->arena + h->L.timeout);
     k.mask = (unsigned long long*)(h->arena + h->L.mask);
-    const bool planning = (cfg->task == AG_TASK_PLANNING);
+    const bool planning = (cfg->task >= AG_TASK_PLANNING);      // the Customized family (Planning, Balloon, Avoid)
     if (terms && !planning) {
         for (int t = 0; t < 9; ++t) k.terms[t] = (float*)(h->arena + h->L.terms[t]);
         k.cmd = (float4*)(h->arena + h->L.cmd);
@@ -494,11 +510,11 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
         pa.OB = (float4*)(h->arena + h->L.OB);
         pa.GOAL = (float4*)(h->arena + h->L.GOAL);
         pa.PRP = (float4*)(h->arena + h->L.PRP);
-        pa.image = (float*)(h->arena + h->L.image);
+        pa.image = h->L.image ? (float*)(h->arena + h->L.image) : nullptr;
         pa.collisions = (float*)(h->arena + h->L.collisions);
         pa.table = (const float*)(h->arena + h->L.table);
         pa.n_pad = h->n_pad;
-        if (terms) for (int t = 0; t < 11; ++t) pa.terms[t] = (float*)(h->arena + h->L.terms[t]);
+        if (terms) for (int t = 0; t < 11; ++t) pa.terms[t] = h->L.terms[t] ? (float*)(h->arena + h->L.terms[t]) : nullptr;
     }
     k.n = cfg->num_envs;
     fill_params(h);
@@ -511,7 +527,7 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     if (e == hipSuccess) {
         *out = h;
         // planning needs its obstacle table first: the caller runs ag_planning_set_obstacle_table + ag_reset_all
-        rc = planning ? AG_OK : ag_reset_all(h, nullptr);
+        rc = (cfg->task == AG_TASK_PLANNING) ? AG_OK : ag_reset_all(h, nullptr);
         if (rc == AG_OK) e = hipStreamSynchronize(0);
     }
     if (e != hipSuccess || rc != AG_OK) {
@@ -542,6 +558,11 @@ int ag_reset_all(ag_handle h, void* stream) {
         AG_HIP_CHECK(ag::launch_planning_reset_all(k, h->pa, h->num_actions, (hipStream_t)stream));
         return AG_OK;
     }
+    if (h->cfg.task > AG_TASK_PLANNING) {
+        bind_tick(h, k);
+        AG_HIP_CHECK(ag::launch_custom_reset_all(k, h->pa, h->cfg.task, h->num_actions, (hipStream_t)stream));
+        return AG_OK;
+    }
     bind_tick(h, k);
     hipLaunchKernelGGL(reset_all_kernel, dim3(h->n_pad / 256), dim3(256), 0, (hipStream_t)stream, k, h->n_pad,
                        h->num_actions, h->num_obs);
@@ -563,7 +584,7 @@ int ag_term_sum_tiles(int num_envs) { return num_envs > 0 ? (num_envs + 63) / 64
 int ag_step_rollout(ag_handle h, const float* actions_dev, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,
                     float* term_sums_dev, void* stream) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
-    if (h->cfg.task == AG_TASK_PLANNING) return fail(AG_ERR_UNSUPPORTED, "ag_step_rollout: hovering / tracking handles only");
+    if (h->cfg.task >= AG_TASK_PLANNING) return fail(AG_ERR_UNSUPPORTED, "ag_step_rollout: hovering / tracking handles only");
     if (!done_out_dev) return fail(AG_ERR_INVALID_ARG, "done_out_dev is NULL");
     if (term_sums_dev && ((uintptr_t)term_sums_dev & 3)) return fail(AG_ERR_INVALID_ARG, "term_sums_dev must be 4-byte aligned");
     return do_step(h, actions_dev, obs_out_dev, rew_out_dev, nullptr, nullptr, nullptr, stream, done_out_dev, term_sums_dev, true);
@@ -573,7 +594,7 @@ int ag_eval_obs_reward(ag_handle h, const float* processed_actions_dev, const fl
                        void* stream) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
     if (!processed_actions_dev || !cmd_thrusts_dev) return fail(AG_ERR_INVALID_ARG, "processed_actions_dev / cmd_thrusts_dev is NULL");
-    if (h->cfg.task == AG_TASK_PLANNING) return fail(AG_ERR_UNSUPPORTED, "ag_eval_obs_reward: hovering / tracking handles only");
+    if (h->cfg.task >= AG_TASK_PLANNING) return fail(AG_ERR_UNSUPPORTED, "ag_eval_obs_reward: hovering / tracking handles only (use ag_planning_eval_post)");
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
@@ -606,7 +627,7 @@ int ag_get_buffers(ag_handle h, ag_buffers* out) {
     out->reset_ids_dev = (int32_t*)(h->arena + h->L.reset_ids);
     out->reset_count_dev = (int32_t*)(h->arena + h->L.reset_count);
     for (int t = 0; t < 11; ++t)
-        out->reward_terms_dev[t] = (h->cfg.task == AG_TASK_PLANNING) ? h->pa.terms[t] : (t < 9 ? h->k.terms[t] : nullptr);
+        out->reward_terms_dev[t] = (h->cfg.task >= AG_TASK_PLANNING) ? h->pa.terms[t] : (t < 9 ? h->k.terms[t] : nullptr);
     out->cmd_thrusts_dev = (float*)h->k.cmd;
     return AG_OK;
 }
@@ -675,7 +696,7 @@ int ag_planning_set_obstacle_table(ag_handle h, const float* table_host, int n_v
 
 int ag_planning_get_buffers(ag_handle h, ag_planning_buffers* out) {
     if (!h || !out) return fail(AG_ERR_INVALID_ARG, "NULL argument");
-    if (h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    if (h->cfg.task < AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning / balloon / avoid handle");
     out->image_dev = h->pa.image;
     out->collisions_dev = h->pa.collisions;
     return AG_OK;
@@ -683,7 +704,9 @@ int ag_planning_get_buffers(ag_handle h, ag_planning_buffers* out) {
 
 int ag_planning_get_state(ag_handle h, const ag_planning_state_view* view, void* stream) {
     if (!h || !view) return fail(AG_ERR_INVALID_ARG, "NULL argument");
-    if (h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    if (h->cfg.task < AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning / balloon / avoid handle");
+    if (view->obstacles_dev && h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "obstacles_dev: planning handles only");
+    if (view->object_vel_dev && h->cfg.task != AG_TASK_AVOID) return fail(AG_ERR_INVALID_ARG, "object_vel_dev: avoid handles only");
     hipLaunchKernelGGL(planning_get_state_kernel, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        h->k, h->pa, *view);
     AG_HIP_CHECK(hipGetLastError());
@@ -692,7 +715,9 @@ int ag_planning_get_state(ag_handle h, const ag_planning_state_view* view, void*
 
 int ag_planning_set_state(ag_handle h, const ag_planning_state_view* view, void* stream) {
     if (!h || !view) return fail(AG_ERR_INVALID_ARG, "NULL argument");
-    if (h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    if (h->cfg.task < AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning / balloon / avoid handle");
+    if (view->obstacles_dev && h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "obstacles_dev: planning handles only");
+    if (view->object_vel_dev && h->cfg.task != AG_TASK_AVOID) return fail(AG_ERR_INVALID_ARG, "object_vel_dev: avoid handles only");
     hipLaunchKernelGGL(planning_set_state_kernel, dim3((h->cfg.num_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        h->k, h->pa, *view);
     AG_HIP_CHECK(hipGetLastError());
@@ -700,28 +725,33 @@ int ag_planning_set_state(ag_handle h, const ag_planning_state_view* view, void*
 }
 
 int ag_planning_step_with_uniforms(ag_handle h, const float* actions_dev, const float* reset_uniforms_dev, void* stream) {
-    if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    if (!h || h->cfg.task < AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning / balloon / avoid handle");
     return do_step(h, actions_dev, nullptr, nullptr, nullptr, nullptr, reset_uniforms_dev, stream);
 }
 
-int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* collisions_dev, void* stream) {
-    if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* collisions_dev, const float* noise_dev,
+                          void* stream) {
+    if (!h || h->cfg.task < AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning / balloon / avoid handle");
     if (!actions_dev || !collisions_dev) return fail(AG_ERR_INVALID_ARG, "actions_dev / collisions_dev is NULL");
-    if (!h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
+    if (h->cfg.task == AG_TASK_PLANNING && !h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
+    if (noise_dev && h->cfg.task != AG_TASK_BALLOON) return fail(AG_ERR_INVALID_ARG, "noise_dev: balloon handles only (the others add no observation noise)");
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
     k.actions = actions_dev;
     ag::PlanArgs pa = h->pa;
     pa.ext_collisions = collisions_dev;
+    k.ext_noise = noise_dev;
     bind_tick(h, k);
-    hipError_t e = ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 2, (hipStream_t)stream);
+    hipError_t e = (h->cfg.task == AG_TASK_PLANNING)
+                       ? ag::launch_planning_step(k, pa, h->cfg.ctl_mode, 2, (hipStream_t)stream)
+                       : ag::launch_custom_step(k, pa, h->cfg.task, h->cfg.ctl_mode, 2, (hipStream_t)stream);
     if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("planning post-phase launch: ") + hipGetErrorString(e));
     return AG_OK;
 }
 
 int ag_planning_render_now(ag_handle h) {
-    if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
+    if (!h || (h->cfg.task != AG_TASK_PLANNING && h->cfg.task != AG_TASK_AVOID)) return fail(AG_ERR_INVALID_ARG, "not a planning / avoid handle");
     h->force_render = 1;
     return AG_OK;
 }

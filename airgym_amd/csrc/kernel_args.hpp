@@ -50,12 +50,13 @@ struct KArgs {
 
 // Planning-task extras (airgym_amd/csrc/planning_kernel.hip)
 struct PlanArgs {
-    float4* OB;                  // [40][n_pad] obstacle root pose: (x, y, yaw, variant index as int bits)
-    float4* GOAL;                // [n_pad] (goal xyz, prev_related_dist)
-    float4* PRP;                 // [n_pad] (pre_root_positions xyz, esdf_dist)
+    float4* OB;                  // planning: [40][n_pad] obstacle root pose (x, y, yaw, variant index as int bits);
+                                 // avoid: [1][n_pad] velocity of the thrown cube
+    float4* GOAL;                // [n_pad] planning: (goal xyz, prev_related_dist); balloon: balloon xyz; avoid: cube xyz
+    float4* PRP;                 // [n_pad] (pre_root_positions xyz, esdf_dist = min pixel of the last image)
     float* image;                // [n, 212*120]  == full_camera_array [n, 1, 212, 120]
     float* collisions;           // [n]
-    float* terms[11];            // item_reward_info arrays or null
+    float* terms[11];            // item_reward_info arrays or null (planning 11, avoid 8, balloon 6)
     const float* table;          // [100, 8] obstacle variants (centre3, axis3, radius, half length)
     const float* ext_uniforms;   // [n, 121] or null (parity mode)
     const float* ext_collisions; // [n] or null (parity mode: collision flags supplied instead of the geometric test)
@@ -66,6 +67,10 @@ struct PlanArgs {
 hipError_t launch_planning_step(const KArgs& k, const PlanArgs& pa, int ctl, int phase, hipStream_t st);
 hipError_t launch_planning_render(const KArgs& k, const PlanArgs& pa, hipStream_t st);
 hipError_t launch_planning_reset_all(const KArgs& k, const PlanArgs& pa, int num_actions, hipStream_t st);
+// Balloon / Avoid (task = 3 / 4): same phase convention as Planning; Avoid renders with launch_avoid_render
+hipError_t launch_custom_step(const KArgs& k, const PlanArgs& pa, int task, int ctl, int phase, hipStream_t st);
+hipError_t launch_custom_reset_all(const KArgs& k, const PlanArgs& pa, int task, int num_actions, hipStream_t st);
+hipError_t launch_avoid_render(const KArgs& k, const PlanArgs& pa, hipStream_t st);
 
 typedef hipError_t (*StepLauncher)(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
 typedef hipError_t (*EvalLauncher)(const KArgs& k, hipStream_t stream);

@@ -158,6 +158,9 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
     return r;
 }
 
+enum : int { SCENE_PLANNING = 0, SCENE_AVOID = 1 };
+
+template <int SCENE>
 __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const KArgs k, const PlanArgs pa) {
     extern __shared__ float lds[];
     float* img = lds;                                   // [kCamW][kCamH]
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     const V3 goal{g4.x, g4.y, g4.z};
     if (tid == 0) *ncand = 0;
     __syncthreads();
-    if (tid < kNumObst) {
+    if (SCENE == SCENE_PLANNING && tid < kNumObst) {
         const float4 ob = pa.OB[(size_t)tid * pa.n_pad + env];
         // a cylinder farther than far plane + its own extent from the camera cannot be seen: skip it for every pixel
         const float dx = ob.x - cam.o.x, dy = ob.y - cam.o.y;
@@ -230,7 +233,9 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     float vmax = 0.0f;
     for (int p = tid; p < kCamPix; p += kRenderThreads) {
         const int u = p / kCamH, v = p - u * kCamH;
-        float d = (pa.debug_skip & 1) ? 3.0f : depth_pixel_culled(cam, pixel_direction(cam, u, v), cyl, ulo, uhi, u, n, goal);
+        float d;
+        if (SCENE == SCENE_AVOID) d = depth_pixel_box(cam, pixel_direction(cam, u, v), goal);      // GOAL holds the cube position
+        else d = (pa.debug_skip & 1) ? 3.0f : depth_pixel_culled(cam, pixel_direction(cam, u, v), cyl, ulo, uhi, u, n, goal);
         d = d > 4.5f ? 4.5f : d;
         d = fminf(fmaxf(d, 0.0f), 4.5f) / 4.5f;
         img[p] = d;
@@ -364,17 +369,207 @@ hipError_t launch_planning_render(const KArgs& k, const PlanArgs& pa, hipStream_
     static bool attr_set = false;
     const size_t lds = planning_render_lds_bytes();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planning_render_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planning_render_kernel<SCENE_PLANNING>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(planning_render_kernel, dim3(k.n), dim3(kRenderThreads), lds, st, k, pa);
+    hipLaunchKernelGGL(planning_render_kernel<SCENE_PLANNING>, dim3(k.n), dim3(kRenderThreads), lds, st, k, pa);
+    return hipGetLastError();
+}
+
+hipError_t launch_avoid_render(const KArgs& k, const PlanArgs& pa, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = planning_render_lds_bytes();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planning_render_kernel<SCENE_AVOID>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(planning_render_kernel<SCENE_AVOID>, dim3(k.n), dim3(kRenderThreads), lds, st, k, pa);
     return hipGetLastError();
 }
 
 hipError_t launch_planning_reset_all(const KArgs& k, const PlanArgs& pa, int num_actions, hipStream_t st) {
     hipLaunchKernelGGL(planning_reset_all_kernel, dim3(pa.n_pad / 256), dim3(256), 0, st, k, pa, num_actions);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Balloon / Avoid step kernel: one env per lane, same phase split as Planning.
+//   Balloon: GOAL = (balloon xyz, -), PRP = (pre_root_positions, -); 18-dim noisy observation; always PHASE_BOTH.
+//   Avoid  : GOAL = (cube xyz, -), OB slot 0 = (cube velocity, -), PRP = (pre_root_positions, min pixel); 16-dim
+//            observation; PHYS / render / POST on camera steps like Planning.
+// ---------------------------------------------------------------------------------------------------
+template <int TASK, int CTL, int PHASE>
+__global__ __launch_bounds__(64) void custom_step_kernel(const KArgs k, const PlanArgs pa) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    constexpr int NOBS = (TASK == TASK_BALLOON) ? kBalloonNumObs : kAvoidNumObs;
+    constexpr int NTERMS = (TASK == TASK_BALLOON) ? kBalloonNumTerms : kAvoidNumTerms;
+    constexpr int NU = (TASK == TASK_BALLOON) ? kBalloonResetUniforms : kAvoidResetUniforms;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 64 + tid;
+    const bool active = i < k.n;
+    StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (PHASE != PHASE_PHYS && blockIdx.x == 0 && tid == 0) *k.tick_out = P.tick + 1u;
+    const uint32_t env_global = P.env_id_offset + (uint32_t)i;
+
+    EnvState s;
+    CtlState c;
+    load_env(k, i, s);
+    load_ctl<CTL>(k, i, c);
+    float raw_a[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) raw_a[j] = active ? k.actions[(size_t)i * A + j] : 0.0f;
+    const float4 g4 = pa.GOAL[i];
+    V3 tgt{g4.x, g4.y, g4.z};                   // balloon position / cube position
+    V3 obj_v{0.0f, 0.0f, 0.0f};
+    if (TASK == TASK_AVOID) { const float4 v4 = pa.OB[i]; obj_v = V3{v4.x, v4.y, v4.z}; }
+
+    if (PHASE != PHASE_POST) {
+        planning_physics<CTL>(s, c, raw_a, P);
+        if (TASK == TASK_AVOID) avoid_object_step(tgt, obj_v, P.dt);
+    }
+    if (PHASE == PHASE_PHYS) {
+        store_env(k, i, s);
+        store_ctl<CTL>(k, i, c);
+        pa.GOAL[i] = make_float4(tgt.x, tgt.y, tgt.z, 0.0f);
+        pa.OB[i] = make_float4(obj_v.x, obj_v.y, obj_v.z, 0.0f);
+        return;
+    }
+    float pre_a[A];
+    {
+        const float4 p4 = k.PA[i];
+        pre_a[0] = p4.x; pre_a[1] = p4.y; pre_a[2] = p4.z; pre_a[3] = p4.w;
+        if (A == 5) pre_a[A - 1] = k.PA4[i];
+    }
+    const float4 e4 = pa.PRP[i];
+    V3 pre_pos{e4.x, e4.y, e4.z};
+    // check_collisions (customized.py:393-397 -> analytic): ground plane; Avoid: + the cube (the balloon shares the
+    // robot's collision mask and never touches it)
+    int collided = (s.p.z <= kRobotRadius) ? 1 : 0;
+    if (TASK == TASK_AVOID && point_box_distance(s.p, tgt, kCubeHalf) <= kRobotRadius) collided = 1;
+    if (pa.ext_collisions != nullptr) collided = (active && pa.ext_collisions[i] != 0.0f) ? 1 : 0;
+    float obs[NOBS];
+    CustomOut o;
+    if (TASK == TASK_BALLOON) {
+        float z[18];
+        if (k.ext_noise != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) z[j] = active ? k.ext_noise[(size_t)i * 18 + j] : 0.0f;
+        } else if (!P.noise_off) {
+            obs_noise_normals(P, env_global, z);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) z[j] = 0.0f;
+        }
+        balloon_post<CTL>(s, tgt, pre_pos, pre_a, raw_a, collided, z, P, obs, o);
+    } else {
+        avoid_post<CTL>(s, pre_pos, pre_a, raw_a, collided, P, obs, o);
+    }
+    if (o.done) {
+        float u[16];
+        if (pa.ext_uniforms != nullptr) {
+            for (int j = 0; j < NU; ++j) u[j] = active ? pa.ext_uniforms[(size_t)i * NU + j] : 0.5f;
+        } else {
+            custom_reset_uniforms(P, env_global, u);
+        }
+        if (TASK == TASK_BALLOON) balloon_reset(s, c, tgt, pre_pos, pre_a, A, u);
+        else avoid_reset(s, c, tgt, obj_v, pre_pos, pre_a, A, u);
+    }
+    o.timeout = (s.progress > P.max_episode_length) ? 1 : 0;
+    store_env(k, i, s);
+    store_ctl<CTL>(k, i, c);
+    k.PA[i] = make_float4(pre_a[0], pre_a[1], pre_a[2], pre_a[3]);
+    if (A == 5) k.PA4[i] = pre_a[A - 1];
+    pa.GOAL[i] = make_float4(tgt.x, tgt.y, tgt.z, 0.0f);
+    if (TASK == TASK_AVOID) pa.OB[i] = make_float4(obj_v.x, obj_v.y, obj_v.z, 0.0f);
+    pa.PRP[i] = make_float4(pre_pos.x, pre_pos.y, pre_pos.z, e4.w);
+    const unsigned long long ballot = __ballot(active && o.done);
+    if (active) {
+        k.rew[i] = o.rew;
+        k.reset[i] = (long long)o.done;
+        k.timeout[i] = (uint8_t)o.timeout;
+        pa.collisions[i] = (float)collided;
+        if (tid == 0) k.mask[i >> 6] = ballot;
+        if (pa.terms[0] != nullptr) {
+#pragma unroll
+            for (int t = 0; t < NTERMS; ++t) pa.terms[t][i] = o.terms[t];
+        }
+        float* out = k.obs + (size_t)i * NOBS;
+#pragma unroll
+        for (int j = 0; j < NOBS / 2; ++j) reinterpret_cast<float2*>(out)[j] = make_float2(obs[2 * j], obs[2 * j + 1]);
+    }
+}
+
+template <int TASK>
+__global__ void custom_reset_all_kernel(const KArgs k, const PlanArgs pa, int num_actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pa.n_pad) return;
+    StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (i == 0) *k.tick_out = P.tick + 1u;
+    const uint32_t env_global = P.env_id_offset + (uint32_t)i;
+    EnvState s;
+    CtlState c;
+    V3 tgt{0.f, 0.f, 0.f}, obj_v{0.f, 0.f, 0.f}, pre_pos{0.f, 0.f, 0.f};
+    float pre_a[5];
+    float u[16];
+    custom_reset_uniforms(P, env_global, u);
+    if (TASK == TASK_BALLOON) balloon_reset(s, c, tgt, pre_pos, pre_a, num_actions, u);
+    else avoid_reset(s, c, tgt, obj_v, pre_pos, pre_a, num_actions, u);
+    store_env(k, i, s);
+    store_ctl<CTL_POS>(k, i, c);
+    k.PA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    k.PA4[i] = 0.f;
+    pa.GOAL[i] = make_float4(tgt.x, tgt.y, tgt.z, 0.0f);
+    pa.OB[i] = make_float4(obj_v.x, obj_v.y, obj_v.z, 0.0f);
+    pa.PRP[i] = make_float4(0.f, 0.f, 0.f, pa.PRP[i].w);
+    if (i < k.n) {
+        k.rew[i] = 0.f;
+        k.reset[i] = 1;
+        k.timeout[i] = 0;
+        pa.collisions[i] = 0.f;
+        if ((i & 63) == 0) k.mask[i >> 6] = 0ull;
+    }
+}
+
+template <int TASK, int CTL>
+static hipError_t launch_custom_phase(const KArgs& k, const PlanArgs& pa, int phase, hipStream_t st) {
+    const dim3 grid((k.n + 63) / 64), block(64);
+    if (phase == PHASE_BOTH) hipLaunchKernelGGL((custom_step_kernel<TASK, CTL, PHASE_BOTH>), grid, block, 0, st, k, pa);
+    else if (phase == PHASE_PHYS) hipLaunchKernelGGL((custom_step_kernel<TASK, CTL, PHASE_PHYS>), grid, block, 0, st, k, pa);
+    else hipLaunchKernelGGL((custom_step_kernel<TASK, CTL, PHASE_POST>), grid, block, 0, st, k, pa);
+    return hipGetLastError();
+}
+
+// task: TASK_BALLOON / TASK_AVOID.  Avoid has a 16-dim observation with 4 action slots: atti (5 actions) is refused, exactly
+// like Planning - the reference itself fails there (`obs_buf[..., 12:16] = actions_local` with a [N,5] tensor, avoid.py:232).
+hipError_t launch_custom_step(const KArgs& k, const PlanArgs& pa, int task, int ctl, int phase, hipStream_t st) {
+    if (task == TASK_BALLOON) {
+        switch (ctl) {
+            case CTL_POS: return launch_custom_phase<TASK_BALLOON, CTL_POS>(k, pa, phase, st);
+            case CTL_VEL: return launch_custom_phase<TASK_BALLOON, CTL_VEL>(k, pa, phase, st);
+            case CTL_ATTI: return launch_custom_phase<TASK_BALLOON, CTL_ATTI>(k, pa, phase, st);
+            case CTL_RATE: return launch_custom_phase<TASK_BALLOON, CTL_RATE>(k, pa, phase, st);
+            case CTL_PROP: return launch_custom_phase<TASK_BALLOON, CTL_PROP>(k, pa, phase, st);
+        }
+    } else if (task == TASK_AVOID) {
+        switch (ctl) {
+            case CTL_POS: return launch_custom_phase<TASK_AVOID, CTL_POS>(k, pa, phase, st);
+            case CTL_VEL: return launch_custom_phase<TASK_AVOID, CTL_VEL>(k, pa, phase, st);
+            case CTL_RATE: return launch_custom_phase<TASK_AVOID, CTL_RATE>(k, pa, phase, st);
+            case CTL_PROP: return launch_custom_phase<TASK_AVOID, CTL_PROP>(k, pa, phase, st);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_custom_reset_all(const KArgs& k, const PlanArgs& pa, int task, int num_actions, hipStream_t st) {
+    if (task == TASK_BALLOON) hipLaunchKernelGGL(custom_reset_all_kernel<TASK_BALLOON>, dim3(pa.n_pad / 256), dim3(256), 0, st, k, pa, num_actions);
+    else hipLaunchKernelGGL(custom_reset_all_kernel<TASK_AVOID>, dim3(pa.n_pad / 256), dim3(256), 0, st, k, pa, num_actions);
     return hipGetLastError();
 }
 

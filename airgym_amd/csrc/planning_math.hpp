@@ -370,3 +370,277 @@ AG_HD void planning_post(EnvState& s, PlanExtra& x, float* pre_a, const float* r
 }
 
 }  // namespace ag
+
+// =====================================================================================================================
+// Balloon and Avoid: the other two tasks of the Customized family.  Same pre_physics_step as
+// Planning (planning_physics above); what follows restates airgym/envs/task/balloon.py and avoid.py (oracle/custom_ref.py,
+// pinned by tests/golden/{balloon,avoid}_*.npz recorded from the reference's own methods).
+// =====================================================================================================================
+namespace ag {
+
+enum : int { TASK_BALLOON = 3, TASK_AVOID = 4 };
+
+constexpr int kBalloonNumObs = 18, kBalloonNumTerms = 6, kBalloonResetUniforms = 15;
+constexpr int kAvoidNumObs = 16, kAvoidNumTerms = 8, kAvoidResetUniforms = 11;
+constexpr float kCubeHalf = 0.15f;        // env_assets/cubes/1x1: unit cube under a 0.15 scale node
+constexpr int kCustomMaxTerms = 8;
+
+struct CustomOut {
+    float rew;
+    int done;
+    int timeout;
+    float terms[kCustomMaxTerms];
+};
+
+// F.normalize(v, dim=-1): v / max(|v|, 1e-12)
+AG_HD V3 normalize_eps(V3 v) {
+    const float n = fmaxf(sqrtf(v.x * v.x + v.y * v.y + v.z * v.z), 1e-12f);
+    return V3{v.x / n, v.y / n, v.z / n};
+}
+
+AG_HD void quat_to_matrix_div(Q4 q, float* R) {   // quaternion_to_matrix with a true division (feeds observations)
+    const float r = q.w, i = q.x, j = q.y, k = q.z;
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    R[0] = 1.0f - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r); R[4] = 1.0f - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1.0f - two_s * (i * i + j * j);
+}
+
+// ---------------------------------------------------------------------------------------------------------- Balloon
+// reset_idx, balloon.py:57-99.  u[15]: balloon x y z | root x y | root z | euler x y z | linvel(3) | angvel(3)
+AG_HD void balloon_reset(EnvState& s, CtlState& c, V3& balloon, V3& pre_pos, float* pre_a, int num_actions, const float* u) {
+    balloon.x = 0.5f * (2.0f * u[0] + -1.0f) + 2.5f;
+    balloon.y = 2.0f * (2.0f * u[1] + -1.0f) + 0.0f;
+    balloon.z = 0.3f * (2.0f * u[2] + -1.0f) + 1.0f;
+    s.p.x = 0.1f * (2.0f * u[3] + -1.0f) + 0.0f;
+    s.p.y = 0.1f * (2.0f * u[4] + -1.0f) + 0.0f;
+    s.p.z = 0.2f * (2.0f * u[5] + -1.0f) + 1.0f;
+    const float a0 = 0.1f * (kTwoPi * u[6] + -kPi);
+    const float a1 = 0.1f * (kPi * u[7] + 0.0f);                 // torch_rand_float(0, pi)
+    const float a2 = 0.2f * (kTwoPi * u[8] + -kPi);
+    const float cx = cosf(0.5f * a0), sx = sinf(0.5f * a0);
+    const float cy = cosf(0.5f * a1), sy = sinf(0.5f * a1);
+    const float cz = cosf(0.5f * a2), sz = sinf(0.5f * a2);
+    s.q.w = cx * cy * cz - sx * sy * sz;                          // euler 'XYZ' -> quaternion (w > 0 for these angles)
+    s.q.x = sx * cy * cz + cx * sy * sz;
+    s.q.y = cx * sy * cz - sx * cy * sz;
+    s.q.z = cx * cy * sz + sx * sy * cz;
+    s.v = V3{0.5f * (2.0f * u[9] + -1.0f), 0.5f * (2.0f * u[10] + -1.0f), 0.5f * (2.0f * u[11] + -1.0f)};
+    s.w = V3{0.2f * (2.0f * u[12] + -1.0f), 0.2f * (2.0f * u[13] + -1.0f), 0.2f * (2.0f * u[14] + -1.0f)};
+    s.progress = 0;
+    s.was_reset = 1;
+    pre_pos = V3{0.0f, 0.0f, 0.0f};
+    ctl_reset(c, s);
+    for (int i = 0; i < num_actions; ++i) pre_a[i] = 0.0f;
+}
+
+AG_HD void custom_reset_uniforms(const StepParams& P, uint32_t env_global, float* u /*[16]*/) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const U4 r = philox4x32_10(env_global, P.tick, STREAM_RESET, (uint32_t)b, P.key0, P.key1);
+        u[4 * b + 0] = u32_to_unit(r.x); u[4 * b + 1] = u32_to_unit(r.y);
+        u[4 * b + 2] = u32_to_unit(r.z); u[4 * b + 3] = u32_to_unit(r.w);
+    }
+}
+
+// progress++, compute_observations, compute_reward (balloon.py:129-165,172-237).  z[18]: standard normals of add_noise.
+template <int CTL>
+AG_HD void balloon_post(EnvState& s, V3 balloon, V3& pre_pos, float* pre_a, const float* raw_action, int collided,
+                        const float* z, const StepParams& P, float* obs, CustomOut& o) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    float a[A];
+    planning_process_action<CTL>(raw_action, a);
+    s.progress += 1;
+    float R[9];
+    quat_to_matrix_div(s.q, R);
+    // (state + sigma * noise) - target: the balloon never rotates (static actor), its matrix is the identity
+#pragma unroll
+    for (int i = 0; i < 9; ++i) obs[i] = (R[i] + kSigMat * z[i]) - ((i == 0 || i == 4 || i == 8) ? 1.0f : 0.0f);
+    obs[9] = (s.p.x + kSigPos * z[9]) - balloon.x;
+    obs[10] = (s.p.y + kSigPos * z[10]) - balloon.y;
+    obs[11] = (s.p.z + kSigPos * z[11]) - balloon.z;
+    obs[12] = s.v.x + kSigVel * z[12]; obs[13] = s.v.y + kSigVel * z[13]; obs[14] = s.v.z + kSigVel * z[14];
+    obs[15] = s.w.x + kSigAng * z[15]; obs[16] = s.w.y + kSigAng * z[16]; obs[17] = s.w.z + kSigAng * z[17];
+    // ---- compute_quadcopter_reward
+    const V3 rel{balloon.x - s.p.x, balloon.y - s.p.y, balloon.z - s.p.z};
+    const V3 dir = normalize_eps(rel);
+    const float direction_yaw = atan2f(dir.y, dir.x);
+    const float root_yaw = atan2f(-R[1], R[0]);                  // matrix_to_euler_angles(R, 'XYZ')[2]
+    const float yaw_distance = fabsf(yaw_diff(root_yaw, direction_yaw));
+    const float yd = 1.6f * yaw_distance;
+    const float yaw_reward = 1.0f / (1.0f + yd * yd);
+    const V3 rp{balloon.x - pre_pos.x, balloon.y - pre_pos.y, balloon.z - pre_pos.z};
+    const float check = sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z);
+    const float guidance = 30.0f * (sqrtf(rp.x * rp.x + rp.y * rp.y + rp.z * rp.z) - check);
+    const float ups_z = (2.0f * (s.q.w * s.q.w) - 1.0f) + 0.0f + s.q.z * s.q.z * 2.0f;
+    const float hu = (ups_z + 1.0f) / 2.0f;
+    const float ups_reward = 0.5f * (hu * hu);
+    const bool hit = check < 0.1f;
+    const float hit_reward = hit ? 800.0f : 0.0f;
+    float a2 = 0.0f, d2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) { a2 += a[i] * a[i]; const float d = a[i] - pre_a[i]; d2 += d * d; }
+    const float effort = 0.1f * expf(-a2);
+    const float smooth = 0.1f * expf(-sqrtf(d2));
+    const float reward = guidance + yaw_reward + hit_reward + smooth + ups_reward + effort;
+    int done = (s.progress >= P.max_episode_length - 1) ? 1 : 0;
+    done = (a[A - 1] < -1.0f) ? 1 : done;
+    done = (a[A - 1] > 1.0f) ? 1 : done;
+    done = (rel.x < -0.2f) ? 1 : done;
+    done = (s.v.x < 0.0f) ? 1 : done;
+    done = (check > 4.0f) ? 1 : done;
+    done = (s.p.z < 0.5f) ? 1 : done;
+    done = (s.p.z > 1.5f) ? 1 : done;
+    done = hit ? 1 : done;
+    done = collided ? 1 : done;                                  // reset_on_collision, balloon.py:133-135
+    o.terms[0] = guidance; o.terms[1] = hit_reward; o.terms[2] = smooth; o.terms[3] = effort; o.terms[4] = ups_reward;
+    o.terms[5] = reward; o.terms[6] = 0.0f; o.terms[7] = 0.0f;
+    o.rew = reward;
+    o.done = done;
+#pragma unroll
+    for (int i = 0; i < A; ++i) pre_a[i] = a[i];
+    pre_pos = s.p;
+    s.was_reset = done;
+}
+
+// ------------------------------------------------------------------------------------------------------------ Avoid
+// The thrown cube between two steps (build-defined: PhysX in the reference): ballistic semi-implicit Euler, inelastic landing.
+AG_HD void avoid_object_step(V3& p, V3& v, float dt) {
+    const bool parked = (p.x == -999.0f);
+    const bool resting = (p.z <= kCubeHalf) && (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) == 0.0f);
+    if (parked || resting) return;
+    v.z = v.z - kGrav * dt;
+    p = V3{p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt};
+    if (p.z <= kCubeHalf) { p.z = kCubeHalf; v = V3{0.0f, 0.0f, 0.0f}; }
+}
+
+AG_HD float point_box_distance(V3 p, V3 c, float half) {
+    const float dx = fmaxf(fabsf(p.x - c.x) - half, 0.0f);
+    const float dy = fmaxf(fabsf(p.y - c.y) - half, 0.0f);
+    const float dz = fmaxf(fabsf(p.z - c.z) - half, 0.0f);
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+// reset_idx incl. calculate_object_velocity, avoid.py:58-163.  u[11]: mask | theta | aim xyz | root x y | root z | euler x y z
+AG_HD void avoid_reset(EnvState& s, CtlState& c, V3& obj_p, V3& obj_v, V3& pre_pos, float* pre_a, int num_actions, const float* u) {
+    if (u[0] < 0.8f) {
+        const float theta = (kPi / 6.0f) * (2.0f * u[1] + -1.0f);
+        obj_p = V3{4.2f * cosf(theta), 4.2f * sinf(theta), 1.4f};
+        const V3 aim{0.3f * (2.0f * u[2] + -1.0f) + 0.0f, 0.3f * (2.0f * u[3] + -1.0f) + 0.0f, 0.3f * (2.0f * u[4] + -1.0f) + 1.0f};
+        const float dx = aim.x - obj_p.x, dy = aim.y - obj_p.y;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        const float ux = dx / dist, uy = dy / dist;
+        const float t = dist / 4.5f;
+        obj_v = V3{ux * 4.5f, uy * 4.5f, (aim.z - obj_p.z + 0.5f * kGrav * (t * t)) / t};
+    } else {
+        obj_p = V3{-999.0f, -999.0f, 0.0f};
+        obj_v = V3{0.0f, 0.0f, 0.0f};
+    }
+    s.p = V3{0.2f * (2.0f * u[5] + -1.0f) + 0.0f, 0.2f * (2.0f * u[6] + -1.0f) + 0.0f, 0.2f * (2.0f * u[7] + -1.0f) + 1.0f};
+    const float a0 = 0.01f * (kTwoPi * u[8] + -kPi), a1 = 0.01f * (kTwoPi * u[9] + -kPi), a2 = 0.05f * (kTwoPi * u[10] + -kPi);
+    const float cx = cosf(0.5f * a0), sx = sinf(0.5f * a0);
+    const float cy = cosf(0.5f * a1), sy = sinf(0.5f * a1);
+    const float cz = cosf(0.5f * a2), sz = sinf(0.5f * a2);
+    s.q.w = cx * cy * cz - sx * sy * sz;
+    s.q.x = sx * cy * cz + cx * sy * sz;
+    s.q.y = cx * sy * cz - sx * cy * sz;
+    s.q.z = cx * cy * sz + sx * sy * cz;
+    s.v = V3{0.0f, 0.0f, 0.0f};
+    s.w = V3{0.0f, 0.0f, 0.0f};
+    s.progress = 0;
+    s.was_reset = 1;
+    pre_pos = V3{0.0f, 0.0f, 0.0f};
+    ctl_reset(c, s);
+    for (int i = 0; i < num_actions; ++i) pre_a[i] = 0.0f;
+}
+
+// progress++, compute_observations, compute_reward (avoid.py:189-240,242-300); target = P.target (avoid_config.py:11)
+template <int CTL>
+AG_HD void avoid_post(EnvState& s, V3& pre_pos, float* pre_a, const float* raw_action, int collided, const StepParams& P,
+                      float* obs, CustomOut& o) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    float a[A];
+    planning_process_action<CTL>(raw_action, a);
+    s.progress += 1;
+    float R[9];
+    quat_to_matrix_div(s.q, R);
+    const float yaw = atan2f(R[3], R[0]);
+    const float cy = cosf(yaw), sy = sinf(yaw);
+    float L[9];
+    L[0] = cy * R[0] + sy * R[3]; L[1] = cy * R[1] + sy * R[4]; L[2] = cy * R[2] + sy * R[5];
+    L[3] = -sy * R[0] + cy * R[3]; L[4] = -sy * R[1] + cy * R[4]; L[5] = -sy * R[2] + cy * R[5];
+    L[6] = R[6]; L[7] = R[7]; L[8] = R[8];
+    obs[0] = s.p.x - P.target[9]; obs[1] = s.p.y - P.target[10]; obs[2] = s.p.z - P.target[11];
+    obs[3] = atan2f(-L[5], L[8]); obs[4] = asinf(L[2]); obs[5] = atan2f(-L[1], L[0]);
+    obs[6] = cy * s.v.x + sy * s.v.y; obs[7] = -sy * s.v.x + cy * s.v.y; obs[8] = s.v.z;
+    obs[9] = cy * s.w.x + sy * s.w.y; obs[10] = -sy * s.w.x + cy * s.w.y; obs[11] = s.w.z;
+    obs[12] = a[0]; obs[13] = a[1]; obs[14] = a[2]; obs[15] = a[3];
+    // ---- compute_quadcopter_reward
+    const V3 rel{P.target[9] - s.p.x, P.target[10] - s.p.y, P.target[11] - s.p.z};
+    const float root_yaw = atan2f(-R[1], R[0]);
+    const float rh = yaw_diff(P.target_yaw, root_yaw);
+    const float distance = sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z + rh * rh);
+    const float pd = 1.6f * distance;
+    const float pose = 1.0f / (1.0f + pd * pd);
+    const float ups_z = (2.0f * (s.q.w * s.q.w) - 1.0f) + 0.0f + s.q.z * s.q.z * 2.0f;
+    const float hu = (ups_z + 1.0f) / 2.0f;
+    const float ups_reward = hu * hu;
+    const float spinnage = s.w.z * s.w.z;
+    const float spin = 1.0f / (1.0f + spinnage * spinnage);
+    float a2 = 0.0f, d2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) a2 += a[i] * a[i];
+#pragma unroll
+    for (int i = 0; i < A - 1; ++i) { const float d = a[i] - pre_a[i]; d2 += d * d; }
+    const float effort = 0.1f * expf(-a2);
+    const float thrust_reward = 0.05f * (1.0f - fabsf(0.1533f - a[A - 1]));
+    const float smooth = 0.1f * expf(-sqrtf(d2));
+    const float alive = collided ? -500.0f : 0.5f;
+    const float reward = pose + pose * (ups_reward + spin) + effort + smooth + thrust_reward + alive;
+    int done = (s.progress >= P.max_episode_length - 1) ? 1 : 0;
+    done = (s.p.z < 0.3f) ? 1 : done;
+    done = (s.p.z > 1.7f) ? 1 : done;
+    done = (sqrtf(rel.x * rel.x + rel.y * rel.y + rel.z * rel.z) > 2.0f) ? 1 : done;
+    done = (ups_z < 0.0f) ? 1 : done;
+    done = collided ? 1 : done;                                  // reset_on_collision, avoid.py:191-193
+    o.terms[0] = pose; o.terms[1] = ups_reward; o.terms[2] = spin; o.terms[3] = effort; o.terms[4] = smooth;
+    o.terms[5] = thrust_reward; o.terms[6] = alive; o.terms[7] = reward;
+    o.rew = reward;
+    o.done = done;
+#pragma unroll
+    for (int i = 0; i < A; ++i) pre_a[i] = a[i];
+    pre_pos = s.p;
+    s.was_reset = done;
+}
+
+// smallest t > 0 where o + t d enters the axis-aligned cube (exit parameter for a ray starting inside); kInf = miss
+AG_HD float ray_aabb(V3 o, V3 d, V3 c, float half) {
+    float tmin = -kInf, tmax = kInf;
+    bool ok = true;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, cc[3] = {c.x, c.y, c.z};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        if (fabsf(dd[ax]) <= 1e-12f) {
+            ok = ok && (oo[ax] >= cc[ax] - half) && (oo[ax] <= cc[ax] + half);
+        } else {
+            const float inv = 1.0f / dd[ax];
+            const float t0 = (cc[ax] - half - oo[ax]) * inv, t1 = (cc[ax] + half - oo[ax]) * inv;
+            tmin = fmaxf(tmin, fminf(t0, t1));
+            tmax = fminf(tmax, fmaxf(t0, t1));
+        }
+    }
+    if (!(ok && tmax >= tmin && tmax > 0.0f)) return kInf;
+    return tmin > 0.0f ? tmin : tmax;
+}
+
+// z-depth of one pixel of Avoid's scene: the cube and the ground plane
+AG_HD float depth_pixel_box(const Camera& cam, V3 d, V3 box) {
+    float t = ray_aabb(cam.o, d, box, kCubeHalf);
+    if (d.z < -1e-12f) {
+        const float tg = -cam.o.z * fast_rcp(d.z);
+        if (tg > 0.0f) t = fminf(t, tg);
+    }
+    return t <= kCamFar ? t : kInf;
+}
+
+}  // namespace ag

@@ -1,5 +1,5 @@
-"""Task registration, same table shape as the reference's airgym/envs/__init__.py:5-88 (only the tasks
-on BASELINE.json's hot path are implemented; the others raise ValueError from make_env)."""
+"""Task registration, same table shape as the reference's airgym/envs/__init__.py:5-88 (Hovering, Tracking, Planning,
+Balloon, Avoid; maplanning / depthgen raise ValueError from make_env)."""
 from airgym_amd.utils.task_registry import task_registry
 
 TASK_CONFIGS = [
@@ -9,6 +9,10 @@ TASK_CONFIGS = [
      "task_module": "task.tracking", "task_class": "Tracking"},
     {"name": "planning", "config_module": "task.planning_config", "config_class": "PlanningCfg",
      "task_module": "task.planning", "task_class": "Planning"},
+    {"name": "balloon", "config_module": "task.balloon_config", "config_class": "BalloonCfg",
+     "task_module": "task.balloon", "task_class": "Balloon"},
+    {"name": "avoid", "config_module": "task.avoid_config", "config_class": "AvoidCfg",
+     "task_module": "task.avoid", "task_class": "Avoid"},
 ]
 
 

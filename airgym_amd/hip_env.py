@@ -43,6 +43,8 @@ class HipEnvHandle:
         cfg.max_episode_length = int(max_episode_length)
         if target_state is None:
             target_state = [1, 0, 0, 0, 1, 0, 0, 0, 1] + [0] * 9
+            if task == "avoid":
+                target_state[11] = 1            # avoid_config.py:11: hold (0, 0, 1)
         ts = np.asarray(target_state, dtype=np.float32).reshape(18)
         for i in range(18):
             cfg.target_state[i] = float(ts[i])
@@ -77,9 +79,11 @@ class HipEnvHandle:
             with torch.cuda.device(self.device):
                 N.check(self.lib.ag_reset_all(self.h, None), "ag_reset_all")
                 torch.cuda.synchronize(self.device)
+        if task in ("planning", "balloon", "avoid"):
             pb = N.AgPlanningBuffers()
             N.check(self.lib.ag_planning_get_buffers(self.h, ctypes.byref(pb)), "ag_planning_get_buffers")
-            self.image = self._view(pb.image_dev, torch.float32, (n, 1, 212, 120))
+            if pb.image_dev:
+                self.image = self._view(pb.image_dev, torch.float32, (n, 1, 212, 120))
             self.collisions = self._view(pb.collisions_dev, torch.float32, (n,))
         self.reward_terms = None
         self.reward_terms_stacked = None
@@ -174,7 +178,7 @@ class HipEnvHandle:
         actions = self._check_actions(actions)
         noise = noise.to(device=self.device, dtype=torch.float32).contiguous()
         reset_uniforms = reset_uniforms.to(device=self.device, dtype=torch.float32).contiguous()
-        assert noise.shape == (self.num_envs, 18) and reset_uniforms.shape == (self.num_envs, 12)
+        assert noise.shape == (self.num_envs, 18) and reset_uniforms.shape == (self.num_envs, self.RESET_UNIFORMS.get(self.task, 12))
         N.check(self.lib.ag_step_with_inputs(self.h, actions.data_ptr(), noise.data_ptr(), reset_uniforms.data_ptr(),
                                              self._stream()), "ag_step_with_inputs")
 
@@ -210,19 +214,27 @@ class HipEnvHandle:
         torch.cuda.current_stream(self.device).synchronize()  # `keep` must outlive the kernel
 
     # ---- planning extras
+    RESET_UNIFORMS = {"planning": 121, "balloon": 15, "avoid": 11}
+
     def planning_step_with_uniforms(self, actions, reset_uniforms):
         actions = self._check_actions(actions)
         ru = reset_uniforms.to(device=self.device, dtype=torch.float32).contiguous()
-        assert ru.shape == (self.num_envs, 121)
+        assert ru.shape == (self.num_envs, self.RESET_UNIFORMS[self.task])
         N.check(self.lib.ag_planning_step_with_uniforms(self.h, actions.data_ptr(), ru.data_ptr(), self._stream()),
                 "ag_planning_step_with_uniforms")
 
-    def planning_eval_post(self, actions, collisions):
-        """Post-physics half of Planning.step on the current state with supplied collision flags (parity tests)."""
+    def planning_eval_post(self, actions, collisions, noise=None):
+        """Post-physics half of Planning / Balloon / Avoid .step on the current state with supplied collision flags (and,
+        for Balloon, supplied observation noise) - parity tests."""
         actions = self._check_actions(actions)
         c = collisions.to(device=self.device, dtype=torch.float32).contiguous()
         assert c.shape == (self.num_envs,)
-        N.check(self.lib.ag_planning_eval_post(self.h, actions.data_ptr(), c.data_ptr(), self._stream()),
+        z = None
+        if noise is not None:
+            z = noise.to(device=self.device, dtype=torch.float32).contiguous()
+            assert z.shape == (self.num_envs, 18)
+        N.check(self.lib.ag_planning_eval_post(self.h, actions.data_ptr(), c.data_ptr(),
+                                               z.data_ptr() if z is not None else None, self._stream()),
                 "ag_planning_eval_post")
         torch.cuda.current_stream(self.device).synchronize()
 
@@ -234,13 +246,17 @@ class HipEnvHandle:
 
     def planning_get_state(self):
         n = self.num_envs
-        out = {"obstacles": torch.empty(n, 40, 4, device=self.device), "goal": torch.empty(n, 3, device=self.device),
-               "extra": torch.empty(n, 5, device=self.device)}
-        v = N.AgPlanningStateView(out["obstacles"].data_ptr(), out["goal"].data_ptr(), out["extra"].data_ptr())
+        out = {"goal": torch.empty(n, 3, device=self.device), "extra": torch.empty(n, 5, device=self.device)}
+        if self.task == "planning":
+            out["obstacles"] = torch.empty(n, 40, 4, device=self.device)
+        if self.task == "avoid":
+            out["object_vel"] = torch.empty(n, 3, device=self.device)
+        v = N.AgPlanningStateView(out["obstacles"].data_ptr() if "obstacles" in out else None, out["goal"].data_ptr(),
+                                  out["extra"].data_ptr(), out["object_vel"].data_ptr() if "object_vel" in out else None)
         N.check(self.lib.ag_planning_get_state(self.h, ctypes.byref(v), self._stream()), "ag_planning_get_state")
         return out
 
-    def planning_set_state(self, obstacles=None, goal=None, extra=None):
+    def planning_set_state(self, obstacles=None, goal=None, extra=None, object_vel=None):
         keep = []
 
         def p(t, shape):
@@ -251,7 +267,7 @@ class HipEnvHandle:
             keep.append(t)
             return t.data_ptr()
         n = self.num_envs
-        v = N.AgPlanningStateView(p(obstacles, (n, 40, 4)), p(goal, (n, 3)), p(extra, (n, 5)))
+        v = N.AgPlanningStateView(p(obstacles, (n, 40, 4)), p(goal, (n, 3)), p(extra, (n, 5)), p(object_vel, (n, 3)))
         N.check(self.lib.ag_planning_set_state(self.h, ctypes.byref(v), self._stream()), "ag_planning_set_state")
         torch.cuda.current_stream(self.device).synchronize()
 

@@ -233,7 +233,8 @@ class FusedRolloutStep:
         m = agent.model
         sh = agent.rewards_shaper
         return (str(agent.ppo_device).startswith("cuda") and agent.config.get("use_fused_rollout", True)
-                and agent._hip_env is not None and agent._fused_loss_ok() and not m.dict_obs
+                and agent._hip_env is not None and agent._hip_env.task in ("hovering", "tracking")
+                and agent._fused_loss_ok() and not m.dict_obs
                 and m.actor_mlp.activation_name == "elu" and getattr(agent, "heads_w", None) is not None
                 and agent.actions_num in (4, 5) and agent.clip_actions
                 and bool((agent.actions_low == -1).all()) and bool((agent.actions_high == 1).all())

@@ -70,8 +70,12 @@ typedef enum ag_status {
 typedef enum ag_task {
     AG_TASK_HOVERING = 0, /* airgym/envs/base/hovering.py, 18 obs, 24 s episodes */
     AG_TASK_TRACKING = 1, /* airgym/envs/task/tracking.py, 48 obs, 36 s episodes */
-    AG_TASK_PLANNING = 2  /* airgym/envs/task/planning.py (on base/customized.py): 16 obs + 212x120 depth image,
+    AG_TASK_PLANNING = 2, /* airgym/envs/task/planning.py (on base/customized.py): 16 obs + 212x120 depth image,
                              16 s episodes, 40 cylinder obstacles + goal per env; ctl_mode pos|vel|rate|prop */
+    AG_TASK_BALLOON = 3,  /* airgym/envs/task/balloon.py (on base/customized.py): 18 noisy obs relative to a static target
+                             ball, 8 s episodes, no camera; all five ctl modes */
+    AG_TASK_AVOID = 4     /* airgym/envs/task/avoid.py (on base/customized.py): 16 obs + 212x120 depth image, 6 s episodes,
+                             one thrown 0.3 m cube per env (avoid.py:58-90); ctl_mode pos|vel|rate|prop */
 } ag_task;
 
 /* --ctl_mode pos|vel|atti|rate|prop  (README: PY / LV / CTA / CTBR / SRT) */
@@ -112,7 +116,9 @@ typedef struct ag_config {
 /* Reward-term order in ag_buffers.reward_terms[k] (each float[num_envs]).
  * Hovering (hovering.py:448-457): continous_action, effort, thrust, pos, vel_direction, ups, spin, yaw, reward
  * Tracking (tracking.py:285-294): dist_norm, dist_reward, yaw, spin, continous_action, thrust, effort, ups, reward
- * Planning (planning.py:294-305): continous_action, heading, speed, forward, alive, ups, z, esdf, thrust, reach_goal, reward */
+ * Planning (planning.py:294-305): continous_action, heading, speed, forward, alive, ups, z, esdf, thrust, reach_goal, reward
+ * Balloon (balloon.py:228-235): guidance, hit, action_smoothness, effort, ups, reward
+ * Avoid (avoid.py:289-298): pose, ups, spin, effort, action_smoothness, thrust, alive, reward */
 typedef struct ag_buffers {
     int32_t num_envs;
     int32_t num_obs;
@@ -142,7 +148,7 @@ typedef struct ag_state_view {
 int ag_version(void);
 const char* ag_last_error(void);
 
-int ag_num_obs(int task);                      /* 18 / 48, <0 on unknown task */
+int ag_num_obs(int task);                      /* 18 / 48 / 16 / 18 / 16, <0 on unknown task */
 int ag_num_actions(int ctl_mode);              /* 5 for atti else 4 (hovering.py:47) */
 int ag_default_episode_length(int task, double dt);
 size_t ag_arena_bytes(const ag_config* cfg);   /* 0 on invalid cfg */
@@ -331,9 +337,10 @@ typedef struct ag_planning_buffers {
 } ag_planning_buffers;
 
 typedef struct ag_planning_state_view {   /* all DEVICE pointers, any may be NULL */
-    float* obstacles_dev;   /* [num_envs, 40, 4]: root x, y, yaw, variant index (as float) */
-    float* goal_dev;        /* [num_envs, 3] */
+    float* obstacles_dev;   /* planning only: [num_envs, 40, 4]: root x, y, yaw, variant index (as float) */
+    float* goal_dev;        /* [num_envs, 3]: planning goal / balloon position (balloon.py:37-39) / cube position (avoid.py:38-40) */
     float* extra_dev;       /* [num_envs, 5]: pre_root_positions xyz, esdf_dist, prev_related_dist */
+    float* object_vel_dev;  /* avoid only: [num_envs, 3] linear velocity of the thrown cube (avoid.py:41) */
 } ag_planning_state_view;
 
 /* table_host: [n_variants <= 100, 8] = centre xyz, unit axis xyz, radius, half length of each obstacle variant in
@@ -342,14 +349,19 @@ int ag_planning_set_obstacle_table(ag_handle h, const float* table_host, int n_v
 int ag_planning_get_buffers(ag_handle h, ag_planning_buffers* out);
 int ag_planning_get_state(ag_handle h, const ag_planning_state_view* view, void* stream);
 int ag_planning_set_state(ag_handle h, const ag_planning_state_view* view, void* stream);
-/* Parity mode: per-env reset uniforms [num_envs, 121] supplied by the caller (NULL = counter RNG). */
+/* The ag_planning_* entry points below also serve Balloon and Avoid handles (the same Customized family).
+ * Parity mode: per-env reset uniforms supplied by the caller (NULL = counter RNG): planning [num_envs, 121];
+ * balloon [num_envs, 15] = balloon xyz | root xy | root z | euler xyz | linvel | angvel (balloon.py:57-99);
+ * avoid [num_envs, 11] = throw mask | theta | aim xyz | root xy | root z | euler xy | euler z (avoid.py:58-163). */
 int ag_planning_step_with_uniforms(ag_handle h, const float* actions_dev, const float* reset_uniforms_dev, void* stream);
 /* Parity / inspection mode: the post-physics half of Planning.step (planning.py:158-183: progress++, compute_observations,
  * compute_quadcopter_reward, reset of done envs) on the handle's CURRENT state, with the collision flags
  * (Customized.check_collisions, customized.py:393-397) supplied by the caller [num_envs] f32 0/1 instead of the geometric
  * test - how the vectors recorded from the reference's own Planning methods are replayed on the HIP kernel.  actions_dev is
- * the RAW action (the thrust channel is remapped in rate mode exactly as in a step). */
-int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* collisions_dev, void* stream);
+ * the RAW action (the thrust channel is remapped in rate mode exactly as in a step).  noise_dev: balloon handles only,
+ * [num_envs, 18] standard normals of Customized.add_noise (customized.py:450-459) or NULL (counter RNG / noise off). */
+int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* collisions_dev, const float* noise_dev,
+                          void* stream);
 /* Render the camera on the NEXT step regardless of the every-4th-step schedule (planning.py:153-156). */
 int ag_planning_render_now(ag_handle h);
 

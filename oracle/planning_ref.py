@@ -116,8 +116,32 @@ def _ray_capped_cylinders(orig, dirs, centre, axis, r, h):
     return best.min(dim=1).values
 
 
-def render_depth_one(pos, quat_xyzw, centre, axis, r, h, goal):
-    """z-depth image [CAM_H, CAM_W] float32 for one env (inf where nothing is hit within the far plane)."""
+def _ray_aabb(orig, dirs, centre, half):
+    """Slab test: smallest t > 0 where orig + t dirs enters the axis-aligned box (centre [3], half extent), inf = miss.
+    A ray starting inside the box returns its exit parameter."""
+    inf = torch.full((dirs.shape[0],), float("inf"))
+    tmin = torch.full_like(inf, -float("inf"))
+    tmax = inf.clone()
+    ok = torch.ones_like(inf, dtype=torch.bool)
+    for ax in range(3):
+        d = dirs[:, ax]
+        par = d.abs() <= 1e-12
+        inv = 1.0 / torch.where(par, torch.ones_like(d), d)
+        t0 = (centre[ax] - half - orig[ax]) * inv
+        t1 = (centre[ax] + half - orig[ax]) * inv
+        lo, hi = torch.minimum(t0, t1), torch.maximum(t0, t1)
+        inside = (orig[ax] >= centre[ax] - half) & (orig[ax] <= centre[ax] + half)
+        tmin = torch.where(par, tmin, torch.maximum(tmin, lo))
+        tmax = torch.where(par, tmax, torch.minimum(tmax, hi))
+        ok = ok & (~par | inside)
+    hit = ok & (tmax >= tmin) & (tmax > 0)
+    t = torch.where(tmin > 0, tmin, tmax)
+    return torch.where(hit, t, inf)
+
+
+def render_depth_one(pos, quat_xyzw, centre, axis, r, h, goal, box=None):
+    """z-depth image [CAM_H, CAM_W] float32 for one env (inf where nothing is hit within the far plane).
+    goal = None skips the goal sphere; box = (centre [3], half extent) adds an axis-aligned cube (Avoid's thrown object)."""
     fx = camera_fx()
     R = T.quaternion_to_matrix(quat_xyzw[[3, 0, 1, 2]])
     orig = pos + R @ torch.tensor(CAM_OFFSET)
@@ -128,18 +152,20 @@ def render_depth_one(pos, quat_xyzw, centre, axis, r, h, goal):
     d_body = torch.stack((torch.ones(CAM_H, CAM_W), dy[None, :].expand(CAM_H, CAM_W), dz[:, None].expand(CAM_H, CAM_W)), -1)
     dirs = (d_body.reshape(-1, 3) @ R.T)                             # world directions, x-component of body dir = 1
     inf = torch.full((dirs.shape[0],), float("inf"))
-    t = _ray_capped_cylinders(orig, dirs, centre, axis, r, h)
+    t = _ray_capped_cylinders(orig, dirs, centre, axis, r, h) if centre is not None and centre.shape[0] > 0 else inf.clone()
+    if box is not None:
+        t = torch.minimum(t, _ray_aabb(orig, dirs, box[0], box[1]))
     # ground plane z = 0
     tg = torch.where(dirs[:, 2] < -1e-12, -orig[2] / torch.where(dirs[:, 2] < -1e-12, dirs[:, 2], -torch.ones_like(inf)), inf)
     t = torch.minimum(t, torch.where(tg > 0, tg, inf))
-    # goal sphere
-    oc = orig - goal
-    a = (dirs * dirs).sum(-1)
-    b = (dirs * oc[None]).sum(-1)
-    c = (oc * oc).sum() - GOAL_RADIUS ** 2
-    disc = b * b - a * c
-    ts = (-b - torch.sqrt(torch.clamp(disc, min=0.0))) / a
-    t = torch.minimum(t, torch.where((disc >= 0) & (ts > 0), ts, inf))
+    if goal is not None:    # goal sphere
+        oc = orig - goal
+        a = (dirs * dirs).sum(-1)
+        b = (dirs * oc[None]).sum(-1)
+        c = (oc * oc).sum() - GOAL_RADIUS ** 2
+        disc = b * b - a * c
+        ts = (-b - torch.sqrt(torch.clamp(disc, min=0.0))) / a
+        t = torch.minimum(t, torch.where((disc >= 0) & (ts > 0), ts, inf))
     t = torch.where(t <= CAM_FAR, t, inf)                            # the ray parameter IS the z-depth (dir_x = 1)
     return t.reshape(CAM_H, CAM_W)
 

@@ -201,3 +201,60 @@ void agh_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
 }
 
 }  // extern "C"
+
+// ---- Balloon / Avoid (planning_math.hpp): post-physics half and reset, as custom_step_kernel calls them
+template <int TASK, int CTL>
+static void custom_post_t(int n, const StepParams& P, float* rs, float* pa, int32_t* progress, const float* actions, float* goal,
+                          float* objvel, float* prepos, const float* coll, const float* noise, const float* ext_u, float* obs,
+                          float* rew, int32_t* done, float* terms) {
+    constexpr int A = CtlTraits<CTL>::kNumActions;
+    constexpr int NOBS = (TASK == TASK_BALLOON) ? kBalloonNumObs : kAvoidNumObs;
+    constexpr int NU = (TASK == TASK_BALLOON) ? kBalloonResetUniforms : kAvoidResetUniforms;
+    float cs[12] = {0};
+    int32_t wr = 0;
+    for (int i = 0; i < n; ++i) {
+        Arrays a{1, rs + (size_t)i * 13, cs, pa + (size_t)i * A, progress + i, &wr};
+        EnvState s;
+        CtlState c;
+        float pre_a[A];
+        load(a, 0, A, s, c, pre_a);
+        V3 tgt{goal[3 * i], goal[3 * i + 1], goal[3 * i + 2]}, ov{objvel[3 * i], objvel[3 * i + 1], objvel[3 * i + 2]};
+        V3 pp{prepos[3 * i], prepos[3 * i + 1], prepos[3 * i + 2]};
+        float ob[18];
+        CustomOut o;
+        const int collided = coll[i] != 0.0f;
+        if (TASK == TASK_BALLOON) balloon_post<CTL>(s, tgt, pp, pre_a, actions + (size_t)i * A, collided, noise + (size_t)i * 18, P, ob, o);
+        else avoid_post<CTL>(s, pp, pre_a, actions + (size_t)i * A, collided, P, ob, o);
+        if (o.done && ext_u) {
+            if (TASK == TASK_BALLOON) balloon_reset(s, c, tgt, pp, pre_a, A, ext_u + (size_t)i * NU);
+            else avoid_reset(s, c, tgt, ov, pp, pre_a, A, ext_u + (size_t)i * NU);
+        }
+        store(a, 0, A, s, c, pre_a);
+        goal[3 * i] = tgt.x; goal[3 * i + 1] = tgt.y; goal[3 * i + 2] = tgt.z;
+        objvel[3 * i] = ov.x; objvel[3 * i + 1] = ov.y; objvel[3 * i + 2] = ov.z;
+        prepos[3 * i] = pp.x; prepos[3 * i + 1] = pp.y; prepos[3 * i + 2] = pp.z;
+        for (int j = 0; j < NOBS; ++j) obs[(size_t)i * NOBS + j] = ob[j];
+        rew[i] = o.rew; done[i] = o.done;
+        for (int t = 0; t < kCustomMaxTerms; ++t) terms[(size_t)i * kCustomMaxTerms + t] = o.terms[t];
+    }
+}
+
+extern "C" int agh_custom_post(int task, int ctl, int n, int max_len, const float* target18, float* rs, float* pa,
+                               int32_t* progress, const float* actions, float* goal, float* objvel, float* prepos,
+                               const float* coll, const float* noise, const float* ext_u, float* obs, float* rew,
+                               int32_t* done, float* terms) {
+    StepParams P = make_step_params(0, 0.01, max_len, target18, 0, 0, false);
+#define AGH_C(T, C) custom_post_t<T, C>(n, P, rs, pa, progress, actions, goal, objvel, prepos, coll, noise, ext_u, obs, rew, done, terms)
+    if (task == TASK_BALLOON) {
+        if (ctl == CTL_VEL) AGH_C(TASK_BALLOON, CTL_VEL); else if (ctl == CTL_RATE) AGH_C(TASK_BALLOON, CTL_RATE);
+        else if (ctl == CTL_ATTI) AGH_C(TASK_BALLOON, CTL_ATTI); else return -1;
+    } else if (task == TASK_AVOID) {
+        if (ctl == CTL_VEL) AGH_C(TASK_AVOID, CTL_VEL); else if (ctl == CTL_RATE) AGH_C(TASK_AVOID, CTL_RATE); else return -1;
+    } else return -1;
+#undef AGH_C
+    return 0;
+}
+
+extern "C" float agh_ray_aabb(const float* o3, const float* d3, const float* c3, float half) {
+    return ray_aabb(V3{o3[0], o3[1], o3[2]}, V3{d3[0], d3[1], d3[2]}, V3{c3[0], c3[1], c3[2]}, half);
+}

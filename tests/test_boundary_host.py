@@ -41,9 +41,9 @@ def test_config_field_trees_equal_reference():
 def test_registry_and_errors():
     import airgym_amd.envs  # noqa: F401
     from airgym_amd.utils.task_registry import task_registry
-    assert task_registry.get_registered_tasks() == ["hovering", "tracking", "planning"]
+    assert task_registry.get_registered_tasks() == ["hovering", "tracking", "planning", "balloon", "avoid"]
     with pytest.raises(ValueError, match="was not registered"):            # task_registry.py:78-79
-        task_registry.make_env("avoid", Namespace(num_envs=4, ctl_mode="rate", seed=1))
+        task_registry.make_env("maplanning", Namespace(num_envs=4, ctl_mode="rate", seed=1))
     with pytest.raises((ValueError, RuntimeError)):                        # bad ctl_mode is an error, not a print
         task_registry.make_env("hovering", Namespace(num_envs=4, ctl_mode="warp", seed=1, sim_device="cuda:0",
                                                      headless=True))

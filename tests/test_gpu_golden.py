@@ -499,7 +499,8 @@ def test_golden_adaptive_lr_in_adam_kernel(golden):
             assert ppo_ref.adaptive_lr(lr, float(kl)) == lrs[k]                    # oracle == recorded (float64 KL)
             # the kernel sees the KL as float32 (it lives in the gradient buffer) and compares it with the float32 threshold:
             # kl = 2 * thr and kl = thr / 2 exactly stay "inside" on both sides, like the reference's float64 comparison
-            assert abs(state[0].item() - lrs[k]) <= 1e-12 * max(1.0, lrs[k]) + 1e-18, (start, kl, state[0].item(), lrs[k])
+            # (min_lr / max_lr cross the C ABI as float: the 1e-2 bound is 0.00999999978 there)
+            assert abs(state[0].item() - lrs[k]) <= 1e-7 * lrs[k], (start, kl, state[0].item(), lrs[k])
             k += 1
             np.testing.assert_allclose(pd.cpu().numpy(), ref_p.detach().numpy(), rtol=0, atol=3e-6)
     assert k == len(lrs)

@@ -1,0 +1,217 @@
+"""Balloon and Avoid on the MI355X: the HIP kernels through the C ABI against (a) the vectors
+recorded from the REFERENCE's own Balloon / Avoid methods (tests/golden/{balloon,avoid}_*.npz) and (b) the oracle
+(oracle/custom_ref.py) in closed loop, plus the drop-in API and a short PPO run on each task."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Handle():
+    from airgym_amd.hip_env import HipEnvHandle
+    assert torch.cuda.is_available()
+    return HipEnvHandle
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+# ------------------------------------------------------------------------------------------------- golden: Balloon
+def test_balloon_golden_observations_reward_done(Handle, golden):
+    """Balloon.compute_observations + compute_quadcopter_reward of the reference (balloon.py:145-237) replayed on the HIP
+    post-physics kernel.  `vel` handle: its action map is the identity, so the recorded self.actions pass through."""
+    g = golden("balloon_obs_reward")
+    n = g["root_states"].shape[0]
+    env = Handle("balloon", "vel", n, seed=0)
+    env.set_state(root_states=t(g["root_states"]), progress=t((g["progress"] - 1).astype(np.int32)),
+                  pre_actions=t(g["pre_actions"]), was_reset=torch.zeros(n, dtype=torch.int32))
+    extra = torch.zeros(n, 5); extra[:, 0:3] = t(g["pre_root_positions"])
+    env.planning_set_state(goal=t(g["balloon"]), extra=extra)
+    env.planning_eval_post(t(g["actions"]).cuda(), torch.zeros(n), noise=t(g["noise"]))
+    reset = env.reset_buf.cpu().numpy()
+    assert np.array_equal(reset, g["reset"]), np.nonzero(reset != g["reset"])
+    assert list(reset[8:20]) == [1, 0, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1]      # every termination threshold, either side
+    np.testing.assert_allclose(env.obs_buf.cpu().numpy(), g["obs"], rtol=0, atol=2e-6)
+    # guidance = 30 * (difference of two norms ~ 2.5): 30 x 2 ulp(2.5) = 1.4e-5
+    np.testing.assert_allclose(env.rew_buf.cpu().numpy(), g["reward"], rtol=0, atol=5e-5)
+    for k, buf in env.reward_terms.items():
+        np.testing.assert_allclose(buf.cpu().numpy(), g["info_" + k].astype(np.float64), rtol=0, atol=5e-5, err_msg=k)
+    assert env.reward_terms["hit_reward"][8].item() == 800.0 and env.reward_terms["hit_reward"][9].item() == 0.0
+    env.close()
+
+
+def test_balloon_golden_reset(Handle, golden):
+    """Balloon.reset_idx (balloon.py:57-99) with the recorded uniforms through the step kernel's own reset path."""
+    g = golden("balloon_reset")
+    n = g["uniforms"].shape[0]
+    env = Handle("balloon", "rate", n, seed=4, obs_noise=False)
+    rs = torch.zeros(n, 13); rs[:, 6] = 1.0; rs[:, 2] = 2.0                 # above the 1.5 m ceiling: every env terminates
+    env.set_state(root_states=rs, progress=torch.full((n,), 9, dtype=torch.int32), pre_actions=torch.ones(n, 4))
+    a = torch.zeros(n, 4); a[:, 3] = -0.7
+    env.planning_step_with_uniforms(a.cuda(), t(g["uniforms"]))
+    st, ps = env.get_state(), env.planning_get_state()
+    assert (env.reset_buf == 1).all() and np.array_equal(env.reset_buf.cpu().numpy(), g["reset_buf"])
+    np.testing.assert_allclose(st["root_states"].cpu().numpy(), g["root_states"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ps["goal"].cpu().numpy(), g["balloon"], rtol=0, atol=1e-6)
+    assert np.array_equal(st["progress"].cpu().numpy(), g["progress"].astype(np.int32))
+    assert np.array_equal(st["pre_actions"].cpu().numpy(), g["pre_actions"])
+    assert np.array_equal(ps["extra"][:, 0:3].cpu().numpy(), g["pre_root_positions"])
+    env.close()
+
+
+# --------------------------------------------------------------------------------------------------- golden: Avoid
+def test_avoid_golden_observations_reward_done(Handle, golden):
+    """Avoid.compute_observations + compute_quadcopter_reward of the reference (avoid.py:208-300), collision flags supplied."""
+    g = golden("avoid_obs_reward")
+    n = g["root_states"].shape[0]
+    env = Handle("avoid", "vel", n, seed=0)
+    env.set_state(root_states=t(g["root_states"]), progress=t((g["progress"] - 1).astype(np.int32)),
+                  pre_actions=t(g["pre_actions"]), was_reset=torch.zeros(n, dtype=torch.int32))
+    env.planning_eval_post(t(g["actions"]).cuda(), t(g["collisions"]))
+    reset = env.reset_buf.cpu().numpy()
+    # reset_on_collision is applied by the step after compute_reward (avoid.py:191-193); the recorded flags precede it
+    expect = np.maximum(g["reset"], (g["collisions"] > 0).astype(np.int64))
+    assert np.array_equal(reset, expect), np.nonzero(reset != expect)
+    assert list(g["reset"][8:16]) == [0, 1, 0, 1, 0, 1, 0, 1]
+    np.testing.assert_allclose(env.obs_buf.cpu().numpy(), g["obs"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(env.rew_buf.cpu().numpy(), g["reward"], rtol=0, atol=1e-4)        # |reward| up to 500
+    for k, buf in env.reward_terms.items():
+        np.testing.assert_allclose(buf.cpu().numpy(), g["info_" + k], rtol=0, atol=1e-4 if k == "reward" else 2e-6, err_msg=k)
+    assert np.array_equal(env.collisions.cpu().numpy(), g["collisions"])
+    env.close()
+
+
+def test_avoid_golden_reset_and_throw(Handle, golden):
+    """Avoid.reset_idx incl. calculate_object_velocity (avoid.py:58-163) with the recorded uniforms."""
+    g = golden("avoid_reset")
+    n = g["uniforms"].shape[0]
+    env = Handle("avoid", "rate", n, seed=4)
+    rs = torch.zeros(n, 13); rs[:, 6] = 1.0; rs[:, 2] = 2.0                 # above 1.7 m: every env terminates
+    env.set_state(root_states=rs, progress=torch.full((n,), 9, dtype=torch.int32), pre_actions=torch.ones(n, 4))
+    a = torch.zeros(n, 4); a[:, 3] = -0.7
+    env.planning_step_with_uniforms(a.cuda(), t(g["uniforms"]))
+    st, ps = env.get_state(), env.planning_get_state()
+    assert (env.reset_buf == 1).all()
+    np.testing.assert_allclose(st["root_states"].cpu().numpy(), g["root_states"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ps["goal"].cpu().numpy(), g["object_pos"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ps["object_vel"].cpu().numpy(), g["object_vel"], rtol=0, atol=1e-5)
+    parked = g["object_pos"][:, 0] == -999
+    assert np.array_equal(ps["goal"][:, 0].cpu().numpy() == -999, parked) and list(parked[:4]) == [False, True, False, True]
+    assert np.array_equal(st["pre_actions"].cpu().numpy(), g["pre_actions"])
+    env.close()
+
+
+# ------------------------------------------------------------------------------------------- closed loop vs oracle
+@pytest.mark.parametrize("ctl", ["rate", "vel", "atti", "pos", "prop"])
+def test_balloon_closed_loop_vs_oracle(Handle, ctl):
+    from oracle.custom_ref import BalloonRef
+    n, seed = 64, 11
+    ora = BalloonRef(n, ctl, seed=seed)
+    env = Handle("balloon", ctl, n, seed=seed)
+    np.testing.assert_allclose(env.get_state()["root_states"].cpu().numpy(), ora.root_states.numpy(), atol=1e-6)
+    np.testing.assert_allclose(env.planning_get_state()["goal"].cpu().numpy(), ora.balloon_positions.numpy(), atol=1e-6)
+    rng = np.random.default_rng(5)
+    A = env.num_actions
+    n_done = 0
+    for step in range(40):
+        a = rng.uniform(-0.5, 0.5, size=(n, A)).astype(np.float32)
+        if ctl in ("rate", "atti"):
+            a[:, -1] = rng.uniform(-0.75, -0.6, size=n)
+        if ctl == "atti":
+            a[:, 0] = rng.uniform(0.7, 0.95, size=n); a[:, 1:4] *= 0.2
+        if ctl == "vel":
+            a[:, 0] = rng.uniform(0.5, 1.5, size=n)           # fly towards the ball
+        if ctl == "prop":
+            a = rng.uniform(0.1, 0.22, size=(n, A)).astype(np.float32)
+        obs, _, rew, done, ex = ora.step(torch.from_numpy(a))
+        env.step(torch.from_numpy(a).cuda())
+        assert np.array_equal(env.reset_buf.cpu().numpy(), done.numpy()), f"done step {step}"
+        assert np.array_equal(env.compact_reset_ids().cpu().numpy(), ora.last_reset_env_ids.numpy())
+        np.testing.assert_allclose(env.get_state()["root_states"].cpu().numpy(), ora.root_states.numpy(), atol=1e-5)
+        np.testing.assert_allclose(env.obs_buf.cpu().numpy(), obs.numpy(), atol=3e-5)
+        np.testing.assert_allclose(env.rew_buf.cpu().numpy(), rew.numpy(), atol=2e-4)                 # 30 x guidance
+        np.testing.assert_allclose(env.planning_get_state()["goal"].cpu().numpy(), ora.balloon_positions.numpy(), atol=1e-6)
+        for k, v in ex["item_reward_info"].items():
+            np.testing.assert_allclose(env.reward_terms[k].cpu().numpy(), v.double().numpy(), atol=2e-4, err_msg=k)
+        n_done += int(done.sum())
+    assert n_done > 0
+    env.close()
+
+
+def test_avoid_closed_loop_with_rendering_vs_oracle(Handle):
+    from oracle.custom_ref import AvoidRef
+    n, seed = 4, 3
+    ora = AvoidRef(n, "rate", seed=seed)
+    env = Handle("avoid", "rate", n, seed=seed)
+    ps = env.planning_get_state()
+    np.testing.assert_allclose(ps["goal"].cpu().numpy(), ora.object_positions.numpy(), atol=1e-5)
+    np.testing.assert_allclose(ps["object_vel"].cpu().numpy(), ora.object_linvels.numpy(), atol=1e-5)
+    assert (ora.object_positions[:, 0] != -999).any()
+    rng = np.random.default_rng(0)
+    for step in range(16):                  # renders at steps 4, 8, 12, 16; the cube is in view while it flies in
+        a = rng.uniform(-0.2, 0.2, size=(n, 4)).astype(np.float32)
+        a[:, 3] = rng.uniform(-0.72, -0.66, size=n)
+        o, _, rew, done, ex = ora.step(torch.from_numpy(a))
+        env.step(torch.from_numpy(a).cuda())
+        assert np.array_equal(env.reset_buf.cpu().numpy(), done.numpy()), f"done step {step}"
+        np.testing.assert_allclose(env.get_state()["root_states"].cpu().numpy(), ora.root_states.numpy(), atol=1e-5)
+        ps = env.planning_get_state()
+        np.testing.assert_allclose(ps["goal"].cpu().numpy(), ora.object_positions.numpy(), atol=2e-5)
+        np.testing.assert_allclose(ps["object_vel"].cpu().numpy(), ora.object_linvels.numpy(), atol=2e-5)
+        np.testing.assert_allclose(env.obs_buf.cpu().numpy(), o["observation"].numpy(), atol=2e-5)
+        np.testing.assert_allclose(env.rew_buf.cpu().numpy(), rew.numpy(), atol=1e-4)
+        img, ref = env.image.cpu().numpy(), o["image"].numpy()
+        assert (np.abs(img - ref) > 2e-3).mean() < 0.01, f"step {step}: image differs"
+    assert env.image.max() > 1.5
+    env.close()
+
+
+def test_avoid_cube_collision_terminates(Handle):
+    """A cube parked on the vehicle: collision flag, -500 alive reward and termination (avoid.py:259,191-193)."""
+    n = 64
+    env = Handle("avoid", "rate", n, seed=1)
+    pos = env.get_state()["root_states"][:, 0:3].clone()
+    goal = pos.clone(); goal[::2, 0] += 5.0                    # every other cube far away
+    env.planning_set_state(goal=goal, object_vel=torch.zeros(n, 3))
+    env.set_state(was_reset=torch.zeros(n, dtype=torch.int32))
+    a = torch.zeros(n, 4, device="cuda"); a[:, 3] = -0.69
+    env.step(a)
+    hit = env.collisions.bool().cpu()
+    assert hit[1::2].all() and not hit[0::2].any()
+    assert (env.reward_terms["alive_reward"][1::2] == -500).all() and (env.reward_terms["alive_reward"][0::2] == 0.5).all()
+    assert env.reset_buf[1::2].all()
+    env.close()
+
+
+# -------------------------------------------------------------------------------------------------- drop-in + PPO
+@pytest.mark.parametrize("task,use_image", [("balloon", False), ("avoid", True)])
+def test_drop_in_api_and_short_ppo_run(Handle, task, use_image):
+    import os
+    import yaml
+    from argparse import Namespace
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    from airgym_amd.utils.task_registry import task_registry
+    env, cfg = task_registry.make_env(task, Namespace(num_envs=64, ctl_mode="rate", seed=3, sim_device="cuda:0", headless=True))
+    obs, priv = env.reset()
+    o2, _, rew, done, extras = env.step(torch.zeros(64, 4, device="cuda"))
+    if use_image:
+        assert set(obs) == {"image", "observation"} and obs["image"].shape == (64, 1, 212, 120) and obs["observation"].shape == (64, 16)
+        assert set(extras["item_reward_info"]) >= {"pose_reward", "alive_reward", "reward"}
+    else:
+        assert obs.shape == (64, 18) and set(extras["item_reward_info"]) >= {"guidance_reward", "hit_reward", "reward"}
+    assert done.dtype == torch.int64 and rew.shape == (64,)
+    env.close()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", f"ppo_{task}.yaml")))["params"]
+    c = params["config"]
+    c.update(num_actors=256, horizon_length=8, minibatch_size=512, mini_epochs=2, max_epochs=2, write_summaries=False,
+             print_stats=False, save_frequency=0, save_best_after=10 ** 9, device="cuda:0", train_dir="/tmp/airgym_runs_" + task,
+             env_config={"use_image": use_image, "num_envs": 256, "ctl_mode": "rate", "seed": 1, "sim_device": "cuda:0",
+                         "headless": True})
+    agent = A2CAgent("run", params)
+    before = agent.flat_param.clone()
+    agent.train()
+    assert agent.epoch_num == 2 and torch.isfinite(agent.flat_param).all() and not torch.equal(before, agent.flat_param)

@@ -262,3 +262,86 @@ def test_planning_step_matches_oracle(lib, ctl):
     # the z corridor is 0.6 m wide: random rate / thrust actions leave it, so resets are exercised; the velocity and position
     # cascades hold altitude (more so since the mixer stopped turning saturated torque demands into lift)
     assert n_done > 0 or ctl in ("vel", "pos")
+
+
+# ---------------------------------------------------------------------------------------- Balloon / Avoid (row f3)
+def _custom_post(lib, task_id, n, max_len, target, g, goal, objvel, noise, coll, uniforms=None, nobs=18):
+    A = g["actions"].shape[1]
+    rs = np.ascontiguousarray(g["root_states"], np.float32).copy()
+    pa = np.ascontiguousarray(g["pre_actions"], np.float32).copy()
+    progress = (g["progress"] - 1).astype(np.int32)
+    actions = np.ascontiguousarray(g["actions"], np.float32)
+    prepos = np.ascontiguousarray(g.get("pre_root_positions", np.zeros((n, 3))), np.float32).copy()
+    obs = np.zeros((n, nobs), np.float32); rew = np.zeros(n, np.float32); done = np.zeros(n, np.int32)
+    terms = np.zeros((n, 8), np.float32)
+    tgt = np.asarray(target, np.float32)
+    rc = lib.agh_custom_post(task_id, CTLS["vel"], n, max_len, fp(tgt), fp(rs), fp(pa), fp(progress), fp(actions), fp(goal),
+                             fp(objvel), fp(prepos), fp(coll), fp(noise), fp(uniforms) if uniforms is not None else None,
+                             fp(obs), fp(rew), fp(done), fp(terms))
+    assert rc == 0
+    return dict(obs=obs, rew=rew, done=done, terms=terms, rs=rs, pa=pa, progress=progress, goal=goal, objvel=objvel, prepos=prepos)
+
+
+def test_balloon_kernel_math_matches_reference_recordings(lib):
+    """balloon_post / balloon_reset (planning_math.hpp) under g++ against the vectors recorded from the reference's own
+    Balloon methods (tests/golden/balloon_*.npz)."""
+    g = dict(np.load(os.path.join(HERE, "golden", "balloon_obs_reward.npz")))
+    n = g["root_states"].shape[0]
+    ident = [1, 0, 0, 0, 1, 0, 0, 0, 1] + [0] * 9
+    r = _custom_post(lib, 3, n, 800, ident, g, np.ascontiguousarray(g["balloon"], np.float32).copy(), np.zeros((n, 3), np.float32),
+                     np.ascontiguousarray(g["noise"], np.float32), np.zeros(n, np.float32))
+    assert np.array_equal(r["done"], g["reset"].astype(np.int32))
+    np.testing.assert_allclose(r["obs"], g["obs"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(r["rew"], g["reward"], rtol=0, atol=3e-5)
+    for j, k in enumerate(("guidance_reward", "hit_reward", "action_smoothness_reward", "effort_reward", "ups_reward", "reward")):
+        np.testing.assert_allclose(r["terms"][:, j], g["info_" + k].astype(np.float64), rtol=0, atol=3e-5, err_msg=k)
+    # reset with the recorded uniforms: force every row to terminate (z above the ceiling)
+    gr = dict(np.load(os.path.join(HERE, "golden", "balloon_reset.npz")))
+    k = gr["uniforms"].shape[0]
+    rs = np.zeros((k, 13), np.float32); rs[:, 6] = 1; rs[:, 2] = 2.0
+    fake = dict(root_states=rs, pre_actions=np.ones((k, 4), np.float32), progress=np.full(k, 10), actions=np.zeros((k, 4), np.float32))
+    r = _custom_post(lib, 3, k, 800, ident, fake, np.zeros((k, 3), np.float32), np.zeros((k, 3), np.float32),
+                     np.zeros((k, 18), np.float32), np.zeros(k, np.float32), uniforms=np.ascontiguousarray(gr["uniforms"], np.float32))
+    assert r["done"].all()
+    np.testing.assert_allclose(r["rs"], gr["root_states"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(r["goal"], gr["balloon"], rtol=0, atol=1e-6)
+    assert (r["pa"] == 0).all() and (r["progress"] == 0).all() and (r["prepos"] == 0).all()
+
+
+def test_avoid_kernel_math_matches_reference_recordings(lib):
+    """avoid_post / avoid_reset (planning_math.hpp) under g++ against tests/golden/avoid_*.npz."""
+    g = dict(np.load(os.path.join(HERE, "golden", "avoid_obs_reward.npz")))
+    n = g["root_states"].shape[0]
+    target = [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0]
+    r = _custom_post(lib, 4, n, 600, target, g, np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32),
+                     np.zeros((n, 18), np.float32), np.ascontiguousarray(g["collisions"], np.float32), nobs=16)
+    assert np.array_equal(r["done"], np.maximum(g["reset"], (g["collisions"] > 0)).astype(np.int32))
+    np.testing.assert_allclose(r["obs"], g["obs"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["rew"], g["reward"], rtol=0, atol=6e-5)
+    for j, k in enumerate(("pose_reward", "ups_reward", "spin_reward", "effort_reward", "action_smoothness_reward",
+                           "thrust_reward", "alive_reward")):
+        np.testing.assert_allclose(r["terms"][:, j], g["info_" + k], rtol=0, atol=2e-6, err_msg=k)
+    gr = dict(np.load(os.path.join(HERE, "golden", "avoid_reset.npz")))
+    k = gr["uniforms"].shape[0]
+    rs = np.zeros((k, 13), np.float32); rs[:, 6] = 1; rs[:, 2] = 2.0
+    fake = dict(root_states=rs, pre_actions=np.ones((k, 4), np.float32), progress=np.full(k, 10), actions=np.zeros((k, 4), np.float32))
+    r = _custom_post(lib, 4, k, 600, target, fake, np.zeros((k, 3), np.float32), np.zeros((k, 3), np.float32),
+                     np.zeros((k, 18), np.float32), np.zeros(k, np.float32), uniforms=np.ascontiguousarray(gr["uniforms"], np.float32),
+                     nobs=16)
+    assert r["done"].all()
+    np.testing.assert_allclose(r["rs"], gr["root_states"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(r["goal"], gr["object_pos"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(r["objvel"], gr["object_vel"], rtol=0, atol=1e-5)
+
+
+def test_ray_aabb_matches_oracle(lib):
+    from oracle.planning_ref import _ray_aabb
+    lib.agh_ray_aabb.restype = ctypes.c_float
+    rng = np.random.default_rng(0)
+    c = np.array([2.0, 0.3, 1.1], np.float32)
+    for _ in range(200):
+        o = rng.uniform(-1, 1, 3).astype(np.float32); o[2] += 1
+        d = np.array([1.0, rng.uniform(-1, 1), rng.uniform(-0.6, 0.6)], np.float32)
+        ref = _ray_aabb(torch.from_numpy(o), torch.from_numpy(d)[None], torch.from_numpy(c), 0.15)[0].item()
+        got = lib.agh_ray_aabb(fp(o), fp(d), fp(c), ctypes.c_float(0.15))
+        assert (np.isinf(ref) and np.isinf(got)) or abs(ref - got) < 1e-5
