@@ -107,6 +107,7 @@ SYMBOLS = [
     ("ag_create", ctypes.c_int, [ctypes.POINTER(AgConfig), _P, ctypes.POINTER(_P)]),
     ("ag_destroy", ctypes.c_int, [_P]),
     ("ag_reset_all", ctypes.c_int, [_P, _P]),
+    ("ag_reset_envs", ctypes.c_int, [_P, _P, ctypes.c_int, _P]),
     ("ag_step", ctypes.c_int, [_P, _P, _P]),
     ("ag_step_into", ctypes.c_int, [_P, _P, _P, _P, _P, _P]),
     ("ag_step_with_inputs", ctypes.c_int, [_P, _P, _P, _P, _P]),

@@ -128,6 +128,29 @@ __global__ void reset_all_kernel(ag::KArgs k, int n_pad, int num_actions, int nu
     }
 }
 
+// reset_idx(env_ids) for a caller-chosen subset (hovering.py:310-335, tracking.py:159-192): re-randomise the listed envs with
+// the counter RNG of the current tick, flag them reset (reset_buf = 1, bit in the ballot mask), clear progress / pre_actions /
+// controller memory.  One thread per listed id; ids outside [0, n) are ignored.
+__global__ void reset_ids_kernel(ag::KArgs k, const int* ids, int count, int num_actions) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    ag::StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (j == 0) *k.tick_out = P.tick + 1u;
+    if (j >= count) return;
+    const int i = ids[j];
+    if (i < 0 || i >= k.n) return;
+    ag::EnvState s;
+    ag::CtlState c;
+    float pre_a[AG_MAX_ACTIONS];
+    ag::env_reset(s, c, pre_a, num_actions, P, P.env_id_offset + (uint32_t)i);
+    ag::store_env(k, i, s);
+    ag::store_ctl<ag::CTL_POS>(k, i, c);
+    k.PA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    k.PA4[i] = 0.f;
+    k.reset[i] = 1;
+    atomicOr(&k.mask[i >> 6], 1ull << (i & 63));
+}
+
 __global__ void get_state_kernel(ag::KArgs k, ag_state_view v, int num_actions) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k.n) return;
@@ -566,6 +589,25 @@ int ag_reset_all(ag_handle h, void* stream) {
     bind_tick(h, k);
     hipLaunchKernelGGL(reset_all_kernel, dim3(h->n_pad / 256), dim3(256), 0, (hipStream_t)stream, k, h->n_pad,
                        h->num_actions, h->num_obs);
+    AG_HIP_CHECK(hipGetLastError());
+    return AG_OK;
+}
+
+int ag_reset_envs(ag_handle h, const int32_t* env_ids_dev, int count, void* stream) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    if (count < 0 || (count > 0 && !env_ids_dev)) return fail(AG_ERR_INVALID_ARG, "env_ids_dev is NULL or count < 0");
+    if (count == 0) return AG_OK;
+    int rc = ensure_device(h);
+    if (rc) return rc;
+    ag::KArgs k = h->k;
+    bind_tick(h, k);
+    if (h->cfg.task >= AG_TASK_PLANNING) {
+        if (h->cfg.task == AG_TASK_PLANNING && !h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
+        AG_HIP_CHECK(ag::launch_custom_reset_ids(k, h->pa, h->cfg.task, h->num_actions, env_ids_dev, count, (hipStream_t)stream));
+        return AG_OK;
+    }
+    hipLaunchKernelGGL(reset_ids_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, k, env_ids_dev, count,
+                       h->num_actions);
     AG_HIP_CHECK(hipGetLastError());
     return AG_OK;
 }

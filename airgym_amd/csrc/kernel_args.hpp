@@ -71,6 +71,8 @@ hipError_t launch_planning_reset_all(const KArgs& k, const PlanArgs& pa, int num
 hipError_t launch_custom_step(const KArgs& k, const PlanArgs& pa, int task, int ctl, int phase, hipStream_t st);
 hipError_t launch_custom_reset_all(const KArgs& k, const PlanArgs& pa, int task, int num_actions, hipStream_t st);
 hipError_t launch_avoid_render(const KArgs& k, const PlanArgs& pa, hipStream_t st);
+hipError_t launch_custom_reset_ids(const KArgs& k, const PlanArgs& pa, int task, int num_actions, const int* ids, int count,
+                                   hipStream_t st);
 
 typedef hipError_t (*StepLauncher)(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
 typedef hipError_t (*EvalLauncher)(const KArgs& k, hipStream_t stream);

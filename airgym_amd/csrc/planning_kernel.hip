@@ -567,6 +567,55 @@ hipError_t launch_custom_step(const KArgs& k, const PlanArgs& pa, int task, int 
     return hipErrorInvalidValue;
 }
 
+// reset_idx(env_ids) for a caller-chosen subset of a Planning / Balloon / Avoid handle (planning.py:63-136, balloon.py:57-99,
+// avoid.py:91-163): same per-env reset functions as the in-kernel reset of the step.
+template <int TASK>
+__global__ void custom_reset_ids_kernel(const KArgs k, const PlanArgs pa, int num_actions, const int* ids, int count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    StepParams P = k.P;
+    P.tick = *k.tick_in;
+    if (j == 0) *k.tick_out = P.tick + 1u;
+    if (j >= count) return;
+    const int i = ids[j];
+    if (i < 0 || i >= k.n) return;
+    const uint32_t env_global = P.env_id_offset + (uint32_t)i;
+    EnvState s;
+    CtlState c;
+    float pre_a[5];
+    if (TASK == TASK_PLANNING) {
+        PlanExtra x;
+        float u[124];
+        planning_reset_uniforms(P, env_global, u);
+        planning_reset(s, c, x, pre_a, num_actions, u, reinterpret_cast<float*>(pa.OB) + (size_t)i * 4, (size_t)pa.n_pad * 4);
+        pa.GOAL[i] = make_float4(x.goal.x, x.goal.y, x.goal.z, 0.0f);
+        pa.PRP[i] = make_float4(0.f, 0.f, 0.f, pa.PRP[i].w);
+    } else {
+        V3 tgt{0.f, 0.f, 0.f}, obj_v{0.f, 0.f, 0.f}, pre_pos{0.f, 0.f, 0.f};
+        float u[16];
+        custom_reset_uniforms(P, env_global, u);
+        if (TASK == TASK_BALLOON) balloon_reset(s, c, tgt, pre_pos, pre_a, num_actions, u);
+        else avoid_reset(s, c, tgt, obj_v, pre_pos, pre_a, num_actions, u);
+        pa.GOAL[i] = make_float4(tgt.x, tgt.y, tgt.z, 0.0f);
+        pa.OB[i] = make_float4(obj_v.x, obj_v.y, obj_v.z, 0.0f);
+        pa.PRP[i] = make_float4(0.f, 0.f, 0.f, pa.PRP[i].w);
+    }
+    store_env(k, i, s);
+    store_ctl<CTL_POS>(k, i, c);
+    k.PA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    k.PA4[i] = 0.f;
+    k.reset[i] = 1;
+    atomicOr(&k.mask[i >> 6], 1ull << (i & 63));
+}
+
+hipError_t launch_custom_reset_ids(const KArgs& k, const PlanArgs& pa, int task, int num_actions, const int* ids, int count,
+                                   hipStream_t st) {
+    const dim3 grid((count + 255) / 256), block(256);
+    if (task == TASK_PLANNING) hipLaunchKernelGGL(custom_reset_ids_kernel<TASK_PLANNING>, grid, block, 0, st, k, pa, num_actions, ids, count);
+    else if (task == TASK_BALLOON) hipLaunchKernelGGL(custom_reset_ids_kernel<TASK_BALLOON>, grid, block, 0, st, k, pa, num_actions, ids, count);
+    else hipLaunchKernelGGL(custom_reset_ids_kernel<TASK_AVOID>, grid, block, 0, st, k, pa, num_actions, ids, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_custom_reset_all(const KArgs& k, const PlanArgs& pa, int task, int num_actions, hipStream_t st) {
     if (task == TASK_BALLOON) hipLaunchKernelGGL(custom_reset_all_kernel<TASK_BALLOON>, dim3(pa.n_pad / 256), dim3(256), 0, st, k, pa, num_actions);
     else hipLaunchKernelGGL(custom_reset_all_kernel<TASK_AVOID>, dim3(pa.n_pad / 256), dim3(256), 0, st, k, pa, num_actions);

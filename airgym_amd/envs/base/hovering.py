@@ -103,13 +103,12 @@ class Hovering(BaseTask):
         return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def reset_idx(self, env_ids):
-        """Only the all-envs reset is a host call; per-env resets happen inside the step kernel
-        (hovering.py:300-302).  Partial host resets are not part of the reference's call graph
-        (base_task.py:109 passes arange(num_envs); hovering.py:211,302 are in-kernel now)."""
-        if len(env_ids) != self.num_envs:
-            raise NotImplementedError("per-env resets are performed by the step kernel; "
-                                      "use set_root_states() to overwrite states from the host")
-        self.hip.reset_all()
+        """hovering.py:310-335 as a host call.  The resets the reference issues from inside step() (hovering.py:211,302) happen
+        in the step kernel; this entry serves BaseTask.reset() (all envs, base_task.py:109) and callers that reset a subset."""
+        if len(env_ids) == self.num_envs:
+            self.hip.reset_all()
+        else:
+            self.hip.reset_envs(env_ids)
 
     def compute_observations(self):
         return self.obs_buf

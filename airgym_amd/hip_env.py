@@ -124,6 +124,14 @@ class HipEnvHandle:
     def reset_all(self):
         N.check(self.lib.ag_reset_all(self.h, self._stream()), "ag_reset_all")
 
+    def reset_envs(self, env_ids):
+        """reset_idx(env_ids) for a subset (ag_reset_envs): env_ids = integer tensor / sequence of local env ids."""
+        ids = torch.as_tensor(env_ids).to(device=self.device, dtype=torch.int32).contiguous().view(-1)
+        if ids.numel() == 0:
+            return
+        N.check(self.lib.ag_reset_envs(self.h, ids.data_ptr(), int(ids.numel()), self._stream()), "ag_reset_envs")
+        torch.cuda.current_stream(self.device).synchronize()      # `ids` must outlive the kernel
+
     def step(self, actions):
         actions = self._check_actions(actions)
         N.check(self.lib.ag_step(self.h, actions.data_ptr(), self._stream()), "ag_step")

@@ -112,11 +112,39 @@ class FlatAdam:
                                       self.b1, self.b2, self.eps, self.wd, float(max_grad_norm), float(kl_threshold),
                                       float(min_lr), float(max_lr), stream), "ag_adam_clip_step")
 
-    def state_dict(self):
-        return {"lr": self.lr.item(), "step": self.step_t.item(), "exp_avg": self.exp_avg.clone(),
-                "exp_avg_sq": self.exp_avg_sq.clone(), "betas": (self.b1, self.b2), "eps": self.eps}
+    def state_dict(self, layout=None):
+        """torch.optim.Adam's state_dict layout (what the reference saves, a2c_base.py:528-542, and feeds back to
+        optimizer.load_state_dict, :576-577): per-parameter exp_avg / exp_avg_sq / step in `model.parameters()` order.
+        `layout` = [(offset, shape)] of every parameter in that order inside the flat buffer; without it the private flat
+        form is returned (unit tests of the optimizer alone)."""
+        if layout is None:
+            return {"lr": self.lr.item(), "step": self.step_t.item(), "exp_avg": self.exp_avg.clone(),
+                    "exp_avg_sq": self.exp_avg_sq.clone(), "betas": (self.b1, self.b2), "eps": self.eps}
+        step = torch.tensor(float(self.step_t.item()))
+        state = {}
+        for idx, (off, shape) in enumerate(layout):
+            n = int(np.prod(shape)) if len(shape) else 1
+            state[idx] = {"step": step.clone(), "exp_avg": self.exp_avg[off:off + n].view(shape).clone(),
+                          "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shape).clone()}
+        group = {"lr": self.lr.item(), "betas": (self.b1, self.b2), "eps": self.eps, "weight_decay": self.wd,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(layout)))}
+        return {"state": state, "param_groups": [group]}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, layout=None):
+        if "param_groups" in sd:            # torch.optim.Adam layout (this build's checkpoints and the reference's)
+            assert layout is not None, "the torch layout needs the parameter layout"
+            self.lr.fill_(float(sd["param_groups"][0]["lr"]))
+            steps = [float(st["step"]) for st in sd["state"].values() if "step" in st]
+            self.step_t.fill_(max(steps) if steps else 0.0)
+            for idx, (off, shape) in enumerate(layout):
+                st = sd["state"].get(idx)
+                if st is None:
+                    continue
+                n = int(np.prod(shape)) if len(shape) else 1
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            return
         self.lr.fill_(sd["lr"])
         self.step_t.fill_(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
@@ -349,6 +377,8 @@ class A2CAgent:
             self._term_tiles = torch.zeros(H, (N + 63) // 64, 12, **f)
         from airgym_amd.lib.agent.fused_update import FusedRolloutStep
         self._fused_rollout = FusedRolloutStep(self) if FusedRolloutStep.supported(self) else None
+        if self._fused_rollout is not None and getattr(self, "_restored_noise_counter", None) is not None:
+            self._fused_rollout.counter.fill_(int(self._restored_noise_counter))
 
     def _obs_at(self, n):
         return {k: v[n] for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict) else self.obs_buf[n]
@@ -836,22 +866,45 @@ class A2CAgent:
                 w.add_scalar("episode_lengths/" + tag, ml, x)
 
     # ------------------------------------------------------------------ checkpoints (a2c_base.py:528-587)
+    def _optimizer_layout(self):
+        """(offset, shape) inside the flat buffers of every trainable parameter, in model.parameters() order = the index
+        order of torch.optim.Adam(self.model.parameters()) in the reference (a2c_continuous.py:401)."""
+        base = self.flat_param.data_ptr()
+        return [((p.data_ptr() - base) // 4, tuple(p.shape)) for p in self.model.parameters() if p.requires_grad]
+
     def get_full_state_weights(self):
+        """a2c_base.py:528-542 - same keys, `optimizer` in torch.optim.Adam's state_dict layout; `rollout_noise_counter` is
+        this build's addition (the Philox counter of the fused rollout's action noise, so a resumed run does not replay
+        the noise sequence of rollout 0)."""
         state = {"model": self.model.state_dict(), "epoch": self.epoch_num, "frame": self.frame,
-                 "optimizer": self.optimizer.state_dict(), "last_mean_rewards": self.last_mean_rewards,
+                 "optimizer": self.optimizer.state_dict(self._optimizer_layout()), "last_mean_rewards": self.last_mean_rewards,
                  "env_state": self.vec_env.get_env_state()}
+        fr = getattr(self, "_fused_rollout", None)
+        if fr is not None:
+            state["rollout_noise_counter"] = int(fr.counter.item())
         return state
 
     def set_full_state_weights(self, weights, set_epoch=True):
-        self.model.load_state_dict(weights["model"])
+        sd = weights["model"]
+        own = self.model.state_dict()
+        # a frozen VAE encoder is not part of this model's state (it is loaded from vae_model.pth); the reference registers it
+        # as `actor_enc.*` and saves it with the policy: accept such checkpoints by dropping those keys
+        extra = [k for k in sd if k.startswith("actor_enc.") and k not in own]
+        if extra:
+            sd = {k: v for k, v in sd.items() if k not in extra}
+        self.model.load_state_dict(sd)
         if set_epoch:
             self.epoch_num = weights.get("epoch", 0)
             self.frame = weights.get("frame", 0)
         opt = weights.get("optimizer")
-        if isinstance(opt, dict) and "exp_avg" in opt:
-            self.optimizer.load_state_dict(opt)
+        if isinstance(opt, dict) and ("exp_avg" in opt or "param_groups" in opt):
+            self.optimizer.load_state_dict(opt, self._optimizer_layout())
         self.last_mean_rewards = weights.get("last_mean_rewards", -100500)
         self.vec_env.set_env_state(weights.get("env_state"))
+        self._restored_noise_counter = weights.get("rollout_noise_counter")
+        fr = getattr(self, "_fused_rollout", None)
+        if fr is not None and self._restored_noise_counter is not None:
+            fr.counter.fill_(int(self._restored_noise_counter))
 
     def save(self, fn):
         torch_ext.save_checkpoint(fn, self.get_full_state_weights())

@@ -15,6 +15,7 @@
  *                        (airgym/envs/base/base_task.py:40-95, airgym/envs/base/hovering.py:42-152,173-201)
  *                        and ParallelRate/Atti/Vel/PosControl(num_envs) (hovering.py:93-123)
  *   ag_reset_all         BaseTask.reset()'s reset_idx(all) half (base_task.py:107-111, hovering.py:310-335)
+ *   ag_reset_envs        reset_idx(env_ids) called from the host on a subset (hovering.py:310-335)
  *   ag_step / _into      Hovering.step (hovering.py:286-308) incl. pre_physics_step (:203-281),
  *                        gym.simulate + refresh (PhysX, :290,:283-284), compute_observations (:337-358),
  *                        compute_reward (:360-459), reset_idx (:310-335); Tracking overrides
@@ -157,6 +158,11 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out);
 int ag_destroy(ag_handle h);
 
 int ag_reset_all(ag_handle h, void* stream);
+/* reset_idx(env_ids) as a host call for a SUBSET of the envs (hovering.py:310-335, tracking.py:159-192, planning.py:63-136,
+ * balloon.py:57-99, avoid.py:91-163): env_ids_dev [count] int32 device array (ids outside [0, num_envs) are ignored,
+ * duplicates are harmless).  The listed envs are re-randomised from the counter RNG, reset_buf = 1 and the ballot-mask bit
+ * are set, progress / pre_actions / controller memory cleared; the others are untouched. */
+int ag_reset_envs(ag_handle h, const int32_t* env_ids_dev, int count, void* stream);
 int ag_step(ag_handle h, const float* actions_dev, void* stream);
 /* Same as ag_step but obs / reward / done flags are written to caller buffers (e.g. slot t of a
  * rollout buffer) instead of the handle's own; any of the three may be NULL = use the handle's. */

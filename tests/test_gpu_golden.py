@@ -504,3 +504,54 @@ def test_golden_adaptive_lr_in_adam_kernel(golden):
             k += 1
             np.testing.assert_allclose(pd.cpu().numpy(), ref_p.detach().numpy(), rtol=0, atol=3e-6)
     assert k == len(lrs)
+
+
+# ---------------------------------------------------------------------------------------------- host reset_idx(subset)
+@pytest.mark.parametrize("task", ["hovering", "tracking"])
+def test_host_reset_of_a_subset_matches_oracle(Handle, task):
+    """reset_idx(env_ids) called from the host on a subset (hovering.py:310-335 / tracking.py:159-192 -> ag_reset_envs): the
+    listed envs are re-randomised exactly like the oracle's reset_idx with the same counter tick, flagged reset and cleared;
+    every other env is untouched; the next step treats them like any freshly reset env (zero thrust for one step, Q2)."""
+    n, seed = 300, 31
+    ora = CLS[task](n, "rate", seed=seed)
+    env = Handle(task, "rate", n, seed=seed)
+    rng = np.random.default_rng(2)
+    for t_ in range(5):
+        a = rng.uniform(-0.5, 0.5, size=(n, 4)).astype(np.float32); a[:, 3] = -0.7
+        ora.step(torch.from_numpy(a)); env.step(torch.from_numpy(a).cuda())
+    ids = torch.tensor([0, 7, 63, 64, 65, 128, 299, 7], dtype=torch.int64)          # a duplicate is harmless
+    before = env.get_state()
+    ora.reset_idx(torch.unique(ids)); ora.tick += 1
+    env.reset_envs(ids)
+    st = env.get_state()
+    np.testing.assert_allclose(st["root_states"].cpu().numpy(), ora.root_states.numpy(), rtol=0, atol=1e-6)
+    assert np.array_equal(env.reset_buf.cpu().numpy(), ora.reset_buf.numpy())
+    assert np.array_equal(st["progress"].cpu().numpy(), ora.progress_buf.numpy().astype(np.int32))
+    assert np.array_equal(st["pre_actions"].cpu().numpy(), ora.pre_actions.numpy())
+    mask = torch.ones(n, dtype=torch.bool); mask[ids] = False
+    for k in before:
+        assert torch.equal(before[k][mask.cuda()], st[k][mask.cuda()]), k              # the others are untouched
+    assert np.array_equal(env.compact_reset_ids().cpu().numpy(), np.nonzero(ora.reset_buf.numpy())[0])
+    for t_ in range(3):
+        a = rng.uniform(-0.5, 0.5, size=(n, 4)).astype(np.float32); a[:, 3] = -0.7
+        obs, _, rew, reset, _ = ora.step(torch.from_numpy(a)); env.step(torch.from_numpy(a).cuda())
+        assert np.array_equal(env.reset_buf.cpu().numpy(), reset.numpy())
+        np.testing.assert_allclose(env.get_state()["root_states"].cpu().numpy(), ora.root_states.numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(env.rew_buf.cpu().numpy(), rew.numpy(), rtol=0, atol=1e-5)
+    env.close()
+
+
+def test_host_reset_subset_through_the_task_class(Handle):
+    """Hovering.reset_idx(env_ids) of the drop-in class no longer raises for a subset."""
+    from argparse import Namespace
+    from airgym_amd.utils.task_registry import task_registry
+    env, _ = task_registry.make_env("hovering", Namespace(num_envs=128, ctl_mode="rate", seed=3, sim_device="cuda:0", headless=True))
+    env.reset()
+    env.step(torch.zeros(128, 4, device="cuda"))
+    p0 = env.root_states.clone()
+    env.reset_idx(torch.tensor([3, 77], device="cuda"))
+    p1 = env.root_states
+    changed = (p0 != p1).any(dim=1).cpu()
+    assert changed[3] and changed[77] and int(changed.sum()) == 2
+    assert env.reset_buf[3] == 1 and env.reset_buf[77] == 1 and int(env.progress_buf[3]) == 0
+    env.close()

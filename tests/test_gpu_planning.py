@@ -273,3 +273,42 @@ def test_frozen_vae_model_forward_on_gpu(Handle, golden):
     assert out["actions"].shape == (n, 4) and out["values"].shape == (n, 1)
     assert torch.isfinite(out["mus"]).all() and torch.isfinite(out["values"]).all()
     env.close()
+
+
+def test_player_plays_a_reference_layout_checkpoint_in_the_hip_planning_env(Handle, golden, tmp_path):
+    """SURVEY 8(f)-2 on the GPU: a checkpoint in the key layout of the reference's trained/planning_cnn_rate.pth (names and
+    shapes from the fixture's manifest; deterministic fill, the 778 KB file itself does not travel) -> A2CPlayer.restore
+    (players.py:372-388) -> deterministic play loop (players.py:204-290) on the HIP Planning env with dict observations."""
+    import json
+    import os
+    import yaml
+    from airgym_amd.lib.agent.players import A2CPlayer
+    manifest = json.loads(str(golden("planning_checkpoint")["manifest"]))
+    sd = {}
+    for i, (k, meta) in enumerate(sorted(manifest.items())):
+        n = int(np.prod(meta["shape"])) if meta["shape"] else 1
+        v = 0.05 * torch.cos(0.61803 * torch.arange(n, dtype=torch.float64) + i)
+        if k.endswith("running_var") or k.endswith(".count"):
+            v = v.abs() + 1.0
+        if "num_batches_tracked" in k:
+            v = torch.full((n,), 7.0, dtype=torch.float64)
+        sd[k] = v.reshape(meta["shape"]).to(getattr(torch, meta["dtype"]))
+    fn = str(tmp_path / "planning_like.pth")
+    torch.save({"model": sd, "epoch": 200, "frame": 4915200}, fn)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
+    params["config"].update(num_actors=64, device="cuda:0",
+                            env_config={"use_image": True, "num_envs": 64, "ctl_mode": "rate", "seed": 2, "sim_device": "cuda:0",
+                                        "headless": True},
+                            player={"deterministic": True, "games_num": 10 ** 6, "max_steps": 24, "print_stats": False})
+    p = A2CPlayer(params)
+    assert isinstance(p.obs_shape, dict) and p.obs_shape["image"] == (1, 212, 120) and p.obs_shape["observation"] == (16,)
+    p.restore(fn)
+    for k, v in p.model.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k                        # strict load, key for key
+    obs = p.env.reset()
+    act = p.get_action(obs)
+    assert act.shape == (64, 4) and act.abs().max() <= 1.0 and torch.isfinite(act).all()
+    assert torch.equal(act, p.get_action(obs))                       # deterministic: clamp(mu)
+    res = p.run(print_every=8)
+    assert np.isfinite(res["av_reward"]) and res["games"] > 0        # an untrained fill crashes or leaves the corridor quickly

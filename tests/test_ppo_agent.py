@@ -371,3 +371,35 @@ def test_ppo_diagnostics_tags(tmp_path):
     tags = {t for t, _, _ in logged}
     assert "diagnostics/exp_var" in tags and "diagnostics/clip_frac/2" in tags and "losses/a_loss" in tags
     assert all(x == 1 for t, _, x in logged if t.startswith("diagnostics/"))
+
+
+def test_checkpoint_optimizer_is_torch_adam_layout(tmp_path):
+    """a2c_base.py:528-587: the reference saves optimizer.state_dict() of torch.optim.Adam(model.parameters()) and feeds it back
+    with optimizer.load_state_dict.  This build's checkpoint must load into exactly that optimizer, and a checkpoint written
+    by it must restore this build's moments; `actor_enc.*` keys of a VAE checkpoint are accepted."""
+    torch.manual_seed(5)
+    a = A2CAgent("run", _stub_env.ppo_params(max_epochs=2))
+    a.train()
+    fn = str(tmp_path / "ck"); a.save(fn)
+    ck = torch.load(fn + ".pth", weights_only=False)
+    sd = ck["optimizer"]
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == list(range(len(sd["state"])))
+    # (1) into the reference's optimizer: a fresh model of the same shape + torch.optim.Adam over model.parameters()
+    b = A2CAgent("run", _stub_env.ppo_params(max_epochs=2))
+    ref_opt = torch.optim.Adam([p for p in b.model.parameters() if p.requires_grad], lr=3e-4, eps=1e-8)
+    ref_opt.load_state_dict(sd)                                  # raises on any layout mismatch
+    for p_ref, p_a in zip([p for p in b.model.parameters() if p.requires_grad], [p for p in a.model.parameters() if p.requires_grad]):
+        st = ref_opt.state[p_ref]
+        off = (p_a.data_ptr() - a.flat_param.data_ptr()) // 4
+        assert torch.equal(st["exp_avg"].reshape(-1), a.optimizer.exp_avg[off:off + p_a.numel()])
+        assert float(st["step"]) == a.optimizer.step_t.item() > 0
+    assert ref_opt.param_groups[0]["lr"] == a.optimizer.lr.item()
+    # (2) a state_dict written by torch.optim.Adam (the reference's side) restores this build's moments and step count
+    for st in ref_opt.state.values():
+        st["exp_avg"].mul_(2.0)
+    ck["optimizer"] = ref_opt.state_dict()
+    ck["model"] = dict(ck["model"], **{"actor_enc.conv0.weight": torch.zeros(2, 2)})      # a VAE checkpoint's extra keys
+    torch.save(ck, str(tmp_path / "ref_style.pth"))
+    b.restore(str(tmp_path / "ref_style.pth"))
+    assert torch.allclose(b.optimizer.exp_avg, 2.0 * a.optimizer.exp_avg) and torch.equal(b.optimizer.exp_avg_sq, a.optimizer.exp_avg_sq)
+    assert b.optimizer.step_t.item() == a.optimizer.step_t.item() and torch.equal(b.flat_param, a.flat_param)
