@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 14 translation units compiled in parallel).
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 15 translation units compiled in parallel).
 
     python airgym_amd/csrc/build.py [--force] [--jobs N]
 
@@ -42,6 +42,7 @@ def units():
     out.append((os.path.join(OBJ_DIR, "ppo_kernels.o"), "ppo_kernels.hip", []))
     out.append((os.path.join(OBJ_DIR, "planning_kernel.o"), "planning_kernel.hip", []))
     out.append((os.path.join(OBJ_DIR, "rollout_kernels.o"), "rollout_kernels.hip", []))
+    out.append((os.path.join(OBJ_DIR, "split_gemm.o"), "split_gemm.hip", []))
     return out
 
 

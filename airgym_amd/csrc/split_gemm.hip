@@ -1,0 +1,204 @@
+// split_gemm.hip - float32-accurate GEMM on the bf16 matrix cores of gfx950 (MI355X) for the 256-wide hidden layer of the
+// actor-critic MLP (lib/network/mlp.py:36-39; forward X W^T and the backward dX = dZ W of a2c_continuous.py:299-369).
+//
+// Why: CDNA4 runs f32-input MFMA at the f32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16 rate) and has no xf32/TF32 form
+// (MI355X_MICROARCH.md).  The PPO update is three [196 608 x 256] x [256 x 256] GEMMs per minibatch, i.e. bound by that
+// 157 TFLOP/s.  A float32 value splits EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, by truncation):
+//     a = a1 + a2 + a3,    b = b1 + b2 + b3        (no rounding anywhere: each piece holds 8 consecutive bits)
+// and every product ai*bj of two 8-bit significands is exact in the MFMA's f32 accumulate path.  Keeping the six terms
+//     a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1
+// drops only a2b3 + a3b2 + a3b3 <= 3 * 2^-24 |ab|, the size of ONE f32 rounding of the product - so the result differs
+// from an f32 FMA chain by no more than the accumulation-order noise every f32 GEMM already has (tests/test_gpu_split_gemm.py
+// measures both against float64).  Six bf16 MFMAs cost 6/16 of one f32 MFMA pass: 2.67x the f32-MFMA peak.
+//
+// C[M, 256] = A[M, 256] * B^T, B given as prepared planes (ag_split_gemm_prepare): the weight matrix is split once per
+// optimizer step into the exact LDS image the kernel wants, so the B side of the main loop is a straight 16-byte copy.
+//   workgroup 256 threads = 4 waves; block tile 128 rows x 256 columns (all of N); wave w owns rows 32w..32w+31 as eight
+//   32x32 tiles (v_mfma_f32_32x32x16_bf16, 128 accumulator registers); K in chunks of 16, double-buffered in LDS:
+//     A stage: [plane 3][k-half 2][row 128] x 16 B   (12 KB)   - the wave splits its f32 rows on the fly
+//     B stage: [plane 3][k-half 2][col 256] x 16 B   (24 KB)
+//   72 KB per workgroup -> two workgroups per CU, two waves per SIMD: one wave's LDS traffic and f32->bf16 splitting hide
+//   under the other's MFMAs.  Fragment reads are ds_read_b128 over 32 consecutive 16-byte units: conflict-free.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/airgym_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 256, BK = 16, KDIM = 256;
+constexpr int A_UNITS = 3 * 2 * BM;       // 16-byte units per A stage
+constexpr int B_UNITS = 3 * 2 * BN;       // 16-byte units per B stage
+constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// exact 3-way split of an f32 into bf16 pieces by truncation; returns the pieces as the HIGH halves of three words
+__device__ __forceinline__ void split3(float a, uint32_t& h1, uint32_t& h2, uint32_t& h3) {
+    h1 = __float_as_uint(a) & 0xFFFF0000u;
+    const float r1 = a - __uint_as_float(h1);
+    h2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(h2);
+    h3 = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+__device__ __forceinline__ uint32_t pack_hi(uint32_t even, uint32_t odd) { return (odd & 0xFFFF0000u) | (even >> 16); }
+
+// 2 consecutive-k floats -> one packed word per plane
+__device__ __forceinline__ void split_pair(float x, float y, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
+    uint32_t x1, x2, x3, y1, y2, y3;
+    split3(x, x1, x2, x3);
+    split3(y, y1, y2, y3);
+    w1 = pack_hi(x1, y1); w2 = pack_hi(x2, y2); w3 = pack_hi(x3, y3);
+}
+
+// 8 consecutive-k floats -> three 16-byte bf16x8 units (one per plane)
+__device__ __forceinline__ void split8(const float4 lo, const float4 hi, uint4& p1, uint4& p2, uint4& p3) {
+    split_pair(lo.x, lo.y, p1.x, p2.x, p3.x);
+    split_pair(lo.z, lo.w, p1.y, p2.y, p3.y);
+    split_pair(hi.x, hi.y, p1.z, p2.z, p3.z);
+    split_pair(hi.z, hi.w, p1.w, p2.w, p3.w);
+}
+
+// Weight preparation: W [256, 256] f32 (row-major) -> planes [chunk 16][plane 3][k-half 2][n 256] x 8 bf16, the per-chunk LDS
+// image of the main loop.  transpose = 0: B[n][k] = W[n][k] (forward, X W^T); 1: B[n][k] = W[k][n] (backward dX = dZ W).
+__global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restrict__ W, uint4* __restrict__ planes, int transpose) {
+    const int unit = blockIdx.x * 256 + threadIdx.x;          // one (chunk, k-half, n) unit per thread: 16 * 2 * 256 = 8192
+    if (unit >= 16 * 2 * BN) return;
+    const int n = unit % BN, h = (unit / BN) & 1, c = unit / (2 * BN);
+    const int k0 = c * BK + h * 8;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = transpose ? W[(size_t)(k0 + i) * BN + n] : W[(size_t)n * KDIM + k0 + i];
+    uint4 p1, p2, p3;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
+    uint4* chunk = planes + (size_t)c * B_UNITS;
+    chunk[(0 * 2 + h) * BN + n] = p1;
+    chunk[(1 * 2 + h) * BN + n] = p2;
+    chunk[(2 * 2 + h) * BN + n] = p3;
+}
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
+                                                             const float* __restrict__ bias, float* __restrict__ C, int M) {
+    extern __shared__ uint4 lds[];                         // [2 stages][A_UNITS + B_UNITS] 16-byte units
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    // ---- global -> register staging for one K chunk
+    const int a_row = tid >> 1, a_half = tid & 1;                       // 128 rows x 2 k-halves: one 32-byte piece per thread
+    const int a_grow = min(m0 + a_row, M - 1);                          // rows past M are computed, never stored
+    const float4* a_src = reinterpret_cast<const float4*>(A + (size_t)a_grow * KDIM + a_half * 8);
+    float4 ra0, ra1;
+    uint4 rb0, rb1, rb2, rb3, rb4, rb5;
+#define AG_SG_LOAD(c)                                                                  \
+    do {                                                                               \
+        ra0 = a_src[(c) * (BK / 4)];                                                   \
+        ra1 = a_src[(c) * (BK / 4) + 1];                                               \
+        const uint4* bsrc_ = Bp + (size_t)(c) * B_UNITS + tid;                         \
+        rb0 = bsrc_[0]; rb1 = bsrc_[256]; rb2 = bsrc_[512];                            \
+        rb3 = bsrc_[768]; rb4 = bsrc_[1024]; rb5 = bsrc_[1280];                        \
+    } while (0)
+#define AG_SG_STORE(stage)                                                             \
+    do {                                                                               \
+        uint4* sa_ = lds + (stage) * STAGE_UNITS;                                      \
+        uint4* sb_ = sa_ + A_UNITS + tid;                                              \
+        uint4 p1_, p2_, p3_;                                                           \
+        split8(ra0, ra1, p1_, p2_, p3_);                                               \
+        sa_[(0 * 2 + a_half) * BM + a_row] = p1_;                                      \
+        sa_[(1 * 2 + a_half) * BM + a_row] = p2_;                                      \
+        sa_[(2 * 2 + a_half) * BM + a_row] = p3_;                                      \
+        sb_[0] = rb0; sb_[256] = rb1; sb_[512] = rb2;                                  \
+        sb_[768] = rb3; sb_[1024] = rb4; sb_[1280] = rb5;                              \
+    } while (0)
+
+    AG_SG_LOAD(0);
+    AG_SG_STORE(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, khalf = lane >> 5;
+    constexpr int NCHUNK = KDIM / BK;
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int stage = c & 1;
+        if (c + 1 < NCHUNK) AG_SG_LOAD(c + 1);              // global loads in flight under this chunk's MFMAs
+        const uint4* sa = lds + stage * STAGE_UNITS;
+        const uint4* sb = sa + A_UNITS;
+        const uint4 ua0 = sa[(0 * 2 + khalf) * BM + wave * 32 + l31];
+        const uint4 ua1 = sa[(1 * 2 + khalf) * BM + wave * 32 + l31];
+        const uint4 ua2 = sa[(2 * 2 + khalf) * BM + wave * 32 + l31];
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&ua0);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&ua2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint4 ub0 = sb[(0 * 2 + khalf) * BN + j * 32 + l31];
+            const uint4 ub1 = sb[(1 * 2 + khalf) * BN + j * 32 + l31];
+            const uint4 ub2 = sb[(2 * 2 + khalf) * BN + j * 32 + l31];
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&ub0);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&ub1);
+            const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&ub2);
+            // smallest terms first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+        }
+        if (c + 1 < NCHUNK) AG_SG_STORE(stage ^ 1);         // the other stage was last read before the previous barrier
+        __syncthreads();
+    }
+#undef AG_SG_LOAD
+#undef AG_SG_STORE
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int col = j * 32 + l31;
+        const float bj = HAS_BIAS ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (row < M) C[(size_t)row * BN + col] = acc[j][r] + bj;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" long long ag_split_gemm_plane_bytes(void) { return (long long)(KDIM / BK) * B_UNITS * 16; }
+
+extern "C" int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n, int k, int transpose, void* stream) {
+    if (!W_dev || !planes_dev) return AG_ERR_INVALID_ARG;
+    if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
+    if ((uintptr_t)planes_dev & 15) return AG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(split_prepare_kernel, dim3(16 * 2 * BN / 256), dim3(256), 0, (hipStream_t)stream, W_dev,
+                       (uint4*)planes_dev, transpose);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
+                             void* stream) {
+    if (!A_dev || !planes_dev || !C_dev || M <= 0) return AG_ERR_INVALID_ARG;
+    if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
+    if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * STAGE_UNITS * 16;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return AG_ERR_HIP;
+        attr_set = true;
+    }
+    const dim3 grid((M + BM - 1) / BM), block(256);
+    if (bias_dev) hipLaunchKernelGGL(split_gemm_kernel<true>, grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
+    else hipLaunchKernelGGL(split_gemm_kernel<false>, grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}

@@ -26,6 +26,43 @@ from airgym_amd.lib.core.fused_loss import BOUND_TYPES
 from airgym_amd.lib.network.splitk_linear import SPLIT_K
 
 
+class SplitGemm256:
+    """ag_split_gemm for one [256, 256] weight: float32-accurate products on the bf16 matrix cores (csrc/split_gemm.hip).
+    `planes` hold the exact three-way bf16 split of W (forward, C = X W^T) and of W^T (backward, dX = dZ W); they are
+    refreshed by `prepare()` whenever W changed (once per optimizer step / once per rollout)."""
+
+    @staticmethod
+    def applies(weight, config):
+        return (bool(config.get("use_split_gemm", True)) and weight.is_cuda and tuple(weight.shape) == (256, 256)
+                and weight.dtype == torch.float32)
+
+    def __init__(self, weight, backward=True):
+        self.lib = N.load()
+        self.w = weight
+        nbytes = self.lib.ag_split_gemm_plane_bytes()
+        self.fwd = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        self.bwd = torch.empty(nbytes, dtype=torch.uint8, device=weight.device) if backward else None
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)
+
+    def prepare(self):
+        st = self._stream()
+        N.check(self.lib.ag_split_gemm_prepare(self.w.data_ptr(), self.fwd.data_ptr(), 256, 256, 0, st), "ag_split_gemm_prepare")
+        if self.bwd is not None:
+            N.check(self.lib.ag_split_gemm_prepare(self.w.data_ptr(), self.bwd.data_ptr(), 256, 256, 1, st), "ag_split_gemm_prepare")
+
+    def forward(self, x, out, bias=None):
+        """out [M, 256] = x [M, 256] W^T (+ bias)"""
+        N.check(self.lib.ag_split_gemm(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       out.data_ptr(), x.shape[0], 256, 256, self._stream()), "ag_split_gemm")
+
+    def backward_input(self, dz, out):
+        """out [M, 256] = dz [M, 256] W"""
+        N.check(self.lib.ag_split_gemm(dz.data_ptr(), self.bwd.data_ptr(), None, out.data_ptr(), dz.shape[0], 256, 256,
+                                       self._stream()), "ag_split_gemm")
+
+
 class FusedMLPStep:
     @staticmethod
     def supported(agent):
@@ -95,6 +132,9 @@ class FusedMLPStep:
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
         self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
         self.wt_last = torch.empty(self.layers[-1][0].shape[1], Cl, **f)      # W_last^T, refreshed before every forward
+        # 256 x 256 layers: float32-accurate GEMMs on the bf16 matrix cores (forward and dX); other widths stay with the library
+        self.split = {li: SplitGemm256(w) for li, (w, _, _, _) in enumerate(self.layers)
+                      if li >= 1 and SplitGemm256.applies(w, agent.config)}
         self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 8, **f)
         self.k = 0
 
@@ -146,11 +186,22 @@ class FusedMLPStep:
         x = self.h[0]
         last = len(self.layers) - 1
         heads_done = False
+        for sg in self.split.values():          # the weights moved in the previous optimizer step
+            sg.prepare()
         for li in range(1, len(self.layers)):
             w, b = self.layers[li][0], self.layers[li][1]
             inputs.append(x)
             h = self.h[li]
-            if li == last and self.fuse_heads:      # ELU + the [M,C]x[C,A+1] head product in one pass over z
+            sg = self.split.get(li)
+            if li == last and self.fuse_heads and sg is not None:
+                sg.forward(x, h)                    # bias-free pre-activation; ag_elu_heads adds the bias
+                N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
+                                         M, w.shape[0], A + 1, 0, b.data_ptr(), st), "ag_elu_heads")
+                heads_done = True
+            elif sg is not None:
+                sg.forward(x, h, b)
+                F.elu_(h)
+            elif li == last and self.fuse_heads:      # ELU + the [M,C]x[C,A+1] head product in one pass over z
                 # x W^T as an NN product against a transposed copy of W (the libraries' NN kernel for this shape is 13 %
                 # faster than TN + bias epilogue); the bias is added by the consumers.  No write-back: the buffer keeps the
                 # bias-free pre-activation, the backward pass rebuilds ELU(z + b) on the fly.
@@ -210,7 +261,10 @@ class FusedMLPStep:
             torch.bmm(dz.view(S, M // S, C).transpose(1, 2), xin.view(S, M // S, K), out=self.wgrad_partials[li])
             if li > 0:
                 dh = self.dh[:M * K].view(M, K)
-                torch.mm(dz, w, out=dh)
+                if li in self.split:
+                    self.split[li].backward_input(dz, dh)
+                else:
+                    torch.mm(dz, w, out=dh)
         # ---- every partial-sum reduction (bias / weight gradients of all layers + the head) in two launches
         if self.use_sum_multi:
             N.check(lib.ag_sum_rows_multi(self._jobs, len(self._jobs), self.sum_scratch.data_ptr(), self.sum_scratch.numel(), st),
@@ -259,6 +313,8 @@ class FusedRolloutStep:
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
         self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0
         self.wt_last = torch.empty(self.layers[-1][0].shape[1], Cl, **f)
+        self.split = {li: SplitGemm256(w, backward=False) for li, (w, _) in enumerate(self.layers)
+                      if li >= 1 and SplitGemm256.applies(w, agent.config)}
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         # per-step, per-block episode sums; reduced over blocks ONCE per rollout (end_rollout)
         self.acct_partials = torch.zeros(agent.horizon_length, self.lib.ag_rollout_account_blocks(n), 4,
@@ -274,6 +330,8 @@ class FusedRolloutStep:
         """Transposed copy of the last hidden layer's weight for the NN-form GEMM (parameters are constant in a rollout)."""
         if self.fuse_heads:
             self.wt_last.copy_(self.layers[-1][0].t())
+        for sg in self.split.values():
+            sg.prepare()
 
     def end_rollout(self):
         torch.sum(self.acct_partials, 1, out=self.agent.ep_stats)
@@ -309,7 +367,16 @@ class FusedRolloutStep:
         for li in range(1, len(self.layers)):
             w, b = self.layers[li]
             h = self.h[li]
-            if li == last and self.fuse_heads:
+            sg = self.split.get(li)
+            if li == last and self.fuse_heads and sg is not None:
+                sg.forward(x, h)                          # planes refreshed once per rollout (refresh_weights)
+                N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
+                                         n, w.shape[0], A + 1, 0, b.data_ptr(), st), "ag_elu_heads")
+                heads_done = True
+            elif sg is not None:
+                sg.forward(x, h, b)
+                F.elu_(h)
+            elif li == last and self.fuse_heads:
                 torch.mm(x, self.wt_last, out=h)          # wt_last refreshed once per rollout (begin_rollout)
                 N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
                                          n, w.shape[0], A + 1, 0, b.data_ptr(), st), "ag_elu_heads")

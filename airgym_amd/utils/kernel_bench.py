@@ -113,6 +113,7 @@ def measure_copy_ceiling(device, nbytes=1 << 30, iters=20):
     return 2.0 * nbytes / us / 1e3
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity figure)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate, 64 FLOP/clk/SIMD
 
 
@@ -159,6 +160,16 @@ def measure_update_kernels(agent, iters=20):
                 "frac": flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "us_per_launch": us,
                 "note": "timed as 20 back-to-back launches (sustained-MFMA clocks); inside the minibatch, between HBM-bound "
                         "kernels, the same GEMM takes 185-205 us = 126-140 TFLOP/s (profiles/r01_bench_fused_kernel_trace.md)"})
+    if getattr(fs, "split", None):
+        sg = next(iter(fs.split.values()))
+        sg.prepare()
+        us = _time_us(lambda: sg.forward(x, fs.dz[:M * C].view(M, C)), iters)
+        out.append({"kernel": f"ag_split_gemm [{M}x{K}]x[{K}x{C}] (6 bf16 MFMAs per f32 product, f32-accurate), update forward / dX",
+                    "bound": "mfma", "achieved": 6.0 * flops / us / 1e6, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 6.0 * flops / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, "us_per_launch": us,
+                    "f32_equivalent_tflops": flops / us / 1e6,
+                    "note": "peak = dense bf16 MFMA (2.5 PFLOP/s); the f32-equivalent rate is what replaces the f32-MFMA GEMM "
+                            "(157.3 TFLOP/s peak)"})
     scratch = fs.dz[:M * C].view(M, C)
     scratch.copy_(h)
 

@@ -53,6 +53,7 @@ def build_params(args, world_size):
     c["save_best_after"] = 10 ** 9
     c["use_hip_graph"] = bool(args.graph)
     c["tuned_gemms"] = bool(getattr(args, "tuned_gemms", 1))
+    c["use_split_gemm"] = bool(getattr(args, "split_gemm", 1))
     params["seed"] = 0
     return params
 
@@ -156,6 +157,8 @@ def main():
     ap.add_argument("--minibatches", type=int, default=8, help="optimizer steps per mini-epoch")
     ap.add_argument("--graph", type=int, default=1, help="capture the rollout in a hipGraph")
     ap.add_argument("--tuned-gemms", type=int, default=1, help="apply the shipped TunableOp GEMM table (library kernel choice)")
+    ap.add_argument("--split-gemm", type=int, default=1,
+                    help="256x256 layer GEMMs (forward, dX) as float32-accurate bf16x6 products on the bf16 matrix cores")
     ap.add_argument("--task", default="hovering", choices=["hovering", "tracking"],
                     help="default = BASELINE config 1; 'tracking --ctl vel' = config 2 (side measurement, not the headline)")
     ap.add_argument("--ctl", default="rate", choices=["pos", "vel", "atti", "rate", "prop"])
@@ -225,6 +228,9 @@ def main():
                    "mini_epochs": agent.mini_epochs_num, "minibatch_size": agent.minibatch_size,
                    "policy": "MLP(256,256) actor-critic, fixed sigma", "parallelism": f"dp{world}",
                    "hip_graph_rollout": bool(args.graph),
+                   "hidden_layer_gemm": ("ag_split_gemm: exact 3-way bf16 split of every f32 operand, 6 bf16 MFMAs per product, f32 "
+                                         "accumulate (float32-accurate; tests/test_gpu_split_gemm.py) for forward and dX; wgrad = library f32"
+                                         if getattr(getattr(agent, "_fused_step", None), "split", None) else "library f32 GEMM"),
                    "gemm_selection": ("TunableOp table airgym_amd/assets/tunableop_gfx950.csv (hipBLASLt / rocBLAS fp32)"
                                       if getattr(agent, "tuned_gemms", False) else "hipBLASLt default heuristic (fp32)")},
         "phases": {"rollout_host_enqueue_s": play, "update_s": update, "final_lr": agent.last_lr,

@@ -279,6 +279,18 @@ int ag_mlp_input_layer(const float* obs_dev, const double* mean_dev, const doubl
 int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float* heads_dev, int M, int C, int A1,
                  int write_back, const float* zbias_dev, void* stream);
 
+/* float32-accurate GEMM on the bf16 matrix cores (airgym_amd/csrc/split_gemm.hip) for the 256 x 256 hidden layer
+ * (lib/network/mlp.py:36-39: forward X W^T; autograd's dX = dZ W): every f32 operand is split EXACTLY into three bf16 pieces
+ * and six of the nine cross products are accumulated in f32 - error <= one f32 rounding per product, at 6/16 of the cost of
+ * the f32-input MFMA path (gfx950 has no TF32 form).  n = k = 256 only (AG_ERR_UNSUPPORTED otherwise).
+ *   ag_split_gemm_prepare: W_dev [256, 256] f32 row-major -> planes_dev (ag_split_gemm_plane_bytes() bytes, 16-byte aligned);
+ *       transpose = 0: B = W (C = A W^T), 1: B = W^T (C = A W).  Run once per weight update.
+ *   ag_split_gemm: C_dev [M, 256] = A_dev [M, 256] B^T (+ bias_dev [256] if not NULL). */
+long long ag_split_gemm_plane_bytes(void);
+int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n, int k, int transpose, void* stream);
+int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
+                  void* stream);
+
 /* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block(which) rows
  * (ceil(M / rows) blocks); the caller reduces them over dim 0.
  *   ag_heads_bwd_elu_wgrad: dz = (d_heads Wh) * ELU'(h) (the head's dX formed inside the ELU' pass), plus dwh_partials_dev [blocks, A1, C] of dWh[a,c] = sum_m d_heads[m,a] h[m,c];

@@ -22,17 +22,18 @@ ap.add_argument("--blocks", type=int, nargs="+", default=[0, 1, 2, 3, 4, 64])
 ap.add_argument("--forms", nargs="+", default=["rollout", "api"])
 ap.add_argument("--replays", type=int, default=20)
 ap.add_argument("--nograph", action="store_true", help="eager launches (rocprofv3 counter passes)")
+ap.add_argument("--no-noise", action="store_true", help="observation noise off (diagnostic: what the noise wave costs)")
 a = ap.parse_args()
 print(torch.cuda.get_device_name(0), file=sys.stderr)
 for n in a.envs:
-    env = HipEnvHandle(a.task, a.ctl, n, seed=0, reward_terms=True)
+    env = HipEnvHandle(a.task, a.ctl, n, seed=0, reward_terms=True, obs_noise=not a.no_noise)
     for block in a.blocks:
         env.set_launch_params(block, 1)
         for form in a.forms:
             if form == "rollout" and (block == 1 or block >= 64):
                 continue        # the rollout form exists for the ws2 family only
             r = measure_env_kernel(env, replays=a.replays, rollout_form=(form == "rollout"), use_graph=not a.nograph)
-            r.update(task=a.task, ctl=a.ctl, envs=n, block=block, kernel=kernel_name(a.task, a.ctl, block),
+            r.update(task=a.task, ctl=a.ctl, envs=n, block=block, obs_noise=not a.no_noise, kernel=kernel_name(a.task, a.ctl, block),
                      frac=r["gbps_algorithmic"] / 8000.0)
             print(json.dumps(r), flush=True)
     env.close()
