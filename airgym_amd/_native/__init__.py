@@ -148,6 +148,7 @@ SYMBOLS = [
     ("ag_mlp_input_layer", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, _P]),
     ("ag_elu_heads", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    ("ag_debug_split_gemm_variant", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_gemm_plane_bytes", ctypes.c_longlong, []),
     ("ag_split_gemm_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_gemm", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),

@@ -3,13 +3,14 @@
 //
 // Why: CDNA4 runs f32-input MFMA at the f32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16 rate) and has no xf32/TF32 form
 // (MI355X_MICROARCH.md).  The PPO update is three [196 608 x 256] x [256 x 256] GEMMs per minibatch, i.e. bound by that
-// 157 TFLOP/s.  A float32 value splits EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, by truncation):
-//     a = a1 + a2 + a3,    b = b1 + b2 + b3        (no rounding anywhere: each piece holds 8 consecutive bits)
+// 157 TFLOP/s.  A float32 value splits EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, round to nearest):
+//     a = a1 + a2 + a3,   |a2| <= 2^-8 |a|,  |a3| <= 2^-16 |a|       (likewise b)
 // and every product ai*bj of two 8-bit significands is exact in the MFMA's f32 accumulate path.  Keeping the six terms
 //     a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1
-// drops only a2b3 + a3b2 + a3b3 <= 3 * 2^-24 |ab|, the size of ONE f32 rounding of the product - so the result differs
-// from an f32 FMA chain by no more than the accumulation-order noise every f32 GEMM already has (tests/test_gpu_split_gemm.py
-// measures both against float64).  Six bf16 MFMAs cost 6/16 of one f32 MFMA pass: 2.67x the f32-MFMA peak.
+// drops only a2b3 + a3b2 + a3b3 <= (2^-24 + 2^-24 + 2^-32) |ab| < 2^-23 |ab|: at most one float32 ulp per product (an f32
+// FMA rounds each step to half an ulp) - so the result differs from an f32 FMA chain by no more than the accumulation-order
+// noise every f32 GEMM already has (tests/test_gpu_split_gemm.py measures both against float64).  Six bf16 MFMAs cost
+// 6/16 of one f32 MFMA pass: 2.67x the f32-MFMA peak.  (Inf inputs become NaN: inf - inf in the split.)
 //
 // C[M, 256] = A[M, 256] * B^T, B given as prepared planes (ag_split_gemm_prepare): the weight matrix is split once per
 // optimizer step into the exact LDS image the kernel wants, so the B side of the main loop is a straight 16-byte copy.
@@ -34,23 +35,25 @@ constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// exact 3-way split of an f32 into bf16 pieces by truncation; returns the pieces as the HIGH halves of three words
-__device__ __forceinline__ void split3(float a, uint32_t& h1, uint32_t& h2, uint32_t& h3) {
-    h1 = __float_as_uint(a) & 0xFFFF0000u;
-    const float r1 = a - __uint_as_float(h1);
-    h2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(h2);
-    h3 = __float_as_uint(r2) & 0xFFFF0000u;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// (x, y) -> packed bf16 pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 (x in the low half)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float x, float y) {
+    const f32x2_t v = {x, y};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return *reinterpret_cast<const uint32_t*>(&b);
 }
 
-__device__ __forceinline__ uint32_t pack_hi(uint32_t even, uint32_t odd) { return (odd & 0xFFFF0000u) | (even >> 16); }
-
-// 2 consecutive-k floats -> one packed word per plane
+// Exact 3-way split of two consecutive-k floats into bf16 pieces, one packed word per plane.  a1 = rn_bf16(a), a2 =
+// rn_bf16(a - a1), a3 = a - a1 - a2: both differences are exact in f32 and the last one has at most 8 significant bits, so
+// a == a1 + a2 + a3 with |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a| (round to nearest; truncation would give 2^-7 / 2^-15).
 __device__ __forceinline__ void split_pair(float x, float y, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
-    uint32_t x1, x2, x3, y1, y2, y3;
-    split3(x, x1, x2, x3);
-    split3(y, y1, y2, y3);
-    w1 = pack_hi(x1, y1); w2 = pack_hi(x2, y2); w3 = pack_hi(x3, y3);
+    w1 = cvt_pk_bf16(x, y);
+    const float rx = x - __uint_as_float(w1 << 16), ry = y - __uint_as_float(w1 & 0xFFFF0000u);
+    w2 = cvt_pk_bf16(rx, ry);
+    const float sx = rx - __uint_as_float(w2 << 16), sy = ry - __uint_as_float(w2 & 0xFFFF0000u);
+    w3 = cvt_pk_bf16(sx, sy);
 }
 
 // 8 consecutive-k floats -> three 16-byte bf16x8 units (one per plane)
@@ -79,7 +82,9 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
     chunk[(2 * 2 + h) * BN + n] = p3;
 }
 
-template <bool HAS_BIAS>
+// VAR bit 0: pin the next chunk's global loads to the TOP of the chunk (a whole chunk of MFMAs for them to land) instead of
+// letting the scheduler sink them to shorten live ranges.
+template <bool HAS_BIAS, int VAR>
 __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
                                                              const float* __restrict__ bias, float* __restrict__ C, int M) {
     extern __shared__ uint4 lds[];                         // [2 stages][A_UNITS + B_UNITS] 16-byte units
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
     for (int c = 0; c < NCHUNK; ++c) {
         const int stage = c & 1;
         if (c + 1 < NCHUNK) AG_SG_LOAD(c + 1);              // global loads in flight under this chunk's MFMAs
+        if (VAR & 1) __builtin_amdgcn_sched_barrier(0);
         const uint4* sa = lds + stage * STAGE_UNITS;
         const uint4* sb = sa + A_UNITS;
         const uint4 ua0 = sa[(0 * 2 + khalf) * BM + wave * 32 + l31];
@@ -184,21 +190,34 @@ extern "C" int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
+static int g_split_variant = 1;
+extern "C" int ag_debug_split_gemm_variant(int variant) {
+    if (variant < 0 || variant > 1) return AG_ERR_INVALID_ARG;
+    g_split_variant = variant;
+    return AG_OK;
+}
+
+template <int VAR>
+static int launch_split(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, void* stream) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * STAGE_UNITS * 16;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<false, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<true, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return AG_ERR_HIP;
+        attr_set = true;
+    }
+    const dim3 grid((M + BM - 1) / BM), block(256);
+    if (bias_dev) hipLaunchKernelGGL((split_gemm_kernel<true, VAR>), grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
+    else hipLaunchKernelGGL((split_gemm_kernel<false, VAR>), grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
 extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
                              void* stream) {
     if (!A_dev || !planes_dev || !C_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
-    static bool attr_set = false;
-    const size_t lds = (size_t)2 * STAGE_UNITS * 16;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return AG_ERR_HIP;
-        attr_set = true;
-    }
-    const dim3 grid((M + BM - 1) / BM), block(256);
-    if (bias_dev) hipLaunchKernelGGL(split_gemm_kernel<true>, grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
-    else hipLaunchKernelGGL(split_gemm_kernel<false>, grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
-    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+    return g_split_variant == 0 ? launch_split<0>(A_dev, planes_dev, bias_dev, C_dev, M, stream)
+                                : launch_split<1>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
 }

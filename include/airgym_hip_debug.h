@@ -29,6 +29,9 @@ int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
  * wave, {HW_REG_HW_ID, HW_REG_XCC_ID} into out_dev [ceil(n/64) * 2, 2] u32 (tools/wave_placement.py decodes SIMD / CU / XCC). */
 int ag_debug_wave_placement(ag_handle h, unsigned int* out_dev, void* stream);
 
+/* Scheduling variant of ag_split_gemm's main loop (0 = compiler-placed prefetch, 1 = prefetch pinned to the top of the K chunk). */
+int ag_debug_split_gemm_variant(int variant);
+
 /* Next Planning step renders with parts of the render kernel skipped: bit0 ray-cast, bit1 noise passes, bit2 5x5 pass. */
 int ag_debug_planning_render_parts(ag_handle h, int skip_mask);
 

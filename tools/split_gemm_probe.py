@@ -38,10 +38,14 @@ for M in (65536, 196608):
     planes = torch.empty(lib.ag_split_gemm_plane_bytes(), dtype=torch.uint8, device="cuda")
     N.check(lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st), "prep")
     us_prep = time_us(lambda: lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st))
-    us_split = time_us(lambda: lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st))
+    us_var = {}
+    for var in (0, 1):
+        lib.ag_debug_split_gemm_variant(var)
+        us_var[var] = time_us(lambda: lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st))
+    us_split = us_var[1]
     us_nn = time_us(lambda: torch.mm(A, Wt, out=C))
     us_nt = time_us(lambda: torch.mm(A, W.t(), out=C))
     fl = 2.0 * M * 256 * 256
     print(json.dumps({"M": M, "split_us": us_split, "split_f32_equiv_tflops": fl / us_split / 1e6,
                       "split_bf16_tflops": 6 * fl / us_split / 1e6, "lib_nn_us": us_nn, "lib_nt_us": us_nt,
-                      "lib_tflops": fl / min(us_nn, us_nt) / 1e6, "prepare_us": us_prep}), flush=True)
+                      "lib_tflops": fl / min(us_nn, us_nt) / 1e6, "prepare_us": us_prep, "variant_us": us_var}), flush=True)
