@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
 }
 
 // VAR bit 0: pin the next chunk's global loads to the TOP of the chunk (a whole chunk of MFMAs for them to land) instead of
-// letting the scheduler sink them to shorten live ranges.
+// letting the scheduler sink them to shorten live ranges.  VAR bit 1: waves as 2 x 2 (64 rows x 128 columns each) instead of
+// 4 x 1 (32 rows x 256 columns): fewer LDS fragment reads.
 template <bool HAS_BIAS, int VAR>
 __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
                                                              const float* __restrict__ bias, float* __restrict__ C, int M) {
@@ -136,6 +137,38 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
         if (VAR & 1) __builtin_amdgcn_sched_barrier(0);
         const uint4* sa = lds + stage * STAGE_UNITS;
         const uint4* sb = sa + A_UNITS;
+        if (VAR & 2) {
+            // 2 x 2 waves: wave (wm, wn) owns rows 64 wm .. +63 and columns 128 wn .. +127 (2 x 4 tiles): 18 fragment reads per
+            // chunk instead of 27 (every B fragment feeds two row tiles)
+            const int wm = wave >> 1, wn = wave & 1;
+            bf16x8 a[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const uint4 u = sa[(p * 2 + khalf) * BM + wm * 64 + i * 32 + l31];
+                    a[i][p] = *reinterpret_cast<const bf16x8*>(&u);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 ub0 = sb[(0 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];
+                const uint4 ub1 = sb[(1 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];
+                const uint4 ub2 = sb[(2 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&ub0);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&ub1);
+                const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&ub2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x16& d = acc[i * 4 + j];
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b0, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b2, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b1, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b0, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b1, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b0, d, 0, 0, 0);
+                }
+            }
+        } else {
         const uint4 ua0 = sa[(0 * 2 + khalf) * BM + wave * 32 + l31];
         const uint4 ua1 = sa[(1 * 2 + khalf) * BM + wave * 32 + l31];
         const uint4 ua2 = sa[(2 * 2 + khalf) * BM + wave * 32 + l31];
@@ -158,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
         }
+        }
         if (c + 1 < NCHUNK) AG_SG_STORE(stage ^ 1);         // the other stage was last read before the previous barrier
         __syncthreads();
     }
@@ -166,13 +200,14 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int col = j * 32 + l31;
+    for (int t = 0; t < 8; ++t) {
+        const int col = (VAR & 2) ? ((wave & 1) * 128 + (t & 3) * 32 + l31) : (t * 32 + l31);
+        const int row0 = (VAR & 2) ? (m0 + (wave >> 1) * 64 + (t >> 2) * 32) : (m0 + wave * 32);
         const float bj = HAS_BIAS ? bias[col] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            if (row < M) C[(size_t)row * BN + col] = acc[j][r] + bj;
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (row < M) C[(size_t)row * BN + col] = acc[t][r] + bj;
         }
     }
 }
@@ -192,7 +227,7 @@ extern "C" int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n
 
 static int g_split_variant = 1;
 extern "C" int ag_debug_split_gemm_variant(int variant) {
-    if (variant < 0 || variant > 1) return AG_ERR_INVALID_ARG;
+    if (variant < 0 || variant > 3) return AG_ERR_INVALID_ARG;
     g_split_variant = variant;
     return AG_OK;
 }
@@ -218,6 +253,10 @@ extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const f
     if (!A_dev || !planes_dev || !C_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
-    return g_split_variant == 0 ? launch_split<0>(A_dev, planes_dev, bias_dev, C_dev, M, stream)
-                                : launch_split<1>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+    switch (g_split_variant) {
+        case 0: return launch_split<0>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 1: return launch_split<1>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 2: return launch_split<2>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        default: return launch_split<3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+    }
 }

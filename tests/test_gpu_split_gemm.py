@@ -46,8 +46,9 @@ def test_operand_layout_with_identity_and_asymmetric_matrix(lib):
     D = torch.diag(x).contiguous()
     C3 = _gemm(lib, D, W, transpose=True)
     ref = (x.double()[:, None] * W.double())
-    # a single product: the six kept terms miss a2 b3 + a3 b2 + a3 b3 < 2^-23 |ab| (round-to-nearest split), i.e. <= 1 ulp
-    assert ((C3.double() - ref).abs() <= 1.01 * 2.0 ** -23 * ref.abs() + 1e-30).all()
+    # a single product: the six kept terms miss a2 b3 + a3 b2 + a3 b3 < 2^-23 |ab| (round-to-nearest split) and the last f32
+    # accumulate rounds once more (2^-24): <= 1.5 ulp in total, against 0.5 ulp for one correctly rounded f32 product
+    assert ((C3.double() - ref).abs() <= 1.55 * 2.0 ** -23 * ref.abs() + 1e-30).all()
 
 
 @pytest.mark.parametrize("M", [1, 127, 128, 4097, 196608])
@@ -80,3 +81,21 @@ def test_rejects_other_shapes(lib):
     assert lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 128, 256, 0, _stream()) != 0
     A = torch.zeros(8, 256, device="cuda"); C = torch.zeros(8, 256, device="cuda")
     assert lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), 8, 256, 128, _stream()) != 0
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_scheduling_variants_are_the_same_arithmetic(lib, variant):
+    """The A/B variants (prefetch placement, wave arrangement) order the same six MFMAs per product identically."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = torch.randn(4097, 256, device="cuda", generator=g)
+    W = torch.randn(256, 256, device="cuda", generator=g) / 16.0
+    try:
+        assert lib.ag_debug_split_gemm_variant(0) == 0
+        ref = _gemm(lib, A, W, False)
+        assert lib.ag_debug_split_gemm_variant(variant) == 0
+        got = _gemm(lib, A, W, False)
+    finally:
+        lib.ag_debug_split_gemm_variant(1)
+    assert torch.equal(ref, got)
+    exact = A.double() @ W.double().t()
+    assert ((got.double() - exact).abs() / (A.double().abs() @ W.double().abs().t())).max().item() < 4e-7
