@@ -90,7 +90,22 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
                                                              const float* __restrict__ bias, float* __restrict__ C, int M) {
     extern __shared__ uint4 lds[];                         // [2 stages][A_UNITS + B_UNITS] 16-byte units
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM;
+    const int num_tiles = (M + BM - 1) / BM;
+    if (VAR & 4) {
+        // persistent workgroups, two per CU.  All workgroups run identical tiles, so without help the two on a CU stay in
+        // lockstep and their epilogues (128 KB of C stores each) stall the matrix pipe together.  The second workgroup of
+        // a CU (non-zero LDS base, HW_REG_LDS_ALLOC) starts half a tile late: from then on one stores while the other
+        // multiplies.
+        const unsigned lds_alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+        if ((lds_alloc & 0xFF) != 0) {
+#pragma unroll 1
+            for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ((VAR & 4) ? num_tiles : (int)blockIdx.x + 1); tile += (VAR & 4) ? (int)gridDim.x : num_tiles) {
+    const int m0 = tile * BM;
+    if ((VAR & 4) && tile != (int)blockIdx.x) __syncthreads();      // the previous tile's epilogue is done before LDS is reused
 
     f32x16 acc[8];
 #pragma unroll
@@ -210,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
             if (row < M) C[(size_t)row * BN + col] = acc[t][r] + bj;
         }
     }
+    }   // tile loop
 }
 
 }  // namespace
@@ -225,9 +241,9 @@ extern "C" int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
-static int g_split_variant = 1;
+static int g_split_variant = -1;      // -1 = pick by size (measured on MI355X, profiles/r02_split_gemm.md)
 extern "C" int ag_debug_split_gemm_variant(int variant) {
-    if (variant < 0 || variant > 3) return AG_ERR_INVALID_ARG;
+    if (variant < -1 || variant > 7) return AG_ERR_INVALID_ARG;
     g_split_variant = variant;
     return AG_OK;
 }
@@ -242,7 +258,9 @@ static int launch_split(const float* A_dev, const void* planes_dev, const float*
             return AG_ERR_HIP;
         attr_set = true;
     }
-    const dim3 grid((M + BM - 1) / BM), block(256);
+    int tiles = (M + BM - 1) / BM;
+    if (VAR & 4) tiles = tiles < 512 ? tiles : 512;        // persistent: 2 workgroups on each of the 256 CUs
+    const dim3 grid(tiles), block(256);
     if (bias_dev) hipLaunchKernelGGL((split_gemm_kernel<true, VAR>), grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
     else hipLaunchKernelGGL((split_gemm_kernel<false, VAR>), grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
@@ -253,10 +271,16 @@ extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const f
     if (!A_dev || !planes_dev || !C_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
-    switch (g_split_variant) {
+    // more than one round of workgroups (> 2 per CU): persistent, de-phased, 2 x 2 waves (6); a single round: plain 2 x 2 (2)
+    const int variant = g_split_variant >= 0 ? g_split_variant : (((M + BM - 1) / BM > 512) ? 6 : 2);
+    switch (variant) {
         case 0: return launch_split<0>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 1: return launch_split<1>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 2: return launch_split<2>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        default: return launch_split<3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 3: return launch_split<3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 4: return launch_split<4>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 6: return launch_split<6>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 7: return launch_split<7>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        default: return launch_split<5>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
     }
 }

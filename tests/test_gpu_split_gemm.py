@@ -83,7 +83,7 @@ def test_rejects_other_shapes(lib):
     assert lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), 8, 256, 128, _stream()) != 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_scheduling_variants_are_the_same_arithmetic(lib, variant):
     """The A/B variants (prefetch placement, wave arrangement) order the same six MFMAs per product identically."""
     g = torch.Generator(device="cuda").manual_seed(7)
@@ -95,7 +95,7 @@ def test_scheduling_variants_are_the_same_arithmetic(lib, variant):
         assert lib.ag_debug_split_gemm_variant(variant) == 0
         got = _gemm(lib, A, W, False)
     finally:
-        lib.ag_debug_split_gemm_variant(1)
+        lib.ag_debug_split_gemm_variant(-1)
     assert torch.equal(ref, got)
     exact = A.double() @ W.double().t()
     assert ((got.double() - exact).abs() / (A.double().abs() @ W.double().abs().t())).max().item() < 4e-7

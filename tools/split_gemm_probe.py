@@ -39,10 +39,11 @@ for M in (65536, 196608):
     N.check(lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st), "prep")
     us_prep = time_us(lambda: lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st))
     us_var = {}
-    for var in (0, 1, 2, 3):
+    for var in (0, 2, 3, 4, 6, 7):
         lib.ag_debug_split_gemm_variant(var)
         us_var[var] = time_us(lambda: lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st))
-    us_split = min(us_var.values())
+    lib.ag_debug_split_gemm_variant(-1)
+    us_split = time_us(lambda: lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st))
     us_nn = time_us(lambda: torch.mm(A, Wt, out=C))
     us_nt = time_us(lambda: torch.mm(A, W.t(), out=C))
     fl = 2.0 * M * 256 * 256
