@@ -29,7 +29,13 @@ def time_us(fn, iters=30, warmup=5):
     return a.elapsed_time(b) * 1e3 / iters
 
 
-for M in (65536, 196608):
+import argparse
+_ap = argparse.ArgumentParser()
+_ap.add_argument("--M", type=int, nargs="+", default=[65536, 196608])
+_ap.add_argument("--variants", type=int, nargs="+", default=[0, 2, 3, 4, 6, 7])
+_ap.add_argument("--skip-lib", action="store_true")
+_a = _ap.parse_args()
+for M in _a.M:
     g = torch.Generator(device="cuda").manual_seed(0)
     A = torch.randn(M, 256, device="cuda", generator=g)
     W = torch.randn(256, 256, device="cuda", generator=g) / 16
@@ -39,13 +45,15 @@ for M in (65536, 196608):
     N.check(lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st), "prep")
     us_prep = time_us(lambda: lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st))
     us_var = {}
-    for var in (0, 2, 3, 4, 6, 7):
+    for var in _a.variants:
         lib.ag_debug_split_gemm_variant(var)
         us_var[var] = time_us(lambda: lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st))
     lib.ag_debug_split_gemm_variant(-1)
     us_split = time_us(lambda: lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st))
-    us_nn = time_us(lambda: torch.mm(A, Wt, out=C))
-    us_nt = time_us(lambda: torch.mm(A, W.t(), out=C))
+    us_nn = us_nt = float("nan")
+    if not _a.skip_lib:
+        us_nn = time_us(lambda: torch.mm(A, Wt, out=C))
+        us_nt = time_us(lambda: torch.mm(A, W.t(), out=C))
     fl = 2.0 * M * 256 * 256
     print(json.dumps({"M": M, "split_us": us_split, "split_f32_equiv_tflops": fl / us_split / 1e6,
                       "split_bf16_tflops": 6 * fl / us_split / 1e6, "lib_nn_us": us_nn, "lib_nt_us": us_nt,
