@@ -152,6 +152,11 @@ SYMBOLS = [
     ("ag_split_gemm_plane_bytes", ctypes.c_longlong, []),
     ("ag_split_gemm_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_gemm", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_split_gemm_input_wgrad_rows", ctypes.c_int, []),
+    ("ag_split_gemm_input_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, _P]),
+    ("ag_split_gemm_elu_heads", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, _P]),
     ("ag_wgrad_rows_per_block", ctypes.c_int, [ctypes.c_int]),
     ("ag_input_wgrad_rows", ctypes.c_int, [ctypes.c_int]),
     ("ag_sum_rows_groups", ctypes.c_int, []),

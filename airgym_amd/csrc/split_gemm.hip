@@ -14,8 +14,9 @@
 //
 // C[M, 256] = A[M, 256] * B^T, B given as prepared planes (ag_split_gemm_prepare): the weight matrix is split once per
 // optimizer step into the exact LDS image the kernel wants, so the B side of the main loop is a straight 16-byte copy.
-//   workgroup 256 threads = 4 waves; block tile 128 rows x 256 columns (all of N); wave w owns rows 32w..32w+31 as eight
-//   32x32 tiles (v_mfma_f32_32x32x16_bf16, 128 accumulator registers); K in chunks of 16, double-buffered in LDS:
+//   workgroup 256 threads = 4 waves as 2 x 2; block tile 128 rows x 256 columns (all of N); wave (wm, wn) owns rows
+//   64 wm .. +63 and columns 128 wn .. +127 as 2 x 4 tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16, 128 accumulator
+//   registers); K in chunks of 16, double-buffered in LDS:
 //     A stage: [plane 3][k-half 2][row 128] x 16 B   (12 KB)   - the wave splits its f32 rows on the fly
 //     B stage: [plane 3][k-half 2][col 256] x 16 B   (24 KB)
 //   72 KB per workgroup -> two workgroups per CU, two waves per SIMD: one wave's LDS traffic and f32->bf16 splitting hide
@@ -82,12 +83,124 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
     chunk[(2 * 2 + h) * BN + n] = p3;
 }
 
-// VAR bit 0: pin the next chunk's global loads to the TOP of the chunk (a whole chunk of MFMAs for them to land) instead of
-// letting the scheduler sink them to shorten live ranges.  VAR bit 1: waves as 2 x 2 (64 rows x 128 columns each) instead of
-// 4 x 1 (32 rows x 256 columns): fewer LDS fragment reads.
-template <bool HAS_BIAS, int VAR>
+// VAR bit 0: prescribe the issue order inside a chunk (sched_group_barrier): the next chunk's global loads at the TOP (a
+// whole chunk of MFMAs for them to land) instead of wherever the scheduler sinks them to shorten live ranges.  Bit 1: always
+// set (2 x 2 waves; the 4 x 1 arrangement of the first version read 27 fragments per chunk instead of 18 and was slower).
+// Bit 2: persistent workgroups, the second one of a CU de-phased.  Bit 3: non-temporal stores of C.
+//
+// A1 > 0 (2 x 2 waves only): the forward of the LAST hidden layer with the actor/critic heads folded into the epilogue
+// (lib/network/mlp.py:36-39 followed by the mu / value Linear of a2c_continuous.py's model): C keeps the bias-free
+// pre-activation z (the backward wants it), and heads[m, a] = sum_c ELU(z[m,c] + bias[c]) Wh[a,c] + bh[a] is formed from the
+// accumulators while they are still in registers - the separate ELU + head pass re-read all of z (201 MB per minibatch).
+// Per lane: 4 columns of 32 rows -> A1 partial dot products per row, summed over the 32 lanes of a half-wave with DPP row
+// operations, over the two column halves (waves wn = 0, 1) through LDS.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float sg_dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(moved);
+}
+// sum over each 32-lane half of the wave; valid in lanes 16..31 and 48..63
+__device__ __forceinline__ float sg_half_sum(float v) {
+    v = sg_dpp_add<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v = sg_dpp_add<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    v = sg_dpp_add<0x141, 0xF>(v);       // row_half_mirror
+    v = sg_dpp_add<0x140, 0xF>(v);       // row_mirror
+    v = sg_dpp_add<0x142, 0xA>(v);       // row_bcast15: rows 1, 3 += lane 15 of rows 0, 2
+    return v;
+}
+__device__ __forceinline__ float sg_elu(float z) {      // same form as ppo_kernels.hip elu1
+    return z > 0.f ? z : __builtin_amdgcn_exp2f(z * 1.4426950408889634f) - 1.0f;
+}
+
+//
+// DIN > 0: the backward dX GEMM of the SECOND layer with the whole backward of the FIRST layer folded into its epilogue
+// (autograd of mlp.py:36-39 for a [DIN -> 256 -> 256] trunk): the accumulators are dh1 = dz2 W2; the epilogue multiplies by
+// ELU'(h1) (from the stored activations, h > 0 ? 1 : h + 1), and reduces dW1[c, d] = sum_m dz1[m, c] x[m, d], db1[c] =
+// sum_m dz1[m, c] over the tile's 128 rows into one partial per tile.  Neither dh1 nor dz1 is ever written: nothing upstream
+// of the first layer needs them, and the separate first-layer kernel re-read both dh1 and h1 (402 MB per minibatch).
+// Per lane: 4 columns x 32 rows -> a [4][DIN] register tile (packed v_pk_fma_f32), the input rows broadcast from LDS; the two
+// row halves of a wave (lanes l, l + 32) and the two row blocks (waves wm = 0, 1) are summed through LDS in a fixed order.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// First-layer backward on the matrix cores (split_gemm_kernel, DIN > 0).  For one column tile J of a wave:
+//     G[d, c] = sum over the wave's 64 rows m of  x[m, d] * dz1[m, c],   dz1 = dh1 * ELU'(h1),   x[m, DIN] = 1 (bias gradient)
+// as v_mfma_f32_32x32x16_bf16 products with K = rows.  The contraction index may be enumerated in any order as long as both
+// operands agree, so K step ks of row tile i is taken to be exactly the rows held by accumulator registers 8 ks .. 8 ks + 7 of
+// a lane (rows (e & 3) + 8 (e >> 2) + 16 ks + 4 h for lane half h): the B operand (dz1) is formed from the accumulators IN
+// PLACE, no data movement; the A operand (x, pre-split into the same row order) comes from LDS planes built once per tile.
+// Both operands are split three ways like the main product (six MFMAs per step): float32-accurate.
+template <int J>
+__device__ __forceinline__ void input_wgrad_tile(const f32x16 (&acc)[8], const float* __restrict__ hcol, const uint4* xp_lane,
+                                                 float* mine, int m0, int M, int wm, int khalf, int DIN1) {
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = 0.0f;
+    // activations of step s + PF are requested before step s is worked on (4 steps per column tile: i = s >> 1, ks = s & 1)
+    constexpr int PF = 2;
+    float ring[PF][8];
+#define AG_IW_ROW(s_, e_) (wm * 64 + ((s_) >> 1) * 32 + ((e_) & 3) + 8 * ((e_) >> 2) + 16 * ((s_) & 1) + 4 * khalf)
+#define AG_IW_FETCH(s_)                                                                               \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                     \
+        ring[(s_) % PF][e] = hcol[(size_t)min(m0 + AG_IW_ROW(s_, e), M - 1) * BN + 32 * J]
+#pragma unroll
+    for (int s = 0; s < PF; ++s) AG_IW_FETCH(s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float dz[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y = ring[s % PF][e];
+            dz[e] = acc[(s >> 1) * 4 + J][8 * (s & 1) + e] * (y > 0.0f ? 1.0f : y + 1.0f);
+        }
+        if (s + PF < 4) AG_IW_FETCH(s + PF);
+        uint4 b1, b2, b3;                                   // rows past M need no masking here: their x rows are zero
+        split8(make_float4(dz[0], dz[1], dz[2], dz[3]), make_float4(dz[4], dz[5], dz[6], dz[7]), b1, b2, b3);
+        const uint4 ua1 = xp_lane[(0 * 4 + s) * 128], ua2 = xp_lane[(1 * 4 + s) * 128], ua3 = xp_lane[(2 * 4 + s) * 128];
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1), a2 = *reinterpret_cast<const bf16x8*>(&ua2),
+                     a3 = *reinterpret_cast<const bf16x8*>(&ua3);
+        const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(&b1), c2 = *reinterpret_cast<const bf16x8*>(&b2),
+                     c3 = *reinterpret_cast<const bf16x8*>(&b3);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, c1, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c3, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c2, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c1, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c2, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c1, g, 0, 0, 0);
+        asm volatile("" : "+v"(g));                         // this step's products stay in this step (see the head epilogue)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef AG_IW_FETCH
+#undef AG_IW_ROW
+    // g: column c = this lane's column of tile J, rows d = (r & 3) + 8 (r >> 2) + 4 h; keep d <= DIN (d = DIN: bias gradient)
+    float* dst = mine + J * 32 * DIN1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (d < DIN1) dst[d] = g[r];
+    }
+}
+
+struct SplitEpilogue {
+    const float* bias;         // [256] layer bias: added to C (plain), or inside the ELU only (heads)
+    const float* Wh;           // heads: [A1, 256]
+    const float* bh;           // heads: [A1]
+    float* heads;              // heads: [M, A1]
+    const float* h1;           // input wgrad: [M, 256] first-layer activations
+    const float* x;            // input wgrad: [M, DIN] (normalised) network inputs
+    float* dw_partials;        // input wgrad: [tiles, 256, DIN]
+    float* db_partials;        // input wgrad: [tiles, 256]
+};
+
+template <bool HAS_BIAS, int VAR, int A1, int ABL = 0, int DIN = 0>
 __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
-                                                             const float* __restrict__ bias, float* __restrict__ C, int M) {
+                                                             float* __restrict__ C, int M, const SplitEpilogue ep) {
+    static_assert(A1 == 0 || DIN == 0, "one fused epilogue at a time");
+    static_assert((DIN & 1) == 0 && DIN <= 24, "input width: even (packed FMAs), register tile 4 x DIN");
+    const float* __restrict__ bias = ep.bias;
+    const float* __restrict__ Wh = ep.Wh;
+    const float* __restrict__ bh = ep.bh;
+    float* __restrict__ heads = ep.heads;
     extern __shared__ uint4 lds[];                         // [2 stages][A_UNITS + B_UNITS] 16-byte units
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int num_tiles = (M + BM - 1) / BM;
@@ -107,12 +220,6 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
     const int m0 = tile * BM;
     if ((VAR & 4) && tile != (int)blockIdx.x) __syncthreads();      // the previous tile's epilogue is done before LDS is reused
 
-    f32x16 acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-
     // ---- global -> register staging for one K chunk
     const int a_row = tid >> 1, a_half = tid & 1;                       // 128 rows x 2 k-halves: one 32-byte piece per thread
     const int a_grow = min(m0 + a_row, M - 1);                          // rows past M are computed, never stored
@@ -121,18 +228,24 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
     uint4 rb0, rb1, rb2, rb3, rb4, rb5;
 #define AG_SG_LOAD(c)                                                                  \
     do {                                                                               \
-        ra0 = a_src[(c) * (BK / 4)];                                                   \
-        ra1 = a_src[(c) * (BK / 4) + 1];                                               \
-        const uint4* bsrc_ = Bp + (size_t)(c) * B_UNITS + tid;                         \
-        rb0 = bsrc_[0]; rb1 = bsrc_[256]; rb2 = bsrc_[512];                            \
-        rb3 = bsrc_[768]; rb4 = bsrc_[1024]; rb5 = bsrc_[1280];                        \
+        if (!(ABL & 1) || (c) == 0) {                                                  \
+            ra0 = a_src[(c) * (BK / 4)];                                               \
+            ra1 = a_src[(c) * (BK / 4) + 1];                                           \
+        }                                                                              \
+        if (!(ABL & 2) || (c) == 0) {                                                  \
+            const uint4* bsrc_ = Bp + (size_t)(c) * B_UNITS + tid;                     \
+            rb0 = bsrc_[0]; rb1 = bsrc_[256]; rb2 = bsrc_[512];                        \
+            rb3 = bsrc_[768]; rb4 = bsrc_[1024]; rb5 = bsrc_[1280];                    \
+        }                                                                              \
     } while (0)
 #define AG_SG_STORE(stage)                                                             \
     do {                                                                               \
         uint4* sa_ = lds + (stage) * STAGE_UNITS;                                      \
         uint4* sb_ = sa_ + A_UNITS + tid;                                              \
         uint4 p1_, p2_, p3_;                                                           \
-        split8(ra0, ra1, p1_, p2_, p3_);                                               \
+        if (ABL & 4) {                                                                 \
+            p1_ = *reinterpret_cast<uint4*>(&ra0); p2_ = *reinterpret_cast<uint4*>(&ra1); p3_ = p1_; \
+        } else split8(ra0, ra1, p1_, p2_, p3_);                                        \
         sa_[(0 * 2 + a_half) * BM + a_row] = p1_;                                      \
         sa_[(1 * 2 + a_half) * BM + a_row] = p2_;                                      \
         sa_[(2 * 2 + a_half) * BM + a_row] = p3_;                                      \
@@ -142,88 +255,186 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
 
     AG_SG_LOAD(0);
     AG_SG_STORE(0);
+    int c1 = 1;      // opaque, so that chunk 1's loads stay BEHIND chunk 0's stores and reuse its staging registers (hoisted to
+    asm volatile("" : "+s"(c1) : : "memory");      // the top they need a second set: spills, each behind an s_waitcnt vmcnt(0))
+    AG_SG_LOAD(c1);
     __syncthreads();
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
     const int l31 = lane & 31, khalf = lane >> 5;
     constexpr int NCHUNK = KDIM / BK;
-    for (int c = 0; c < NCHUNK; ++c) {
+    // 2 x 2 waves: wave (wm, wn) owns rows 64 wm .. +63 and columns 128 wn .. +127 (2 x 4 tiles of 32 x 32): 18 fragment
+    // reads per chunk (every B fragment feeds two row tiles).  Products smallest first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1.
+    const int wm = wave >> 1, wn = wave & 1;
+#define AG_SG_COMPUTE(stage_)                                                                          \
+    do {                                                                                               \
+        const uint4* sa_ = lds + (stage_) * STAGE_UNITS;                                               \
+        const uint4* sb_ = sa_ + A_UNITS;                                                              \
+        bf16x8 a_[2][3];                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
+                const uint4 u_ = sa_[(p * 2 + khalf) * BM + wm * 64 + i * 32 + l31];                   \
+                a_[i][p] = *reinterpret_cast<const bf16x8*>(&u_);                                      \
+            }                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+            const uint4 ub0_ = sb_[(0 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];                    \
+            const uint4 ub1_ = sb_[(1 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];                    \
+            const uint4 ub2_ = sb_[(2 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];                    \
+            const bf16x8 b0_ = *reinterpret_cast<const bf16x8*>(&ub0_);                                \
+            const bf16x8 b1_ = *reinterpret_cast<const bf16x8*>(&ub1_);                                \
+            const bf16x8 b2_ = *reinterpret_cast<const bf16x8*>(&ub2_);                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+                f32x16& d_ = acc[i * 4 + j];                                                           \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][2], b0_, d_, 0, 0, 0);              \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][0], b2_, d_, 0, 0, 0);              \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][1], b1_, d_, 0, 0, 0);              \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][1], b0_, d_, 0, 0, 0);              \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][0], b1_, d_, 0, 0, 0);              \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][0], b0_, d_, 0, 0, 0);              \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+    // Global loads run TWO chunks ahead of the MFMAs and are issued at the END of a chunk, right after the registers they
+    // fill were drained into LDS: issued at the top of the chunk that precedes their use, LLVM sinks them into the store block
+    // (same condition, only user there) and every chunk ends waiting for HBM; here they have a full chunk to land and cost
+    // no extra registers.  VAR bit 0 additionally prescribes the issue order of LDS reads and MFMAs (sched_group_barrier):
+    // the A fragments and TWO column tiles of B fragments first, then 12 MFMAs per column tile with the reads one tile ahead.
+#define AG_SG_ORDER()                                                                                  \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    } while (0)
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK - 1; ++c) {
         const int stage = c & 1;
-        if (c + 1 < NCHUNK) AG_SG_LOAD(c + 1);              // global loads in flight under this chunk's MFMAs
-        if (VAR & 1) __builtin_amdgcn_sched_barrier(0);
-        const uint4* sa = lds + stage * STAGE_UNITS;
-        const uint4* sb = sa + A_UNITS;
-        if (VAR & 2) {
-            // 2 x 2 waves: wave (wm, wn) owns rows 64 wm .. +63 and columns 128 wn .. +127 (2 x 4 tiles): 18 fragment reads per
-            // chunk instead of 27 (every B fragment feeds two row tiles)
-            const int wm = wave >> 1, wn = wave & 1;
-            bf16x8 a[2][3];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const uint4 u = sa[(p * 2 + khalf) * BM + wm * 64 + i * 32 + l31];
-                    a[i][p] = *reinterpret_cast<const bf16x8*>(&u);
-                }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint4 ub0 = sb[(0 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];
-                const uint4 ub1 = sb[(1 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];
-                const uint4 ub2 = sb[(2 * 2 + khalf) * BN + wn * 128 + j * 32 + l31];
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&ub0);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&ub1);
-                const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&ub2);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f32x16& d = acc[i * 4 + j];
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b0, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b2, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b1, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b0, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b1, d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b0, d, 0, 0, 0);
-                }
-            }
-        } else {
-        const uint4 ua0 = sa[(0 * 2 + khalf) * BM + wave * 32 + l31];
-        const uint4 ua1 = sa[(1 * 2 + khalf) * BM + wave * 32 + l31];
-        const uint4 ua2 = sa[(2 * 2 + khalf) * BM + wave * 32 + l31];
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&ua0);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1);
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(&ua2);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint4 ub0 = sb[(0 * 2 + khalf) * BN + j * 32 + l31];
-            const uint4 ub1 = sb[(1 * 2 + khalf) * BN + j * 32 + l31];
-            const uint4 ub2 = sb[(2 * 2 + khalf) * BN + j * 32 + l31];
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&ub0);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&ub1);
-            const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(&ub2);
-            // smallest terms first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
-        }
-        }
-        if (c + 1 < NCHUNK) AG_SG_STORE(stage ^ 1);         // the other stage was last read before the previous barrier
-        __syncthreads();
+        AG_SG_COMPUTE(stage);
+        if (VAR & 1) AG_SG_ORDER();
+        AG_SG_STORE(stage ^ 1);                             // chunk c + 1; that stage was last read before the previous barrier
+        const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;      // (the last trip reloads a chunk it does not need)
+        AG_SG_LOAD(cn);
+        if (!(ABL & 16)) __syncthreads();
     }
+    AG_SG_COMPUTE((NCHUNK - 1) & 1);
+    if (VAR & 1) AG_SG_ORDER();
+    if (A1 > 0 || DIN > 0) __syncthreads();                 // the fused epilogues reuse the stages
+#undef AG_SG_COMPUTE
+#undef AG_SG_ORDER
 #undef AG_SG_LOAD
 #undef AG_SG_STORE
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if constexpr (A1 > 0) {
+        int late = 0;       // opaque zero: keeps the 4 + 4 A1 per-column constants (tile-invariant, so LLVM would hoist them out
+        asm volatile("" : "+s"(late) : : "memory");      // of the persistent loop) out of the main loop's live ranges
+        float bcol[4], wcol[A1][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = wn * 128 + j * 32 + l31 + late;
+            bcol[j] = bias[col];
+#pragma unroll
+            for (int a = 0; a < A1; ++a) wcol[a][j] = Wh[a * BN + col];
+        }
+        float* hs = reinterpret_cast<float*>(lds);          // [wn 2][row 128][A1]; the stages are idle after the last barrier
+        const int sel = lane & 15;
+        float* hs_lane = hs + (wn * BM + wm * 64 + 4 * khalf) * A1 + sel + late;      // + a compile-time row offset per store
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rloc = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const bool live = m0 + rloc < M;
+                float part[A1];
+#pragma unroll
+                for (int a = 0; a < A1; ++a) part[a] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[i * 4 + j][r];
+                    if (live) C[(size_t)(m0 + rloc) * BN + wn * 128 + j * 32 + l31] = v;
+                    const float e = sg_elu(v + bcol[j]);
+#pragma unroll
+                    for (int a = 0; a < A1; ++a) part[a] = fmaf(e, wcol[a][j], part[a]);
+                }
+                float out = 0.0f;
+#pragma unroll
+                for (int a = 0; a < A1; ++a) {
+                    const float sum = sg_half_sum(part[a]);
+                    out = (sel == a) ? sum : out;
+                }
+                if ((lane & 16) && sel < A1) hs_lane[(i * 32 + (r & 3) + 8 * (r >> 2)) * A1] = out;
+                __builtin_amdgcn_sched_barrier(0);      // one row group at a time: interleaving them spills
+            }
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < M) {
+#pragma unroll
+            for (int a = 0; a < A1; ++a)
+                heads[(size_t)(m0 + tid) * A1 + a] = hs[tid * A1 + a] + hs[(BM + tid) * A1 + a] + bh[a];
+        }
+    } else if constexpr (DIN > 0) {
+        constexpr int RW = DIN + 1;                         // reduction row: DIN weight-gradient entries + the bias gradient
+        uint4* xp = lds;                                    // [plane 3][step 4][wm 2][h 2][d 32] x 16 B = 24 KB: x, split, in K order
+        float* red = reinterpret_cast<float*>(lds + 3 * 4 * 128);      // [wm 2][BN][RW]
+        int late = 0;                                       // (opaque zero, as above)
+        asm volatile("" : "+s"(late) : : "memory");
+        const int m0e = m0 + late;          // opaque too: or the row addresses are formed before the main loop and spilled
+        // one unit = the 8 rows of (wm, step, lane half h) for one input column d, as three bf16x8 pieces; d = DIN is the
+        // all-ones column that yields the bias gradient, d > DIN and rows past M are zero (which also masks the tail tile)
+        for (int u = tid; u < 512; u += 256) {
+            const int d = u & 31, h = (u >> 5) & 1, w2 = (u >> 6) & 1, st = u >> 7;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int row = m0e + w2 * 64 + (st >> 1) * 32 + (e & 3) + 8 * (e >> 2) + 16 * (st & 1) + 4 * h;
+                const float xv = (d < DIN) ? ep.x[(size_t)min(row, M - 1) * DIN + d] : (d == DIN ? 1.0f : 0.0f);
+                v[e] = row < M ? xv : 0.0f;
+            }
+            uint4 p1, p2, p3;
+            split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
+            xp[(0 * 4 + st) * 128 + (w2 * 2 + h) * 32 + d] = p1;
+            xp[(1 * 4 + st) * 128 + (w2 * 2 + h) * 32 + d] = p2;
+            xp[(2 * 4 + st) * 128 + (w2 * 2 + h) * 32 + d] = p3;
+        }
+        __syncthreads();
+        const float* hcol = ep.h1 + wn * 128 + l31 + late;
+        const uint4* xp_lane = xp + (wm * 2 + khalf) * 32 + l31;
+        float* mine = red + ((size_t)wm * BN + wn * 128 + l31) * RW;
+        input_wgrad_tile<0>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+        input_wgrad_tile<1>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+        input_wgrad_tile<2>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+        input_wgrad_tile<3>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+        __syncthreads();
+        // the two row blocks (wm = 0, 1) in a fixed order: deterministic
+        for (int idx = tid; idx < BN * RW; idx += 256) {
+            const int c = idx / RW, d = idx - c * RW;
+            const float v = red[idx] + red[BN * RW + idx];
+            if (d < DIN) ep.dw_partials[((size_t)tile * BN + c) * DIN + d] = v;
+            else ep.db_partials[(size_t)tile * BN + c] = v;
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const int col = (VAR & 2) ? ((wave & 1) * 128 + (t & 3) * 32 + l31) : (t * 32 + l31);
-        const int row0 = (VAR & 2) ? (m0 + (wave >> 1) * 64 + (t >> 2) * 32) : (m0 + wave * 32);
+        const int col = wn * 128 + (t & 3) * 32 + l31;
+        const int row0 = m0 + wm * 64 + (t >> 2) * 32;
         const float bj = HAS_BIAS ? bias[col] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            if (row < M) C[(size_t)row * BN + col] = acc[t][r] + bj;
+            if (row < M && (!(ABL & 8) || acc[t][r] == 12345.0f)) {
+                if (VAR & 8) __builtin_nontemporal_store(acc[t][r] + bj, &C[(size_t)row * BN + col]);
+                else C[(size_t)row * BN + col] = acc[t][r] + bj;
+            }
         }
+    }
     }
     }   // tile loop
 }
@@ -241,29 +452,78 @@ extern "C" int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
+constexpr bool kOrderedDefault = false;
 static int g_split_variant = -1;      // -1 = pick by size (measured on MI355X, profiles/r02_split_gemm.md)
 extern "C" int ag_debug_split_gemm_variant(int variant) {
-    if (variant < -1 || variant > 7) return AG_ERR_INVALID_ARG;
+    if (variant < -1 || variant > 231) return AG_ERR_INVALID_ARG;      // unknown values are refused at launch
     g_split_variant = variant;
     return AG_OK;
 }
 
-template <int VAR>
-static int launch_split(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, void* stream) {
+constexpr size_t kSplitLds = (size_t)2 * STAGE_UNITS * 16;
+
+template <bool HAS_BIAS, int VAR, int A1, int ABL, int DIN>
+static int launch_split_any(const float* A_dev, const void* planes_dev, float* C_dev, int M, const SplitEpilogue& ep, void* stream) {
     static bool attr_set = false;
-    const size_t lds = (size_t)2 * STAGE_UNITS * 16;
+    auto* fn = split_gemm_kernel<HAS_BIAS, VAR, A1, ABL, DIN>;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<false, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(split_gemm_kernel<true, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess)
             return AG_ERR_HIP;
         attr_set = true;
     }
     int tiles = (M + BM - 1) / BM;
     if (VAR & 4) tiles = tiles < 512 ? tiles : 512;        // persistent: 2 workgroups on each of the 256 CUs
-    const dim3 grid(tiles), block(256);
-    if (bias_dev) hipLaunchKernelGGL((split_gemm_kernel<true, VAR>), grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
-    else hipLaunchKernelGGL((split_gemm_kernel<false, VAR>), grid, block, lds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, bias_dev, C_dev, M);
+    hipLaunchKernelGGL(fn, dim3(tiles), dim3(256), kSplitLds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, C_dev, M, ep);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+template <int VAR, int ABL = 0>
+static int launch_split(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, void* stream) {
+    SplitEpilogue ep = {};
+    ep.bias = bias_dev;
+    return bias_dev ? launch_split_any<true, VAR, 0, ABL, 0>(A_dev, planes_dev, C_dev, M, ep, stream)
+                    : launch_split_any<false, VAR, 0, ABL, 0>(A_dev, planes_dev, C_dev, M, ep, stream);
+}
+
+template <int VAR, int A1>
+static int launch_split_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh, const float* bh,
+                              float* C_dev, float* heads, int M, void* stream) {
+    SplitEpilogue ep = {};
+    ep.bias = bias_dev; ep.Wh = Wh; ep.bh = bh; ep.heads = heads;
+    return launch_split_any<true, VAR, A1, 0, 0>(A_dev, planes_dev, C_dev, M, ep, stream);
+}
+
+extern "C" int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
+                                       const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1,
+                                       void* stream) {
+    if (!A_dev || !planes_dev || !bias_dev || !Wh_dev || !bh_dev || !Z_dev || !heads_dev || M <= 0) return AG_ERR_INVALID_ARG;
+    if (n != BN || k != KDIM || (A1 != 5 && A1 != 6)) return AG_ERR_UNSUPPORTED;
+    if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
+    const bool persistent = g_split_variant >= 0 && (g_split_variant & 4) != 0;
+    const bool ordered = g_split_variant >= 0 ? (g_split_variant & 1) != 0 : kOrderedDefault;
+#define AG_SGH(V, A) launch_split_heads<V, A>(A_dev, planes_dev, bias_dev, Wh_dev, bh_dev, Z_dev, heads_dev, M, stream)
+    if (A1 == 5) return persistent ? (ordered ? AG_SGH(7, 5) : AG_SGH(6, 5)) : (ordered ? AG_SGH(3, 5) : AG_SGH(2, 5));
+    return persistent ? (ordered ? AG_SGH(7, 6) : AG_SGH(6, 6)) : (ordered ? AG_SGH(3, 6) : AG_SGH(2, 6));
+#undef AG_SGH
+}
+
+extern "C" int ag_split_gemm_input_wgrad_rows(void) { return BM; }
+
+extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
+                                         float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream) {
+    if (!dZ_dev || !planes_dev || !h1_dev || !x_dev || !dw_partials_dev || !db_partials_dev || M <= 0) return AG_ERR_INVALID_ARG;
+    if (n != BN || k != KDIM || (D != 16 && D != 18 && D != 20)) return AG_ERR_UNSUPPORTED;
+    if (((uintptr_t)dZ_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
+    SplitEpilogue ep = {};
+    ep.h1 = h1_dev; ep.x = x_dev; ep.dw_partials = dw_partials_dev; ep.db_partials = db_partials_dev;
+    const bool persistent = g_split_variant >= 0 && (g_split_variant & 4) != 0;
+#define AG_SGI(V, DV) launch_split_any<false, V, 0, 0, DV>(dZ_dev, planes_dev, nullptr, M, ep, stream)
+    switch (D) {
+        case 16: return persistent ? AG_SGI(6, 16) : AG_SGI(2, 16);
+        case 18: return persistent ? AG_SGI(6, 18) : AG_SGI(2, 18);
+        default: return persistent ? AG_SGI(6, 20) : AG_SGI(2, 20);
+    }
+#undef AG_SGI
 }
 
 extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
@@ -271,16 +531,24 @@ extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const f
     if (!A_dev || !planes_dev || !C_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
-    // more than one round of workgroups (> 2 per CU): persistent, de-phased, 2 x 2 waves (6); a single round: plain 2 x 2 (2)
-    const int variant = g_split_variant >= 0 ? g_split_variant : (((M + BM - 1) / BM > 512) ? 6 : 2);
+    // plain 2 x 2 by default: back to back in a loop the persistent de-phased form (6) is faster at M = 196 608, between the
+    // update's other kernels it is 7 us slower (in-situ kernel traces, profiles/r02_split_gemm.md)
+    const int variant = g_split_variant >= 0 ? g_split_variant : (2 | (kOrderedDefault ? 1 : 0));
     switch (variant) {
-        case 0: return launch_split<0>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 1: return launch_split<1>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 2: return launch_split<2>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 3: return launch_split<3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 4: return launch_split<4>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 6: return launch_split<6>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 7: return launch_split<7>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        default: return launch_split<5>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 14: return launch_split<14>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 15: return launch_split<15>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+#ifdef AG_SPLIT_ABLATIONS      /* timing experiments only (results are wrong by construction): tools/split_gemm_probe.py --variants */
+        case 100 + 3: return launch_split<6, 3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 100 + 8: return launch_split<6, 8>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 100 + 31: return launch_split<6, 31>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 200 + 3: return launch_split<7, 3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 200 + 8: return launch_split<7, 8>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+        case 200 + 31: return launch_split<7, 31>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+#endif
+        default: return AG_ERR_INVALID_ARG;
     }
 }

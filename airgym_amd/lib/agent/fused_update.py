@@ -57,6 +57,20 @@ class SplitGemm256:
         N.check(self.lib.ag_split_gemm(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr() if bias is not None else None,
                                        out.data_ptr(), x.shape[0], 256, 256, self._stream()), "ag_split_gemm")
 
+    def forward_elu_heads(self, x, z, bias, heads_w, heads_b, heads):
+        """z [M, 256] = x W^T (bias-free pre-activation), heads [M, A1] = ELU(z + bias) heads_w^T + heads_b: the GEMM and
+        what used to be the ag_elu_heads pass over z, in one launch (ag_split_gemm_elu_heads)."""
+        N.check(self.lib.ag_split_gemm_elu_heads(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr(), heads_w.data_ptr(),
+                                                 heads_b.data_ptr(), z.data_ptr(), heads.data_ptr(), x.shape[0], 256, 256,
+                                                 heads_w.shape[0], self._stream()), "ag_split_gemm_elu_heads")
+
+    def backward_input_wgrad(self, dz, h_prev, x_prev, dw_partials, db_partials):
+        """dX = dz W of this layer, consumed in the epilogue by the PREVIOUS (first) layer's backward: ELU'(h_prev), then
+        dw_partials [tiles, 256, D] / db_partials [tiles, 256] against its inputs x_prev [M, D] (ag_split_gemm_input_wgrad)."""
+        N.check(self.lib.ag_split_gemm_input_wgrad(dz.data_ptr(), self.bwd.data_ptr(), h_prev.data_ptr(), x_prev.data_ptr(),
+                                                   dw_partials.data_ptr(), db_partials.data_ptr(), dz.shape[0], 256, 256,
+                                                   x_prev.shape[1], self._stream()), "ag_split_gemm_input_wgrad")
+
     def backward_input(self, dz, out):
         """out [M, 256] = dz [M, 256] W"""
         N.check(self.lib.ag_split_gemm(dz.data_ptr(), self.bwd.data_ptr(), None, out.data_ptr(), dz.shape[0], 256, 256,
@@ -95,9 +109,16 @@ class FusedMLPStep:
         erows = self.lib.ag_elu_bwd_bias_rows_per_block()
         wrows, irows = self.lib.ag_wgrad_rows_per_block(0), max(1, self.lib.ag_input_wgrad_rows(D))
         self.wg_blocks = (M + wrows - 1) // wrows
-        self.in_wg_blocks = (M + irows - 1) // irows
         # small weight gradients folded into the ELU' passes (head: always; first layer: D in {16,18,20}, >= 2 layers)
         self.fuse_input_wgrad = L >= 2 and self.lib.ag_input_wgrad_rows(D) > 0
+        # ... and for a [D -> 256 -> 256] trunk the first layer's whole backward rides in the epilogue of the second layer's
+        # dX GEMM (ag_split_gemm_input_wgrad): dh1 / dz1 are never written, one partial per 128-row tile
+        self.fuse_gemm_input_wgrad = (self.fuse_input_wgrad and L == 2 and bool(agent.config.get("fuse_gemm_input_wgrad", True))
+                                      and SplitGemm256.applies(self.layers[1][0], agent.config)
+                                      and self.layers[0][0].shape[0] == 256)
+        if self.fuse_gemm_input_wgrad:
+            irows = self.lib.ag_split_gemm_input_wgrad_rows()
+        self.in_wg_blocks = (M + irows - 1) // irows
         self.head_wg_partials = torch.empty(self.wg_blocks, self.A + 1, self.layers[-1][0].shape[0], **f)
         self.bias_partials, self.wgrad_partials = [], []
         for li, (w, _, _, _) in enumerate(self.layers):
@@ -135,6 +156,8 @@ class FusedMLPStep:
         # 256 x 256 layers: float32-accurate GEMMs on the bf16 matrix cores (forward and dX); other widths stay with the library
         self.split = {li: SplitGemm256(w) for li, (w, _, _, _) in enumerate(self.layers)
                       if li >= 1 and SplitGemm256.applies(w, agent.config)}
+        # ... and for the last of them the ELU + head product rides in the GEMM epilogue (ag_split_gemm_elu_heads)
+        self.fuse_gemm_heads = bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 in (5, 6)
         self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 8, **f)
         self.k = 0
 
@@ -194,9 +217,12 @@ class FusedMLPStep:
             h = self.h[li]
             sg = self.split.get(li)
             if li == last and self.fuse_heads and sg is not None:
-                sg.forward(x, h)                    # bias-free pre-activation; ag_elu_heads adds the bias
-                N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
-                                         M, w.shape[0], A + 1, 0, b.data_ptr(), st), "ag_elu_heads")
+                if self.fuse_gemm_heads:            # heads formed in the GEMM epilogue; h keeps the bias-free pre-activation
+                    sg.forward_elu_heads(x, h, b, ag.heads_w, ag.heads_b, self.heads)
+                else:
+                    sg.forward(x, h)                # bias-free pre-activation; ag_elu_heads adds the bias
+                    N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(),
+                                             self.heads.data_ptr(), M, w.shape[0], A + 1, 0, b.data_ptr(), st), "ag_elu_heads")
                 heads_done = True
             elif sg is not None:
                 sg.forward(x, h, b)
@@ -259,6 +285,9 @@ class FusedMLPStep:
                 N.check(lib.ag_elu_bwd_bias(dh.data_ptr(), h.data_ptr(), dz.data_ptr(), parts.data_ptr(), M, C, st),
                         "ag_elu_bwd_bias")
             torch.bmm(dz.view(S, M // S, C).transpose(1, 2), xin.view(S, M // S, K), out=self.wgrad_partials[li])
+            if li == 1 and self.fuse_gemm_input_wgrad:
+                self.split[1].backward_input_wgrad(dz, self.h[0], inputs[0], self.wgrad_partials[0], self.bias_partials[0])
+                break
             if li > 0:
                 dh = self.dh[:M * K].view(M, K)
                 if li in self.split:
@@ -315,6 +344,7 @@ class FusedRolloutStep:
         self.wt_last = torch.empty(self.layers[-1][0].shape[1], Cl, **f)
         self.split = {li: SplitGemm256(w, backward=False) for li, (w, _) in enumerate(self.layers)
                       if li >= 1 and SplitGemm256.applies(w, agent.config)}
+        self.fuse_gemm_heads = bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 in (5, 6)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         # per-step, per-block episode sums; reduced over blocks ONCE per rollout (end_rollout)
         self.acct_partials = torch.zeros(agent.horizon_length, self.lib.ag_rollout_account_blocks(n), 4,
@@ -369,9 +399,12 @@ class FusedRolloutStep:
             h = self.h[li]
             sg = self.split.get(li)
             if li == last and self.fuse_heads and sg is not None:
-                sg.forward(x, h)                          # planes refreshed once per rollout (refresh_weights)
-                N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(),
-                                         n, w.shape[0], A + 1, 0, b.data_ptr(), st), "ag_elu_heads")
+                if self.fuse_gemm_heads:                  # planes refreshed once per rollout (refresh_weights)
+                    sg.forward_elu_heads(x, h, b, ag.heads_w, ag.heads_b, self.heads)
+                else:
+                    sg.forward(x, h)
+                    N.check(lib.ag_elu_heads(h.data_ptr(), ag.heads_w.data_ptr(), ag.heads_b.data_ptr(),
+                                             self.heads.data_ptr(), n, w.shape[0], A + 1, 0, b.data_ptr(), st), "ag_elu_heads")
                 heads_done = True
             elif sg is not None:
                 sg.forward(x, h, b)

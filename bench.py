@@ -54,6 +54,8 @@ def build_params(args, world_size):
     c["use_hip_graph"] = bool(args.graph)
     c["tuned_gemms"] = bool(getattr(args, "tuned_gemms", 1))
     c["use_split_gemm"] = bool(getattr(args, "split_gemm", 1))
+    c["fuse_gemm_heads"] = bool(getattr(args, "fuse_gemm_heads", 1))
+    c["fuse_gemm_input_wgrad"] = bool(getattr(args, "fuse_gemm_input_wgrad", 1))
     params["seed"] = 0
     return params
 
@@ -159,6 +161,9 @@ def main():
     ap.add_argument("--tuned-gemms", type=int, default=1, help="apply the shipped TunableOp GEMM table (library kernel choice)")
     ap.add_argument("--split-gemm", type=int, default=1,
                     help="256x256 layer GEMMs (forward, dX) as float32-accurate bf16x6 products on the bf16 matrix cores")
+    ap.add_argument("--split-variant", type=int, default=-1, help="debug: pin the ag_split_gemm kernel variant (-1 = by size)")
+    ap.add_argument("--fuse-gemm-heads", type=int, default=1, help="ELU + heads in the last hidden layer's GEMM epilogue")
+    ap.add_argument("--fuse-gemm-input-wgrad", type=int, default=1, help="first layer's backward in the dX GEMM's epilogue")
     ap.add_argument("--task", default="hovering", choices=["hovering", "tracking"],
                     help="default = BASELINE config 1; 'tracking --ctl vel' = config 2 (side measurement, not the headline)")
     ap.add_argument("--ctl", default="rate", choices=["pos", "vel", "atti", "rate", "prop"])
@@ -177,6 +182,9 @@ def main():
 
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
     params = build_params(args, world)
+    if args.split_variant >= 0:
+        from airgym_amd import _native
+        _native.check(_native.load().ag_debug_split_gemm_variant(args.split_variant), "ag_debug_split_gemm_variant")
     agent = A2CAgent("bench", params)
     agent.init_tensors()
     agent.obs = agent.env_reset()

@@ -285,11 +285,26 @@ int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float*
  * the f32-input MFMA path (gfx950 has no TF32 form).  n = k = 256 only (AG_ERR_UNSUPPORTED otherwise).
  *   ag_split_gemm_prepare: W_dev [256, 256] f32 row-major -> planes_dev (ag_split_gemm_plane_bytes() bytes, 16-byte aligned);
  *       transpose = 0: B = W (C = A W^T), 1: B = W^T (C = A W).  Run once per weight update.
- *   ag_split_gemm: C_dev [M, 256] = A_dev [M, 256] B^T (+ bias_dev [256] if not NULL). */
+ *   ag_split_gemm: C_dev [M, 256] = A_dev [M, 256] B^T (+ bias_dev [256] if not NULL).
+ *   ag_split_gemm_elu_heads: the last hidden layer and the actor/critic heads in one launch (mlp.py:36-39 + the mu / value
+ *       Linear): Z_dev [M, 256] = A B^T WITHOUT the bias (what ag_heads_bwd_elu_wgrad(zbias) reads back), heads_dev [M, A1] =
+ *       ELU(Z + bias_dev) Wh_dev^T + bh_dev formed from the accumulators (Wh_dev [A1, 256], A1 in {5, 6}) - the same
+ *       result as ag_split_gemm followed by ag_elu_heads(write_back = 0, zbias = bias_dev) without re-reading Z.
+ *   ag_split_gemm_input_wgrad: the backward dX GEMM of the second layer with the first layer's whole backward in its epilogue
+ *       (autograd of mlp.py:36-39 for a [D -> 256 -> 256] trunk; what ag_split_gemm(dZ, W^T planes) followed by
+ *       ag_elu_bwd_input_wgrad computes): dh1 = dZ_dev W stays in registers, is multiplied by ELU'(h1_dev) and reduced against
+ *       x_dev [M, D] over each tile of ag_split_gemm_input_wgrad_rows() rows: dw_partials_dev [tiles, 256, D], db_partials_dev
+ *       [tiles, 256] (tiles = ceil(M / rows); the caller sums over dim 0, e.g. ag_sum_rows_multi).  Neither dh1 nor dz1 is
+ *       written.  D in {16, 18, 20}. */
 long long ag_split_gemm_plane_bytes(void);
 int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n, int k, int transpose, void* stream);
 int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
                   void* stream);
+int ag_split_gemm_input_wgrad_rows(void);
+int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
+                              float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
+int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
+                            const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1, void* stream);
 
 /* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block(which) rows
  * (ceil(M / rows) blocks); the caller reduces them over dim 0.

@@ -29,7 +29,9 @@ int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
  * wave, {HW_REG_HW_ID, HW_REG_XCC_ID} into out_dev [ceil(n/64) * 2, 2] u32 (tools/wave_placement.py decodes SIMD / CU / XCC). */
 int ag_debug_wave_placement(ag_handle h, unsigned int* out_dev, void* stream);
 
-/* Scheduling variant of ag_split_gemm's main loop (-1 = by size (default); bit 0 = prefetch pinned to the top of the K chunk, bit 1 = waves as 2 x 2 instead of 4 x 1, bit 2 = persistent workgroups with the second one of each CU started half a tile late). */
+/* Scheduling variant of ag_split_gemm / ag_split_gemm_elu_heads (-1 = by size (default); bit 0 = prescribed issue order of LDS
+ * reads and MFMAs inside a K chunk, bit 1 = always set (2 x 2 waves), bit 2 = persistent workgroups with the second one of each
+ * CU started half a tile late, bit 3 = non-temporal stores of C).  Values without a kernel are refused at launch. */
 int ag_debug_split_gemm_variant(int variant);
 
 /* Next Planning step renders with parts of the render kernel skipped: bit0 ray-cast, bit1 noise passes, bit2 5x5 pass. */

@@ -30,9 +30,31 @@ def time_us(fn, iters=30, warmup=5):
 
 
 import argparse
+import statistics
+
+
+def round_robin_us(cands, rounds=12, iters=6):
+    """Median over `rounds` of each candidate's mean launch time, candidates interleaved: the clock of an MFMA-bound kernel
+    drifts with temperature, so back-to-back blocks per candidate compare different clocks."""
+    s = torch.cuda.current_stream()
+    for fn in cands.values():
+        fn()
+    out = {k: [] for k in cands}
+    for _ in range(rounds):
+        for k, fn in cands.items():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s)
+            for _ in range(iters):
+                fn()
+            b.record(s)
+            b.synchronize()
+            out[k].append(a.elapsed_time(b) * 1e3 / iters)
+    return {k: round(statistics.median(v), 2) for k, v in out.items()}
+
+
 _ap = argparse.ArgumentParser()
 _ap.add_argument("--M", type=int, nargs="+", default=[65536, 196608])
-_ap.add_argument("--variants", type=int, nargs="+", default=[0, 2, 3, 4, 6, 7])
+_ap.add_argument("--variants", type=int, nargs="+", default=[2, 3, 6, 7, 14])
 _ap.add_argument("--skip-lib", action="store_true")
 _a = _ap.parse_args()
 for M in _a.M:
@@ -43,18 +65,38 @@ for M in _a.M:
     C = torch.empty(M, 256, device="cuda")
     planes = torch.empty(lib.ag_split_gemm_plane_bytes(), dtype=torch.uint8, device="cuda")
     N.check(lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st), "prep")
-    us_prep = time_us(lambda: lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st))
-    us_var = {}
-    for var in _a.variants:
-        lib.ag_debug_split_gemm_variant(var)
-        us_var[var] = time_us(lambda: lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st))
-    lib.ag_debug_split_gemm_variant(-1)
-    us_split = time_us(lambda: lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st))
-    us_nn = us_nt = float("nan")
+    b = torch.randn(256, device="cuda", generator=g); Wh = torch.randn(5, 256, device="cuda", generator=g) / 16
+    bh = torch.zeros(5, device="cuda"); H = torch.empty(M, 5, device="cuda")
+
+    def plain(var):
+        def f():
+            lib.ag_debug_split_gemm_variant(var)
+            lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), M, 256, 256, st)
+        return f
+
+    def fused(var):
+        def f():
+            lib.ag_debug_split_gemm_variant(var)
+            lib.ag_split_gemm_elu_heads(A.data_ptr(), planes.data_ptr(), b.data_ptr(), Wh.data_ptr(), bh.data_ptr(),
+                                        C.data_ptr(), H.data_ptr(), M, 256, 256, 5, st)
+        return f
+
+    cands = {f"v{v}": plain(v) for v in _a.variants}
+    cands["auto"] = plain(-1)
+    cands["fused_auto"] = fused(-1)
+    for v in (2, 3, 6, 7):
+        cands[f"fused_v{v}"] = fused(v)
+    cands["elu_heads"] = lambda: lib.ag_elu_heads(C.data_ptr(), Wh.data_ptr(), bh.data_ptr(), H.data_ptr(), M, 256, 5, 0,
+                                                   b.data_ptr(), st)
+    cands["prepare"] = lambda: lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st)
     if not _a.skip_lib:
-        us_nn = time_us(lambda: torch.mm(A, Wt, out=C))
-        us_nt = time_us(lambda: torch.mm(A, W.t(), out=C))
+        cands["lib_nn"] = lambda: torch.mm(A, Wt, out=C)
+        cands["lib_nt"] = lambda: torch.mm(A, W.t(), out=C)
+    us = round_robin_us(cands)
+    lib.ag_debug_split_gemm_variant(-1)
     fl = 2.0 * M * 256 * 256
-    print(json.dumps({"M": M, "split_us": us_split, "split_f32_equiv_tflops": fl / us_split / 1e6,
-                      "split_bf16_tflops": 6 * fl / us_split / 1e6, "lib_nn_us": us_nn, "lib_nt_us": us_nt,
-                      "lib_tflops": fl / min(us_nn, us_nt) / 1e6, "prepare_us": us_prep, "variant_us": us_var}), flush=True)
+    rec = {"M": M, "us": us, "split_f32_equiv_tflops": round(fl / us["auto"] / 1e6, 1),
+           "split_bf16_tflops": round(6 * fl / us["auto"] / 1e6, 1)}
+    if not _a.skip_lib:
+        rec["lib_tflops"] = round(fl / min(us["lib_nn"], us["lib_nt"]) / 1e6, 1)
+    print(json.dumps(rec), flush=True)
