@@ -157,6 +157,11 @@ SYMBOLS = [
                                                  ctypes.c_int, _P]),
     ("ag_split_gemm_elu_heads", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, _P]),
+    ("ag_relu_bn_planes_per_block", ctypes.c_int, []),
+    ("ag_relu_bn_stats", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_apply", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_bwd_reduce", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_bwd_dx", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_wgrad_rows_per_block", ctypes.c_int, [ctypes.c_int]),
     ("ag_input_wgrad_rows", ctypes.c_int, [ctypes.c_int]),
     ("ag_sum_rows_groups", ctypes.c_int, []),

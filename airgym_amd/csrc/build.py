@@ -43,6 +43,7 @@ def units():
     out.append((os.path.join(OBJ_DIR, "planning_kernel.o"), "planning_kernel.hip", []))
     out.append((os.path.join(OBJ_DIR, "rollout_kernels.o"), "rollout_kernels.hip", []))
     out.append((os.path.join(OBJ_DIR, "split_gemm.o"), "split_gemm.hip", []))
+    out.append((os.path.join(OBJ_DIR, "cnn_kernels.o"), "cnn_kernels.hip", []))
     return out
 
 

@@ -1,6 +1,7 @@
 """Depth-image feature extractor (reference: lib/network/cnn.py:3-33): three stride-2 convolutions, each
 followed by ReLU and BatchNorm, global average pooling, one Linear to `feature_dim`.  Module names
 (`features.<i>`, `fc`) are the reference's so that `trained/planning_cnn_rate.pth` style checkpoints load."""
+import torch
 import torch.nn as nn
 
 
@@ -13,7 +14,22 @@ class CNNFeatureExtractor(nn.Module):
         layers.append(nn.AdaptiveAvgPool2d((1, 1)))
         self.features = nn.Sequential(*layers)
         self.fc = nn.Linear(64, feature_dim)
+        self.fused_relu_bn = True       # False: the plain torch modules (MIOpen batch norm), e.g. for A/B timing
 
     def forward(self, x):
-        x = self.features(x)
+        if x.is_cuda and self.fused_relu_bn:
+            # ReLU + BatchNorm2d pairs run as one node on csrc/cnn_kernels.hip (the modules stay for the state dict)
+            from airgym_amd.lib.network.fused_relu_bn import relu_batchnorm, usable
+            layers = list(self.features)
+            i = 0
+            while i < len(layers):
+                if (isinstance(layers[i], nn.ReLU) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d)
+                        and usable(x, layers[i + 1]) and (layers[i + 1].training or not torch.is_grad_enabled())):
+                    x = relu_batchnorm(x, layers[i + 1])
+                    i += 2
+                else:
+                    x = layers[i](x)
+                    i += 1
+        else:
+            x = self.features(x)
         return self.fc(x.view(x.size(0), -1))

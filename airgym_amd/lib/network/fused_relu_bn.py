@@ -1,0 +1,87 @@
+"""ReLU -> BatchNorm2d as one autograd node on the HIP kernels of csrc/cnn_kernels.hip (reference modules:
+lib/network/cnn.py:3-33, `nn.ReLU()` followed by `nn.BatchNorm2d(c)`).
+
+Same arithmetic as the two torch modules - batch statistics (biased variance) in training with the running statistics
+updated by `momentum` from the unbiased variance, running statistics in eval - but the ReLU output is never written
+(the backward recomputes it from the convolution output) and every pass runs over the whole chip instead of MIOpen's
+16-64 workgroups.  The modules themselves stay in the network (state-dict keys, `num_batches_tracked`)."""
+import ctypes
+
+import torch
+
+from airgym_amd import _native as N
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _blocks(lib, n, c):
+    ppb = lib.ag_relu_bn_planes_per_block()
+    return (n * c + ppb - 1) // ppb
+
+
+def usable(x, bn):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and bn.num_features <= 64
+            and bn.affine and bn.track_running_stats)
+
+
+class _ReluBatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        lib = N.load()
+        n, c, h, w = x.shape
+        hw, m = h * w, n * h * w
+        partials = torch.empty(_blocks(lib, n, c), c, 2, dtype=torch.float32, device=x.device)
+        N.check(lib.ag_relu_bn_stats(x.data_ptr(), partials.data_ptr(), n, c, hw, _stream(x)), "ag_relu_bn_stats")
+        sums = partials.sum(0, dtype=torch.float64)
+        mean = sums[:, 0] / m
+        var = torch.clamp(sums[:, 1] / m - mean * mean, min=0.0)
+        invstd = torch.rsqrt(var + eps)
+        scale = gamma.double() * invstd
+        shift = beta.double() - mean * scale
+        y = torch.empty_like(x)
+        scale32, shift32 = scale.float(), shift.float()      # named: a temporary's storage is recycled before the launch reads it
+        N.check(lib.ag_relu_bn_apply(x.data_ptr(), scale32.data_ptr(), shift32.data_ptr(), y.data_ptr(), n, c, hw,
+                                     _stream(x)), "ag_relu_bn_apply")
+        with torch.no_grad():                   # nn.BatchNorm2d: running = (1 - momentum) running + momentum stat (unbiased var)
+            running_mean.mul_(1.0 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_((var * (m / max(m - 1, 1))).to(running_var.dtype), alpha=momentum)
+        ctx.save_for_backward(x, gamma, mean.float(), invstd.float())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        lib = N.load()
+        n, c, h, w = x.shape
+        hw, m = h * w, n * h * w
+        dy = dy.contiguous()
+        partials = torch.empty(_blocks(lib, n, c), c, 2, dtype=torch.float32, device=x.device)
+        N.check(lib.ag_relu_bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(),
+                                          n, c, hw, _stream(x)), "ag_relu_bn_bwd_reduce")
+        sums = partials.sum(0, dtype=torch.float64).float().contiguous()      # [C, 2] = (dbeta, dgamma)
+        coef = torch.stack((mean, invstd, gamma.detach() * invstd, torch.full_like(mean, 1.0 / m)), dim=1).contiguous()
+        dx = torch.empty_like(x)
+        N.check(lib.ag_relu_bn_bwd_dx(dy.data_ptr(), x.data_ptr(), coef.data_ptr(), sums.data_ptr(), dx.data_ptr(), n, c, hw,
+                                      _stream(x)), "ag_relu_bn_bwd_dx")
+        return dx, sums[:, 1].clone(), sums[:, 0].clone(), None, None, None, None
+
+
+def relu_batchnorm(x, bn):
+    """relu then `bn` (an nn.BatchNorm2d) on the HIP kernels; x is the convolution output [N, C, H, W]."""
+    if bn.training:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        return _ReluBatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, float(bn.eps))
+    lib = N.load()
+    n, c, h, w = x.shape
+    with torch.no_grad():
+        scale = bn.weight.double() * torch.rsqrt(bn.running_var.double() + bn.eps)
+        shift = bn.bias.double() - bn.running_mean.double() * scale
+        y = torch.empty_like(x)
+        scale32, shift32 = scale.float(), shift.float()
+        N.check(lib.ag_relu_bn_apply(x.data_ptr(), scale32.data_ptr(), shift32.data_ptr(), y.data_ptr(), n, c, h * w,
+                                     _stream(x)), "ag_relu_bn_apply")
+    return y

@@ -306,6 +306,25 @@ int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const
 int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
                             const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1, void* stream);
 
+/* ReLU followed by BatchNorm2d on [N, C, H, W] float32 (NCHW, C <= 64) for the depth-image feature extractor (reference:
+ * lib/network/cnn.py:3-33: Conv2d -> ReLU -> BatchNorm2d, three times) - airgym_amd/csrc/cnn_kernels.hip.  The ReLU output is
+ * never materialised; x is the CONVOLUTION output.  HW = H * W.  blocks = ceil(N * C / ag_relu_bn_planes_per_block()).
+ *   ag_relu_bn_stats     : partials_dev [blocks, C, 2] = per-channel (sum, sum of squares) of relu(x); the caller sums over
+ *                          dim 0 and forms mean / biased variance (nn.BatchNorm2d training statistics).
+ *   ag_relu_bn_apply     : y = relu(x) * scale[c] + shift[c]   (scale = gamma invstd, shift = beta - mean scale; with the
+ *                          running statistics this is the eval-mode forward).
+ *   ag_relu_bn_bwd_reduce: partials_dev [blocks, C, 2] = per-channel (sum dy, sum dy * xhat), xhat = (relu(x) - mean) invstd.
+ *   ag_relu_bn_bwd_dx    : dx = [x > 0] coef[c][2] (dy - sums[c][0] coef[c][3] - xhat sums[c][1] coef[c][3]);
+ *                          coef_dev [C, 4] = {mean, invstd, gamma invstd, 1 / (N HW)}, sums_dev [C, 2] = {dbeta, dgamma}. */
+int ag_relu_bn_planes_per_block(void);
+int ag_relu_bn_stats(const float* x_dev, float* partials_dev, int N, int C, int HW, void* stream);
+int ag_relu_bn_apply(const float* x_dev, const float* scale_dev, const float* shift_dev, float* y_dev, int N, int C, int HW,
+                     void* stream);
+int ag_relu_bn_bwd_reduce(const float* dy_dev, const float* x_dev, const float* mean_dev, const float* invstd_dev,
+                          float* partials_dev, int N, int C, int HW, void* stream);
+int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev, float* dx_dev,
+                      int N, int C, int HW, void* stream);
+
 /* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block(which) rows
  * (ceil(M / rows) blocks); the caller reduces them over dim 0.
  *   ag_heads_bwd_elu_wgrad: dz = (d_heads Wh) * ELU'(h) (the head's dX formed inside the ELU' pass), plus dwh_partials_dev [blocks, A1, C] of dWh[a,c] = sum_m d_heads[m,a] h[m,c];

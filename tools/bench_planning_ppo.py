@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--encoder", default="cnn", choices=["cnn", "vae"])
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen find mode)")
+    ap.add_argument("--fused-relu-bn", type=int, default=1, help="ReLU + BatchNorm2d pairs on csrc/cnn_kernels.hip")
     args = ap.parse_args()
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
@@ -43,6 +44,9 @@ def main():
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
     agent = A2CAgent("planning_bench", params)
     # (channels_last was tried: MIOpen falls back to its naive kernels for these shapes, 137 s per epoch instead of 5.7 s)
+    for mod in agent.model.modules():
+        if hasattr(mod, "fused_relu_bn"):
+            mod.fused_relu_bn = bool(args.fused_relu_bn)
     agent.init_tensors()
     agent.obs = agent.env_reset()
     for _ in range(args.warmup):
