@@ -132,6 +132,7 @@ SYMBOLS = [
     ("ag_planning_step_with_uniforms", ctypes.c_int, [_P, _P, _P, _P]),
     ("ag_planning_eval_post", ctypes.c_int, [_P, _P, _P, _P, _P]),
     ("ag_planning_render_now", ctypes.c_int, [_P]),
+    ("ag_planning_last_step_rendered", ctypes.c_int, [_P]),
     ("ag_debug_planning_render_parts", ctypes.c_int, [_P, ctypes.c_int]),
     ("ag_ppo_loss_finalize", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),

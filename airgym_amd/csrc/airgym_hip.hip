@@ -97,6 +97,7 @@ struct ag_env {
     bool table_set;    // planning: obstacle variant table uploaded
     uint64_t counter;  // planning: pre_physics_step counter driving the camera schedule (planning.py:153-156)
     int force_render;  // planning: render on the next step regardless of the schedule
+    int last_rendered; // planning / avoid: 1 if the most recent step produced a new depth image
     uint64_t tick;     // host mirror of the device tick (exact unless a captured graph is being replayed)
     int parity;        // which of the two device tick slots the next launch reads
     int block;
@@ -402,6 +403,7 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
         // cam_dt / dt = 4 (planning.py:153-156, avoid.py:181-185); Balloon has no onboard camera (balloon_config.py:52)
         const bool render = (task != AG_TASK_BALLOON) && (h->force_render || (h->counter % 4 == 0));
         h->force_render = 0;
+        h->last_rendered = render ? 1 : 0;
         // every kernel of this step reads the same tick; only the last one publishes tick + 1
         uint32_t* slots = (uint32_t*)(h->arena + h->L.tick);
         k.tick_in = slots + h->parity;
@@ -790,6 +792,11 @@ int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* co
                        : ag::launch_custom_step(k, pa, h->cfg.task, h->cfg.ctl_mode, 2, (hipStream_t)stream);
     if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("planning post-phase launch: ") + hipGetErrorString(e));
     return AG_OK;
+}
+
+int ag_planning_last_step_rendered(ag_handle h) {
+    if (!h || (h->cfg.task != AG_TASK_PLANNING && h->cfg.task != AG_TASK_AVOID)) return -1;
+    return h->last_rendered;
 }
 
 int ag_planning_render_now(ag_handle h) {

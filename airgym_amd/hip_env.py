@@ -246,6 +246,13 @@ class HipEnvHandle:
                 "ag_planning_eval_post")
         torch.cuda.current_stream(self.device).synchronize()
 
+    def last_step_rendered(self):
+        """True if the most recent step wrote a new depth image (the camera runs every 4th step)."""
+        r = self.lib.ag_planning_last_step_rendered(self.h)
+        if r < 0:
+            raise RuntimeError("this task has no camera")
+        return bool(r)
+
     def planning_render_next_step(self, debug_skip=0):
         if debug_skip:
             N.check(self.lib.ag_debug_planning_render_parts(self.h, int(debug_skip)), "ag_debug_planning_render_parts")

@@ -345,7 +345,21 @@ class A2CAgent:
     def init_tensors(self):
         H, N, dev = self.horizon_length, self.num_actors * self.num_agents, self.ppo_device
         f = dict(dtype=torch.float32, device=dev)
-        if isinstance(self.obs_shape, dict):
+        self._hip_env = getattr(getattr(self.vec_env, "env", None), "hip", None)   # zero-copy path if available
+        # Frozen image encoder (Planning with the depth VAE, lib/network/vae_image_encoder.py:34-53): its features are computed
+        # ONCE per rendered image, during the rollout, and the rollout buffer keeps the [N, latent] features instead of the
+        # [N, 1, 212, 120] images - the update then never runs the encoder (the reference re-encodes every minibatch of every
+        # mini-epoch; same features up to the image normaliser having moved on meanwhile).
+        self._cache_latents = (isinstance(self.obs_shape, dict) and getattr(self.model, "frozen_features_cacheable", False)
+                               and bool(self.config.get("cache_frozen_features", True)) and self._hip_env is not None)
+        if self._cache_latents:
+            self.obs_buf = {"observation": torch.zeros((H + 1, N) + tuple(self.obs_shape["observation"]), **f),
+                            "latent": torch.zeros(H + 1, N, self.model.feature_dim, **f)}
+            ishape = tuple(self.obs_shape["image"])
+            d = dict(dtype=torch.float64, device=dev)
+            # moments of the images rendered during the rollout; merged into the image normaliser at the start of the update
+            self._img_moments = [torch.zeros(ishape, **d), torch.zeros(ishape, **d), torch.zeros((), **d)]
+        elif isinstance(self.obs_shape, dict):
             self.obs_buf = {k: torch.zeros((H + 1, N) + tuple(shp), **f) for k, shp in self.obs_shape.items()}
         else:
             self.obs_buf = torch.zeros((H + 1, N) + tuple(self.obs_shape), **f)
@@ -362,7 +376,6 @@ class A2CAgent:
         self.current_shaped_rewards = torch.zeros(N, self.value_size, **f)
         self.current_lengths = torch.zeros(N, **f)
         self.ep_stats = torch.zeros(H, 4, dtype=torch.float64, device=dev)    # count, sum rew, sum shaped, sum len
-        self._hip_env = getattr(getattr(self.vec_env, "env", None), "hip", None)   # zero-copy path if available
         # Episode/<reward term>: per-step means accumulated on device (reference: RLGPUAlgoObserver.process_infos
         # appends every step's item_reward_info and averages at print time, lib/utils/isaacgym_utils.py:66-99)
         terms = getattr(self._hip_env, "reward_terms", None) if self._hip_env is not None else None
@@ -383,8 +396,31 @@ class A2CAgent:
     def _obs_at(self, n):
         return {k: v[n] for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict) else self.obs_buf[n]
 
+    @torch.no_grad()
+    def _encode_current_image(self, n, count_moments=True):
+        """latent slot n <- frozen-encoder features of the env's current depth image (normaliser state as of now)"""
+        img = self._hip_env.image
+        self.model.eval()
+        self.obs_buf["latent"][n].copy_(self.model.encode_image(img))
+        if count_moments and self.normalize_input:
+            mean, var, cnt = self._img_moments
+            bc = float(img.shape[0])
+            bm, bv = img.mean(0).double(), img.var(0).double()
+            delta = bm - mean
+            tot = cnt + bc
+            m2 = var * cnt + bv * bc + delta ** 2 * cnt * bc / tot
+            mean.add_(delta * bc / tot)
+            var.copy_(m2 / tot)
+            cnt.copy_(tot)
+
     def _obs_store(self, n, obs):
-        if isinstance(self.obs_buf, dict):
+        if getattr(self, "_cache_latents", False):
+            self.obs_buf["observation"][n].copy_(obs["observation"])
+            if "latent" in obs:
+                self.obs_buf["latent"][n].copy_(obs["latent"])
+            else:
+                self._encode_current_image(n, count_moments=False)
+        elif isinstance(self.obs_buf, dict):
             for k, v in self.obs_buf.items():
                 v[n].copy_(obs[k])
         else:
@@ -420,7 +456,14 @@ class A2CAgent:
         self.sigmas_buf[n].copy_(res["sigmas"])
         env_actions = self.preprocess_actions(res["actions"])
         if self._hip_env is not None:
-            if isinstance(self.obs_buf, dict):     # Planning: state vector into the slot, image copied from the camera buffer
+            if self._cache_latents:                # Planning, frozen encoder: features refreshed only when the camera ran
+                self._hip_env.step_into(env_actions, self.obs_buf["observation"][n + 1], self.raw_rewards_buf[n], None)
+                self.dones_buf[n + 1].copy_(self._hip_env.reset_buf)
+                if self._hip_env.last_step_rendered():
+                    self._encode_current_image(n + 1)
+                else:
+                    self.obs_buf["latent"][n + 1].copy_(self.obs_buf["latent"][n])
+            elif isinstance(self.obs_buf, dict):   # Planning: state vector into the slot, image copied from the camera buffer
                 self._hip_env.step_into(env_actions, self.obs_buf["observation"][n + 1], self.raw_rewards_buf[n], None)
                 self.dones_buf[n + 1].copy_(self._hip_env.reset_buf)
                 self.obs_buf["image"][n + 1].copy_(self._hip_env.image)
@@ -477,6 +520,9 @@ class A2CAgent:
         def rollout():
             if fr is not None:
                 fr.begin_rollout()
+            if self._cache_latents:
+                # slot 0 carries the previous rollout's last features: re-encode with the normaliser as it is after the update
+                self._encode_current_image(0, count_moments=False)
             for n in range(H):
                 self._rollout_step(n)
             if fr is not None:
@@ -699,6 +745,12 @@ class A2CAgent:
         a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
         if self.normalize_input:
             self.model.running_mean_std.eval()   # statistics are merged explicitly (model.update_stats), never by .train()
+            if getattr(self, "_cache_latents", False):
+                # the update sees features, not images: the image normaliser takes this rollout's rendered images here instead
+                mean, var, cnt = self._img_moments
+                self.model.running_mean_std.running_mean_std["image"].merge_moments(mean, var, cnt)
+                for t in self._img_moments:
+                    t.zero_()
         self.model.stats_group = self.group if (self.multi_gpu and self.sync_normalizers) else None
         if self._fused_step is not None:
             self._fused_step.begin_epoch()

@@ -51,6 +51,18 @@ class RunningMeanStd(nn.Module):
         self.running_var.copy_(m2 / tot_count)
         self.count.copy_(tot_count)
 
+    @torch.no_grad()
+    def merge_moments(self, mean, var, batch_count):
+        """Merge pre-computed batch moments (float64 tensors `mean`, `var` of shape insize and a 0-d `batch_count`) with the
+        same parallel-variance formula as update(); a zero count leaves the statistics unchanged."""
+        delta = mean - self.running_mean
+        tot_count = self.count + batch_count
+        new_mean = self.running_mean + delta * batch_count / tot_count
+        m2 = self.running_var * self.count + var * batch_count + delta ** 2 * self.count * batch_count / tot_count
+        self.running_mean.copy_(new_mean)
+        self.running_var.copy_(m2 / tot_count)
+        self.count.copy_(tot_count)
+
     def _update_hip(self, x):
         """Same merge in two HIP launches (`ag_rms_update`): float64 column moments, then the in-place merge."""
         import ctypes

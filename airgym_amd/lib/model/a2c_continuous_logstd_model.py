@@ -122,6 +122,16 @@ class ModelA2CContinuousLogStd(nn.Module):
     def norm_observation(self, observation):
         return self._norm(self.running_mean_std.running_mean_std["observation"], observation) if self.normalize_input else observation
 
+    def encode_image(self, image):
+        """Frozen-VAE features of a batch of depth images, normalised with the image statistics as they are NOW."""
+        return self._frozen[0].encode(self.norm_image(image))
+
+    @property
+    def frozen_features_cacheable(self):
+        """True when the image features are a deterministic function of the image and the normaliser state (frozen VAE,
+        posterior means): they can then be computed once per rendered image instead of once per forward."""
+        return bool(self.has_vae and self._frozen and not self._frozen[0].return_sampled_latent)
+
     def denorm_value(self, value):
         return self.value_mean_std(value, denorm=True) if self.normalize_value else value
 
@@ -133,8 +143,10 @@ class ModelA2CContinuousLogStd(nn.Module):
     # ---- forward
     def trunk(self, obs, heads_only=False):
         if self.dict_obs and self.has_vae:
-            normed_image = self.norm_image(obs["image"])
-            feat = self._frozen[0].encode(normed_image)       # one frozen encoder serves actor and critic (same weights)
+            if "latent" in obs:       # features of the frozen encoder computed once, when the image was rendered (agent cache)
+                feat = obs["latent"]
+            else:
+                feat = self.encode_image(obs["image"])        # one frozen encoder serves actor and critic (same weights)
             a_in = self.norm_observation(torch.cat((obs["observation"], feat), dim=-1))
             a_out = self.actor_mlp(a_in)
             c_out = self.critic_mlp(a_in) if self.separate else a_out

@@ -416,6 +416,10 @@ int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* co
                           void* stream);
 /* Render the camera on the NEXT step regardless of the every-4th-step schedule (planning.py:153-156). */
 int ag_planning_render_now(ag_handle h);
+/* 1 if the most recent step (or reset) wrote a new depth image, 0 if the image buffer still holds the previous one (the camera
+ * runs every 4th step), -1 for a handle without a camera.  Lets a caller that derives features from the image with a FROZEN
+ * encoder (lib/network/vae_image_encoder.py:34-53) re-encode only when the image changed. */
+int ag_planning_last_step_rendered(ag_handle h);
 
 /* Benchmark / diagnostic knobs are not part of this interface: see airgym_hip_debug.h. */
 

@@ -312,3 +312,78 @@ def test_player_plays_a_reference_layout_checkpoint_in_the_hip_planning_env(Hand
     assert torch.equal(act, p.get_action(obs))                       # deterministic: clamp(mu)
     res = p.run(print_every=8)
     assert np.isfinite(res["av_reward"]) and res["games"] > 0        # an untrained fill crashes or leaves the corridor quickly
+
+
+def _vae_agent(envs, cache, horizon=8, seed=0):
+    import os
+    import yaml
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
+    c = params["config"]
+    c.update(num_actors=envs, horizon_length=horizon, mini_epochs=2, minibatch_size=envs * horizon // 2, device="cuda:0",
+             max_epochs=-1, write_summaries=False, print_stats=False, save_frequency=0, save_best_after=10 ** 9,
+             cache_frozen_features=cache, use_hip_graph=False)
+    c["env_config"] = {"use_image": True, "num_envs": envs, "ctl_mode": "rate", "seed": seed, "sim_device": "cuda:0",
+                       "headless": True}
+    params["network"].pop("cnn", None)
+    params["network"]["vae"] = {"latent_dims": 64, "allow_random_init": True, "image_res": [120, 212],
+                                "interpolation_mode": "bilinear", "return_sampled_latent": False}
+    params["seed"] = seed
+    torch.manual_seed(seed)
+    agent = A2CAgent("vae_cache_test", params)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    return agent
+
+
+def test_frozen_encoder_features_are_cached_per_rendered_image():
+    """Planning with the frozen depth VAE: the rollout keeps [N, 64] features instead of images, re-encodes only on the steps
+    the camera ran (every 4th, planning.py:153-156), and the cached features equal a fresh encoding of the image the env
+    holds; the update runs on the features (no encoder), trains, and the image normaliser still sees the rendered images."""
+    agent = _vae_agent(64, True)
+    assert agent._cache_latents and set(agent.obs_buf) == {"observation", "latent"}
+    assert agent.obs_buf["latent"].shape == (9, 64, 64)
+    calls = []
+    enc = agent.model._frozen[0]
+    orig = enc.encode
+    enc.encode = lambda im: (calls.append(im.shape[0]), orig(im))[1]
+    rms = agent.model.running_mean_std.running_mean_std["image"]
+    count0 = float(rms.count)
+    agent.epoch_num = 1
+    st = agent.train_epoch()
+    # 8 steps -> 2 camera steps (+ slot 0 re-encoded at the start of the rollout); nothing in the update
+    assert calls == [64, 64, 64], calls
+    assert float(rms.count) == count0 + 2 * 64
+    # the rollout's last slot (carried into slot 0) == a fresh encoding of the env's current image under the normaliser state
+    # the ROLLOUT used; the update has moved the normaliser since, so compare through a second rollout start instead
+    lat_last = agent.obs_buf["latent"][0].clone()
+    agent.model.eval()
+    fresh = agent.model.encode_image(agent._hip_env.image)
+    assert fresh.shape == lat_last.shape and torch.isfinite(fresh).all()
+    calls.clear()
+    batch = agent.play_steps()
+    assert torch.allclose(batch["obses"]["latent"].view(64, 8, 64)[:, 0], fresh, atol=1e-6)
+    lat = batch["obses"]["latent"].view(64, 8, 64)
+    ren = [t for t in range(1, 8) if not torch.equal(lat[:, t], lat[:, t - 1])]
+    assert len(ren) <= 2 and len(calls) == 1 + len(ren) + (2 - len(ren))          # features change only on camera steps
+    for k in ("a_loss", "c_loss", "kl"):
+        assert st[k] == st[k]
+    assert "image" not in batch["obses"]
+
+
+def test_cached_features_match_uncached_training_step():
+    """Same seeds, cache on / off: with the input normaliser frozen (normalize_input false) the two paths see identical
+    features, so one PPO epoch produces the same losses and the same parameters."""
+    outs = []
+    for cache in (True, False):
+        agent = _vae_agent(32, cache, horizon=4, seed=3)
+        agent.normalize_input = False
+        agent.model.normalize_input = False
+        agent.epoch_num = 1
+        st = agent.train_epoch()
+        outs.append((st, agent.flat_param.clone()))
+    (a, pa), (b, pb) = outs
+    for k in ("a_loss", "c_loss", "entropy"):
+        assert abs(float(a[k]) - float(b[k])) <= 1e-5 * max(1.0, abs(float(b[k]))), (k, a[k], b[k])
+    assert (pa - pb).abs().max().item() <= 1e-5

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--encoder", default="cnn", choices=["cnn", "vae"])
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen find mode)")
+    ap.add_argument("--encode-chunk", type=int, default=0, help="vae: images per encoder call (0 = all at once)")
     ap.add_argument("--fused-relu-bn", type=int, default=1, help="ReLU + BatchNorm2d pairs on csrc/cnn_kernels.hip")
     args = ap.parse_args()
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +39,8 @@ def main():
     if args.encoder == "vae":
         params["network"].pop("cnn", None)
         params["network"]["vae"] = {"latent_dims": 64, "allow_random_init": True, "image_res": [120, 212],
-                                    "interpolation_mode": "bilinear", "return_sampled_latent": False}
+                                    "interpolation_mode": "bilinear", "return_sampled_latent": False,
+                                    "encode_chunk": args.encode_chunk}
     params["seed"] = 0
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
