@@ -387,6 +387,7 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
+    k.stagger = 0;
     k.actions = actions;
     if (obs_out) k.obs = obs_out;
     if (rew_out) k.rew = rew_out;
@@ -577,6 +578,7 @@ int ag_reset_all(ag_handle h, void* stream) {
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
+    k.stagger = 0;
     if (h->cfg.task == AG_TASK_PLANNING) {
         if (!h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
         bind_tick(h, k);
@@ -602,6 +604,7 @@ int ag_reset_envs(ag_handle h, const int32_t* env_ids_dev, int count, void* stre
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
+    k.stagger = 0;
     bind_tick(h, k);
     if (h->cfg.task >= AG_TASK_PLANNING) {
         if (h->cfg.task == AG_TASK_PLANNING && !h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
@@ -642,6 +645,7 @@ int ag_eval_obs_reward(ag_handle h, const float* processed_actions_dev, const fl
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
+    k.stagger = 0;
     k.eval_actions = processed_actions_dev;
     k.eval_cmd = cmd_thrusts_dev;
     k.ext_noise = noise_dev;
@@ -782,6 +786,7 @@ int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* co
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
+    k.stagger = 0;
     k.actions = actions_dev;
     ag::PlanArgs pa = h->pa;
     pa.ext_collisions = collisions_dev;
@@ -844,7 +849,7 @@ int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds) {
     if (!(block_size >= 0 && block_size <= 4) && block_size != 64 && block_size != 128 && block_size != 256)
         return fail(AG_ERR_INVALID_ARG, "block_size must be 0 (wave-specialised, default), 1..4 (its A/B variants), 64, 128 or 256");
     h->block = block_size;
-    h->obs_via_lds = obs_via_lds ? 1 : 0;
+    h->obs_via_lds = obs_via_lds;       // (block_size 0: values > 1 = the de-phasing experiment, stagger = value - 1)
     return AG_OK;
 }
 

@@ -39,6 +39,7 @@ struct KArgs {
     // parity / inspection mode (ag_eval_obs_reward): processed actions + controller output supplied by the caller
     const float* eval_actions;   // [n, A]
     const float* eval_cmd;       // [n, 4]
+    int stagger;                 // experiment (ag_set_launch_params): every second workgroup of a CU starts this many x 0.5 us late
     // RNG tick lives in device memory so that a captured hipGraph of env steps replays with fresh
     // counters: each launch reads tick_in and thread 0 publishes tick+1 to tick_out (the two slots
     // alternate launch to launch; stream order between launches makes the hand-off race-free).

@@ -275,6 +275,15 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k) {
     __shared__ float tileB[64 * SB];
     __shared__ float tileT[64 * ST];
 
+    if (k.stagger > 0) {
+        // de-phasing experiment: the workgroups of a launch run in lockstep (all load, all compute, all store); every second
+        // workgroup of a CU (by its LDS allocation slot) starts late so that its memory phases meet the others' arithmetic
+        const unsigned base = __builtin_amdgcn_s_getreg((31 << 11) | 6) & 0xFF;      // HW_REG_LDS_ALLOC.LDS_BASE, 256-byte units
+        if (((base + 4) / 46) & 1) {
+#pragma unroll 1
+            for (int q = 0; q < k.stagger; ++q) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const int hw_wave = threadIdx.x >> 6;
     const int wave = FLIP ? (hw_wave ^ ((blockIdx.x >> 1) & 1)) : hw_wave;
     const int lane = threadIdx.x & 63;
@@ -481,7 +490,9 @@ static hipError_t launch_step(const KArgs& k, int block, int obs_via_lds, hipStr
     }
     const dim3 g64((n + 63) / 64);
     if (block == 0) {   // wave-specialised geometry, second form (default: state stored after the reward, measured faster)
-        hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, false, false>), g64, dim3(128), 0, stream, k);
+        KArgs ks = k;
+        ks.stagger = obs_via_lds > 1 ? obs_via_lds - 1 : 0;
+        hipLaunchKernelGGL((step_kernel_ws2<TASK, CTL, false, false>), g64, dim3(128), 0, stream, ks);
         return hipGetLastError();
     }
     // A/B variants of the wave-specialised kernel (ag_set_launch_params block_size 1..4; tools/sweep_env_kernel.py)

@@ -298,7 +298,7 @@ class HipEnvHandle:
         N.check(self.lib.ag_set_target_state(self.h, arr), "ag_set_target_state")
 
     def set_launch_params(self, block_size=64, obs_via_lds=True):
-        N.check(self.lib.ag_set_launch_params(self.h, int(block_size), int(bool(obs_via_lds))), "ag_set_launch_params")
+        N.check(self.lib.ag_set_launch_params(self.h, int(block_size), int(obs_via_lds)), "ag_set_launch_params")
 
     @property
     def tick(self):

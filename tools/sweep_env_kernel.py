@@ -22,18 +22,19 @@ ap.add_argument("--blocks", type=int, nargs="+", default=[0, 1, 2, 3, 4, 64])
 ap.add_argument("--forms", nargs="+", default=["rollout", "api"])
 ap.add_argument("--replays", type=int, default=20)
 ap.add_argument("--nograph", action="store_true", help="eager launches (rocprofv3 counter passes)")
+ap.add_argument("--stagger", type=int, nargs="+", default=[0], help="block 0 only: de-phase every second workgroup of a CU by k x 0.5 us")
 ap.add_argument("--no-noise", action="store_true", help="observation noise off (diagnostic: what the noise wave costs)")
 a = ap.parse_args()
 print(torch.cuda.get_device_name(0), file=sys.stderr)
 for n in a.envs:
     env = HipEnvHandle(a.task, a.ctl, n, seed=0, reward_terms=True, obs_noise=not a.no_noise)
-    for block in a.blocks:
-        env.set_launch_params(block, 1)
+    for block, stag in [(b, s) for b in a.blocks for s in (a.stagger if b == 0 else [0])]:
+        env.set_launch_params(block, 1 + stag)
         for form in a.forms:
             if form == "rollout" and (block == 1 or block >= 64):
                 continue        # the rollout form exists for the ws2 family only
             r = measure_env_kernel(env, replays=a.replays, rollout_form=(form == "rollout"), use_graph=not a.nograph)
-            r.update(task=a.task, ctl=a.ctl, envs=n, block=block, obs_noise=not a.no_noise, kernel=kernel_name(a.task, a.ctl, block),
+            r.update(task=a.task, ctl=a.ctl, envs=n, block=block, stagger=stag, obs_noise=not a.no_noise, kernel=kernel_name(a.task, a.ctl, block),
                      frac=r["gbps_algorithmic"] / 8000.0)
             print(json.dumps(r), flush=True)
     env.close()
