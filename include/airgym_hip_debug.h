@@ -22,7 +22,8 @@ int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void
 /* Launch geometry of the Hovering/Tracking step kernel: block_size 0 = wave-specialised kernel (default: physics wave +
  * noise wave per 64 envs, state stored after the reward), 2 = same with the state stored right after the integration,
  * 3 / 4 = 2 / 0 with alternating wave roles per workgroup, 1 = the first wave-specialised form (round 1), 64 / 128 / 256 = one wave per
- * 64 envs with that workgroup size (obs staged through LDS or not). */
+ * 64 envs with that workgroup size (obs staged through LDS or not).  With block_size 0, obs_via_lds = 1 + k (k > 0) is the
+ * de-phasing experiment of DESIGN.md 4.1: every second workgroup of a CU starts k x 0.5 us late (measured: never faster). */
 int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
 
 /* Where the hardware places the step kernel's waves: launches its geometry (ceil(n/64) workgroups x 2 waves) and writes, per
