@@ -152,6 +152,7 @@ SYMBOLS = [
     ("ag_debug_split_gemm_variant", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_gemm_plane_bytes", ctypes.c_longlong, []),
     ("ag_split_gemm_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_split_gemm_prepare_pair", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_gemm", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_gemm_input_wgrad_rows", ctypes.c_int, []),
     ("ag_split_gemm_input_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -67,8 +67,16 @@ __device__ __forceinline__ void split8(const float4 lo, const float4 hi, uint4& 
 
 // Weight preparation: W [256, 256] f32 (row-major) -> planes [chunk 16][plane 3][k-half 2][n 256] x 8 bf16, the per-chunk LDS
 // image of the main loop.  transpose = 0: B[n][k] = W[n][k] (forward, X W^T); 1: B[n][k] = W[k][n] (backward dX = dZ W).
-__global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restrict__ W, uint4* __restrict__ planes, int transpose) {
-    const int unit = blockIdx.x * 256 + threadIdx.x;          // one (chunk, k-half, n) unit per thread: 16 * 2 * 256 = 8192
+__global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restrict__ W, uint4* __restrict__ planes, int transpose,
+                                                            uint4* __restrict__ planes_t) {
+    // one (chunk, k-half, n) unit per thread: 16 * 2 * 256 = 8192 per image; blocks past the first image write the TRANSPOSED
+    // image into planes_t (both in one launch: ag_split_gemm_prepare_pair)
+    int unit = blockIdx.x * 256 + threadIdx.x;
+    if (unit >= 16 * 2 * BN) {
+        unit -= 16 * 2 * BN;
+        planes = planes_t;
+        transpose = !transpose;
+    }
     if (unit >= 16 * 2 * BN) return;
     const int n = unit % BN, h = (unit / BN) & 1, c = unit / (2 * BN);
     const int k0 = c * BK + h * 8;
@@ -448,7 +456,16 @@ extern "C" int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
     if ((uintptr_t)planes_dev & 15) return AG_ERR_INVALID_ARG;
     hipLaunchKernelGGL(split_prepare_kernel, dim3(16 * 2 * BN / 256), dim3(256), 0, (hipStream_t)stream, W_dev,
-                       (uint4*)planes_dev, transpose);
+                       (uint4*)planes_dev, transpose, (uint4*)nullptr);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, void* planes_t_dev, int n, int k, void* stream) {
+    if (!W_dev || !planes_dev || !planes_t_dev) return AG_ERR_INVALID_ARG;
+    if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
+    if (((uintptr_t)planes_dev | (uintptr_t)planes_t_dev) & 15) return AG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(split_prepare_kernel, dim3(2 * 16 * 2 * BN / 256), dim3(256), 0, (hipStream_t)stream, W_dev,
+                       (uint4*)planes_dev, 0, (uint4*)planes_t_dev);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 

@@ -48,9 +48,11 @@ class SplitGemm256:
 
     def prepare(self):
         st = self._stream()
-        N.check(self.lib.ag_split_gemm_prepare(self.w.data_ptr(), self.fwd.data_ptr(), 256, 256, 0, st), "ag_split_gemm_prepare")
         if self.bwd is not None:
-            N.check(self.lib.ag_split_gemm_prepare(self.w.data_ptr(), self.bwd.data_ptr(), 256, 256, 1, st), "ag_split_gemm_prepare")
+            N.check(self.lib.ag_split_gemm_prepare_pair(self.w.data_ptr(), self.fwd.data_ptr(), self.bwd.data_ptr(), 256, 256, st),
+                    "ag_split_gemm_prepare_pair")
+        else:
+            N.check(self.lib.ag_split_gemm_prepare(self.w.data_ptr(), self.fwd.data_ptr(), 256, 256, 0, st), "ag_split_gemm_prepare")
 
     def forward(self, x, out, bias=None):
         """out [M, 256] = x [M, 256] W^T (+ bias)"""

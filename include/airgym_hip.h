@@ -285,6 +285,7 @@ int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float*
  * the f32-input MFMA path (gfx950 has no TF32 form).  n = k = 256 only (AG_ERR_UNSUPPORTED otherwise).
  *   ag_split_gemm_prepare: W_dev [256, 256] f32 row-major -> planes_dev (ag_split_gemm_plane_bytes() bytes, 16-byte aligned);
  *       transpose = 0: B = W (C = A W^T), 1: B = W^T (C = A W).  Run once per weight update.
+ *   ag_split_gemm_prepare_pair: both images of one weight in one launch (planes_dev: transpose 0, planes_t_dev: transpose 1).
  *   ag_split_gemm: C_dev [M, 256] = A_dev [M, 256] B^T (+ bias_dev [256] if not NULL).
  *   ag_split_gemm_elu_heads: the last hidden layer and the actor/critic heads in one launch (mlp.py:36-39 + the mu / value
  *       Linear): Z_dev [M, 256] = A B^T WITHOUT the bias (what ag_heads_bwd_elu_wgrad(zbias) reads back), heads_dev [M, A1] =
@@ -298,6 +299,7 @@ int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float*
  *       written.  D in {16, 18, 20}. */
 long long ag_split_gemm_plane_bytes(void);
 int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n, int k, int transpose, void* stream);
+int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, void* planes_t_dev, int n, int k, void* stream);
 int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
                   void* stream);
 int ag_split_gemm_input_wgrad_rows(void);

@@ -214,3 +214,15 @@ def test_fused_first_layer_backward_rejects_bad_arguments(lib):
     assert lib.ag_split_gemm_input_wgrad(*a, 4, 256, 128, 18, _stream()) != 0
     assert lib.ag_split_gemm_input_wgrad(*a[:2], None, *a[3:], 4, 256, 256, 18, _stream()) != 0
     assert lib.ag_split_gemm_input_wgrad(*a, 0, 256, 256, 18, _stream()) != 0
+
+
+def test_prepare_pair_equals_two_prepares(lib):
+    from airgym_amd import _native as N
+    g = torch.Generator(device="cuda").manual_seed(5)
+    W = torch.randn(256, 256, device="cuda", generator=g)
+    nb = lib.ag_split_gemm_plane_bytes()
+    a, b, c, d = (torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(4))
+    N.check(lib.ag_split_gemm_prepare(W.data_ptr(), a.data_ptr(), 256, 256, 0, _stream()), "prepare")
+    N.check(lib.ag_split_gemm_prepare(W.data_ptr(), b.data_ptr(), 256, 256, 1, _stream()), "prepare")
+    N.check(lib.ag_split_gemm_prepare_pair(W.data_ptr(), c.data_ptr(), d.data_ptr(), 256, 256, _stream()), "prepare_pair")
+    assert torch.equal(a, c) and torch.equal(b, d) and not torch.equal(a, b)
