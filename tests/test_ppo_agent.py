@@ -403,3 +403,57 @@ def test_checkpoint_optimizer_is_torch_adam_layout(tmp_path):
     b.restore(str(tmp_path / "ref_style.pth"))
     assert torch.allclose(b.optimizer.exp_avg, 2.0 * a.optimizer.exp_avg) and torch.equal(b.optimizer.exp_avg_sq, a.optimizer.exp_avg_sq)
     assert b.optimizer.step_t.item() == a.optimizer.step_t.item() and torch.equal(b.flat_param, a.flat_param)
+
+
+def test_running_mean_std_merge_moments_equals_update():
+    """RunningMeanStd.merge_moments (used when the image normaliser is fed the rendered images' accumulated moments instead of
+    minibatches) == update() on the same batch; merging two batches' moments first == updating with their concatenation."""
+    from airgym_amd.lib.core.running_mean_std import RunningMeanStd
+    torch.manual_seed(0)
+    x1, x2 = torch.randn(37, 5) * 3 + 1, torch.randn(21, 5) * 0.5 - 2
+    a, b = RunningMeanStd((5,)), RunningMeanStd((5,))
+    a.update(x1)
+    b.merge_moments(x1.mean(0).double(), x1.var(0).double(), torch.tensor(37.0, dtype=torch.float64))
+    for k in ("running_mean", "running_var", "count"):
+        assert torch.allclose(getattr(a, k), getattr(b, k), rtol=1e-12, atol=1e-12), k
+    # accumulate (x1, x2) with the agent's formula, then merge once: same as one update with the concatenation up to the
+    # biased/unbiased variance convention update() itself uses (x.var is unbiased, the merge treats it as a population variance)
+    mean = torch.zeros(5, dtype=torch.float64); var = torch.zeros(5, dtype=torch.float64); cnt = torch.zeros((), dtype=torch.float64)
+    for x in (x1, x2):
+        bc, bm, bv = float(x.shape[0]), x.mean(0).double(), x.var(0).double()
+        delta, tot = bm - mean, cnt + bc
+        m2 = var * cnt + bv * bc + delta ** 2 * cnt * bc / tot
+        mean = mean + delta * bc / tot; var = m2 / tot; cnt = tot
+    c, d = RunningMeanStd((5,)), RunningMeanStd((5,))
+    c.merge_moments(mean, var, cnt)
+    d.update(x1); d.update(x2)
+    assert torch.allclose(c.count, d.count)
+    assert torch.allclose(c.running_mean, d.running_mean, rtol=1e-10, atol=1e-12)
+    assert torch.allclose(c.running_var, d.running_var, rtol=1e-10, atol=1e-12)
+    # a zero count leaves the statistics untouched
+    before = (c.running_mean.clone(), c.running_var.clone(), c.count.clone())
+    c.merge_moments(torch.zeros(5, dtype=torch.float64), torch.zeros(5, dtype=torch.float64), torch.zeros((), dtype=torch.float64))
+    assert all(torch.equal(x, y) for x, y in zip(before, (c.running_mean, c.running_var, c.count)))
+
+
+def test_vae_model_accepts_cached_features():
+    """ModelA2CContinuousLogStd with the frozen VAE: {'observation', 'latent'} observations give exactly what
+    {'observation', 'image'} give when `latent` = encode_image(image)."""
+    from airgym_amd.lib.model.a2c_continuous_logstd_model import ModelA2CContinuousLogStd
+    torch.manual_seed(1)
+    params = {"network": {"separate": False, "mlp": {"units": [32, 32], "activation": "elu"},
+                          "space": {"continuous": {"fixed_sigma": True}},
+                          "vae": {"latent_dims": 64, "allow_random_init": True, "image_res": [120, 212],
+                                  "interpolation_mode": "bilinear", "return_sampled_latent": False}},
+              "config": {"normalize_input": True, "normalize_value": True}}
+    m = ModelA2CContinuousLogStd(params, {"actions_num": 4, "input_shape": {"image": (1, 212, 120), "observation": (16,)}}).eval()
+    assert m.frozen_features_cacheable
+    img, ob = torch.rand(3, 1, 212, 120), torch.randn(3, 16)
+    with torch.no_grad():
+        lat = m.encode_image(img)
+        mu1, _, v1 = m.trunk({"image": img, "observation": ob})
+        mu2, _, v2 = m.trunk({"latent": lat, "observation": ob})
+    assert lat.shape == (3, 64) and torch.equal(mu1, mu2) and torch.equal(v1, v2)
+    params["network"]["vae"]["return_sampled_latent"] = True
+    m2 = ModelA2CContinuousLogStd(params, {"actions_num": 4, "input_shape": {"image": (1, 212, 120), "observation": (16,)}})
+    assert not m2.frozen_features_cacheable
