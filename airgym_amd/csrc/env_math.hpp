@@ -51,9 +51,12 @@ constexpr float kYawTorquePerCmd = 0.2f;
 
 // Control cascade gains: oracle/px4_cascade.py (PX4 multicopter defaults; build's own spec).
 constexpr float kCtlDt = 0.01f, kInvCtlDt = 100.0f;
-constexpr float kRateKp[3] = {0.15f, 0.15f, 0.2f};
-constexpr float kRateKi[3] = {0.2f, 0.2f, 0.1f};
-constexpr float kRateKd[3] = {0.003f, 0.003f, 0.0f};
+#ifndef AG_EXPERIMENT_RATE_GAIN      /* system-identification probe only (tools/play_reference_policy.py); the spec is 1 */
+#define AG_EXPERIMENT_RATE_GAIN 1.0f
+#endif
+constexpr float kRateKp[3] = {0.15f * AG_EXPERIMENT_RATE_GAIN, 0.15f * AG_EXPERIMENT_RATE_GAIN, 0.2f * AG_EXPERIMENT_RATE_GAIN};
+constexpr float kRateKi[3] = {0.2f * AG_EXPERIMENT_RATE_GAIN, 0.2f * AG_EXPERIMENT_RATE_GAIN, 0.1f * AG_EXPERIMENT_RATE_GAIN};
+constexpr float kRateKd[3] = {0.003f * AG_EXPERIMENT_RATE_GAIN, 0.003f * AG_EXPERIMENT_RATE_GAIN, 0.0f};
 constexpr float kRateIntLim = 0.3f;
 constexpr float kRateIAttenInv = (float)(1.0 / (400.0 * 3.14159265358979323846 / 180.0));
 constexpr float kMixRP = 0.70710678f, kMixYaw = 1.0f;

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--image-flips", nargs="*", default=[], choices=["u", "v", "uv"],
                     help="renderer-convention probe: re-fly the reference policy with the image mirrored left-right (u), "
                          "upside-down (v) or both")
+    ap.add_argument("--only-reference", action="store_true", help="skip the random / zero-action baselines")
     ap.add_argument("--thrust-gains", type=float, nargs="*", default=[],
                     help="system-identification probe: re-fly the reference policy with its thrust command scaled by k")
     args = ap.parse_args()
@@ -35,6 +36,8 @@ def main():
     out = {}
     names = ["reference_policy", "random", "zero"] + [f"reference_policy_thrust_x{k}" for k in args.thrust_gains] \
         + [f"reference_policy_flip_{f}" for f in args.image_flips]
+    if args.only_reference:
+        names = [n for n in names if n.startswith("reference_policy")]
     for name in names:
         env = vecenv.create_vec_env("planning", args.envs, use_image=True, num_envs=args.envs, ctl_mode="rate", seed=0,
                                     sim_device="cuda:0", headless=True)
@@ -45,6 +48,7 @@ def main():
         done_len, done_rew, n_done, rew_sum, n_goal = 0.0, 0.0, 0, 0.0, 0
         causes = {"altitude_band": 0, "heading": 0, "collision_or_bounds": 0}
         thrust_sum, speed_sum = 0.0, 0.0
+        lat_sum, up_sum, act_sum = 0.0, 0.0, torch.zeros(4, device="cuda")
         for t in range(args.steps):
             with torch.no_grad():
                 if name.startswith("reference_policy"):
@@ -66,6 +70,7 @@ def main():
             ep_rew += rew
             rew_sum += float(rew.mean())
             thrust_sum += float(act[:, 3].mean()); speed_sum += float(obs["observation"][:, 6].mean())
+            lat_sum += float(obs["observation"][:, 7].mean()); up_sum += float(obs["observation"][:, 8].mean()); act_sum += act.mean(0)
             d = dones.bool()
             if d.any():
                 done_len += float(ep_len[d].sum()); done_rew += float(ep_rew[d].sum()); n_done += int(d.sum())
@@ -83,7 +88,9 @@ def main():
                      "mean_episode_reward": round(done_rew / max(n_done, 1), 2), "mean_reward_per_step": round(rew_sum / args.steps, 4),
                      "goal_reached_fraction": round(n_goal / max(n_done, 1), 4),
                      "termination_causes": {k: round(v / max(n_done, 1), 3) for k, v in causes.items()},
-                     "mean_thrust_action": round(thrust_sum / args.steps, 3), "mean_forward_speed": round(speed_sum / args.steps, 3)}
+                     "mean_thrust_action": round(thrust_sum / args.steps, 3), "mean_forward_speed": round(speed_sum / args.steps, 3),
+                     "mean_lateral_speed": round(lat_sum / args.steps, 3), "mean_vertical_speed": round(up_sum / args.steps, 3),
+                     "mean_action": [round(float(v) / args.steps, 3) for v in act_sum]}
         env.env.hip.close()
     print(json.dumps(out, indent=1))
 
