@@ -514,7 +514,8 @@ class A2CAgent:
         # render the camera (every 4th, planning.py:153-156), so its cadence survives replay only if H % 4 == 0
         planning = getattr(self._hip_env, "task", None) == "planning"
         graphable = (self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0
-                     and (not planning or H % 4 == 0))
+                     and (not planning or H % 4 == 0)
+                     and not self._cache_latents)      # the frozen encoder runs MIOpen's find step: not inside a capture
         fr = self._fused_rollout
 
         def rollout():
