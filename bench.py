@@ -67,8 +67,12 @@ def _time_oracle(n, threads, budget_s, max_steps=2000):
     env = HoveringRef(n, "rate", seed=0)
     g = torch.Generator().manual_seed(1)
     acts = [torch.randn(n, 4, generator=g).clamp_(-1, 1) for _ in range(8)]
-    for i in range(2):
-        env.step(acts[i])
+    t0 = time.time()
+    env.step(acts[0])                      # warm-up; a setting whose single step already eats the budget is reported from it
+    warm = time.time() - t0
+    if warm > budget_s:
+        return n / warm, 1, warm
+    env.step(acts[1])
     t0 = time.time()
     steps = 0
     while time.time() - t0 < budget_s and steps < max_steps:
@@ -83,7 +87,9 @@ def cpu_baseline(seconds_target=24.0):
     of the workload: BASELINE config 1's N = 65 536 with a sweep of the torch thread count (the best is `value`), and
     BASELINE config 0's N = 64.  `cores` = the threads used for `value`; `host_cores` = what the box has."""
     host = os.cpu_count() or 1
-    sweep = sorted({t for t in (1, 4, 8, 16, 32, 64, host) if t <= host})
+    # thread counts beyond 64 are not swept: on the 256-core GPU host one 65 536-env step with 256 torch threads took 100 s
+    # (0.0006 M env-steps/s, round-2 measurement) - oversubscription of tiny ops, and minutes of bench time
+    sweep = sorted({t for t in (1, 4, 8, 16, 32, 64, host) if t <= min(host, 64)})
     n = ENVS_PER_GPU
     per = seconds_target * 0.75 / len(sweep)
     swept = {}
