@@ -387,3 +387,29 @@ def test_cached_features_match_uncached_training_step():
     for k in ("a_loss", "c_loss", "entropy"):
         assert abs(float(a[k]) - float(b[k])) <= 1e-5 * max(1.0, abs(float(b[k]))), (k, a[k], b[k])
     assert (pa - pb).abs().max().item() <= 1e-5
+
+
+def test_last_step_rendered_follows_the_camera_schedule(Handle):
+    """ag_planning_last_step_rendered: true exactly on the steps that rewrote the depth image (every 4th step, planning.py:153-156,
+    or when a render was forced), and the image buffer is bit-identical across the steps in between; Balloon has no camera."""
+    n = 32
+    env = Handle("planning", "rate", n, seed=5)
+    a = torch.zeros(n, 4, device="cuda"); a[:, 3] = -0.69
+    flags, changed = [], []
+    prev = env.image.clone()
+    for t in range(9):
+        env.step(a)
+        flags.append(env.last_step_rendered())
+        changed.append(not torch.equal(env.image, prev))
+        prev = env.image.clone()
+    assert sum(flags) == 2 and flags == changed, (flags, changed)
+    idx = [i for i, f in enumerate(flags) if f]
+    assert idx[1] - idx[0] == 4
+    env.planning_render_next_step()
+    env.step(a)
+    assert env.last_step_rendered()
+    env.close()
+    b = Handle("balloon", "rate", 8, seed=1)
+    with pytest.raises(RuntimeError):
+        b.last_step_rendered()
+    b.close()
