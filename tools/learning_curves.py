@@ -21,13 +21,16 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 
-def run(name, envs, minibatches, epochs, every, units=(256, 256)):
+def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=None):
     class A:
         pass
     A.envs, A.minibatches, A.graph, A.task, A.ctl, A.tuned_gemms = envs, minibatches, 1, "hovering", "rate", 1
     params = bench.build_params(A, 1)
     params["network"]["mlp"]["units"] = list(units)
-    torch.manual_seed(0)
+    params["seed"] = seed
+    params["config"]["env_config"]["seed"] = seed
+    params["config"].update(extra or {})
+    torch.manual_seed(seed)
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
     agent = A2CAgent("curve", params)
     agent.init_tensors()
@@ -58,10 +61,18 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=120)
     ap.add_argument("--small-epochs", type=int, default=480)
     ap.add_argument("--every", type=int, default=10)
+    ap.add_argument("--seeds", type=int, nargs="+", default=[0])
+    ap.add_argument("--only", default="", help="substring of the run name: run only those")
+    ap.add_argument("--fused-epilogues", type=int, default=1, help="0: fuse_gemm_heads / fuse_gemm_input_wgrad off (A/B)")
     a = ap.parse_args()
-    print(json.dumps(run("headline: 65536 envs, 8 minibatches/mini-epoch (196608 samples)", 65536, 8, a.epochs, a.every)), flush=True)
-    print(json.dumps(run("65536 envs, reference ratio: 48 minibatches/mini-epoch (32768 samples)", 65536, 48, a.epochs, a.every)), flush=True)
-    print(json.dumps(run("shipped small config: 4096 envs, 48 minibatches/mini-epoch (2048 samples), MLP(256,256)", 4096, 48,
-                         a.small_epochs, a.every * 4)), flush=True)
-    print(json.dumps(run("shipped small config with the shipped network [64,128,64]", 4096, 48, a.small_epochs, a.every * 4,
-                         units=(64, 128, 64))), flush=True)
+    extra = {} if a.fused_epilogues else {"fuse_gemm_heads": False, "fuse_gemm_input_wgrad": False}
+    runs = [("headline: 65536 envs, 8 minibatches/mini-epoch (196608 samples)", 65536, 8, a.epochs, a.every, (256, 256)),
+            ("65536 envs, reference ratio: 48 minibatches/mini-epoch (32768 samples)", 65536, 48, a.epochs, a.every, (256, 256)),
+            ("shipped small config: 4096 envs, 48 minibatches/mini-epoch (2048 samples), MLP(256,256)", 4096, 48, a.small_epochs,
+             a.every * 4, (256, 256)),
+            ("shipped small config with the shipped network [64,128,64]", 4096, 48, a.small_epochs, a.every * 4, (64, 128, 64))]
+    for seed in a.seeds:
+        for name, envs, mbs, epochs, every, units in runs:
+            if a.only in name and epochs > 0:
+                tag = name + (f" [seed {seed}]" if seed else "") + ("" if a.fused_epilogues else " [epilogues unfused]")
+                print(json.dumps(run(tag, envs, mbs, epochs, every, units=units, seed=seed, extra=extra)), flush=True)
