@@ -86,6 +86,16 @@ for M in _a.M:
     cands["fused_auto"] = fused(-1)
     for v in (2, 3, 6, 7):
         cands[f"fused_v{v}"] = fused(v)
+    h1 = torch.nn.functional.elu(torch.randn(M, 256, device="cuda", generator=g))
+    xin = torch.randn(M, 18, device="cuda", generator=g)
+    tiles = (M + 127) // 128
+    dwp = torch.empty(tiles, 256, 18, device="cuda"); dbp = torch.empty(tiles, 256, device="cuda")
+
+    def input_wgrad():
+        lib.ag_debug_split_gemm_variant(-1)
+        lib.ag_split_gemm_input_wgrad(A.data_ptr(), planes.data_ptr(), h1.data_ptr(), xin.data_ptr(), dwp.data_ptr(), dbp.data_ptr(),
+                                      M, 256, 256, 18, st)
+    cands["input_wgrad"] = input_wgrad
     cands["elu_heads"] = lambda: lib.ag_elu_heads(C.data_ptr(), Wh.data_ptr(), bh.data_ptr(), H.data_ptr(), M, 256, 5, 0,
                                                    b.data_ptr(), st)
     cands["prepare"] = lambda: lib.ag_split_gemm_prepare(W.data_ptr(), planes.data_ptr(), 256, 256, 0, st)
