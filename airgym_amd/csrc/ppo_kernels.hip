@@ -538,32 +538,40 @@ __global__ __launch_bounds__(256) void input_layer_reg_kernel(const float* __res
     const int tpr = C / CPT;
     const int rgroups = 256 / tpr;
     const int colg = threadIdx.x % tpr, rg = threadIdx.x / tpr;
-    float w[D][CPT];
-    float b[CPT];
+    // column PAIRS in two-wide vectors: the D x CPT FMAs of a row become D x CPT / 2 v_pk_fma_f32 (same IEEE fma per element, same
+    // order - bit-identical results); with scalar FMAs the kernel sat at ~55 % of its vector-ALU ceiling while writing h
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    constexpr int CP = CPT / 2;
+    f32x2_t w[D][CP];
+    f32x2_t b[CP];
     if (rg < rgroups) {
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            b[j] = bias[colg * CPT + j];
+        for (int j = 0; j < CP; ++j) {
+            b[j] = f32x2_t{bias[colg * CPT + 2 * j], bias[colg * CPT + 2 * j + 1]};
 #pragma unroll
-            for (int d = 0; d < D; ++d) w[d][j] = W[(size_t)(colg * CPT + j) * D + d];
+            for (int d = 0; d < D; ++d)
+                w[d][j] = f32x2_t{W[(size_t)(colg * CPT + 2 * j) * D + d], W[(size_t)(colg * CPT + 2 * j + 1) * D + d]};
         }
     }
     __syncthreads();
     if (rg >= rgroups) return;
     for (int r = rg; r < rows; r += rgroups) {
         const float* xr = xs + r * D;
-        float acc[CPT];
+        f32x2_t acc[CP];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) acc[j] = b[j];
+        for (int j = 0; j < CP; ++j) acc[j] = b[j];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const float x = xr[d];
 #pragma unroll
-            for (int j = 0; j < CPT; ++j) acc[j] = fmaf(x, w[d][j], acc[j]);
+            for (int j = 0; j < CP; ++j) acc[j] = __builtin_elementwise_fma(f32x2_t{x, x}, w[d][j], acc[j]);
         }
         float o[CPT];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) o[j] = elu1(acc[j]);
+        for (int j = 0; j < CP; ++j) {
+            o[2 * j] = elu1(acc[j].x);
+            o[2 * j + 1] = elu1(acc[j].y);
+        }
         reinterpret_cast<vec_t*>(h + (size_t)(row0 + r) * C)[colg] = *reinterpret_cast<const vec_t*>(o);
     }
 }
