@@ -150,26 +150,48 @@ def measure_update_kernels(agent, iters=20):
     if fs.fuse_heads:       # what the step runs: NN product against the transposed weight copy (rocBLAS / hipBLASLt via TunableOp)
         fs.wt_last.copy_(w.t())
         us = _time_us(lambda: torch.mm(x, fs.wt_last, out=fs.dz[:M * C].view(M, C)), iters)
-        label = f"library f32 GEMM (NN) [{M}x{K}]x[{K}x{C}], update forward"
+        label = f"library f32 GEMM (NN) [{M}x{K}]x[{K}x{C}] (the forward product under --split-gemm 0; for reference)"
     else:
         us = _time_us(lambda: torch.addmm(b, x, w.t(), out=fs.dz[:M * C].view(M, C)), iters)
-        label = f"library f32 GEMM (TN + bias) [{M}x{K}]x[{K}x{C}], update forward"
+        label = f"library f32 GEMM (TN + bias) [{M}x{K}]x[{K}x{C}] (the forward product under --split-gemm 0; for reference)"
     flops = 2.0 * M * C * K
     out.append({"kernel": label, "bound": "mfma",
                 "achieved": flops / us / 1e6, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "us_per_launch": us,
                 "note": "timed as 20 back-to-back launches (sustained-MFMA clocks); inside the minibatch, between HBM-bound "
                         "kernels, the same GEMM takes 185-205 us = 126-140 TFLOP/s (profiles/r01_bench_fused_kernel_trace.md)"})
+    # the weight gradient of the 256 x 256 layer as the step runs it: split-K batched GEMM of the library (f32 MFMA)
+    S = fs.wgrad_partials[-1].shape[0]
+    if M % S == 0:
+        dzv, xv = fs.dz[:M * C].view(S, M // S, C).transpose(1, 2), x.view(S, M // S, K)
+        us = _time_us(lambda: torch.bmm(dzv, xv, out=fs.wgrad_partials[-1]), iters)
+        out.append({"kernel": f"library f32 split-K weight gradient [{C}x{M}]x[{M}x{K}] ({S} slices)", "bound": "mfma",
+                    "achieved": flops / us / 1e6, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "us_per_launch": us,
+                    "note": "the one GEMM of the update still at the f32 matrix-core rate (90 % pipe occupancy, "
+                            "profiles/r02_update_kernels_pmc.md)"})
     if getattr(fs, "split", None):
         sg = next(iter(fs.split.values()))
         sg.prepare()
+
+        def mfma(name, us, fl, note):
+            out.append({"kernel": name, "bound": "mfma", "achieved": 6.0 * fl / us / 1e6, "peak": BF16_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": 6.0 * fl / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, "us_per_launch": us,
+                        "f32_equivalent_tflops": fl / us / 1e6, "note": note})
+        peak_note = ("peak = dense bf16 MFMA (2.5 PFLOP/s); the f32-equivalent rate is what replaces the f32-MFMA GEMM "
+                     "(157.3 TFLOP/s peak)")
         us = _time_us(lambda: sg.forward(x, fs.dz[:M * C].view(M, C)), iters)
-        out.append({"kernel": f"ag_split_gemm [{M}x{K}]x[{K}x{C}] (6 bf16 MFMAs per f32 product, f32-accurate), update forward / dX",
-                    "bound": "mfma", "achieved": 6.0 * flops / us / 1e6, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": 6.0 * flops / us / 1e6 / BF16_MFMA_PEAK_TFLOPS, "us_per_launch": us,
-                    "f32_equivalent_tflops": flops / us / 1e6,
-                    "note": "peak = dense bf16 MFMA (2.5 PFLOP/s); the f32-equivalent rate is what replaces the f32-MFMA GEMM "
-                            "(157.3 TFLOP/s peak)"})
+        mfma(f"ag_split_gemm [{M}x{K}]x[{K}x{C}] (6 bf16 MFMAs per f32 product, f32-accurate), plain", us, flops, peak_note)
+        if getattr(fs, "fuse_gemm_heads", False) and fs.fuse_heads:
+            us = _time_us(lambda: sg.forward_elu_heads(x, fs.dz[:M * C].view(M, C), b, agent.heads_w, agent.heads_b, fs.heads), iters)
+            mfma("ag_split_gemm_elu_heads (update forward of the last hidden layer + ELU + heads, as the step runs it)", us,
+                 flops + 2.0 * M * C * A1, "replaces ag_split_gemm + ag_elu_heads (one pass over z less)")
+        if getattr(fs, "fuse_gemm_input_wgrad", False):
+            D0 = fs.layers[0][0].shape[1]
+            us = _time_us(lambda: sg.backward_input_wgrad(h, fs.h[0], fs.xn, fs.wgrad_partials[0], fs.bias_partials[0]), iters)
+            mfma("ag_split_gemm_input_wgrad (dX of layer 2 + ELU' + dW1 / db1 on the matrix cores, as the step runs it)", us,
+                 flops + 2.0 * M * C * 32, "replaces ag_split_gemm + ag_elu_bwd_input_wgrad; dh1 / dz1 never written; the "
+                 "epilogue's K = rows products are counted at their padded size (32 input columns)")
     scratch = fs.dz[:M * C].view(M, C)
     scratch.copy_(h)
 
@@ -178,17 +200,19 @@ def measure_update_kernels(agent, iters=20):
                     "frac": nbytes / us / 1e3 / HBM_PEAK_GBPS, "us_per_launch": us, "algo_bytes": nbytes})
     us = _time_us(lambda: lib.ag_elu_heads(scratch.data_ptr(), agent.heads_w.data_ptr(), agent.heads_b.data_ptr(),
                                             fs.heads.data_ptr(), M, C, A1, 0, None, st), iters)
-    hbm("ag_elu_heads (ELU + head product, pre-activation kept)", us, 4.0 * M * (C + A1))
+    hbm("ag_elu_heads (ELU + head product, pre-activation kept)" + (" - folded into the GEMM epilogue in the step, shown for reference"
+        if getattr(fs, "fuse_gemm_heads", False) and getattr(fs, "split", None) else ""), us, 4.0 * M * (C + A1))
     parts = fs.bias_partials[-1]
     us = _time_us(lambda: lib.ag_heads_bwd_elu_wgrad(fs.d_heads.data_ptr(), agent.heads_w.data_ptr(), h.data_ptr(),
                                                       scratch.data_ptr(), parts.data_ptr(), fs.head_wg_partials.data_ptr(),
                                                       M, C, A1, 1, None, st), iters)
     hbm("ag_heads_bwd_elu_wgrad (head dX + ELU' + head wgrad)", us, 4.0 * M * (2 * C + A1))
-    if fs.fuse_input_wgrad:
+    if fs.fuse_input_wgrad and lib.ag_input_wgrad_rows(fs.layers[0][0].shape[1]) > 0:
         D = fs.layers[0][0].shape[1]
         C0 = fs.layers[0][0].shape[0]
         iparts = fs.bias_partials[0]
         us = _time_us(lambda: lib.ag_elu_bwd_input_wgrad(fs.dh.data_ptr(), fs.h[0].data_ptr(), fs.xn.data_ptr(),
                                                           fs.wgrad_partials[0].data_ptr(), iparts.data_ptr(), M, C0, D, st), iters)
-        hbm("ag_elu_bwd_input_wgrad (ELU' + first-layer wgrad)", us, 4.0 * M * (2 * C0 + D))
+        hbm("ag_elu_bwd_input_wgrad (ELU' + first-layer wgrad)" + (" - folded into the dX GEMM's epilogue in the step, shown for reference"
+            if getattr(fs, "fuse_gemm_input_wgrad", False) else ""), us, 4.0 * M * (2 * C0 + D))
     return out
