@@ -83,3 +83,33 @@ def test_vecenv_registration_and_spaces():
     from airgym_amd.lib.utils.spaces import Dict
     d = Dict({"image": Box(0, 1, shape=(1, 212, 120)), "observation": b})
     assert d["image"].shape == (1, 212, 120) and set(d.spaces) == {"image", "observation"}
+
+
+def test_bench_cpu_baseline_is_bounded(monkeypatch):
+    """bench.py's CPU-baseline leg must fit its time budget whatever the host looks like: the thread sweep stops at 64 threads
+    (on the 256-core GPU host one 65 536-env step with 256 torch threads took 100 s) and a setting whose warm-up step already
+    exceeds its share is reported from that step instead of being run again."""
+    import sys
+    import time
+    sys.path.insert(0, REPO)
+    import bench
+    import torch
+    calls = []
+    real = bench._time_oracle
+
+    def spy(n, threads, budget_s, max_steps=2000):
+        calls.append((n, threads))
+        return real(min(n, 256), threads, min(budget_s, 0.2), max_steps=3)       # keep the test fast: tiny env count / budget
+    monkeypatch.setattr(bench, "_time_oracle", spy)
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 256)
+    t0 = time.time()
+    before = torch.get_num_threads()
+    out = bench.cpu_baseline(2.0)
+    torch.set_num_threads(before)
+    assert time.time() - t0 < 30
+    swept = sorted({t for n, t in calls if n == bench.ENVS_PER_GPU})
+    assert swept == [1, 4, 8, 16, 32, 64] and out["host_cores"] == 256 and out["cores"] in swept
+    assert set(out) >= {"value", "unit", "cores", "kind", "sample", "thread_sweep", "config0"} and out["kind"] == "port"
+    # a setting slower than its budget returns after ONE step
+    v, steps, dt = real(64, 1, 0.0)
+    assert steps == 1 and v > 0
