@@ -90,3 +90,20 @@ def test_actor_critic_with_frozen_vae():
     assert all(p.grad is None for p in m._frozen[0].encoder.parameters())
     m.double()                                     # _apply reaches the unregistered encoder too
     assert next(m._frozen[0].encoder.parameters()).dtype == torch.float64
+
+
+def test_chunked_encoding_equals_one_call():
+    """network.vae.encode_chunk only bounds the batch per convolution call: same features, same order."""
+    import torch
+    from airgym_amd.lib.network.vae import FrozenVAEEncoder
+    torch.manual_seed(0)
+    cfg = {"latent_dims": 64, "allow_random_init": True, "image_res": [120, 212], "interpolation_mode": "bilinear"}
+    a = FrozenVAEEncoder(cfg, device="cpu")
+    b = FrozenVAEEncoder(dict(cfg, encode_chunk=3), device="cpu")
+    b.encoder.load_state_dict(a.encoder.state_dict())
+    img = torch.rand(8, 1, 212, 120)
+    za, zb = a.encode(img), b.encode(img)
+    assert za.shape == (8, 64) and torch.allclose(za, zb, atol=1e-6)
+    prev = torch.backends.cudnn.benchmark
+    a.encode(img[:2])
+    assert torch.backends.cudnn.benchmark == prev
