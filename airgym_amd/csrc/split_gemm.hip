@@ -470,7 +470,7 @@ extern "C" int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, 
 }
 
 constexpr bool kOrderedDefault = false;
-static int g_split_variant = -1;      // -1 = pick by size (measured on MI355X, profiles/r02_split_gemm.md)
+static int g_split_variant = -1;      // -1 = the default: plain 2 x 2 grid at every size (in-situ A/B, profiles/r02_split_gemm.md)
 extern "C" int ag_debug_split_gemm_variant(int variant) {
     if (variant < -1 || variant > 231) return AG_ERR_INVALID_ARG;      // unknown values are refused at launch
     g_split_variant = variant;
