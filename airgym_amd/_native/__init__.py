@@ -12,12 +12,16 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libairgym_hip.so")
+# AIRGYM_EXPERIMENTS=1 (tools/ only): the experiments build, which adds the ag_debug_* entry points of
+# include/airgym_hip_debug.h (`python airgym_amd/csrc/build.py --experiments`); the product never sets it
+EXPERIMENTS = os.environ.get("AIRGYM_EXPERIMENTS", "0") == "1"
+LIB_PATH = os.path.join(_HERE, "libairgym_hip_exp.so" if EXPERIMENTS else "libairgym_hip.so")
 
 AG_TASKS = {"hovering": 0, "tracking": 1, "planning": 2, "balloon": 3, "avoid": 4}
 AG_CTL_MODES = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
 AG_FLAG_REWARD_TERMS = 1 << 0
 AG_FLAG_OBS_NOISE_OFF = 1 << 1
+AG_FLAG_FIX_TIME_OUTS = 1 << 2
 AG_NUM_REWARD_TERMS = 11
 
 AG_ERR_UNKNOWN_TASK = -2
@@ -90,6 +94,22 @@ class AgStateView(ctypes.Structure):
     ]
 
 
+class AgRolloutTail(ctypes.Structure):
+    """ag_rollout_tail (include/airgym_hip.h)"""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("heads_dev", ctypes.c_void_p), ("logstd_dev", ctypes.c_void_p), ("vmean_dev", ctypes.c_void_p),
+        ("vvar_dev", ctypes.c_void_p), ("veps", ctypes.c_float), ("seed", ctypes.c_ulonglong),
+        ("counter_dev", ctypes.c_void_p), ("horizon", ctypes.c_int), ("slot", ctypes.c_int), ("id_offset", ctypes.c_longlong),
+        ("actions_dev", ctypes.c_void_p), ("neglogp_dev", ctypes.c_void_p), ("values_dev", ctypes.c_void_p),
+        ("mus_dev", ctypes.c_void_p), ("sigmas_dev", ctypes.c_void_p),
+        ("scale", ctypes.c_float), ("shift", ctypes.c_float), ("min_val", ctypes.c_float), ("max_val", ctypes.c_float),
+        ("log_val", ctypes.c_int), ("gamma", ctypes.c_float), ("bootstrap_timeouts", ctypes.c_int),
+        ("shaped_dev", ctypes.c_void_p), ("cur_rew_dev", ctypes.c_void_p), ("cur_shaped_dev", ctypes.c_void_p),
+        ("cur_len_dev", ctypes.c_void_p), ("partials_dev", ctypes.c_void_p),
+    ]
+
+
 # every symbol include/airgym_hip.h declares: (name, restype, argtypes)
 _P = ctypes.c_void_p
 class AgSumJob(ctypes.Structure):
@@ -113,6 +133,7 @@ SYMBOLS = [
     ("ag_step_with_inputs", ctypes.c_int, [_P, _P, _P, _P, _P]),
     ("ag_term_sum_tiles", ctypes.c_int, [ctypes.c_int]),
     ("ag_step_rollout", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ("ag_step_rollout_fused", ctypes.c_int, [_P, ctypes.POINTER(AgRolloutTail), _P, _P, _P, _P, _P]),
     ("ag_eval_obs_reward", ctypes.c_int, [_P, _P, _P, _P, _P]),
     ("ag_get_buffers", ctypes.c_int, [_P, ctypes.POINTER(AgBuffers)]),
     ("ag_get_state", ctypes.c_int, [_P, ctypes.POINTER(AgStateView), _P]),
@@ -121,10 +142,6 @@ SYMBOLS = [
     ("ag_set_target_state", ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     ("ag_get_tick", ctypes.c_uint64, [_P]),
     ("ag_set_tick", ctypes.c_int, [_P, ctypes.c_uint64]),
-    ("ag_set_launch_params", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
-    ("ag_debug_touch", ctypes.c_int, [_P, _P, _P]),
-    ("ag_debug_wave_placement", ctypes.c_int, [_P, _P, _P]),
-    ("ag_debug_touch_variant", ctypes.c_int, [_P, _P, ctypes.c_int, _P]),
     ("ag_planning_set_obstacle_table", ctypes.c_int, [_P, _P, ctypes.c_int]),
     ("ag_planning_get_buffers", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningBuffers)]),
     ("ag_planning_get_state", ctypes.c_int, [_P, ctypes.POINTER(AgPlanningStateView), _P]),
@@ -133,7 +150,6 @@ SYMBOLS = [
     ("ag_planning_eval_post", ctypes.c_int, [_P, _P, _P, _P, _P]),
     ("ag_planning_render_now", ctypes.c_int, [_P]),
     ("ag_planning_last_step_rendered", ctypes.c_int, [_P]),
-    ("ag_debug_planning_render_parts", ctypes.c_int, [_P, ctypes.c_int]),
     ("ag_ppo_loss_finalize", ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, ctypes.c_float,
                                             ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),
     ("ag_rms_scratch_doubles", ctypes.c_longlong, [ctypes.c_int]),
@@ -149,11 +165,12 @@ SYMBOLS = [
     ("ag_mlp_input_layer", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, _P]),
     ("ag_elu_heads", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
-    ("ag_debug_split_gemm_variant", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_gemm_plane_bytes", ctypes.c_longlong, []),
     ("ag_split_gemm_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_gemm_prepare_pair", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_gemm", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_split_wgrad_slices", ctypes.c_int, [ctypes.c_int]),
+    ("ag_split_wgrad", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_gemm_input_wgrad_rows", ctypes.c_int, []),
     ("ag_split_gemm_input_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_int, _P]),
@@ -180,12 +197,22 @@ SYMBOLS = [
                                    ctypes.c_int, ctypes.c_int, _P, _P, _P, _P, ctypes.POINTER(ctypes.c_int), _P]),
 ]
 
+# include/airgym_hip_debug.h: present in the experiments build only
+DEBUG_SYMBOLS = [
+    ("ag_debug_touch", ctypes.c_int, [_P, _P, _P]),
+    ("ag_debug_wave_placement", ctypes.c_int, [_P, _P, _P]),
+    ("ag_debug_touch_variant", ctypes.c_int, [_P, _P, ctypes.c_int, _P]),
+    ("ag_debug_planning_render_parts", ctypes.c_int, [_P, ctypes.c_int]),
+    ("ag_debug_split_gemm_variant", ctypes.c_int, [ctypes.c_int]),
+    ("ag_debug_split_wgrad_ordered", ctypes.c_int, [ctypes.c_int]),
+]
+
 _lib = None
 
 
 def _build():
     from airgym_amd.csrc import build as _b
-    return _b.build(verbose=False)
+    return _b.build(verbose=False, experiments=EXPERIMENTS)
 
 
 def load(rebuild_if_missing=True):
@@ -207,7 +234,7 @@ def load(rebuild_if_missing=True):
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
-    for name, res, args in SYMBOLS:
+    for name, res, args in SYMBOLS + (DEBUG_SYMBOLS if EXPERIMENTS else []):
         fn = getattr(lib, name)  # AttributeError = the .so is stale w.r.t. the header
         fn.restype = res
         fn.argtypes = args

@@ -12,7 +12,7 @@
 #include <string>
 
 #include "../../include/airgym_hip.h"
-#include "../../include/airgym_hip_debug.h"
+#include "handle.hpp"
 #include "kernel_args.hpp"
 #include "planning_math.hpp"
 
@@ -36,10 +36,7 @@ constexpr int kPad = 256;
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-struct Layout {
-    size_t S[4], C[4], PA, PA4, obs, rew, reset, timeout, mask, reset_ids, reset_count, tick, terms[11], cmd, total;
-    size_t OB, GOAL, PRP, image, collisions, table;   // planning only
-};
+using Layout = AgLayout;
 
 Layout make_layout(int n, int num_obs, bool terms, int task = 0) {
     const size_t np = align_up((size_t)n, kPad);
@@ -85,24 +82,6 @@ const ag::StepLauncher kLaunchers[2][5] = {
 };
 
 }  // namespace
-
-struct ag_env {
-    ag_config cfg;
-    int num_obs, num_actions, n_pad;
-    char* arena;
-    bool owns_arena;
-    Layout L;
-    ag::KArgs k;       // pointers + StepParams template for launches
-    ag::PlanArgs pa;   // planning extras
-    bool table_set;    // planning: obstacle variant table uploaded
-    uint64_t counter;  // planning: pre_physics_step counter driving the camera schedule (planning.py:153-156)
-    int force_render;  // planning: render on the next step regardless of the schedule
-    int last_rendered; // planning / avoid: 1 if the most recent step produced a new depth image
-    uint64_t tick;     // host mirror of the device tick (exact unless a captured graph is being replayed)
-    int parity;        // which of the two device tick slots the next launch reads
-    int block;
-    int obs_via_lds;
-};
 
 namespace {
 
@@ -242,68 +221,6 @@ __global__ __launch_bounds__(1024) void compact_reset_ids_kernel(const unsigned 
     if (tid == 0) *count = base;
 }
 
-// Diagnostic: same loads/stores as the Hovering/CTBR step (7 float4 in, 7 float4 + obs row + reward + flags out),
-// no arithmetic.  Its duration is the launch + memory-latency floor any one-launch-per-step design pays.
-__global__ __launch_bounds__(64) void touch_kernel(ag::KArgs k, const float* actions, int num_obs) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    ag::EnvState s;
-    ag::CtlState c;
-    ag::load_env(k, i, s);
-    ag::load_ctl<ag::CTL_RATE>(k, i, c);
-    const float4 pa = k.PA[i];
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < k.n) a = reinterpret_cast<const float4*>(actions)[i];
-    s.p.x += 1e-30f * (pa.x + a.x);
-    ag::store_env(k, i, s);
-    ag::store_ctl<ag::CTL_RATE>(k, i, c);
-    k.PA[i] = a;
-    if (i < k.n) {
-        k.rew[i] = s.p.x;
-        k.reset[i] = 0;
-        k.timeout[i] = 0;
-        float* o = k.obs + (size_t)i * num_obs;
-        for (int j = 0; j < num_obs; j += 2) reinterpret_cast<float2*>(o)[j >> 1] = make_float2(s.p.y, s.p.z);
-    }
-}
-
-// Diagnostic variants of touch_kernel: MODE 1 = non-temporal stores, 2 = non-temporal loads + stores, 3 = empty kernel
-// (pure dependent-launch boundary).  Used by tools/touch_probe.py to price the kernel boundary.
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-typedef float nt_f2 __attribute__((ext_vector_type(2)));
-
-template <int MODE>
-__global__ __launch_bounds__(64) void touch_variant_kernel(ag::KArgs k, const float* actions, int num_obs) {
-    if (MODE == 3) return;
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    nt_f4 in[7];
-    const nt_f4* src[7] = {(const nt_f4*)k.S[0], (const nt_f4*)k.S[1], (const nt_f4*)k.S[2], (const nt_f4*)k.S[3],
-                           (const nt_f4*)k.C[0], (const nt_f4*)k.C[1], (const nt_f4*)k.PA};
-#pragma unroll
-    for (int j = 0; j < 7; ++j) in[j] = (MODE == 2) ? __builtin_nontemporal_load(src[j] + i) : src[j][i];
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < k.n) a = reinterpret_cast<const float4*>(actions)[i];
-    in[0].x += 1e-30f * (in[6].x + a.x);
-    in[6] = nt_f4{a.x, a.y, a.z, a.w};
-    nt_f4* dst[7] = {(nt_f4*)k.S[0], (nt_f4*)k.S[1], (nt_f4*)k.S[2], (nt_f4*)k.S[3], (nt_f4*)k.C[0], (nt_f4*)k.C[1], (nt_f4*)k.PA};
-#pragma unroll
-    for (int j = 0; j < 7; ++j) __builtin_nontemporal_store(in[j], dst[j] + i);
-    if (i < k.n) {
-        __builtin_nontemporal_store(in[0].x, k.rew + i);
-        k.reset[i] = 0;
-        k.timeout[i] = 0;
-        float* o = k.obs + (size_t)i * num_obs;
-        for (int j = 0; j < num_obs; j += 2) __builtin_nontemporal_store(nt_f2{in[0].y, in[0].z}, reinterpret_cast<nt_f2*>(o) + (j >> 1));
-    }
-}
-
-// Diagnostic: where does the hardware put the waves of the step kernel's launch geometry (grid n/64 x 128 threads)?
-// One uint2 per wave: HW_ID (wave / SIMD / CU / SE fields) and XCC_ID.
-__global__ __launch_bounds__(128) void wave_placement_kernel(uint2* out) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID (gfx940+)
-    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 2 + (threadIdx.x >> 6)] = make_uint2(hw, xcc);
-}
-
 __global__ void planning_get_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_planning_state_view v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= k.n) return;
@@ -339,7 +256,8 @@ __global__ void planning_set_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_plann
 
 void fill_params(ag_env* h) {
     h->k.P = ag::make_step_params(h->cfg.task, h->cfg.dt, h->cfg.max_episode_length, h->cfg.target_state, h->cfg.seed,
-                                  h->cfg.env_id_offset, (h->cfg.flags & AG_FLAG_OBS_NOISE_OFF) != 0);
+                                  h->cfg.env_id_offset, (h->cfg.flags & AG_FLAG_OBS_NOISE_OFF) != 0,
+                                  (h->cfg.flags & AG_FLAG_FIX_TIME_OUTS) != 0);
 }
 
 int validate(const ag_config* cfg) {
@@ -377,17 +295,16 @@ void bind_tick(ag_env* h, ag::KArgs& k) {
 
 int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int64_t* reset_out,
             const float* noise, const float* uniforms, void* stream, uint8_t* done_u8 = nullptr,
-            float* term_sums = nullptr, bool rollout_form = false) {
+            float* term_sums = nullptr, bool rollout_form = false, const ag::TailArgs* tail = nullptr) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
-    if (!actions) return fail(AG_ERR_INVALID_ARG, "actions_dev is NULL");
-    if (h->num_actions == 4 && ((uintptr_t)actions & 15)) return fail(AG_ERR_INVALID_ARG, "actions_dev must be 16-byte aligned");
+    if (!actions && !tail) return fail(AG_ERR_INVALID_ARG, "actions_dev is NULL");
+    if (actions && h->num_actions == 4 && ((uintptr_t)actions & 15)) return fail(AG_ERR_INVALID_ARG, "actions_dev must be 16-byte aligned");
     if (obs_out && ((uintptr_t)obs_out & 15)) return fail(AG_ERR_INVALID_ARG, "obs_out_dev must be 16-byte aligned");
     if (h->cfg.task < AG_TASK_PLANNING && (noise == nullptr) != (uniforms == nullptr))
         return fail(AG_ERR_INVALID_ARG, "noise_dev and reset_uniforms_dev must be given together");
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
-    k.stagger = 0;
     k.actions = actions;
     if (obs_out) k.obs = obs_out;
     if (rew_out) k.rew = rew_out;
@@ -399,7 +316,7 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
         ag::PlanArgs pa = h->pa;
         pa.ext_uniforms = uniforms;
         k.ext_noise = noise;            // Balloon parity mode: [n,18] observation noise
-        pa.debug_skip = h->force_render >> 1;
+        pa.debug_skip = h->force_render >> 1;      // non-zero in the experiments build only
         h->counter += 1;
         // cam_dt / dt = 4 (planning.py:153-156, avoid.py:181-185); Balloon has no onboard camera (balloon_config.py:52)
         const bool render = (task != AG_TASK_BALLOON) && (h->force_render || (h->counter % 4 == 0));
@@ -429,15 +346,13 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
     }
     k.ext_noise = noise;
     k.ext_uniforms = uniforms;
-    int block = h->block;
     if (rollout_form) {   // u8 done flags, per-tile reward-term sums, no per-env term / cmd arrays
         k.reset_u8 = done_u8;
         k.term_sums = term_sums;
         k.cmd = nullptr;
-        if (block == 1 || block >= 64) block = 0;   // the rollout form exists for the default kernel family only
     }
     bind_tick(h, k);
-    hipError_t e = kLaunchers[h->cfg.task][h->cfg.ctl_mode](k, block, h->obs_via_lds, (hipStream_t)stream);
+    hipError_t e = kLaunchers[h->cfg.task][h->cfg.ctl_mode](k, tail, (hipStream_t)stream);
     if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
     return AG_OK;
 }
@@ -546,8 +461,6 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     fill_params(h);
     h->tick = 0;
     h->parity = 0;
-    h->block = 0;      // wave-specialised kernel
-    h->obs_via_lds = 1;
     // valid state from the start: everything randomised and flagged reset (base_task.py:75)
     hipError_t e = hipMemsetAsync(h->arena, 0, h->L.total, 0);
     if (e == hipSuccess) {
@@ -578,7 +491,6 @@ int ag_reset_all(ag_handle h, void* stream) {
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
-    k.stagger = 0;
     if (h->cfg.task == AG_TASK_PLANNING) {
         if (!h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
         bind_tick(h, k);
@@ -604,7 +516,6 @@ int ag_reset_envs(ag_handle h, const int32_t* env_ids_dev, int count, void* stre
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
-    k.stagger = 0;
     bind_tick(h, k);
     if (h->cfg.task >= AG_TASK_PLANNING) {
         if (h->cfg.task == AG_TASK_PLANNING && !h->table_set) return fail(AG_ERR_INVALID_ARG, "planning: call ag_planning_set_obstacle_table first");
@@ -637,6 +548,32 @@ int ag_step_rollout(ag_handle h, const float* actions_dev, float* obs_out_dev, f
     return do_step(h, actions_dev, obs_out_dev, rew_out_dev, nullptr, nullptr, nullptr, stream, done_out_dev, term_sums_dev, true);
 }
 
+int ag_step_rollout_fused(ag_handle h, const ag_rollout_tail* t, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,
+                          float* term_sums_dev, void* stream) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    if (h->cfg.task >= AG_TASK_PLANNING) return fail(AG_ERR_UNSUPPORTED, "ag_step_rollout_fused: hovering / tracking handles only");
+    if (!t || t->struct_size != sizeof(ag_rollout_tail)) return fail(AG_ERR_INVALID_ARG, "ag_rollout_tail is NULL or struct_size mismatch (ABI)");
+    if (!done_out_dev) return fail(AG_ERR_INVALID_ARG, "done_out_dev is NULL");
+    if (!t->heads_dev || !t->logstd_dev || !t->counter_dev || !t->actions_dev || !t->neglogp_dev || !t->values_dev || !t->mus_dev ||
+        !t->sigmas_dev || !t->shaped_dev || !t->cur_rew_dev || !t->cur_shaped_dev || !t->cur_len_dev || !t->partials_dev)
+        return fail(AG_ERR_INVALID_ARG, "ag_rollout_tail: a required device pointer is NULL");
+    if ((t->vmean_dev == nullptr) != (t->vvar_dev == nullptr)) return fail(AG_ERR_INVALID_ARG, "vmean_dev and vvar_dev go together");
+    if (t->horizon <= 0 || t->slot < 0) return fail(AG_ERR_INVALID_ARG, "horizon must be > 0 and slot >= 0");
+    if (h->num_actions == 4 && (((uintptr_t)t->actions_dev | (uintptr_t)t->mus_dev | (uintptr_t)t->sigmas_dev) & 15))
+        return fail(AG_ERR_INVALID_ARG, "actions_dev / mus_dev / sigmas_dev must be 16-byte aligned");
+    if (term_sums_dev && ((uintptr_t)term_sums_dev & 3)) return fail(AG_ERR_INVALID_ARG, "term_sums_dev must be 4-byte aligned");
+    ag::TailArgs ta;
+    ta.heads = t->heads_dev; ta.logstd = t->logstd_dev; ta.vmean = t->vmean_dev; ta.vvar = t->vvar_dev; ta.veps = t->veps;
+    ta.key0 = (uint32_t)(t->seed & 0xFFFFFFFFull); ta.key1 = (uint32_t)(t->seed >> 32);
+    ta.counter = (const long long*)t->counter_dev; ta.horizon = t->horizon; ta.slot = t->slot; ta.id_offset = t->id_offset;
+    ta.actions = t->actions_dev; ta.neglogp = t->neglogp_dev; ta.values = t->values_dev; ta.mus = t->mus_dev; ta.sigmas = t->sigmas_dev;
+    ta.scale = t->scale; ta.shift = t->shift; ta.min_val = t->min_val; ta.max_val = t->max_val; ta.log_val = t->log_val;
+    ta.gamma = t->gamma; ta.bootstrap = t->bootstrap_timeouts;
+    ta.shaped = t->shaped_dev; ta.cur_rew = t->cur_rew_dev; ta.cur_shaped = t->cur_shaped_dev; ta.cur_len = t->cur_len_dev;
+    ta.partials = t->partials_dev;
+    return do_step(h, nullptr, obs_out_dev, rew_out_dev, nullptr, nullptr, nullptr, stream, done_out_dev, term_sums_dev, true, &ta);
+}
+
 int ag_eval_obs_reward(ag_handle h, const float* processed_actions_dev, const float* cmd_thrusts_dev, const float* noise_dev,
                        void* stream) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
@@ -645,7 +582,6 @@ int ag_eval_obs_reward(ag_handle h, const float* processed_actions_dev, const fl
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
-    k.stagger = 0;
     k.eval_actions = processed_actions_dev;
     k.eval_cmd = cmd_thrusts_dev;
     k.ext_noise = noise_dev;
@@ -786,7 +722,6 @@ int ag_planning_eval_post(ag_handle h, const float* actions_dev, const float* co
     int rc = ensure_device(h);
     if (rc) return rc;
     ag::KArgs k = h->k;
-    k.stagger = 0;
     k.actions = actions_dev;
     ag::PlanArgs pa = h->pa;
     pa.ext_collisions = collisions_dev;
@@ -807,49 +742,6 @@ int ag_planning_last_step_rendered(ag_handle h) {
 int ag_planning_render_now(ag_handle h) {
     if (!h || (h->cfg.task != AG_TASK_PLANNING && h->cfg.task != AG_TASK_AVOID)) return fail(AG_ERR_INVALID_ARG, "not a planning / avoid handle");
     h->force_render = 1;
-    return AG_OK;
-}
-
-int ag_debug_planning_render_parts(ag_handle h, int skip_mask) {
-    if (!h || h->cfg.task != AG_TASK_PLANNING) return fail(AG_ERR_INVALID_ARG, "not a planning handle");
-    if (skip_mask < 0 || skip_mask > 7) return fail(AG_ERR_INVALID_ARG, "skip_mask: bit0 ray-cast, bit1 noise passes, bit2 5x5 pass");
-    h->force_render = 1 | (skip_mask << 1);
-    return AG_OK;
-}
-
-int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void* stream) {
-    if (!h || !actions_dev) return AG_ERR_INVALID_ARG;
-    const dim3 grid((h->cfg.num_envs + 63) / 64), block(64);
-    const int nobs = h->num_obs;
-    if (mode == 1) hipLaunchKernelGGL(touch_variant_kernel<1>, grid, block, 0, (hipStream_t)stream, h->k, actions_dev, nobs);
-    else if (mode == 2) hipLaunchKernelGGL(touch_variant_kernel<2>, grid, block, 0, (hipStream_t)stream, h->k, actions_dev, nobs);
-    else if (mode == 3) hipLaunchKernelGGL(touch_variant_kernel<3>, grid, block, 0, (hipStream_t)stream, h->k, actions_dev, nobs);
-    else return AG_ERR_INVALID_ARG;
-    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
-}
-
-int ag_debug_wave_placement(ag_handle h, unsigned int* out_dev, void* stream) {
-    if (!h || !out_dev) return fail(AG_ERR_INVALID_ARG, "NULL argument");
-    hipLaunchKernelGGL(wave_placement_kernel, dim3((h->cfg.num_envs + 63) / 64), dim3(128), 0, (hipStream_t)stream,
-                       (uint2*)out_dev);
-    AG_HIP_CHECK(hipGetLastError());
-    return AG_OK;
-}
-
-int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream) {
-    if (!h || !actions_dev) return fail(AG_ERR_INVALID_ARG, "NULL argument");
-    hipLaunchKernelGGL(touch_kernel, dim3((h->cfg.num_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->k,
-                       actions_dev, h->num_obs);
-    AG_HIP_CHECK(hipGetLastError());
-    return AG_OK;
-}
-
-int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds) {
-    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
-    if (!(block_size >= 0 && block_size <= 4) && block_size != 64 && block_size != 128 && block_size != 256)
-        return fail(AG_ERR_INVALID_ARG, "block_size must be 0 (wave-specialised, default), 1..4 (its A/B variants), 64, 128 or 256");
-    h->block = block_size;
-    h->obs_via_lds = obs_via_lds;       // (block_size 0: values > 1 = the de-phasing experiment, stagger = value - 1)
     return AG_OK;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 15 translation units compiled in parallel).
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 17 translation units compiled in parallel).
 
-    python airgym_amd/csrc/build.py [--force] [--jobs N]
+    python airgym_amd/csrc/build.py [--force] [--jobs N] [--experiments]
 
 The library lands in-tree at airgym_amd/_native/libairgym_hip.so (git-ignored, shipped to the GPU box by gpurun).
 """
@@ -18,12 +18,14 @@ PKG = os.path.dirname(HERE)
 LIB_DIR = os.path.join(PKG, "_native")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIB_DIR, "libairgym_hip.so")
+LIB_EXP = os.path.join(LIB_DIR, "libairgym_hip_exp.so")      # --experiments: + include/airgym_hip_debug.h (tools/ only)
 ARCH = "gfx950"
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
-HEADERS = ["env_math.hpp", "planning_math.hpp", "kernel_args.hpp", os.path.join("..", "..", "include", "airgym_hip.h")]
+HEADERS = ["env_math.hpp", "planning_math.hpp", "kernel_args.hpp", "rollout_math.hpp", "handle.hpp", "split_common.hpp",
+           os.path.join("..", "..", "include", "airgym_hip.h")]
 
 
 def _newer(target, deps):
@@ -33,17 +35,19 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def units():
+def units(experiments=False):
+    """(object, source, defines) of every translation unit.  The experiments build compiles the same sources with
+    -DAG_EXPERIMENTS into its own object directory and adds experiments.hip."""
+    od = os.path.join(OBJ_DIR, "exp") if experiments else OBJ_DIR
+    x = ["-DAG_EXPERIMENTS"] if experiments else []
     out = []
     for task in (0, 1):
         for ctl in range(5):
-            out.append((os.path.join(OBJ_DIR, f"step_{task}_{ctl}.o"), "step_kernel.hip", [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}"]))
-    out.append((os.path.join(OBJ_DIR, "airgym_hip.o"), "airgym_hip.hip", []))
-    out.append((os.path.join(OBJ_DIR, "ppo_kernels.o"), "ppo_kernels.hip", []))
-    out.append((os.path.join(OBJ_DIR, "planning_kernel.o"), "planning_kernel.hip", []))
-    out.append((os.path.join(OBJ_DIR, "rollout_kernels.o"), "rollout_kernels.hip", []))
-    out.append((os.path.join(OBJ_DIR, "split_gemm.o"), "split_gemm.hip", []))
-    out.append((os.path.join(OBJ_DIR, "cnn_kernels.o"), "cnn_kernels.hip", []))
+            out.append((os.path.join(od, f"step_{task}_{ctl}.o"), "step_kernel.hip", [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}"] + x))
+    for name in ("airgym_hip", "ppo_kernels", "planning_kernel", "rollout_kernels", "split_gemm", "split_wgrad", "cnn_kernels"):
+        out.append((os.path.join(od, name + ".o"), name + ".hip", list(x)))
+    if experiments:
+        out.append((os.path.join(od, "experiments.o"), "experiments.hip", list(x)))
     return out
 
 
@@ -53,11 +57,14 @@ def compile_one(obj, src, defs, extra):
     return obj, r.returncode, (r.stdout + r.stderr).strip(), " ".join(cmd)
 
 
-def build(force=False, jobs=None, extra=(), verbose=True):
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def build(force=False, jobs=None, extra=(), verbose=True, experiments=False):
+    os.makedirs(os.path.join(OBJ_DIR, "exp") if experiments else OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    todo = [(o, s, d) for (o, s, d) in units() if force or _newer(o, [os.path.join(HERE, s)] + hdrs)]
+    lib = LIB_EXP if experiments else LIB
+    hdrs = [os.path.join(HERE, h) for h in HEADERS if os.path.exists(os.path.join(HERE, h))] + [os.path.abspath(__file__)]
+    if experiments:
+        hdrs.append(os.path.join(HERE, "..", "..", "include", "airgym_hip_debug.h"))
+    todo = [(o, s, d) for (o, s, d) in units(experiments) if force or _newer(o, [os.path.join(HERE, s)] + hdrs)]
     t0 = time.time()
     if todo:
         jobs = jobs or min(len(todo), os.cpu_count() or 4)
@@ -67,25 +74,27 @@ def build(force=False, jobs=None, extra=(), verbose=True):
                     print(log)
                 if rc != 0:
                     raise RuntimeError(f"hipcc failed ({rc}): {cmd}\n{log}")
-    objs = [o for (o, _, _) in units()]
-    if todo or _newer(LIB, objs):
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    objs = [o for (o, _, _) in units(experiments)]
+    if todo or _newer(lib, objs):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed: {' '.join(cmd)}\n{r.stdout}{r.stderr}")
     if verbose:
-        print(f"[airgym_amd] {LIB} ready ({len(todo)} units rebuilt, {time.time() - t0:.1f}s)")
-    return LIB
+        print(f"[airgym_amd] {lib} ready ({len(todo)} units rebuilt, {time.time() - t0:.1f}s)")
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--experiments", action="store_true",
+                    help="build libairgym_hip_exp.so: the library + the ag_debug_* entry points (include/airgym_hip_debug.h)")
     ap.add_argument("extra", nargs="*", help="extra hipcc flags, e.g. -Rpass-analysis=kernel-resource-usage")
     a = ap.parse_args()
     try:
-        build(a.force, a.jobs, a.extra)
+        build(a.force, a.jobs, a.extra, experiments=a.experiments)
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

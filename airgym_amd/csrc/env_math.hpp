@@ -96,6 +96,7 @@ struct StepParams {
     uint32_t tick;         // env-step index of the handle
     uint32_t env_id_offset;
     uint32_t noise_off;
+    uint32_t fix_time_outs; // AG_FLAG_FIX_TIME_OUTS (opt-in): see step_timeout()
     // reset distribution (hovering.py:316-329 / tracking.py:166-179)
     float reset_pos_scale[3], reset_pos_offset[3], reset_euler_scale[3];
     float reset_linvel_scale, reset_angvel_scale;
@@ -105,7 +106,7 @@ struct StepParams {
 // hovering.py:316-329 / tracking.py:166-179).  The oracle multiplies f32 tensors by python
 // doubles, i.e. the scalar is rounded to f32 once: dt, dt/2 and dt/6 are formed in double first.
 inline StepParams make_step_params(int task, double dt, int max_episode_length, const float* target18, uint64_t seed,
-                                   uint32_t env_id_offset, bool noise_off) {
+                                   uint32_t env_id_offset, bool noise_off, bool fix_time_outs = false) {
     StepParams P;
     P.dt = (float)dt;
     P.half_dt = (float)(0.5 * dt);
@@ -118,6 +119,7 @@ inline StepParams make_step_params(int task, double dt, int max_episode_length, 
     P.tick = 0;
     P.env_id_offset = env_id_offset;
     P.noise_off = noise_off ? 1u : 0u;
+    P.fix_time_outs = fix_time_outs ? 1u : 0u;
     if (task == 1) {
         P.reset_pos_scale[0] = P.reset_pos_scale[1] = P.reset_pos_scale[2] = 0.1f;
         P.reset_pos_offset[0] = P.reset_pos_offset[1] = 0.0f;
@@ -768,6 +770,15 @@ AG_HD void compute_reward(const EnvState& s, const float* R, const float* a, con
     o.done = done;
 }
 
+// time_out_buf, hovering.py:304: `progress_buf > max_episode_length`, evaluated AFTER reset_idx has zeroed the progress of
+// every env that reached max - 1 (:435) - never true, so the PPO loop's time-out bootstrap (a2c_base.py:672-673) never
+// fires (quirk Q3; reproduced by default).  P.fix_time_outs (AG_FLAG_FIX_TIME_OUTS, opt-in) flags instead the envs whose
+// episode reached the time limit this step: progress_end = progress_buf after the increment, before the reset.
+AG_HD int step_timeout(int progress_end, int progress_now, const StepParams& P) {
+    return P.fix_time_outs ? ((progress_end >= P.max_episode_length - 1) ? 1 : 0)
+                           : ((progress_now > P.max_episode_length) ? 1 : 0);
+}
+
 // ---------------------------------------------------------------------------
 // One full env step (Hovering.step, hovering.py:286-308), in two halves so that a kernel can put the state stores
 // between them (the state is final after the physics unless the env terminates):
@@ -854,9 +865,10 @@ AG_HD void env_step(EnvState& s, CtlState& c, float* pre_a, const float* raw_act
     env_observe_reward<TASK, CTL, EXT, CLEAN_OBS>(s, a, pre_a, o.cmd, P, env_global, ext_noise, obs, o);
 #pragma unroll
     for (int i = 0; i < A; ++i) pre_a[i] = a[i];  // hovering.py:369
+    const int progress_end = s.progress;
     s.was_reset = o.done;
     if (o.done) env_reset_done<CTL, EXT>(s, c, pre_a, P, env_global, ext_uniforms);
-    o.timeout = (s.progress > P.max_episode_length) ? 1 : 0;  // hovering.py:304 (never true, Q3)
+    o.timeout = step_timeout(progress_end, s.progress, P);  // hovering.py:304 (never true by default, Q3)
 }
 
 // reset_idx(all) at creation / BaseTask.reset (base_task.py:107-111)

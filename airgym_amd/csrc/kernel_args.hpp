@@ -39,7 +39,6 @@ struct KArgs {
     // parity / inspection mode (ag_eval_obs_reward): processed actions + controller output supplied by the caller
     const float* eval_actions;   // [n, A]
     const float* eval_cmd;       // [n, 4]
-    int stagger;                 // experiment (ag_set_launch_params): every second workgroup of a CU starts this many x 0.5 us late
     // RNG tick lives in device memory so that a captured hipGraph of env steps replays with fresh
     // counters: each launch reads tick_in and thread 0 publishes tick+1 to tick_out (the two slots
     // alternate launch to launch; stream order between launches makes the hand-off race-free).
@@ -47,6 +46,26 @@ struct KArgs {
     uint32_t* tick_out;
     int n;
     StepParams P;
+};
+
+// Rollout head + tail fused into the env-step launch (ag_step_rollout_fused; step_kernel_ws2<.., true>): what
+// ag_policy_sample reads / writes in front of the step and what ag_rollout_account reads / writes behind it
+// (lib/agent/a2c_base.py:651-695).
+struct TailArgs {
+    const float* heads;          // [n, A+1] mu | normalised value
+    const float* logstd;         // [A]
+    const double* vmean;         // [1] or null (value de-normalisation, base_model.py:29-35)
+    const double* vvar;
+    float veps;
+    uint32_t key0, key1;         // Philox key of the action noise
+    const long long* counter;    // [1] rollout counter (device): tick = counter * horizon + slot
+    int horizon, slot;
+    long long id_offset;         // global id of local env 0 for the action noise
+    float* actions; float* neglogp; float* values; float* mus; float* sigmas;   // rollout slot t
+    float scale, shift, min_val, max_val; int log_val; float gamma; int bootstrap;   // reward shaper, time-out bootstrap
+    float* shaped;               // [n] shaped reward of slot t
+    float* cur_rew; float* cur_shaped; float* cur_len;   // [n] running episode sums (read-modify-write)
+    double* partials;            // [ceil(n/64), 4] per-tile {episodes ended, sum reward, sum shaped, sum length}
 };
 
 // Planning-task extras (airgym_amd/csrc/planning_kernel.hip)
@@ -75,11 +94,11 @@ hipError_t launch_avoid_render(const KArgs& k, const PlanArgs& pa, hipStream_t s
 hipError_t launch_custom_reset_ids(const KArgs& k, const PlanArgs& pa, int task, int num_actions, const int* ids, int count,
                                    hipStream_t st);
 
-typedef hipError_t (*StepLauncher)(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
+typedef hipError_t (*StepLauncher)(const KArgs& k, const TailArgs* tail, hipStream_t stream);
 typedef hipError_t (*EvalLauncher)(const KArgs& k, hipStream_t stream);
 
 // defined in step_kernel.hip compiled with -DAG_TASK=<t> -DAG_CTL=<c>
-#define AG_DECL_LAUNCHER(t, c) hipError_t launch_step_##t##_##c(const KArgs& k, int block, int obs_via_lds, hipStream_t stream);
+#define AG_DECL_LAUNCHER(t, c) hipError_t launch_step_##t##_##c(const KArgs& k, const TailArgs* tail, hipStream_t stream);
 AG_DECL_LAUNCHER(0, 0) AG_DECL_LAUNCHER(0, 1) AG_DECL_LAUNCHER(0, 2) AG_DECL_LAUNCHER(0, 3) AG_DECL_LAUNCHER(0, 4)
 AG_DECL_LAUNCHER(1, 0) AG_DECL_LAUNCHER(1, 1) AG_DECL_LAUNCHER(1, 2) AG_DECL_LAUNCHER(1, 3) AG_DECL_LAUNCHER(1, 4)
 #undef AG_DECL_LAUNCHER

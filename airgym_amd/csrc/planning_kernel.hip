@@ -15,6 +15,13 @@
 #include "kernel_args.hpp"
 #include "planning_math.hpp"
 
+// experiments build only (build.py --experiments; tools/render_probe.py): parts of the render kernel can be skipped for timing
+#ifdef AG_EXPERIMENTS
+#define AG_DEBUG_SKIP(pa, bit) ((pa).debug_skip & (bit))
+#else
+#define AG_DEBUG_SKIP(pa, bit) false
+#endif
+
 namespace ag {
 
 enum : int { PHASE_BOTH = 0, PHASE_PHYS = 1, PHASE_POST = 2 };
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
         const int u = p / kCamH, v = p - u * kCamH;
         float d;
         if (SCENE == SCENE_AVOID) d = depth_pixel_box(cam, pixel_direction(cam, u, v), goal);      // GOAL holds the cube position
-        else d = (pa.debug_skip & 1) ? 3.0f : depth_pixel_culled(cam, pixel_direction(cam, u, v), cyl, ulo, uhi, u, n, goal);
+        else d = AG_DEBUG_SKIP(pa, 1) ? 3.0f : depth_pixel_culled(cam, pixel_direction(cam, u, v), cyl, ulo, uhi, u, n, goal);
         d = d > 4.5f ? 4.5f : d;
         d = fminf(fmaxf(d, 0.0f), 4.5f) / 4.5f;
         img[p] = d;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     float mx = block_reduce(vmax, red, true);
     // ---- pass 2: additive N(0, 0.1), clamp to [0, max] (customized.py:406-409); 4 pixels per Philox block
     vmax = 0.0f;
-    for (int b = tid; b < ((pa.debug_skip & 2) ? 0 : kCamPix / 4); b += kRenderThreads) {
+    for (int b = tid; b < (AG_DEBUG_SKIP(pa, 2) ? 0 : kCamPix / 4); b += kRenderThreads) {
         const U4 r = philox4x32_10(env_global, P.tick, STREAM_IMG_ADD, (uint32_t)b, P.key0, P.key1);
         float z[4];
         box_muller(r.x, r.y, z[0], z[1]);
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     }
     mx = block_reduce(vmax, red, true);
     // ---- pass 3: multiplicative N(1, 0.3), clamp to [0, max] (customized.py:411-414)
-    for (int b = tid; b < ((pa.debug_skip & 2) ? 0 : kCamPix / 4); b += kRenderThreads) {
+    for (int b = tid; b < (AG_DEBUG_SKIP(pa, 2) ? 0 : kCamPix / 4); b += kRenderThreads) {
         const U4 r = philox4x32_10(env_global, P.tick, STREAM_IMG_MUL, (uint32_t)b, P.key0, P.key1);
         float z[4];
         box_muller(r.x, r.y, z[0], z[1]);
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(kRenderThreads) void planning_render_kernel(const K
     // ---- pass 4: 5x5 cross-correlation with zero padding (F.conv2d, customized.py:416-424), min pixel
     float vmin = kInf;
     float* out = pa.image + (size_t)env * kCamPix;
-    for (int p = tid; p < ((pa.debug_skip & 4) ? 0 : kCamPix); p += kRenderThreads) {
+    for (int p = tid; p < (AG_DEBUG_SKIP(pa, 4) ? 0 : kCamPix); p += kRenderThreads) {
         const int u = p / kCamH, v = p - u * kCamH;
         float acc = 0.0f;
         if (u >= 2 && u < kCamW - 2 && v >= 2 && v < kCamH - 2) {     // interior: no bounds checks (97 % of the pixels)

@@ -11,11 +11,9 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/airgym_hip.h"
-#include "env_math.hpp"
+#include "rollout_math.hpp"
 
 namespace {
-
-constexpr uint32_t kStreamPolicy = 16;   // Philox stream id of the action noise (env streams are 0..5)
 
 struct SampleArgs {
     const float* heads; const float* logstd; const double* vmean; const double* vvar; float veps;
@@ -31,34 +29,23 @@ __global__ __launch_bounds__(256) void policy_sample_kernel(const SampleArgs k) 
     const uint32_t tick = (uint32_t)(*k.counter) * (uint32_t)k.horizon + (uint32_t)k.slot;
     const uint32_t env = (uint32_t)(k.id_offset + i);
     float z[6];
-    {
-        const ag::U4 r = ag::philox4x32_10(env, tick, kStreamPolicy, 0u, k.key0, k.key1);
-        ag::box_muller(r.x, r.y, z[0], z[1]);
-        ag::box_muller(r.z, r.w, z[2], z[3]);
-        if (A > 4) {
-            const ag::U4 r2 = ag::philox4x32_10(env, tick, kStreamPolicy, 1u, k.key0, k.key1);
-            ag::box_muller(r2.x, r2.y, z[4], z[5]);
-        }
-    }
-    const float* h = k.heads + (size_t)i * (A + 1);
-    float q = 0.f, ls_sum = 0.f;
+    ag::policy_normals<A>(env, tick, k.key0, k.key1, z);
+    float h[A + 1], ls[A], act[A], mu[A], sigma[A], ea[A], nlp, v;
+#pragma unroll
+    for (int a = 0; a <= A; ++a) h[a] = k.heads[(size_t)i * (A + 1) + a];
+#pragma unroll
+    for (int a = 0; a < A; ++a) ls[a] = k.logstd[a];
+    const bool denorm = k.vmean != nullptr;
+    ag::policy_sample_row<A>(h, ls, z, denorm, denorm ? (float)k.vmean[0] : 0.f, denorm ? (float)k.vvar[0] : 1.f, k.veps, act, mu,
+                             sigma, ea, nlp, v);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-        const float ls = k.logstd[a];
-        const float sigma = expf(ls);
-        const float mu = h[a];
-        const float act = mu + sigma * z[a];
-        const float zz = (act - mu) / sigma;      // what the update recomputes from the stored action
-        q += zz * zz;
-        ls_sum += ls;
-        k.actions[(size_t)i * A + a] = act;
-        k.mus[(size_t)i * A + a] = mu;
-        k.sigmas[(size_t)i * A + a] = sigma;
-        if (k.env_actions) k.env_actions[(size_t)i * A + a] = fminf(fmaxf(act, -1.0f), 1.0f);
+        k.actions[(size_t)i * A + a] = act[a];
+        k.mus[(size_t)i * A + a] = mu[a];
+        k.sigmas[(size_t)i * A + a] = sigma[a];
+        if (k.env_actions) k.env_actions[(size_t)i * A + a] = ea[a];
     }
-    k.neglogp[i] = 0.5f * q + 0.5f * 1.8378770664093453f * (float)A + ls_sum;
-    float v = h[A];
-    if (k.vmean) v = sqrtf((float)k.vvar[0] + k.veps) * fminf(fmaxf(v, -5.0f), 5.0f) + (float)k.vmean[0];
+    k.neglogp[i] = nlp;
     k.values[i] = v;
 }
 
@@ -74,9 +61,7 @@ __global__ __launch_bounds__(256) void rollout_account_kernel(const AccountArgs 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < k.n) {
         const float r = k.raw_reward[i];
-        float sh = (r + k.shift) * k.scale;
-        sh = fminf(fmaxf(sh, k.min_val), k.max_val);
-        if (k.log_val) sh = logf(sh);
+        float sh = ag::shape_reward(r, ag::ShapeParams{k.scale, k.shift, k.min_val, k.max_val, k.log_val, k.gamma});
         if (k.timeouts && k.timeouts[i]) sh += k.gamma * k.values[i];
         k.shaped[i] = sh;
         float cr = k.cur_rew[i] + r, cs = k.cur_shaped[i] + sh, cl = k.cur_len[i] + 1.0f;

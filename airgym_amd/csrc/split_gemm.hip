@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "../../include/airgym_hip.h"
+#include "split_common.hpp"
 
 namespace {
 
@@ -32,38 +33,6 @@ constexpr int BM = 128, BN = 256, BK = 16, KDIM = 256;
 constexpr int A_UNITS = 3 * 2 * BM;       // 16-byte units per A stage
 constexpr int B_UNITS = 3 * 2 * BN;       // 16-byte units per B stage
 constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
-
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-// (x, y) -> packed bf16 pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 (x in the low half)
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float x, float y) {
-    const f32x2_t v = {x, y};
-    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
-    return *reinterpret_cast<const uint32_t*>(&b);
-}
-
-// Exact 3-way split of two consecutive-k floats into bf16 pieces, one packed word per plane.  a1 = rn_bf16(a), a2 =
-// rn_bf16(a - a1), a3 = a - a1 - a2: both differences are exact in f32 and the last one has at most 8 significant bits, so
-// a == a1 + a2 + a3 with |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a| (round to nearest; truncation would give 2^-7 / 2^-15).
-__device__ __forceinline__ void split_pair(float x, float y, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
-    w1 = cvt_pk_bf16(x, y);
-    const float rx = x - __uint_as_float(w1 << 16), ry = y - __uint_as_float(w1 & 0xFFFF0000u);
-    w2 = cvt_pk_bf16(rx, ry);
-    const float sx = rx - __uint_as_float(w2 << 16), sy = ry - __uint_as_float(w2 & 0xFFFF0000u);
-    w3 = cvt_pk_bf16(sx, sy);
-}
-
-// 8 consecutive-k floats -> three 16-byte bf16x8 units (one per plane)
-__device__ __forceinline__ void split8(const float4 lo, const float4 hi, uint4& p1, uint4& p2, uint4& p3) {
-    split_pair(lo.x, lo.y, p1.x, p2.x, p3.x);
-    split_pair(lo.z, lo.w, p1.y, p2.y, p3.y);
-    split_pair(hi.x, hi.y, p1.z, p2.z, p3.z);
-    split_pair(hi.z, hi.w, p1.w, p2.w, p3.w);
-}
 
 // Weight preparation: W [256, 256] f32 (row-major) -> planes [chunk 16][plane 3][k-half 2][n 256] x 8 bf16, the per-chunk LDS
 // image of the main loop.  transpose = 0: B[n][k] = W[n][k] (forward, X W^T); 1: B[n][k] = W[k][n] (backward dX = dZ W).
@@ -469,24 +438,30 @@ extern "C" int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, 
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
-constexpr bool kOrderedDefault = false;
-static int g_split_variant = -1;      // -1 = the default: plain 2 x 2 grid at every size (in-situ A/B, profiles/r02_split_gemm.md)
+constexpr int kDefaultVar = 2;      // 2 x 2 waves, plain grid
+// Scheduling variants (VAR bits 0 / 2 / 3) and timing ablations (ABL) are measured negatives (profiles/r02_split_gemm.md): the
+// shipped library instantiates the plain 2 x 2 grid only; the experiments build keeps the others selectable for tools/.
+#ifdef AG_EXPERIMENTS
+static int g_split_variant = -1;      // -1 = the default
 extern "C" int ag_debug_split_gemm_variant(int variant) {
     if (variant < -1 || variant > 231) return AG_ERR_INVALID_ARG;      // unknown values are refused at launch
     g_split_variant = variant;
     return AG_OK;
 }
+#endif
 
 constexpr size_t kSplitLds = (size_t)2 * STAGE_UNITS * 16;
 
 template <bool HAS_BIAS, int VAR, int A1, int ABL, int DIN>
 static int launch_split_any(const float* A_dev, const void* planes_dev, float* C_dev, int M, const SplitEpilogue& ep, void* stream) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {};      // per device ordinal: the dynamic-LDS limit is an attribute of (function, device)
     auto* fn = split_gemm_kernel<HAS_BIAS, VAR, A1, ABL, DIN>;
-    if (!attr_set) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess)
             return AG_ERR_HIP;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     int tiles = (M + BM - 1) / BM;
     if (VAR & 4) tiles = tiles < 512 ? tiles : 512;        // persistent: 2 workgroups on each of the 256 CUs
@@ -516,11 +491,16 @@ extern "C" int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_de
     if (!A_dev || !planes_dev || !bias_dev || !Wh_dev || !bh_dev || !Z_dev || !heads_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM || (A1 != 5 && A1 != 6)) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
-    const bool persistent = g_split_variant >= 0 && (g_split_variant & 4) != 0;
-    const bool ordered = g_split_variant >= 0 ? (g_split_variant & 1) != 0 : kOrderedDefault;
 #define AG_SGH(V, A) launch_split_heads<V, A>(A_dev, planes_dev, bias_dev, Wh_dev, bh_dev, Z_dev, heads_dev, M, stream)
-    if (A1 == 5) return persistent ? (ordered ? AG_SGH(7, 5) : AG_SGH(6, 5)) : (ordered ? AG_SGH(3, 5) : AG_SGH(2, 5));
-    return persistent ? (ordered ? AG_SGH(7, 6) : AG_SGH(6, 6)) : (ordered ? AG_SGH(3, 6) : AG_SGH(2, 6));
+#ifdef AG_EXPERIMENTS
+    const bool persistent = g_split_variant >= 0 && (g_split_variant & 4) != 0;
+    const bool ordered = g_split_variant >= 0 && (g_split_variant & 1) != 0;
+    if (persistent || ordered) {
+        if (A1 == 5) return persistent ? (ordered ? AG_SGH(7, 5) : AG_SGH(6, 5)) : AG_SGH(3, 5);
+        return persistent ? (ordered ? AG_SGH(7, 6) : AG_SGH(6, 6)) : AG_SGH(3, 6);
+    }
+#endif
+    return A1 == 5 ? AG_SGH(kDefaultVar, 5) : AG_SGH(kDefaultVar, 6);
 #undef AG_SGH
 }
 
@@ -533,12 +513,20 @@ extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes
     if (((uintptr_t)dZ_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
     SplitEpilogue ep = {};
     ep.h1 = h1_dev; ep.x = x_dev; ep.dw_partials = dw_partials_dev; ep.db_partials = db_partials_dev;
-    const bool persistent = g_split_variant >= 0 && (g_split_variant & 4) != 0;
 #define AG_SGI(V, DV) launch_split_any<false, V, 0, 0, DV>(dZ_dev, planes_dev, nullptr, M, ep, stream)
+#ifdef AG_EXPERIMENTS
+    if (g_split_variant >= 0 && (g_split_variant & 4) != 0) {
+        switch (D) {
+            case 16: return AG_SGI(6, 16);
+            case 18: return AG_SGI(6, 18);
+            default: return AG_SGI(6, 20);
+        }
+    }
+#endif
     switch (D) {
-        case 16: return persistent ? AG_SGI(6, 16) : AG_SGI(2, 16);
-        case 18: return persistent ? AG_SGI(6, 18) : AG_SGI(2, 18);
-        default: return persistent ? AG_SGI(6, 20) : AG_SGI(2, 20);
+        case 16: return AG_SGI(kDefaultVar, 16);
+        case 18: return AG_SGI(kDefaultVar, 18);
+        default: return AG_SGI(kDefaultVar, 20);
     }
 #undef AG_SGI
 }
@@ -548,9 +536,10 @@ extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const f
     if (!A_dev || !planes_dev || !C_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
-    // plain 2 x 2 by default: back to back in a loop the persistent de-phased form (6) is faster at M = 196 608, between the
+    // plain 2 x 2 grid: back to back in a loop the persistent de-phased form (6) is faster at M = 196 608, between the
     // update's other kernels it is 7 us slower (in-situ kernel traces, profiles/r02_split_gemm.md)
-    const int variant = g_split_variant >= 0 ? g_split_variant : (2 | (kOrderedDefault ? 1 : 0));
+#ifdef AG_EXPERIMENTS
+    const int variant = g_split_variant >= 0 ? g_split_variant : kDefaultVar;
     switch (variant) {
         case 2: return launch_split<2>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 3: return launch_split<3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
@@ -558,14 +547,16 @@ extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const f
         case 7: return launch_split<7>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 14: return launch_split<14>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 15: return launch_split<15>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-#ifdef AG_SPLIT_ABLATIONS      /* timing experiments only (results are wrong by construction): tools/split_gemm_probe.py --variants */
+        /* timing ablations (results are wrong by construction): tools/split_gemm_probe.py --variants */
         case 100 + 3: return launch_split<6, 3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 100 + 8: return launch_split<6, 8>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 100 + 31: return launch_split<6, 31>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 200 + 3: return launch_split<7, 3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 200 + 8: return launch_split<7, 8>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
         case 200 + 31: return launch_split<7, 31>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-#endif
         default: return AG_ERR_INVALID_ARG;
     }
+#else
+    return launch_split<kDefaultVar>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
+#endif
 }

@@ -16,7 +16,7 @@ from . import _native as N
 
 class HipEnvHandle:
     def __init__(self, task, ctl_mode, num_envs, device="cuda:0", seed=0, env_id_offset=0, dt=0.01,
-                 max_episode_length=0, target_state=None, reward_terms=True, obs_noise=True):
+                 max_episode_length=0, target_state=None, reward_terms=True, obs_noise=True, fix_time_outs=False):
         if task not in N.AG_TASKS:
             raise ValueError(f"Task with name: {task} was not registered")
         if ctl_mode not in N.AG_CTL_MODES:
@@ -36,7 +36,11 @@ class HipEnvHandle:
         cfg.ctl_mode = N.AG_CTL_MODES[ctl_mode]
         cfg.num_envs = self.num_envs
         cfg.device = self.device.index or 0
-        cfg.flags = (N.AG_FLAG_REWARD_TERMS if reward_terms else 0) | (0 if obs_noise else N.AG_FLAG_OBS_NOISE_OFF)
+        cfg.flags = ((N.AG_FLAG_REWARD_TERMS if reward_terms else 0) | (0 if obs_noise else N.AG_FLAG_OBS_NOISE_OFF)
+                     | (N.AG_FLAG_FIX_TIME_OUTS if fix_time_outs else 0))
+        if fix_time_outs and task not in ("hovering", "tracking"):
+            raise ValueError("fix_time_outs: Hovering / Tracking only")
+        self.fix_time_outs = bool(fix_time_outs)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.env_id_offset = int(env_id_offset)
         cfg.dt = float(dt)
@@ -167,6 +171,22 @@ class HipEnvHandle:
         N.check(self.lib.ag_step_rollout(self.h, actions.data_ptr(), obs_out.data_ptr(), rew_out.data_ptr(),
                                          done_out.data_ptr(), tp, self._stream()), "ag_step_rollout")
 
+    def step_rollout_fused(self, tail, obs_out, rew_out, done_out, term_sums=None):
+        """One rollout step in ONE launch: policy sampling + env step + reward shaping / episode accounting
+        (ag_step_rollout_fused).  `tail` is a filled N.AgRolloutTail; the other arguments as step_rollout."""
+        n = self.num_envs
+        assert obs_out.is_contiguous() and obs_out.dtype == torch.float32 and obs_out.numel() == n * self.num_obs
+        assert rew_out.is_contiguous() and rew_out.dtype == torch.float32 and rew_out.numel() == n
+        assert done_out.is_contiguous() and done_out.dtype == torch.uint8 and done_out.numel() == n
+        assert obs_out.device == self.device and rew_out.device == self.device and done_out.device == self.device
+        tp = None
+        if term_sums is not None:
+            assert term_sums.is_contiguous() and term_sums.dtype == torch.float32 and term_sums.device == self.device
+            assert term_sums.numel() == self.lib.ag_term_sum_tiles(n) * 12
+            tp = term_sums.data_ptr()
+        N.check(self.lib.ag_step_rollout_fused(self.h, ctypes.byref(tail), obs_out.data_ptr(), rew_out.data_ptr(),
+                                               done_out.data_ptr(), tp, self._stream()), "ag_step_rollout_fused")
+
     def eval_obs_reward(self, processed_actions, cmd_thrusts, noise=None):
         """compute_observations + compute_quadcopter_reward on the CURRENT state with the reference-recorded inputs
         (ag_eval_obs_reward; parity tests).  Results land in obs_buf / rew_buf / reset_buf / reward_terms."""
@@ -254,7 +274,7 @@ class HipEnvHandle:
         return bool(r)
 
     def planning_render_next_step(self, debug_skip=0):
-        if debug_skip:
+        if debug_skip:      # experiments build only (AIRGYM_EXPERIMENTS=1)
             N.check(self.lib.ag_debug_planning_render_parts(self.h, int(debug_skip)), "ag_debug_planning_render_parts")
         else:
             N.check(self.lib.ag_planning_render_now(self.h), "ag_planning_render_now")
@@ -296,9 +316,6 @@ class HipEnvHandle:
         ts = np.asarray(target_state, dtype=np.float32).reshape(18)
         arr = (ctypes.c_float * 18)(*[float(x) for x in ts])
         N.check(self.lib.ag_set_target_state(self.h, arr), "ag_set_target_state")
-
-    def set_launch_params(self, block_size=64, obs_via_lds=True):
-        N.check(self.lib.ag_set_launch_params(self.h, int(block_size), int(obs_via_lds)), "ag_set_launch_params")
 
     @property
     def tick(self):

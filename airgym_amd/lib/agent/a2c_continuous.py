@@ -405,7 +405,9 @@ class A2CAgent:
         if count_moments and self.normalize_input:
             mean, var, cnt = self._img_moments
             bc = float(img.shape[0])
-            bm, bv = img.mean(0).double(), img.var(0).double()
+            # unbiased like RunningMeanStd.update (running_mean_std.py:31-62); one env has no variance estimate: 0, not NaN
+            bm = img.mean(0).double()
+            bv = img.var(0).double() if img.shape[0] > 1 else torch.zeros_like(bm)
             delta = bm - mean
             tot = cnt + bc
             m2 = var * cnt + bv * bc + delta ** 2 * cnt * bc / tot
@@ -510,11 +512,12 @@ class A2CAgent:
     @torch.no_grad()
     def play_steps(self):
         H = self.horizon_length
-        # capture needs an even horizon (device tick ping-pong); Planning decides on the HOST, at capture time, which steps
-        # render the camera (every 4th, planning.py:153-156), so its cadence survives replay only if H % 4 == 0
-        planning = getattr(self._hip_env, "task", None) == "planning"
+        # capture needs an even horizon (device tick ping-pong); the camera tasks (Planning, Avoid) decide on the HOST, at
+        # capture time, which steps render (every 4th, planning.py:153-156, avoid.py:181-185), so the cadence survives replay
+        # only if H % 4 == 0
+        camera = self._hip_env is not None and getattr(self._hip_env, "image", None) is not None
         graphable = (self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0
-                     and (not planning or H % 4 == 0)
+                     and (not camera or H % 4 == 0)
                      and not self._cache_latents)      # the frozen encoder runs MIOpen's find step: not inside a capture
         fr = self._fused_rollout
 
@@ -621,6 +624,7 @@ class A2CAgent:
         loss.backward()
         with torch.no_grad():
             self.flat_grad[-1] = stats[4]
+        self._last_clip = stats[5]      # diagnostics/clip_frac/<mini-epoch> on the dict-observation configs too
         return stats[0], stats[1], stats[2], stats[3], None, None
 
     def _loss_and_backward(self, mb):
@@ -749,6 +753,15 @@ class A2CAgent:
             if getattr(self, "_cache_latents", False):
                 # the update sees features, not images: the image normaliser takes this rollout's rendered images here instead
                 mean, var, cnt = self._img_moments
+                if self.multi_gpu and self.sync_normalizers:
+                    # the same statistics on every rank (like RunningMeanStd.update with a group): merge the ranks' moments
+                    packed = torch.cat(((mean * cnt).reshape(-1), ((var + mean * mean) * cnt).reshape(-1), cnt.reshape(1)))
+                    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+                    npx = mean.numel()
+                    tot = packed[-1].clamp_min(1.0)
+                    gmean = (packed[:npx] / tot).view_as(mean)
+                    gvar = ((packed[npx:2 * npx] / tot).view_as(var) - gmean * gmean).clamp_min(0.0)
+                    mean, var, cnt = gmean, gvar, packed[-1]
                 self.model.running_mean_std.running_mean_std["image"].merge_moments(mean, var, cnt)
                 for t in self._img_moments:
                     t.zero_()
@@ -940,8 +953,9 @@ class A2CAgent:
     def set_full_state_weights(self, weights, set_epoch=True):
         sd = weights["model"]
         own = self.model.state_dict()
-        # a frozen VAE encoder is not part of this model's state (it is loaded from vae_model.pth); the reference registers it
-        # as `actor_enc.*` and saves it with the policy: accept such checkpoints by dropping those keys
+        # a frozen VAE encoder is not part of this model's state (it is loaded from vae_model.pth); the reference's
+        # VAEImageEncoder is not an nn.Module either and is never saved - `actor_enc.*` keys can only come from checkpoints of
+        # earlier versions of this build, which are accepted by dropping them
         extra = [k for k in sd if k.startswith("actor_enc.") and k not in own]
         if extra:
             sd = {k: v for k, v in sd.items() if k not in extra}

@@ -123,6 +123,7 @@ class FusedMLPStep:
         self.in_wg_blocks = (M + irows - 1) // irows
         self.head_wg_partials = torch.empty(self.wg_blocks, self.A + 1, self.layers[-1][0].shape[0], **f)
         self.bias_partials, self.wgrad_partials = [], []
+        self.split_wgrad = set()      # layers whose weight gradient runs on the bf16 matrix cores (256 x 256, li >= 1)
         for li, (w, _, _, _) in enumerate(self.layers):
             C, K = w.shape
             if li == L - 1:
@@ -134,6 +135,10 @@ class FusedMLPStep:
             self.bias_partials.append(torch.empty(nb, C, **f))
             if li == 0 and self.fuse_input_wgrad:
                 self.wgrad_partials.append(torch.empty(self.in_wg_blocks, C, K, **f))
+            elif self._split_wgrad_ok(w, agent.config):
+                # ag_split_wgrad: one partial per row slice (= per CU), each operand read once (csrc/split_wgrad.hip)
+                self.wgrad_partials.append(torch.empty(self.lib.ag_split_wgrad_slices(M), C, K, **f))
+                self.split_wgrad.add(li)
             else:
                 self.wgrad_partials.append(torch.empty(SPLIT_K, C, K, **f))
         # every partial-sum reduction of the step runs in ONE ag_sum_rows_multi call (two launches) after the backward
@@ -162,6 +167,18 @@ class FusedMLPStep:
         self.fuse_gemm_heads = bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 in (5, 6)
         self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 8, **f)
         self.k = 0
+
+    @staticmethod
+    def _split_wgrad_ok(weight, config):
+        return SplitGemm256.applies(weight, config) and bool(config.get("use_split_wgrad", True))
+
+    @property
+    def gemm_description(self):
+        if not self.split:
+            return "library f32 GEMM"
+        return ("ag_split_gemm: exact 3-way bf16 split of every f32 operand, 6 bf16 MFMAs per product, f32 accumulate "
+                "(float32-accurate; tests/test_gpu_split_gemm.py) for forward, dX"
+                + (" and dW (ag_split_wgrad: no library GEMM left in the update)" if self.split_wgrad else "; dW = library f32"))
 
     def begin_epoch(self):
         self.k = 0
@@ -286,7 +303,11 @@ class FusedMLPStep:
             else:
                 N.check(lib.ag_elu_bwd_bias(dh.data_ptr(), h.data_ptr(), dz.data_ptr(), parts.data_ptr(), M, C, st),
                         "ag_elu_bwd_bias")
-            torch.bmm(dz.view(S, M // S, C).transpose(1, 2), xin.view(S, M // S, K), out=self.wgrad_partials[li])
+            if li in self.split_wgrad:
+                wp = self.wgrad_partials[li]
+                N.check(lib.ag_split_wgrad(dz.data_ptr(), xin.data_ptr(), wp.data_ptr(), M, C, K, wp.shape[0], st), "ag_split_wgrad")
+            else:
+                torch.bmm(dz.view(S, M // S, C).transpose(1, 2), xin.view(S, M // S, K), out=self.wgrad_partials[li])
             if li == 1 and self.fuse_gemm_input_wgrad:
                 self.split[1].backward_input_wgrad(dz, self.h[0], inputs[0], self.wgrad_partials[0], self.bias_partials[0])
                 break
@@ -307,9 +328,9 @@ class FusedMLPStep:
 
 
 class FusedRolloutStep:
-    """One step of A2CBase.play_steps (lib/agent/a2c_base.py:651-695) as six launches:
-    ag_mlp_input_layer -> [GEMM (+ELU)] -> ag_elu_heads -> ag_policy_sample -> ag_step_rollout -> ag_rollout_account
-    (+ two one-kernel reductions for the logged statistics).  The action noise is Philox-based and counter-keyed, so the
+    """One step of A2CBase.play_steps (lib/agent/a2c_base.py:651-695) as three launches:
+    ag_mlp_input_layer -> ag_split_gemm_elu_heads -> ag_step_rollout_fused (policy sampling + env step + reward / episode
+    accounting; `fuse_rollout_tail: false` = the separate ag_policy_sample -> ag_step_rollout -> ag_rollout_account launches).  The action noise is Philox-based and counter-keyed, so the
     captured hipGraph of the whole rollout draws fresh noise on every replay (begin_rollout bumps the device counter)."""
 
     @staticmethod
@@ -353,6 +374,52 @@ class FusedRolloutStep:
                                          dtype=torch.float64, device=dev)
         self.seed = (int(agent.params.get("seed", 0) or 0) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & 0xFFFFFFFFFFFFFFFF
         self.id_offset = agent.global_rank * n
+        # policy sampling + env step + reward / episode accounting in ONE launch (ag_step_rollout_fused): the rollout step is
+        # input layer -> GEMM (+heads) -> that launch
+        self.fuse_tail = bool(agent.config.get("fuse_rollout_tail", True))
+        if self.fuse_tail:
+            self.acct_partials = torch.zeros(agent.horizon_length, self.lib.ag_term_sum_tiles(n), 4, dtype=torch.float64, device=dev)
+        self._tails = {}
+
+    @property
+    def launches_per_step(self):
+        gemms = len(self.layers) - 1
+        return 1 + gemms + (0 if (self.fuse_gemm_heads and self.split) else 1) + (1 if self.fuse_tail else 3)
+
+    def _tail(self, slot):
+        """ag_rollout_tail of rollout slot `slot` (pointers are fixed for the life of the agent: built once per slot)"""
+        t = self._tails.get(slot)
+        if t is not None:
+            return t
+        ag, m = self.agent, self.agent.model
+        vms = m.value_mean_std if m.normalize_value else None
+        sh = ag.rewards_shaper
+        t = N.AgRolloutTail()
+        t.struct_size = ctypes.sizeof(N.AgRolloutTail)
+        t.heads_dev = self.heads.data_ptr()
+        t.logstd_dev = m.logstd.data_ptr()
+        t.vmean_dev = vms.running_mean.data_ptr() if vms is not None else None
+        t.vvar_dev = vms.running_var.data_ptr() if vms is not None else None
+        t.veps = float(vms.epsilon) if vms is not None else 0.0
+        t.seed = self.seed
+        t.counter_dev = self.counter.data_ptr()
+        t.horizon, t.slot, t.id_offset = ag.horizon_length, slot, self.id_offset
+        t.actions_dev = ag.actions_buf[slot].data_ptr()
+        t.neglogp_dev = ag.neglogpacs_buf[slot].data_ptr()
+        t.values_dev = ag.values_buf[slot].data_ptr()
+        t.mus_dev = ag.mus_buf[slot].data_ptr()
+        t.sigmas_dev = ag.sigmas_buf[slot].data_ptr()
+        t.scale, t.shift = float(sh.scale_value), float(sh.shift_value)
+        t.min_val, t.max_val = float(sh.min_val), float(sh.max_val)
+        t.log_val, t.gamma = int(bool(sh.log_val)), float(ag.gamma)
+        t.bootstrap_timeouts = int(bool(ag.value_bootstrap))
+        t.shaped_dev = ag.rewards_buf[slot].data_ptr()
+        t.cur_rew_dev = ag.current_rewards.data_ptr()
+        t.cur_shaped_dev = ag.current_shaped_rewards.data_ptr()
+        t.cur_len_dev = ag.current_lengths.data_ptr()
+        t.partials_dev = self.acct_partials[slot].data_ptr()
+        self._tails[slot] = t
+        return t
 
     def begin_rollout(self):
         self.counter.add_(1)      # captured with the rollout graph: every replay advances the noise counter
@@ -429,6 +496,10 @@ class FusedRolloutStep:
         ag, lib, m = self.agent, self.lib, self.agent.model
         n, A = self.n, self.A
         self.heads_of(ag.obs_buf[slot])
+        if self.fuse_tail:
+            ag._hip_env.step_rollout_fused(self._tail(slot), ag.obs_buf[slot + 1], ag.raw_rewards_buf[slot], ag.dones_buf[slot + 1],
+                                           ag._term_tiles[slot] if ag._term_tiles is not None else None)
+            return
         st = self._stream()
         vms = m.value_mean_std if m.normalize_value else None
         N.check(lib.ag_policy_sample(self.heads.data_ptr(), m.logstd.data_ptr(),

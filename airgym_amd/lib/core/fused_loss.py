@@ -47,7 +47,9 @@ class _FusedPPOLossFn(torch.autograd.Function):
         d_logstd = sums[4:4 + A] - float(entropy_coef)
         loss = a_loss + 0.5 * c_loss * critic_coef - entropy * entropy_coef + b_loss * float(bounds_loss_coef or 0.0)
         ctx.save_for_backward(d_heads, d_logstd)
-        stats = torch.stack((a_loss, c_loss, entropy, b_loss, kl))
+        # sums[-1] = rows whose probability ratio left [1 - e_clip, 1 + e_clip] / M = PpoDiagnostics' clip fraction
+        # (lib/core/dignostics.py:49-59; torch_ext.policy_clip_fraction :168-178)
+        stats = torch.stack((a_loss, c_loss, entropy, b_loss, kl, sums[nsums - 1]))
         ctx.mark_non_differentiable(stats)
         return loss, stats
 
@@ -59,7 +61,7 @@ class _FusedPPOLossFn(torch.autograd.Function):
 
 def fused_ppo_loss(heads, logstd, actions, old_neglogp, advantages, returns, old_values, old_mu, old_sigma, *,
                    e_clip, critic_coef, entropy_coef, bounds_loss_coef, clip_value, bound_loss_type, write_back=True):
-    """-> (loss, stats[a_loss, c_loss, entropy, b_loss, kl]).  With write_back the rows of old_mu / old_sigma are
+    """-> (loss, stats[a_loss, c_loss, entropy, b_loss, kl, clip_frac]).  With write_back the rows of old_mu / old_sigma are
     overwritten by the current policy after being read (PPODataset.update_mu_sigma)."""
     bt = BOUND_TYPES[bound_loss_type] if bounds_loss_coef is not None else 0
     return _FusedPPOLossFn.apply(heads, logstd, actions, old_neglogp, advantages, returns, old_values, old_mu,

@@ -22,8 +22,10 @@ def _blocks(lib, n, c):
 
 
 def usable(x, bn):
+    # momentum = None means a cumulative average (factor 1 / num_batches_tracked) in nn.BatchNorm2d: not implemented by the
+    # fused node, such a layer stays on the library path
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and bn.num_features <= 64
-            and bn.affine and bn.track_running_stats)
+            and bn.affine and bn.track_running_stats and bn.momentum is not None)
 
 
 class _ReluBatchNormTrain(torch.autograd.Function):
@@ -73,7 +75,7 @@ def relu_batchnorm(x, bn):
     if bn.training:
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+        momentum = float(bn.momentum)      # usable() refuses momentum = None
         return _ReluBatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, float(bn.eps))
     lib = N.load()
     n, c, h, w = x.shape

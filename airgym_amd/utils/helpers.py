@@ -48,6 +48,8 @@ def update_cfg_from_args(env_cfg, args):
             env_cfg.seed = args.seed
         if getattr(args, "env_id_offset", None) is not None:
             env_cfg.env.env_id_offset = args.env_id_offset
+        # this build's opt-in (AG_FLAG_FIX_TIME_OUTS); always assigned: the registered cfg object is shared between calls
+        env_cfg.env.fix_time_outs = bool(getattr(args, "fix_time_outs", False))
     return env_cfg
 
 

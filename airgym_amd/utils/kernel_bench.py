@@ -24,16 +24,22 @@ def algo_bytes(task, ctl_mode, num_obs, num_actions):
     return reads + writes
 
 
-KERNEL_VARIANTS = {0: "step_kernel_ws2<{t},{c},false,false>", 1: "step_kernel_ws<{t},{c}>", 2: "step_kernel_ws2<{t},{c},true,false>",
-                   3: "step_kernel_ws2<{t},{c},true,true>", 4: "step_kernel_ws2<{t},{c},false,true>"}
 _TASK_ID = {"hovering": 0, "tracking": 1}
 _CTL_ID = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
 
 
-def kernel_name(task, ctl_mode, variant=0):
-    """Symbol (as rocprofv3 prints it) of the env-step kernel a handle launches for launch-params variant `variant`."""
-    fmt = KERNEL_VARIANTS.get(variant, "step_kernel<{t},{c}," + str(variant) + ",...>")
-    return "ag::" + fmt.format(t=_TASK_ID[task], c=_CTL_ID[ctl_mode])
+def kernel_name(task, ctl_mode, fused=False):
+    """Symbol (as rocprofv3 prints it) of the env-step kernel: step_kernel_ws2<task, ctl, FUSED> (csrc/step_kernel.hip)."""
+    return "ag::step_kernel_ws2<%d,%d,%s>" % (_TASK_ID[task], _CTL_ID[ctl_mode], "true" if fused else "false")
+
+
+def fused_algo_bytes(task, ctl_mode, num_obs, num_actions):
+    """Algorithmic bytes per env-step of ag_step_rollout_fused = the env step's minus the action read (the action
+    goes from the sampler to the integrator through LDS) plus what the rollout head and tail move: heads in (A+1 f32),
+    actions / mus / sigmas (A f32 each), neglogp, values, shaped reward out, running episode reward / shaped reward / length
+    read and written."""
+    A = num_actions
+    return algo_bytes(task, ctl_mode, num_obs, A) - 4 * A + 4 * (A + 1) + 3 * 4 * A + 3 * 4 + 2 * 3 * 4
 
 
 def measure_env_kernel(env, steps_per_graph=48, replays=52, warmup_replays=3, use_graph=True, seed=1, rollout_form=True):
@@ -104,6 +110,68 @@ def measure_env_kernel(env, steps_per_graph=48, replays=52, warmup_replays=3, us
     }
 
 
+@torch.no_grad()
+def measure_fused_rollout_kernel(agent, steps_per_graph=48, replays=52, warmup_replays=3):
+    """ag_step_rollout_fused exactly as FusedRolloutStep launches it (policy sampling + env step + accounting, heads held
+    fixed at what the freshly initialised policy emits), timed like measure_env_kernel: hipGraph of launches, HIP events on the
+    launch stream.  Uses scratch rollout slots so that the agent's own buffers are not disturbed."""
+    import ctypes
+
+    from airgym_amd import _native as N
+    fr, env = agent._fused_rollout, agent._hip_env
+    dev, n, A, H = env.device, env.num_envs, env.num_actions, agent.horizon_length
+    f = dict(device=dev, dtype=torch.float32)
+    obs = torch.zeros(H + 1, n, env.num_obs, **f)
+    rew = torch.zeros(H, n, **f)
+    done = torch.zeros(H + 1, n, dtype=torch.uint8, device=dev)
+    tiles = torch.zeros(H, (n + 63) // 64, 12, **f)
+    acts, mus, sig = (torch.zeros(H, n, A, **f) for _ in range(3))
+    nlp, val, shp = (torch.zeros(H, n, **f) for _ in range(3))
+    cur = torch.zeros(3, n, **f)
+    parts = torch.zeros(H, (n + 63) // 64, 4, dtype=torch.float64, device=dev)
+    heads = torch.zeros(n, A + 1, **f)               # mu = 0 (freshly initialised policy), value 0
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    tails = []
+    for s in range(H):
+        src = fr._tail(s)
+        t = N.AgRolloutTail()
+        ctypes.memmove(ctypes.byref(t), ctypes.byref(src), ctypes.sizeof(t))
+        t.heads_dev, t.counter_dev = heads.data_ptr(), counter.data_ptr()
+        t.actions_dev, t.mus_dev, t.sigmas_dev = acts[s].data_ptr(), mus[s].data_ptr(), sig[s].data_ptr()
+        t.neglogp_dev, t.values_dev, t.shaped_dev = nlp[s].data_ptr(), val[s].data_ptr(), shp[s].data_ptr()
+        t.cur_rew_dev, t.cur_shaped_dev, t.cur_len_dev = cur[0].data_ptr(), cur[1].data_ptr(), cur[2].data_ptr()
+        t.partials_dev = parts[s].data_ptr()
+        tails.append(t)
+
+    def one(k):
+        s = k % H
+        env.step_rollout_fused(tails[s], obs[s + 1], rew[s], done[s + 1], tiles[s])
+    stream = torch.cuda.Stream(device=dev)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for k in range(4):
+            one(k)
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            for k in range(steps_per_graph):
+                one(k)
+        for _ in range(warmup_replays):
+            graph.replay()
+        stream.synchronize()
+        start.record(stream)
+        for _ in range(replays):
+            graph.replay()
+        stop.record(stream)
+        stop.synchronize()
+    total = steps_per_graph * replays
+    us = start.elapsed_time(stop) * 1e3 / total
+    b = fused_algo_bytes(env.task, env.ctl_mode, env.num_obs, A)
+    return {"us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "gbps_algorithmic": n * b / (us * 1e-6) / 1e9,
+            "algo_bytes_per_env_step": b, "steps_timed": total, "kernel": kernel_name(env.task, env.ctl_mode, True),
+            "form": "ag_step_rollout_fused"}
+
+
 def measure_copy_ceiling(device, nbytes=1 << 30, iters=20):
     """Achievable HBM bandwidth of this device: a device-to-device copy of `nbytes` (read + write counted), GB/s."""
     src = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -111,6 +179,82 @@ def measure_copy_ceiling(device, nbytes=1 << 30, iters=20):
     src.fill_(1)
     us = _time_us(lambda: dst.copy_(src), iters=iters, warmup=3)
     return 2.0 * nbytes / us / 1e3
+
+
+def env_kernel_source_sha():
+    """Provenance key of the env-step kernel: sha256 over the sources it is compiled from.  The PMC traffic figure is read
+    from a committed file (counters cannot be read live); it is only quoted when the file was measured on THESE sources."""
+    import hashlib
+    import os
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    h = hashlib.sha256()
+    for f in ("step_kernel.hip", "env_math.hpp", "kernel_args.hpp"):
+        with open(os.path.join(here, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(repo, key, kernel):
+    """(bytes per launch, source note) from profiles/*_env_kernel_pmc.json, newest round first - or (None, why not)."""
+    import glob
+    import json
+    import os
+    sha = env_kernel_source_sha()
+    why = "no PMC record for this kernel"
+    for path in sorted(glob.glob(os.path.join(repo, "profiles", "r*_env_kernel_pmc.json")), reverse=True):
+        rec = json.load(open(path)).get(key)
+        if not rec or rec.get("kernel") != kernel:
+            continue
+        if rec.get("source_sha") != sha:
+            why = (f"stale: {os.path.basename(path)} was measured on kernel sources {rec.get('source_sha')}, this build is {sha} "
+                   f"(re-run tools/gpu_pmc_env.sh)")
+            continue
+        return rec["traffic_bytes_per_launch"], rec["source"]
+    return None, why
+
+
+def roofline_object(agent, hip, args, repo):
+    """bench.py's `roofline` (+ `env_only`): the env-step kernel exactly as the PPO rollout launches it, 48 launches per hipGraph
+    x 52 replays = 2 496 steps (the 2 400-step time limit fires inside the timed region), HIP events on the launch stream."""
+    task, ctl = args.task, args.ctl
+    fr = getattr(agent, "_fused_rollout", None)
+    fused = bool(getattr(fr, "fuse_tail", False))
+    r = measure_env_kernel(hip, steps_per_graph=48, replays=52, rollout_form=True)
+    r_api = measure_env_kernel(hip, steps_per_graph=48, replays=10, rollout_form=False)
+    kname = kernel_name(task, ctl, False)
+    traffic, tsrc = (None, "PMC passes exist for 65 536 envs per launch only")
+    if args.envs == 65536:
+        traffic, tsrc = pmc_traffic(repo, f"{task}_{ctl}", kname)
+    copy_gbps = measure_copy_ceiling(agent.ppo_device)
+    roof = {
+        "bound": "hbm", "achieved": r["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
+        "kernel": kname, "entry_point": "ag_step_rollout (env step alone: actions in, obs / reward / u8 done out)",
+        "us_per_launch": r["us_per_step"], "launches_timed": r["steps_timed"],
+        "algo_bytes_per_env_step": r["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
+        "kernel_source_sha": env_kernel_source_sha(),
+        "copy_ceiling_gbps": copy_gbps, "frac_of_copy_ceiling": r["gbps_algorithmic"] / copy_gbps,
+        "drop_in_ag_step": {"us_per_launch": r_api["us_per_step"], "frac": r_api["gbps_algorithmic"] / HBM_PEAK_GBPS,
+                            "note": "ag_step: int64 reset_buf + nine per-env item_reward_info arrays + cmd_thrusts "
+                                    "(+59 B/env-step of outputs the reference's Hovering.step exposes)"},
+    }
+    out = {"roofline": roof,
+           "env_only": {"value": r["env_steps_per_s"], "unit": "env-steps/s",
+                        "note": "env-step kernel only (rollout form), synthetic N(0,1) clamped actions, hipGraph replay"}}
+    if fused:
+        rf = measure_fused_rollout_kernel(agent, steps_per_graph=48, replays=52)
+        ftraffic, fsrc = (None, "PMC passes exist for 65 536 envs per launch only")
+        if args.envs == 65536:
+            ftraffic, fsrc = pmc_traffic(repo, f"{task}_{ctl}_fused", rf["kernel"])
+        roof["rollout_fused"] = {
+            "bound": "hbm", "achieved": rf["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": rf["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": ftraffic, "traffic_source": fsrc,
+            "kernel": rf["kernel"], "entry_point": "ag_step_rollout_fused (what FusedRolloutStep launches: policy sample + env "
+                                                   "step + reward shaping / episode accounting)",
+            "us_per_launch": rf["us_per_step"], "launches_timed": rf["steps_timed"],
+            "algo_bytes_per_env_step": rf["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
+            "frac_of_copy_ceiling": rf["gbps_algorithmic"] / copy_gbps}
+    return out
 
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity figure)

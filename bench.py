@@ -2,15 +2,20 @@
 """bench.py - headline benchmark: env-steps/sec of the Hovering PPO job, 65 536 envs per GPU.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W            (no WORLD_SIZE in the environment: re-launches ITSELF as N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                (already one process per GPU: runs as launched)
 
 One "step" = one PPO epoch on synthetic (random-init policy) data: a 24-step rollout of 65 536 envs per
 GPU through the fused HIP env kernel with MLP(256,256) policy inference, GAE, and 5 mini-epochs of PPO
 updates (fp32, Adam, grad-clip, KL-adaptive LR; one RCCL all-reduce per optimizer step when N > 1).
 `value` = N * 65536 * 24 * K / wall time, wall time = max over ranks between two barriers.
 
-Extra objects on the same JSON line (rank 0, N == 1 only for cpu_baseline):
+N > 1 adds `rccl`: the ranks the process group actually has, and the latency of the job's one collective (the flat
+gradient all-reduce, a2c_base.py:293-309) timed on its own.  Fewer visible devices than --gpus: ONE JSON line with an
+`error` key, exit code 0 (nothing was measured; the driver's parser sees why).
+
+Extra objects on the same JSON line (rank 0; update_kernels / cpu_baseline / shipped_ratio at N == 1 only):
   roofline     - the env-step kernel alone: K launches replayed from a hipGraph, timed with HIP events on the
                  launch stream; achieved = 287 B/env-step * 65536 / duration vs 8 TB/s HBM peak
   env_only     - env-steps/s of that kernel-only loop (what `cpu_baseline` is comparable to)
@@ -54,6 +59,8 @@ def build_params(args, world_size):
     c["use_hip_graph"] = bool(args.graph)
     c["tuned_gemms"] = bool(getattr(args, "tuned_gemms", 1))
     c["use_split_gemm"] = bool(getattr(args, "split_gemm", 1))
+    c["use_split_wgrad"] = bool(getattr(args, "split_wgrad", 1))
+    c["fuse_rollout_tail"] = bool(getattr(args, "fuse_rollout_tail", 1))
     c["fuse_gemm_heads"] = bool(getattr(args, "fuse_gemm_heads", 1))
     c["fuse_gemm_input_wgrad"] = bool(getattr(args, "fuse_gemm_input_wgrad", 1))
     params["seed"] = 0
@@ -156,7 +163,68 @@ def shipped_ratio_line(args, world, epochs=3, warmup=2):
     return out
 
 
-def main():
+def _load_agent_class(spec):
+    """'pkg.module:Class' -> the class.  The default is the product agent; tests pass a stub (tests/_stub_bench_agent.py)
+    to exercise the launcher, the barriers and the collective without a GPU."""
+    mod, _, name = spec.partition(":")
+    import importlib
+    return getattr(importlib.import_module(mod), name)
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: check the node has N devices, then re-execute this file
+    as N ranks (rank r -> cuda:r via LOCAL_RANK; rendezvous on 127.0.0.1) and pass rank 0's JSON line through.
+    (reference launch: torchrun + LOCAL_RANK / RANK / WORLD_SIZE, lib/agent/a2c_base.py:109-123.)"""
+    import subprocess
+    have = torch.cuda.device_count() if args.device != "cpu" else args.gpus
+    if have < args.gpus:
+        print(json.dumps({"metric": f"env_steps_per_sec_{args.task}_{args.envs}_envs_per_gpu", "value": None,
+                          "unit": "env-steps/s", "n_gpus": args.gpus, "error": f"needs {args.gpus} devices, {have} visible",
+                          "devices_visible": have, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def rccl_probe(agent, world, iters=100):
+    """The job's only collective, on its own: all-reduce (sum) of the flat gradient buffer (+ the appended KL), `iters`
+    back-to-back calls on the training stream.  `ranks_seen` is what the process group reports, not what was asked for."""
+    buf = torch.zeros_like(agent.flat_grad)
+    cuda = buf.is_cuda
+    for _ in range(5):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=agent.group)
+    if cuda:
+        torch.cuda.synchronize(buf.device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=agent.group)
+    if cuda:
+        torch.cuda.synchronize(buf.device)
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=buf.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ones = torch.ones(1, dtype=torch.float64, device=buf.device)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    return {"ranks_seen": dist.get_world_size(), "ranks_counted_by_allreduce": int(ones.item()),
+            "backend": dist.get_backend(), "allreduce_us": t.item() / iters * 1e6, "bytes": buf.numel() * buf.element_size(),
+            "iters": iters, "per_epoch": agent.mini_epochs_num * agent.num_minibatches,
+            "note": "one all-reduce of the flat gradient (+KL) per optimizer step is the job's only data-path collective"}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -166,43 +234,66 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="capture the rollout in a hipGraph")
     ap.add_argument("--tuned-gemms", type=int, default=1, help="apply the shipped TunableOp GEMM table (library kernel choice)")
     ap.add_argument("--split-gemm", type=int, default=1,
-                    help="256x256 layer GEMMs (forward, dX) as float32-accurate bf16x6 products on the bf16 matrix cores")
-    ap.add_argument("--split-variant", type=int, default=-1, help="debug: pin the ag_split_gemm kernel variant (-1 = by size)")
+                    help="256x256 layer GEMMs (forward, dX, dW) as float32-accurate bf16x6 products on the bf16 matrix cores")
+    ap.add_argument("--split-wgrad", type=int, default=1, help="the 256x256 weight gradient on the bf16 matrix cores (0 = library f32)")
     ap.add_argument("--fuse-gemm-heads", type=int, default=1, help="ELU + heads in the last hidden layer's GEMM epilogue")
     ap.add_argument("--fuse-gemm-input-wgrad", type=int, default=1, help="first layer's backward in the dX GEMM's epilogue")
+    ap.add_argument("--fuse-rollout-tail", type=int, default=1,
+                    help="policy sampling + env step + reward/episode accounting as ONE launch (ag_step_rollout_fused)")
     ap.add_argument("--task", default="hovering", choices=["hovering", "tracking"],
                     help="default = BASELINE config 1; 'tracking --ctl vel' = config 2 (side measurement, not the headline)")
     ap.add_argument("--ctl", default="rate", choices=["pos", "vel", "atti", "rate", "prop"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-shipped-ratio", action="store_true", help="skip the second line at 48 minibatches per mini-epoch")
-    args = ap.parse_args()
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = launcher / collective test only (gloo)")
+    ap.add_argument("--dist-backend", default=None, help="default: nccl (= RCCL) on cuda, gloo on cpu")
+    ap.add_argument("--agent", default="airgym_amd.lib.agent.a2c_continuous:A2CAgent",
+                    help="module:Class of the agent (tests substitute a stub to exercise the launcher without a GPU)")
+    args = ap.parse_args(argv)
 
     world = int(os.getenv("WORLD_SIZE", "1"))
     rank = int(os.getenv("RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called the way the driver calls it (`python bench.py --gpus N`): become N ranks
+        sys.exit(self_launch(args, argv))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without torch.distributed.run)")
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        have = torch.cuda.device_count()
+        if have < world:
+            if rank == 0:
+                print(json.dumps({"metric": f"env_steps_per_sec_{args.task}_{args.envs}_envs_per_gpu", "value": None,
+                                  "unit": "env-steps/s", "n_gpus": world, "error": f"needs {world} devices, {have} visible",
+                                  "devices_visible": have, "steps": args.steps, "warmup": args.warmup}), flush=True)
+            return
 
-    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    A2CAgent = _load_agent_class(args.agent)
     params = build_params(args, world)
-    if args.split_variant >= 0:
-        from airgym_amd import _native
-        _native.check(_native.load().ag_debug_split_gemm_variant(args.split_variant), "ag_debug_split_gemm_variant")
+    if not on_gpu:
+        params["config"]["device"] = "cpu"
+        params["config"]["env_config"]["sim_device"] = "cpu"
+    params["config"]["dist_backend"] = args.dist_backend or ("nccl" if on_gpu else "gloo")
     agent = A2CAgent("bench", params)
     agent.init_tensors()
     agent.obs = agent.env_reset()
     agent.broadcast_parameters()
     dev = agent.ppo_device
 
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+
     def barrier():
-        torch.cuda.synchronize(dev)
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
+    rccl = rccl_probe(agent, world) if world > 1 else None      # before the timed region: also warms the communicator
     for _ in range(args.warmup):
         agent.epoch_num += 1
         agent.train_epoch()
@@ -223,6 +314,7 @@ def main():
         elapsed = t.item()
     H = agent.horizon_length
     total_env_steps = world * args.envs * H * args.steps
+    fs = getattr(agent, "_fused_step", None)
     out = {
         "metric": f"env_steps_per_sec_{args.task}_{args.envs}_envs_per_gpu",
         "value": total_env_steps / elapsed,
@@ -242,9 +334,8 @@ def main():
                    "mini_epochs": agent.mini_epochs_num, "minibatch_size": agent.minibatch_size,
                    "policy": "MLP(256,256) actor-critic, fixed sigma", "parallelism": f"dp{world}",
                    "hip_graph_rollout": bool(args.graph),
-                   "hidden_layer_gemm": ("ag_split_gemm: exact 3-way bf16 split of every f32 operand, 6 bf16 MFMAs per product, f32 "
-                                         "accumulate (float32-accurate; tests/test_gpu_split_gemm.py) for forward and dX; wgrad = library f32"
-                                         if getattr(getattr(agent, "_fused_step", None), "split", None) else "library f32 GEMM"),
+                   "rollout_launches_per_step": getattr(getattr(agent, "_fused_rollout", None), "launches_per_step", None),
+                   "hidden_layer_gemm": getattr(fs, "gemm_description", "library f32 GEMM"),
                    "gemm_selection": ("TunableOp table airgym_amd/assets/tunableop_gfx950.csv (hipBLASLt / rocBLAS fp32)"
                                       if getattr(agent, "tuned_gemms", False) else "hipBLASLt default heuristic (fp32)")},
         "phases": {"rollout_host_enqueue_s": play, "update_s": update, "final_lr": agent.last_lr,
@@ -252,44 +343,29 @@ def main():
                    "finite": bool(all(map(lambda x: x == x and abs(x) != float("inf"),
                                           (last_stats["kl"], last_stats["a_loss"], last_stats["c_loss"]))))},
     }
-    if not args.no_shipped_ratio and (args.task, args.ctl) == ("hovering", "rate") and args.minibatches != 48:
+    if rccl is not None:
+        out["rccl"] = rccl
+    hip = getattr(agent, "_hip_env", None)
+    # N > 1: every rank measures its own env kernel at the same time (nobody idles in a barrier while rank 0 works); the
+    # legs that need a second agent or a minute of host time run at N == 1 only
+    roof = None
+    if not args.no_roofline and hip is not None:
+        from airgym_amd.utils.kernel_bench import roofline_object
+        roof = roofline_object(agent, hip, args, REPO)
+    if world == 1 and not args.no_shipped_ratio and (args.task, args.ctl) == ("hovering", "rate") and args.minibatches != 48 \
+            and hip is not None:
         out["shipped_ratio"] = shipped_ratio_line(args, world)
     if rank == 0:
-        hip = agent._hip_env
-        if not args.no_roofline and hip is not None:
-            from airgym_amd.utils.kernel_bench import (kernel_name, measure_copy_ceiling, measure_env_kernel,
-                                                       measure_update_kernels)
-            # the env-step kernel exactly as the PPO rollout launches it (ag_step_rollout), 48 launches per hipGraph x 52
-            # replays = 2 496 steps: the 2 400-step time limit fires inside the timed region
-            r = measure_env_kernel(hip, steps_per_graph=48, replays=52, rollout_form=True)
-            r_api = measure_env_kernel(hip, steps_per_graph=48, replays=10, rollout_form=False)
-            kname = kernel_name(args.task, args.ctl, 0)
-            traffic, tsrc = None, None      # HBM bytes per launch from rocprofv3 PMC passes (cannot be read live)
-            pmc = os.path.join(REPO, "profiles", "r02_env_kernel_pmc.json")
-            if os.path.exists(pmc) and args.envs == ENVS_PER_GPU:
-                rec = json.load(open(pmc)).get(f"{args.task}_{args.ctl}")
-                if rec and rec.get("kernel") == kname:
-                    traffic, tsrc = rec["traffic_bytes_per_launch"], rec["source"]
-            copy_gbps = measure_copy_ceiling(dev)
-            out["roofline"] = {
-                "bound": "hbm", "achieved": r["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
-                "kernel": kname, "entry_point": "ag_step_rollout (what FusedRolloutStep launches)",
-                "us_per_launch": r["us_per_step"], "launches_timed": r["steps_timed"],
-                "algo_bytes_per_env_step": r["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
-                "copy_ceiling_gbps": copy_gbps, "frac_of_copy_ceiling": r["gbps_algorithmic"] / copy_gbps,
-                "drop_in_ag_step": {"us_per_launch": r_api["us_per_step"], "frac": r_api["gbps_algorithmic"] / HBM_PEAK_GBPS,
-                                    "note": "ag_step: int64 reset_buf + nine per-env item_reward_info arrays + cmd_thrusts "
-                                            "(+59 B/env-step of outputs the reference's Hovering.step exposes)"},
-            }
-            uk = measure_update_kernels(agent)      # where the epoch's time actually goes
-            for e in uk:
-                if e["bound"] == "hbm":
-                    e["frac_of_copy_ceiling"] = e["achieved"] / copy_gbps
-            out["update_kernels"] = uk
-            out["env_only"] = {"value": r["env_steps_per_s"], "unit": "env-steps/s",
-                               "note": "env-step kernel only (rollout form), synthetic N(0,1) clamped actions, hipGraph replay"}
-        if world == 1 and not args.no_cpu_baseline and (args.task, args.ctl) == ("hovering", "rate"):
+        if roof is not None:
+            out.update(roof)
+            if world == 1:
+                from airgym_amd.utils.kernel_bench import measure_update_kernels
+                uk = measure_update_kernels(agent)      # where the epoch's time actually goes
+                for e in uk:
+                    if e["bound"] == "hbm":
+                        e["frac_of_copy_ceiling"] = e["achieved"] / out["roofline"]["copy_ceiling_gbps"]
+                out["update_kernels"] = uk
+        if world == 1 and on_gpu and not args.no_cpu_baseline and (args.task, args.ctl) == ("hovering", "rate"):
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

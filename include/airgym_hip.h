@@ -21,6 +21,8 @@
  *                        compute_reward (:360-459), reset_idx (:310-335); Tracking overrides
  *                        (airgym/envs/task/tracking.py:159-296); the rlPx4Controller calls
  *                        set_q_world/set_status/update (hovering.py:235-250)
+ *   ag_step_rollout      the same step in the form A2CBase.play_steps consumes (lib/agent/a2c_base.py:662-695)
+ *   ag_step_rollout_fused  that step with the policy sampling in front of it and the reward / episode accounting behind it
  *   ag_step_with_inputs  same, random numbers supplied by the caller (parity mode)
  *   ag_get_buffers       the tensors the env exposes: obs_buf, rew_buf, reset_buf, time_out_buf,
  *                        extras["item_reward_info"] (base_task.py:72-76, hovering.py:304-308,448-457)
@@ -90,7 +92,12 @@ typedef enum ag_ctl_mode {
 
 enum {
     AG_FLAG_REWARD_TERMS = 1u << 0, /* emit the 9 item_reward_info arrays + cmd_thrusts each step */
-    AG_FLAG_OBS_NOISE_OFF = 1u << 1 /* testing aid: skip add_noise (reference: always on, hovering.py:343) */
+    AG_FLAG_OBS_NOISE_OFF = 1u << 1, /* testing aid: skip add_noise (reference: always on, hovering.py:343) */
+    AG_FLAG_FIX_TIME_OUTS = 1u << 2  /* opt-in (Hovering / Tracking): time_out_buf flags the envs whose episode reached the time
+                                        limit this step (progress >= max_episode_length - 1 before the reset).  Default off =
+                                        the reference: hovering.py:304 evaluates `progress_buf > max_episode_length` AFTER
+                                        reset_idx zeroed the progress (:300-302,:435), so extras["time_outs"] is never true and
+                                        the PPO loop's bootstrap (lib/agent/a2c_base.py:672-673) never fires */
 };
 
 #define AG_NUM_REWARD_TERMS 11 /* Hovering/Tracking use the first 9, Planning all 11 */
@@ -128,7 +135,7 @@ typedef struct ag_buffers {
     float* obs_dev;           /* [num_envs, num_obs] row-major f32 */
     float* rew_dev;           /* [num_envs] f32 */
     int64_t* reset_dev;       /* [num_envs] int64 0/1 (base_task.py:75) */
-    uint8_t* timeout_dev;     /* [num_envs] u8  progress > max_episode_length (hovering.py:304) */
+    uint8_t* timeout_dev;     /* [num_envs] u8  progress > max_episode_length (hovering.py:304; see AG_FLAG_FIX_TIME_OUTS) */
     uint64_t* reset_mask_dev; /* [ceil(num_envs/64)] one ballot word per wavefront, bit l = env 64*w+l done */
     int32_t* reset_ids_dev;   /* [num_envs] ascending ids, valid after ag_compact_reset_ids */
     int32_t* reset_count_dev; /* [1] */
@@ -177,6 +184,43 @@ int ag_step_into(ag_handle h, const float* actions_dev, float* obs_out_dev, floa
 int ag_term_sum_tiles(int num_envs);
 int ag_step_rollout(ag_handle h, const float* actions_dev, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,
                     float* term_sums_dev, void* stream);
+/* One whole step of A2CBase.play_steps behind the policy GEMMs (lib/agent/a2c_base.py:651-695) as ONE launch: what
+ * ag_policy_sample does in front of ag_step_rollout (get_action_values' sampling, a2c_continuous_logstd_model.py:159-167;
+ * preprocess_actions, a2c_base.py:229-236) and what ag_rollout_account does behind it (rewards_shaper + time-out bootstrap,
+ * :668-673; current_rewards / current_lengths and the sums over the episodes that ended, :678-695) run inside the env-step
+ * kernel: the action goes from the sampler to the integrator through LDS, reward / done flags reach the accounting in LDS.
+ * Same arithmetic as the three separate calls (bit-identical outputs; the episode sums are per 64-env tile instead of per
+ * 256-env block).  partials_dev: [ag_term_sum_tiles(num_envs), 4] double.  Other members: as the arguments of the same
+ * name of ag_policy_sample / ag_rollout_account; bootstrap_timeouts != 0 adds gamma * value where the step's time-out flag
+ * is set.  Hovering / Tracking handles. */
+typedef struct ag_rollout_tail {
+    uint32_t struct_size;            /* = sizeof(ag_rollout_tail), ABI guard */
+    const float* heads_dev;          /* [n, A+1] mu | normalised value */
+    const float* logstd_dev;         /* [A] */
+    const double* vmean_dev;         /* [1] or NULL */
+    const double* vvar_dev;          /* [1] or NULL */
+    float veps;
+    unsigned long long seed;         /* Philox key of the action noise */
+    const long long* counter_dev;    /* [1] rollout counter */
+    int horizon, slot;
+    long long id_offset;
+    float* actions_dev;              /* [n, A] */
+    float* neglogp_dev;              /* [n] */
+    float* values_dev;               /* [n] */
+    float* mus_dev;                  /* [n, A] */
+    float* sigmas_dev;               /* [n, A] */
+    float scale, shift, min_val, max_val;
+    int log_val;
+    float gamma;
+    int bootstrap_timeouts;
+    float* shaped_dev;               /* [n] */
+    float* cur_rew_dev;              /* [n] read-modify-write */
+    float* cur_shaped_dev;           /* [n] read-modify-write */
+    float* cur_len_dev;              /* [n] read-modify-write */
+    double* partials_dev;            /* [ag_term_sum_tiles(n), 4] {episodes ended, sum reward, sum shaped, sum length} */
+} ag_rollout_tail;
+int ag_step_rollout_fused(ag_handle h, const ag_rollout_tail* tail, float* obs_out_dev, float* rew_out_dev,
+                          uint8_t* done_out_dev, float* term_sums_dev, void* stream);
 /* Parity mode: noise_dev [num_envs,18] standard normals, reset_uniforms_dev [num_envs,12] U[0,1). */
 int ag_step_with_inputs(ag_handle h, const float* actions_dev, const float* noise_dev,
                         const float* reset_uniforms_dev, void* stream);
@@ -297,6 +341,13 @@ int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float*
  *       x_dev [M, D] over each tile of ag_split_gemm_input_wgrad_rows() rows: dw_partials_dev [tiles, 256, D], db_partials_dev
  *       [tiles, 256] (tiles = ceil(M / rows); the caller sums over dim 0, e.g. ag_sum_rows_multi).  Neither dh1 nor dz1 is
  *       written.  D in {16, 18, 20}. */
+/*   ag_split_wgrad: the weight gradient of the same layer, dW [256, 256] = dZ_dev^T X_dev (dZ_dev, X_dev: [M, 256] f32 row-major;
+ *       autograd's grad_weight of mlp.py:36-39), both operands split three ways on the fly, the contraction running over the
+ *       rows.  K = M is cut into `slices` contiguous row ranges, one workgroup each (ag_split_wgrad_slices(M) = one per CU, at
+ *       most one per 16 rows); slice s writes partials_dev [s, 256, 256] and the caller sums over dim 0 in a fixed order
+ *       (ag_sum_rows_multi).  Each operand is read from HBM once. */
+int ag_split_wgrad_slices(int M);
+int ag_split_wgrad(const float* dZ_dev, const float* X_dev, float* partials_dev, int M, int n, int k, int slices, void* stream);
 long long ag_split_gemm_plane_bytes(void);
 int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n, int k, int transpose, void* stream);
 int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, void* planes_t_dev, int n, int k, void* stream);
@@ -423,7 +474,8 @@ int ag_planning_render_now(ag_handle h);
  * encoder (lib/network/vae_image_encoder.py:34-53) re-encode only when the image changed. */
 int ag_planning_last_step_rendered(ag_handle h);
 
-/* Benchmark / diagnostic knobs are not part of this interface: see airgym_hip_debug.h. */
+/* Benchmark / diagnostic knobs are not part of this interface nor of the shipped library: see airgym_hip_debug.h
+ * (experiments build, `python airgym_amd/csrc/build.py --experiments`). */
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,10 @@
 /*
  * airgym_hip_debug.h - benchmark and diagnostic entry points of libairgym_hip.so.
  *
- * NOT part of the drop-in interface (include/airgym_hip.h): nothing here replaces reference behaviour.  These exist so
- * that bench.py / tools/ can price the launch floor and A/B the launch geometry of the env-step kernel on the same
- * handle, and so that the Planning render kernel's phases can be timed separately.
+ * NOT part of the drop-in interface (include/airgym_hip.h) and NOT in the shipped libairgym_hip.so: these symbols exist only
+ * in libairgym_hip_exp.so (`python airgym_amd/csrc/build.py --experiments`, loaded by tools/ with AIRGYM_EXPERIMENTS=1).
+ * Nothing here replaces reference behaviour.  They let tools/ price the launch floor of the env-step kernel, see where the
+ * hardware places its waves, pin scheduling variants of the split GEMM and time the Planning render kernel's phases.
  */
 #ifndef AIRGYM_HIP_DEBUG_H
 #define AIRGYM_HIP_DEBUG_H
@@ -19,13 +20,6 @@ int ag_debug_touch(ag_handle h, const float* actions_dev, void* stream);
 /* mode 1 = non-temporal stores, 2 = non-temporal loads + stores, 3 = empty kernel (pure dependent-launch boundary) */
 int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void* stream);
 
-/* Launch geometry of the Hovering/Tracking step kernel: block_size 0 = wave-specialised kernel (default: physics wave +
- * noise wave per 64 envs, state stored after the reward), 2 = same with the state stored right after the integration,
- * 3 / 4 = 2 / 0 with alternating wave roles per workgroup, 1 = the first wave-specialised form (round 1), 64 / 128 / 256 = one wave per
- * 64 envs with that workgroup size (obs staged through LDS or not).  With block_size 0, obs_via_lds = 1 + k (k > 0) is the
- * de-phasing experiment of DESIGN.md 4.1: every second workgroup of a CU starts k x 0.5 us late (measured: never faster). */
-int ag_set_launch_params(ag_handle h, int block_size, int obs_via_lds);
-
 /* Where the hardware places the step kernel's waves: launches its geometry (ceil(n/64) workgroups x 2 waves) and writes, per
  * wave, {HW_REG_HW_ID, HW_REG_XCC_ID} into out_dev [ceil(n/64) * 2, 2] u32 (tools/wave_placement.py decodes SIMD / CU / XCC). */
 int ag_debug_wave_placement(ag_handle h, unsigned int* out_dev, void* stream);
@@ -34,6 +28,10 @@ int ag_debug_wave_placement(ag_handle h, unsigned int* out_dev, void* stream);
  * reads and MFMAs inside a K chunk, bit 1 = always set (2 x 2 waves), bit 2 = persistent workgroups with the second one of each
  * CU started half a tile late, bit 3 = non-temporal stores of C).  Values without a kernel are refused at launch. */
 int ag_debug_split_gemm_variant(int variant);
+
+/* ag_split_wgrad: 1 (default) = the issue order of a chunk is prescribed (staging work spread between the MFMAs), 0 = left to
+ * the compiler. */
+int ag_debug_split_wgrad_ordered(int on);
 
 /* Next Planning step renders with parts of the render kernel skipped: bit0 ray-cast, bit1 noise passes, bit2 5x5 pass. */
 int ag_debug_planning_render_parts(ag_handle h, int skip_mask);

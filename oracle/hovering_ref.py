@@ -91,8 +91,11 @@ class HoveringRef:
     action_limits = ACTION_LIMITS
 
     def __init__(self, num_envs, ctl_mode="rate", seed=0, env_id_offset=0, dt=0.01,
-                 target_state=None, integrator="rk4"):
+                 target_state=None, integrator="rk4", fix_time_outs=False):
         assert ctl_mode in ACTION_LIMITS, f"unknown ctl_mode {ctl_mode!r}"
+        # opt-in of the BUILD, not of the reference (AG_FLAG_FIX_TIME_OUTS): time_out_buf = "reached the time limit this step"
+        # instead of the reference's never-true expression (hovering.py:304 after the reset of :300-302 zeroed the progress)
+        self.fix_time_outs = bool(fix_time_outs)
         self.num_envs = num_envs
         self.ctl_mode = ctl_mode
         self.num_actions = 5 if ctl_mode == "atti" else 4          # hovering.py:47
@@ -215,10 +218,13 @@ class HoveringRef:
         self.compute_reward()
         reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
         self.last_reset_env_ids = reset_env_ids
+        progress_end = self.progress_buf.clone()
         if len(reset_env_ids) > 0:
             u = None if reset_uniforms is None else reset_uniforms[reset_env_ids]
             self.reset_idx(reset_env_ids, u)
-        self.time_out_buf = self.progress_buf > self.max_episode_length
+        self.time_out_buf = self.progress_buf > self.max_episode_length      # hovering.py:304: never true (quirk Q3)
+        if self.fix_time_outs:
+            self.time_out_buf = progress_end >= self.max_episode_length - 1
         self.extras["time_outs"] = self.time_out_buf
         self.extras["item_reward_info"] = self.item_reward_info
         self.tick += 1

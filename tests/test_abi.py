@@ -7,7 +7,8 @@ import re
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = [os.path.join(REPO, "include", "airgym_hip.h"), os.path.join(REPO, "include", "airgym_hip_debug.h")]
+HEADER = os.path.join(REPO, "include", "airgym_hip.h")
+DEBUG_HEADER = os.path.join(REPO, "include", "airgym_hip_debug.h")      # experiments build only
 
 
 @pytest.fixture(scope="module")
@@ -16,9 +17,8 @@ def lib():
     return _native.load()
 
 
-def declared_symbols():
-    src = "\n".join(open(h).read() for h in HEADERS)
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+def declared_symbols(header=HEADER):
+    src = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
     return sorted(set(re.findall(r"\b(ag_[a-z_0-9]+)\s*\(", src)))
 
 
@@ -32,6 +32,19 @@ def test_header_symbols_are_exported(lib):
 def test_binding_table_covers_header():
     from airgym_amd import _native
     assert sorted(n for n, _, _ in _native.SYMBOLS) == declared_symbols()
+    assert sorted(n for n, _, _ in _native.DEBUG_SYMBOLS) == declared_symbols(DEBUG_HEADER)
+
+
+def test_shipped_library_has_no_experiment_entry_points(lib):
+    """include/airgym_hip_debug.h (launch-floor probes, scheduling variants, render-phase skipping) lives in the experiments
+    build only: the shipped library exports none of it, and nothing named ag_debug_* / ag_set_launch_params at all."""
+    for name in declared_symbols(DEBUG_HEADER) + ["ag_set_launch_params"]:
+        assert not hasattr(lib, name), f"{name} leaked into the shipped library"
+    exp = os.path.join(REPO, "airgym_amd", "_native", "libairgym_hip_exp.so")
+    if os.path.exists(exp):
+        e = ctypes.CDLL(exp)
+        for name in declared_symbols(DEBUG_HEADER) + declared_symbols():
+            assert hasattr(e, name), f"{name} missing from the experiments build"
 
 
 def test_struct_sizes_match_header(lib):
@@ -121,6 +134,11 @@ def test_ppo_kernel_entry_points_validate_arguments_before_any_launch(lib):
     assert lib.ag_mlp_input_layer(p, pd, None, p, p, p, p, 8, 18, 256, 1e-5, 5.0, None) == inval    # mean without var
     assert lib.ag_policy_sample(p, p, pd, None, 1e-5, 0, p, 24, 0, 0, p, p, p, p, p, None, 8, 4, None) == inval
     assert lib.ag_gae(p, p, p, p, 0.99, 0.95, p, p, 0, 8, None) == inval
+    # round 3: weight gradient on the matrix cores, fused rollout step
+    assert lib.ag_split_wgrad_slices(0) == 0 and lib.ag_term_sum_tiles(65) == 2
+    assert lib.ag_split_wgrad(None, p, p, 64, 256, 256, 4, None) == inval
+    assert lib.ag_split_wgrad(p, p, p, 64, 128, 256, 4, None) == unsupported                         # 256 x 256 layers only
+    assert lib.ag_step_rollout_fused(None, None, p, p, p, None, None) == inval                       # no handle
     jobs = (N.AgSumJob * 13)()
     for j in range(13):
         jobs[j] = N.AgSumJob(p.value, p.value, 4, 8)

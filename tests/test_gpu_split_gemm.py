@@ -83,36 +83,6 @@ def test_rejects_other_shapes(lib):
     assert lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), 8, 256, 128, _stream()) != 0
 
 
-def _bad_variant_is_refused(lib, A, W):
-    """variant numbers without a kernel (the 4 x 1 wave arrangement of the first version is gone) fail at launch, loudly"""
-    planes = torch.empty(lib.ag_split_gemm_plane_bytes(), dtype=torch.uint8, device="cuda")
-    C = torch.empty(A.shape[0], 256, device="cuda")
-    try:
-        return lib.ag_split_gemm(A.data_ptr(), planes.data_ptr(), None, C.data_ptr(), A.shape[0], 256, 256, _stream()) != 0
-    finally:
-        lib.ag_debug_split_gemm_variant(-1)
-
-
-@pytest.mark.parametrize("variant", [2, 3, 6, 7, 14, 15])
-def test_scheduling_variants_are_the_same_arithmetic(lib, variant):
-    """The A/B variants (issue order, persistent workgroups, non-temporal stores) order the same six MFMAs per product
-    identically; the fused-head launch follows the same variant bits."""
-    g = torch.Generator(device="cuda").manual_seed(7)
-    A = torch.randn(4097, 256, device="cuda", generator=g)
-    W = torch.randn(256, 256, device="cuda", generator=g) / 16.0
-    try:
-        assert lib.ag_debug_split_gemm_variant(2) == 0
-        ref = _gemm(lib, A, W, False)
-        assert lib.ag_debug_split_gemm_variant(variant) == 0
-        got = _gemm(lib, A, W, False)
-    finally:
-        lib.ag_debug_split_gemm_variant(-1)
-    assert torch.equal(ref, got)
-    assert lib.ag_debug_split_gemm_variant(1) == 0 and _bad_variant_is_refused(lib, A, W)
-    exact = A.double() @ W.double().t()
-    assert ((got.double() - exact).abs() / (A.double().abs() @ W.double().abs().t())).max().item() < 4e-7
-
-
 @pytest.mark.parametrize("M", [1, 127, 129, 4097, 65536, 196608])
 @pytest.mark.parametrize("A1", [5, 6])
 def test_fused_elu_heads_epilogue(lib, M, A1):

@@ -4,6 +4,7 @@ import ctypes
 import json
 import os
 import sys
+os.environ.setdefault("AIRGYM_EXPERIMENTS", "1")      # ag_debug_split_gemm_variant lives in the experiments build
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch + memory-latency floor of one env-step launch: same bytes as the step kernel, no arithmetic."""
 import ctypes, os, sys
+os.environ.setdefault("AIRGYM_EXPERIMENTS", "1")      # ag_debug_* live in the experiments build
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from airgym_amd.hip_env import HipEnvHandle
