@@ -16,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # include/airgym_hip_debug.h (`python airgym_amd/csrc/build.py --experiments`); the product never sets it
 EXPERIMENTS = os.environ.get("AIRGYM_EXPERIMENTS", "0") == "1"
 LIB_PATH = os.path.join(_HERE, "libairgym_hip_exp.so" if EXPERIMENTS else "libairgym_hip.so")
+if EXPERIMENTS and os.environ.get("AIRGYM_EXP_LIB"):      # a variant of the experiments build (build.py --experiments --tag)
+    LIB_PATH = os.path.abspath(os.environ["AIRGYM_EXP_LIB"])
 
 AG_TASKS = {"hovering": 0, "tracking": 1, "planning": 2, "balloon": 3, "avoid": 4}
 AG_CTL_MODES = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}

@@ -57,7 +57,12 @@ def compile_one(obj, src, defs, extra):
     return obj, r.returncode, (r.stdout + r.stderr).strip(), " ".join(cmd)
 
 
-def build(force=False, jobs=None, extra=(), verbose=True, experiments=False):
+def build(force=False, jobs=None, extra=(), verbose=True, experiments=False, tag=None):
+    """tag (experiments only): build a VARIANT of the experiments library with the extra -D flags in `extra` into
+    libairgym_hip_exp_<tag>.so (always a full rebuild into its own object directory); load it with AIRGYM_EXP_LIB=<path>."""
+    if tag:
+        assert experiments, "--tag is for experiment variants"
+        return _build_variant(tag, list(extra), jobs, verbose)
     os.makedirs(os.path.join(OBJ_DIR, "exp") if experiments else OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     lib = LIB_EXP if experiments else LIB
@@ -85,16 +90,36 @@ def build(force=False, jobs=None, extra=(), verbose=True, experiments=False):
     return lib
 
 
+def _build_variant(tag, extra, jobs, verbose):
+    od = os.path.join(OBJ_DIR, "exp_" + tag)
+    os.makedirs(od, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    lib = os.path.join(LIB_DIR, f"libairgym_hip_exp_{tag}.so")
+    todo = [(os.path.join(od, os.path.basename(o)), s, d) for (o, s, d) in units(True)]
+    with cf.ThreadPoolExecutor(jobs or min(len(todo), os.cpu_count() or 4)) as ex:
+        for obj, rc, log, cmd in ex.map(lambda u: compile_one(*u, extra), todo):
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed ({rc}): {cmd}\n{log}")
+    r = subprocess.run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + [o for (o, _, _) in todo],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed: {r.stdout}{r.stderr}")
+    if verbose:
+        print(f"[airgym_amd] {lib} ready (variant {tag}: {' '.join(extra)})")
+    return lib
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--experiments", action="store_true",
                     help="build libairgym_hip_exp.so: the library + the ag_debug_* entry points (include/airgym_hip_debug.h)")
+    ap.add_argument("--tag", default=None, help="with --experiments: build a variant library libairgym_hip_exp_<tag>.so")
     ap.add_argument("extra", nargs="*", help="extra hipcc flags, e.g. -Rpass-analysis=kernel-resource-usage")
     a = ap.parse_args()
     try:
-        build(a.force, a.jobs, a.extra, experiments=a.experiments)
+        build(a.force, a.jobs, a.extra, experiments=a.experiments, tag=a.tag)
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

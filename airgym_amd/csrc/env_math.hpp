@@ -51,12 +51,9 @@ constexpr float kYawTorquePerCmd = 0.2f;
 
 // Control cascade gains: oracle/px4_cascade.py (PX4 multicopter defaults; build's own spec).
 constexpr float kCtlDt = 0.01f, kInvCtlDt = 100.0f;
-#ifndef AG_EXPERIMENT_RATE_GAIN      /* system-identification probe only (tools/play_reference_policy.py); the spec is 1 */
-#define AG_EXPERIMENT_RATE_GAIN 1.0f
-#endif
-constexpr float kRateKp[3] = {0.15f * AG_EXPERIMENT_RATE_GAIN, 0.15f * AG_EXPERIMENT_RATE_GAIN, 0.2f * AG_EXPERIMENT_RATE_GAIN};
-constexpr float kRateKi[3] = {0.2f * AG_EXPERIMENT_RATE_GAIN, 0.2f * AG_EXPERIMENT_RATE_GAIN, 0.1f * AG_EXPERIMENT_RATE_GAIN};
-constexpr float kRateKd[3] = {0.003f * AG_EXPERIMENT_RATE_GAIN, 0.003f * AG_EXPERIMENT_RATE_GAIN, 0.0f};
+constexpr float kRateKp[3] = {0.15f, 0.15f, 0.2f};
+constexpr float kRateKi[3] = {0.2f, 0.2f, 0.1f};
+constexpr float kRateKd[3] = {0.003f, 0.003f, 0.0f};
 constexpr float kRateIntLim = 0.3f;
 constexpr float kRateIAttenInv = (float)(1.0 / (400.0 * 3.14159265358979323846 / 180.0));
 constexpr float kMixRP = 0.70710678f, kMixYaw = 1.0f;
@@ -457,7 +454,11 @@ AG_HD void controller_update(CtlState& c, const EnvState& s, const float* a, flo
         cmd[0] = a[0]; cmd[1] = a[1]; cmd[2] = a[2]; cmd[3] = a[3];
         return;
     }
+#if defined(AG_EXP_CASCADE) && (AG_EXP_CASCADE & 1)      /* identification probe (tools/cascade_sweep.py): world-frame omega */
+    const V3 wbv = s.w;
+#else
     const V3 wbv = quat_rotate_inverse(s.q, s.w);
+#endif
     const float wb[3] = {wbv.x, wbv.y, wbv.z};
     float rate_sp[3];
     float thrust;

@@ -29,10 +29,11 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 256, BK = 16, KDIM = 256;
-constexpr int A_UNITS = 3 * 2 * BM;       // 16-byte units per A stage
+constexpr int BN = 256, BK = 16, KDIM = 256;
 constexpr int B_UNITS = 3 * 2 * BN;       // 16-byte units per B stage
-constexpr int STAGE_UNITS = A_UNITS + B_UNITS;
+// row tile: WM waves x 64 rows (WM = 2: 128 rows, 4 waves, two workgroups per CU; WM = 4: 256 rows, 8 waves, one per CU)
+constexpr int a_units(int bm) { return 3 * 2 * bm; }          // 16-byte units per A stage
+constexpr int stage_units(int bm) { return a_units(bm) + B_UNITS; }
 
 // Weight preparation: W [256, 256] f32 (row-major) -> planes [chunk 16][plane 3][k-half 2][n 256] x 8 bf16, the per-chunk LDS
 // image of the main loop.  transpose = 0: B[n][k] = W[n][k] (forward, X W^T); 1: B[n][k] = W[k][n] (backward dX = dZ W).
@@ -60,12 +61,7 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
     chunk[(2 * 2 + h) * BN + n] = p3;
 }
 
-// VAR bit 0: prescribe the issue order inside a chunk (sched_group_barrier): the next chunk's global loads at the TOP (a
-// whole chunk of MFMAs for them to land) instead of wherever the scheduler sinks them to shorten live ranges.  Bit 1: always
-// set (2 x 2 waves; the 4 x 1 arrangement of the first version read 27 fragments per chunk instead of 18 and was slower).
-// Bit 2: persistent workgroups, the second one of a CU de-phased.  Bit 3: non-temporal stores of C.
-//
-// A1 > 0 (2 x 2 waves only): the forward of the LAST hidden layer with the actor/critic heads folded into the epilogue
+// A1 > 0: the forward of the LAST hidden layer with the actor/critic heads folded into the epilogue
 // (lib/network/mlp.py:36-39 followed by the mu / value Linear of a2c_continuous.py's model): C keeps the bias-free
 // pre-activation z (the backward wants it), and heads[m, a] = sum_c ELU(z[m,c] + bias[c]) Wh[a,c] + bh[a] is formed from the
 // accumulators while they are still in registers - the separate ELU + head pass re-read all of z (201 MB per minibatch).
@@ -106,9 +102,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // a lane (rows (e & 3) + 8 (e >> 2) + 16 ks + 4 h for lane half h): the B operand (dz1) is formed from the accumulators IN
 // PLACE, no data movement; the A operand (x, pre-split into the same row order) comes from LDS planes built once per tile.
 // Both operands are split three ways like the main product (six MFMAs per step): float32-accurate.
-template <int J>
+template <int J, int WM>
 __device__ __forceinline__ void input_wgrad_tile(const f32x16 (&acc)[8], const float* __restrict__ hcol, const uint4* xp_lane,
                                                  float* mine, int m0, int M, int wm, int khalf, int DIN1) {
+    constexpr int XS = WM * 2 * 32;                          // units per (plane, step) of the x image
     f32x16 g;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = 0.0f;
@@ -133,7 +130,7 @@ __device__ __forceinline__ void input_wgrad_tile(const f32x16 (&acc)[8], const f
         if (s + PF < 4) AG_IW_FETCH(s + PF);
         uint4 b1, b2, b3;                                   // rows past M need no masking here: their x rows are zero
         split8(make_float4(dz[0], dz[1], dz[2], dz[3]), make_float4(dz[4], dz[5], dz[6], dz[7]), b1, b2, b3);
-        const uint4 ua1 = xp_lane[(0 * 4 + s) * 128], ua2 = xp_lane[(1 * 4 + s) * 128], ua3 = xp_lane[(2 * 4 + s) * 128];
+        const uint4 ua1 = xp_lane[(0 * 4 + s) * XS], ua2 = xp_lane[(1 * 4 + s) * XS], ua3 = xp_lane[(2 * 4 + s) * XS];
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1), a2 = *reinterpret_cast<const bf16x8*>(&ua2),
                      a3 = *reinterpret_cast<const bf16x8*>(&ua3);
         const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(&b1), c2 = *reinterpret_cast<const bf16x8*>(&b2),
@@ -169,9 +166,13 @@ struct SplitEpilogue {
     float* db_partials;        // input wgrad: [tiles, 256]
 };
 
-template <bool HAS_BIAS, int VAR, int A1, int ABL = 0, int DIN = 0>
-__global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
-                                                             float* __restrict__ C, int M, const SplitEpilogue ep) {
+template <bool HAS_BIAS, int A1, int DIN, int WM>
+__global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
+                                                                  float* __restrict__ C, int M, const SplitEpilogue ep) {
+    constexpr int BM = WM * 64, NT = WM * 128;               // rows per tile, threads per workgroup
+    constexpr int A_UNITS = a_units(BM), STAGE_UNITS = stage_units(BM);
+    constexpr int BPT = B_UNITS / NT;                        // B-plane units copied per thread per chunk (6 or 3)
+    static_assert(WM == 2 || WM == 4, "4 or 8 waves");
     static_assert(A1 == 0 || DIN == 0, "one fused epilogue at a time");
     static_assert((DIN & 1) == 0 && DIN <= 24, "input width: even (packed FMAs), register tile 4 x DIN");
     const float* __restrict__ bias = ep.bias;
@@ -180,54 +181,35 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
     float* __restrict__ heads = ep.heads;
     extern __shared__ uint4 lds[];                         // [2 stages][A_UNITS + B_UNITS] 16-byte units
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int num_tiles = (M + BM - 1) / BM;
-    if (VAR & 4) {
-        // persistent workgroups, two per CU.  All workgroups run identical tiles, so without help the two on a CU stay in
-        // lockstep and their epilogues (128 KB of C stores each) stall the matrix pipe together.  The second workgroup of
-        // a CU (non-zero LDS base, HW_REG_LDS_ALLOC) starts half a tile late: from then on one stores while the other
-        // multiplies.
-        const unsigned lds_alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);
-        if ((lds_alloc & 0xFF) != 0) {
-#pragma unroll 1
-            for (int i = 0; i < 6; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < ((VAR & 4) ? num_tiles : (int)blockIdx.x + 1); tile += (VAR & 4) ? (int)gridDim.x : num_tiles) {
+    const int tile = blockIdx.x;
     const int m0 = tile * BM;
-    if ((VAR & 4) && tile != (int)blockIdx.x) __syncthreads();      // the previous tile's epilogue is done before LDS is reused
 
     // ---- global -> register staging for one K chunk
-    const int a_row = tid >> 1, a_half = tid & 1;                       // 128 rows x 2 k-halves: one 32-byte piece per thread
+    const int a_row = tid >> 1, a_half = tid & 1;                       // BM rows x 2 k-halves: one 32-byte piece per thread
     const int a_grow = min(m0 + a_row, M - 1);                          // rows past M are computed, never stored
     const float4* a_src = reinterpret_cast<const float4*>(A + (size_t)a_grow * KDIM + a_half * 8);
     float4 ra0, ra1;
-    uint4 rb0, rb1, rb2, rb3, rb4, rb5;
+    uint4 rb0, rb1, rb2, rb3, rb4, rb5;                                 // (rb3..5: 4-wave tiles only; named, not an array: LLVM
+    static_assert(BPT == 3 || BPT == 6, "B copy per thread");           //  left an indexed array in scratch)
 #define AG_SG_LOAD(c)                                                                  \
     do {                                                                               \
-        if (!(ABL & 1) || (c) == 0) {                                                  \
-            ra0 = a_src[(c) * (BK / 4)];                                               \
-            ra1 = a_src[(c) * (BK / 4) + 1];                                           \
-        }                                                                              \
-        if (!(ABL & 2) || (c) == 0) {                                                  \
-            const uint4* bsrc_ = Bp + (size_t)(c) * B_UNITS + tid;                     \
-            rb0 = bsrc_[0]; rb1 = bsrc_[256]; rb2 = bsrc_[512];                        \
-            rb3 = bsrc_[768]; rb4 = bsrc_[1024]; rb5 = bsrc_[1280];                    \
-        }                                                                              \
+        ra0 = a_src[(c) * (BK / 4)];                                                   \
+        ra1 = a_src[(c) * (BK / 4) + 1];                                               \
+        const uint4* bsrc_ = Bp + (size_t)(c) * B_UNITS + tid;                         \
+        rb0 = bsrc_[0]; rb1 = bsrc_[NT]; rb2 = bsrc_[2 * NT];                          \
+        if (BPT == 6) { rb3 = bsrc_[3 * NT]; rb4 = bsrc_[4 * NT]; rb5 = bsrc_[5 * NT]; } \
     } while (0)
 #define AG_SG_STORE(stage)                                                             \
     do {                                                                               \
         uint4* sa_ = lds + (stage) * STAGE_UNITS;                                      \
         uint4* sb_ = sa_ + A_UNITS + tid;                                              \
         uint4 p1_, p2_, p3_;                                                           \
-        if (ABL & 4) {                                                                 \
-            p1_ = *reinterpret_cast<uint4*>(&ra0); p2_ = *reinterpret_cast<uint4*>(&ra1); p3_ = p1_; \
-        } else split8(ra0, ra1, p1_, p2_, p3_);                                        \
+        split8(ra0, ra1, p1_, p2_, p3_);                                               \
         sa_[(0 * 2 + a_half) * BM + a_row] = p1_;                                      \
         sa_[(1 * 2 + a_half) * BM + a_row] = p2_;                                      \
         sa_[(2 * 2 + a_half) * BM + a_row] = p3_;                                      \
-        sb_[0] = rb0; sb_[256] = rb1; sb_[512] = rb2;                                  \
-        sb_[768] = rb3; sb_[1024] = rb4; sb_[1280] = rb5;                              \
+        sb_[0] = rb0; sb_[NT] = rb1; sb_[2 * NT] = rb2;                                \
+        if (BPT == 6) { sb_[3 * NT] = rb3; sb_[4 * NT] = rb4; sb_[5 * NT] = rb5; }     \
     } while (0)
 
     AG_SG_LOAD(0);
@@ -245,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
 
     const int l31 = lane & 31, khalf = lane >> 5;
     constexpr int NCHUNK = KDIM / BK;
-    // 2 x 2 waves: wave (wm, wn) owns rows 64 wm .. +63 and columns 128 wn .. +127 (2 x 4 tiles of 32 x 32): 18 fragment
+    // WM x 2 waves: wave (wm, wn) owns rows 64 wm .. +63 and columns 128 wn .. +127 (2 x 4 tiles of 32 x 32): 18 fragment
     // reads per chunk (every B fragment feeds two row tiles).  Products smallest first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1.
     const int wm = wave >> 1, wn = wave & 1;
 #define AG_SG_COMPUTE(stage_)                                                                          \
@@ -279,33 +261,19 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
     // Global loads run TWO chunks ahead of the MFMAs and are issued at the END of a chunk, right after the registers they
     // fill were drained into LDS: issued at the top of the chunk that precedes their use, LLVM sinks them into the store block
     // (same condition, only user there) and every chunk ends waiting for HBM; here they have a full chunk to land and cost
-    // no extra registers.  VAR bit 0 additionally prescribes the issue order of LDS reads and MFMAs (sched_group_barrier):
-    // the A fragments and TWO column tiles of B fragments first, then 12 MFMAs per column tile with the reads one tile ahead.
-#define AG_SG_ORDER()                                                                                  \
-    do {                                                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-    } while (0)
+    // no extra registers.
 #pragma unroll 1
     for (int c = 0; c < NCHUNK - 1; ++c) {
         const int stage = c & 1;
         AG_SG_COMPUTE(stage);
-        if (VAR & 1) AG_SG_ORDER();
         AG_SG_STORE(stage ^ 1);                             // chunk c + 1; that stage was last read before the previous barrier
         const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;      // (the last trip reloads a chunk it does not need)
         AG_SG_LOAD(cn);
-        if (!(ABL & 16)) __syncthreads();
+        __syncthreads();
     }
     AG_SG_COMPUTE((NCHUNK - 1) & 1);
-    if (VAR & 1) AG_SG_ORDER();
     if (A1 > 0 || DIN > 0) __syncthreads();                 // the fused epilogues reuse the stages
 #undef AG_SG_COMPUTE
-#undef AG_SG_ORDER
 #undef AG_SG_LOAD
 #undef AG_SG_STORE
 
@@ -321,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
 #pragma unroll
             for (int a = 0; a < A1; ++a) wcol[a][j] = Wh[a * BN + col];
         }
-        float* hs = reinterpret_cast<float*>(lds);          // [wn 2][row 128][A1]; the stages are idle after the last barrier
+        float* hs = reinterpret_cast<float*>(lds);          // [wn 2][row BM][A1]; the stages are idle after the last barrier
         const int sel = lane & 15;
         float* hs_lane = hs + (wn * BM + wm * 64 + 4 * khalf) * A1 + sel + late;      // + a compile-time row offset per store
 #pragma unroll
@@ -359,15 +327,16 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
         }
     } else if constexpr (DIN > 0) {
         constexpr int RW = DIN + 1;                         // reduction row: DIN weight-gradient entries + the bias gradient
-        uint4* xp = lds;                                    // [plane 3][step 4][wm 2][h 2][d 32] x 16 B = 24 KB: x, split, in K order
-        float* red = reinterpret_cast<float*>(lds + 3 * 4 * 128);      // [wm 2][BN][RW]
+        constexpr int XS = WM * 2 * 32;                     // units per (plane, step)
+        uint4* xp = lds;                                    // [plane 3][step 4][wm WM][h 2][d 32] x 16 B (24 / 48 KB): x, split, in K order
+        float* red = reinterpret_cast<float*>(lds + 3 * 4 * XS);       // [wm WM][BN][RW]
         int late = 0;                                       // (opaque zero, as above)
         asm volatile("" : "+s"(late) : : "memory");
         const int m0e = m0 + late;          // opaque too: or the row addresses are formed before the main loop and spilled
         // one unit = the 8 rows of (wm, step, lane half h) for one input column d, as three bf16x8 pieces; d = DIN is the
         // all-ones column that yields the bias gradient, d > DIN and rows past M are zero (which also masks the tail tile)
-        for (int u = tid; u < 512; u += 256) {
-            const int d = u & 31, h = (u >> 5) & 1, w2 = (u >> 6) & 1, st = u >> 7;
+        for (int u = tid; u < 4 * XS; u += NT) {
+            const int d = u & 31, h = (u >> 5) & 1, w2 = (u >> 6) % WM, st = u / XS;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -377,23 +346,24 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
             }
             uint4 p1, p2, p3;
             split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
-            xp[(0 * 4 + st) * 128 + (w2 * 2 + h) * 32 + d] = p1;
-            xp[(1 * 4 + st) * 128 + (w2 * 2 + h) * 32 + d] = p2;
-            xp[(2 * 4 + st) * 128 + (w2 * 2 + h) * 32 + d] = p3;
+            xp[(0 * 4 + st) * XS + (w2 * 2 + h) * 32 + d] = p1;
+            xp[(1 * 4 + st) * XS + (w2 * 2 + h) * 32 + d] = p2;
+            xp[(2 * 4 + st) * XS + (w2 * 2 + h) * 32 + d] = p3;
         }
         __syncthreads();
         const float* hcol = ep.h1 + wn * 128 + l31 + late;
         const uint4* xp_lane = xp + (wm * 2 + khalf) * 32 + l31;
         float* mine = red + ((size_t)wm * BN + wn * 128 + l31) * RW;
-        input_wgrad_tile<0>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
-        input_wgrad_tile<1>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
-        input_wgrad_tile<2>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
-        input_wgrad_tile<3>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+        input_wgrad_tile<0, WM>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+        input_wgrad_tile<1, WM>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+        input_wgrad_tile<2, WM>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+        input_wgrad_tile<3, WM>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
         __syncthreads();
-        // the two row blocks (wm = 0, 1) in a fixed order: deterministic
-        for (int idx = tid; idx < BN * RW; idx += 256) {
+        // the WM row blocks in a fixed order: deterministic
+        for (int idx = tid; idx < BN * RW; idx += NT) {
             const int c = idx / RW, d = idx - c * RW;
-            const float v = red[idx] + red[BN * RW + idx];
+            float v = red[idx] + red[BN * RW + idx];
+            if (WM == 4) v = (v + red[2 * BN * RW + idx]) + red[3 * BN * RW + idx];
             if (d < DIN) ep.dw_partials[((size_t)tile * BN + c) * DIN + d] = v;
             else ep.db_partials[(size_t)tile * BN + c] = v;
         }
@@ -406,14 +376,10 @@ __global__ __launch_bounds__(256, 2) void split_gemm_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            if (row < M && (!(ABL & 8) || acc[t][r] == 12345.0f)) {
-                if (VAR & 8) __builtin_nontemporal_store(acc[t][r] + bj, &C[(size_t)row * BN + col]);
-                else C[(size_t)row * BN + col] = acc[t][r] + bj;
-            }
+            if (row < M) C[(size_t)row * BN + col] = acc[t][r] + bj;
         }
     }
     }
-    }   // tile loop
 }
 
 }  // namespace
@@ -438,52 +404,57 @@ extern "C" int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, 
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
-constexpr int kDefaultVar = 2;      // 2 x 2 waves, plain grid
-// Scheduling variants (VAR bits 0 / 2 / 3) and timing ablations (ABL) are measured negatives (profiles/r02_split_gemm.md): the
-// shipped library instantiates the plain 2 x 2 grid only; the experiments build keeps the others selectable for tools/.
+// Row-tile size of the launches: WM = 2 (128 rows, 4 waves, two workgroups per CU) or 4 (256 rows, 8 waves, one per CU).
+// Shipped: 4 - every B-plane chunk fetched from L2 feeds twice the MFMAs and a thread copies 3 instead of 6 plane units per
+// chunk; in situ (bench.py, same box, interleaved runs) 31.4-31.6 vs 32.2-32.3 ms per epoch (profiles/r03_split_gemm.md).
+#define AG_SPLIT_DEFAULT_WM 4
+constexpr int kDefaultWM = AG_SPLIT_DEFAULT_WM;
 #ifdef AG_EXPERIMENTS
-static int g_split_variant = -1;      // -1 = the default
-extern "C" int ag_debug_split_gemm_variant(int variant) {
-    if (variant < -1 || variant > 231) return AG_ERR_INVALID_ARG;      // unknown values are refused at launch
-    g_split_variant = variant;
+#include <stdlib.h>
+static int g_split_wm = [] { const char* e = getenv("AIRGYM_SPLIT_WM"); return (e && atoi(e) == 4) ? 4 : ((e && atoi(e) == 2) ? 2 : kDefaultWM); }();
+extern "C" int ag_debug_split_gemm_variant(int wm) {      // 2 | 4; -1 = default
+    if (wm != -1 && wm != 2 && wm != 4) return AG_ERR_INVALID_ARG;
+    g_split_wm = wm < 0 ? kDefaultWM : wm;
     return AG_OK;
 }
+#else
+constexpr int g_split_wm = kDefaultWM;
 #endif
 
-constexpr size_t kSplitLds = (size_t)2 * STAGE_UNITS * 16;
+template <int DIN, int WM>
+constexpr size_t split_lds_bytes() {
+    size_t stages = (size_t)2 * stage_units(WM * 64) * 16;
+    // the first-layer-backward epilogue re-uses the stages for the split x image and the per-row-block reduction buffer
+    size_t epi = DIN > 0 ? (size_t)3 * 4 * (WM * 2 * 32) * 16 + (size_t)WM * BN * (DIN + 1) * 4 : 0;
+    return stages > epi ? stages : epi;
+}
 
-template <bool HAS_BIAS, int VAR, int A1, int ABL, int DIN>
+template <bool HAS_BIAS, int A1, int DIN, int WM>
 static int launch_split_any(const float* A_dev, const void* planes_dev, float* C_dev, int M, const SplitEpilogue& ep, void* stream) {
     static bool attr_set[64] = {};      // per device ordinal: the dynamic-LDS limit is an attribute of (function, device)
-    auto* fn = split_gemm_kernel<HAS_BIAS, VAR, A1, ABL, DIN>;
+    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM>;
+    constexpr size_t lds_bytes = split_lds_bytes<DIN, WM>();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplitLds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return AG_ERR_HIP;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    int tiles = (M + BM - 1) / BM;
-    if (VAR & 4) tiles = tiles < 512 ? tiles : 512;        // persistent: 2 workgroups on each of the 256 CUs
-    hipLaunchKernelGGL(fn, dim3(tiles), dim3(256), kSplitLds, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, C_dev, M, ep);
+    constexpr int BM = WM * 64;
+    const int tiles = (M + BM - 1) / BM;
+    hipLaunchKernelGGL(fn, dim3(tiles), dim3(WM * 128), lds_bytes, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, C_dev, M, ep);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
-template <int VAR, int ABL = 0>
-static int launch_split(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, void* stream) {
-    SplitEpilogue ep = {};
-    ep.bias = bias_dev;
-    return bias_dev ? launch_split_any<true, VAR, 0, ABL, 0>(A_dev, planes_dev, C_dev, M, ep, stream)
-                    : launch_split_any<false, VAR, 0, ABL, 0>(A_dev, planes_dev, C_dev, M, ep, stream);
-}
-
-template <int VAR, int A1>
-static int launch_split_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh, const float* bh,
-                              float* C_dev, float* heads, int M, void* stream) {
-    SplitEpilogue ep = {};
-    ep.bias = bias_dev; ep.Wh = Wh; ep.bh = bh; ep.heads = heads;
-    return launch_split_any<true, VAR, A1, 0, 0>(A_dev, planes_dev, C_dev, M, ep, stream);
-}
+// dispatch on the runtime tile choice (a constant in the shipped build: only that instantiation is compiled)
+#ifdef AG_EXPERIMENTS
+#define AG_SG_DISPATCH(call2, call4) (g_split_wm == 4 ? (call4) : (call2))
+#elif AG_SPLIT_DEFAULT_WM == 4
+#define AG_SG_DISPATCH(call2, call4) (call4)
+#else
+#define AG_SG_DISPATCH(call2, call4) (call2)
+#endif
 
 extern "C" int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
                                        const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1,
@@ -491,20 +462,15 @@ extern "C" int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_de
     if (!A_dev || !planes_dev || !bias_dev || !Wh_dev || !bh_dev || !Z_dev || !heads_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM || (A1 != 5 && A1 != 6)) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
-#define AG_SGH(V, A) launch_split_heads<V, A>(A_dev, planes_dev, bias_dev, Wh_dev, bh_dev, Z_dev, heads_dev, M, stream)
-#ifdef AG_EXPERIMENTS
-    const bool persistent = g_split_variant >= 0 && (g_split_variant & 4) != 0;
-    const bool ordered = g_split_variant >= 0 && (g_split_variant & 1) != 0;
-    if (persistent || ordered) {
-        if (A1 == 5) return persistent ? (ordered ? AG_SGH(7, 5) : AG_SGH(6, 5)) : AG_SGH(3, 5);
-        return persistent ? (ordered ? AG_SGH(7, 6) : AG_SGH(6, 6)) : AG_SGH(3, 6);
-    }
-#endif
-    return A1 == 5 ? AG_SGH(kDefaultVar, 5) : AG_SGH(kDefaultVar, 6);
+    SplitEpilogue ep = {};
+    ep.bias = bias_dev; ep.Wh = Wh_dev; ep.bh = bh_dev; ep.heads = heads_dev;
+#define AG_SGH(A, W) launch_split_any<true, A, 0, W>(A_dev, planes_dev, Z_dev, M, ep, stream)
+    if (A1 == 5) return AG_SG_DISPATCH(AG_SGH(5, 2), AG_SGH(5, 4));
+    return AG_SG_DISPATCH(AG_SGH(6, 2), AG_SGH(6, 4));
 #undef AG_SGH
 }
 
-extern "C" int ag_split_gemm_input_wgrad_rows(void) { return BM; }
+extern "C" int ag_split_gemm_input_wgrad_rows(void) { return g_split_wm * 64; }
 
 extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
                                          float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream) {
@@ -513,20 +479,11 @@ extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes
     if (((uintptr_t)dZ_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
     SplitEpilogue ep = {};
     ep.h1 = h1_dev; ep.x = x_dev; ep.dw_partials = dw_partials_dev; ep.db_partials = db_partials_dev;
-#define AG_SGI(V, DV) launch_split_any<false, V, 0, 0, DV>(dZ_dev, planes_dev, nullptr, M, ep, stream)
-#ifdef AG_EXPERIMENTS
-    if (g_split_variant >= 0 && (g_split_variant & 4) != 0) {
-        switch (D) {
-            case 16: return AG_SGI(6, 16);
-            case 18: return AG_SGI(6, 18);
-            default: return AG_SGI(6, 20);
-        }
-    }
-#endif
+#define AG_SGI(DV, W) launch_split_any<false, 0, DV, W>(dZ_dev, planes_dev, nullptr, M, ep, stream)
     switch (D) {
-        case 16: return AG_SGI(kDefaultVar, 16);
-        case 18: return AG_SGI(kDefaultVar, 18);
-        default: return AG_SGI(kDefaultVar, 20);
+        case 16: return AG_SG_DISPATCH(AG_SGI(16, 2), AG_SGI(16, 4));
+        case 18: return AG_SG_DISPATCH(AG_SGI(18, 2), AG_SGI(18, 4));
+        default: return AG_SG_DISPATCH(AG_SGI(20, 2), AG_SGI(20, 4));
     }
 #undef AG_SGI
 }
@@ -536,27 +493,10 @@ extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const f
     if (!A_dev || !planes_dev || !C_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
-    // plain 2 x 2 grid: back to back in a loop the persistent de-phased form (6) is faster at M = 196 608, between the
-    // update's other kernels it is 7 us slower (in-situ kernel traces, profiles/r02_split_gemm.md)
-#ifdef AG_EXPERIMENTS
-    const int variant = g_split_variant >= 0 ? g_split_variant : kDefaultVar;
-    switch (variant) {
-        case 2: return launch_split<2>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 3: return launch_split<3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 6: return launch_split<6>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 7: return launch_split<7>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 14: return launch_split<14>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 15: return launch_split<15>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        /* timing ablations (results are wrong by construction): tools/split_gemm_probe.py --variants */
-        case 100 + 3: return launch_split<6, 3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 100 + 8: return launch_split<6, 8>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 100 + 31: return launch_split<6, 31>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 200 + 3: return launch_split<7, 3>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 200 + 8: return launch_split<7, 8>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        case 200 + 31: return launch_split<7, 31>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-        default: return AG_ERR_INVALID_ARG;
-    }
-#else
-    return launch_split<kDefaultVar>(A_dev, planes_dev, bias_dev, C_dev, M, stream);
-#endif
+    SplitEpilogue ep = {};
+    ep.bias = bias_dev;
+#define AG_SGP(HB, W) launch_split_any<HB, 0, 0, W>(A_dev, planes_dev, C_dev, M, ep, stream)
+    if (bias_dev) return AG_SG_DISPATCH(AG_SGP(true, 2), AG_SGP(true, 4));
+    return AG_SG_DISPATCH(AG_SGP(false, 2), AG_SGP(false, 4));
+#undef AG_SGP
 }

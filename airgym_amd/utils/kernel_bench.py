@@ -304,16 +304,29 @@ def measure_update_kernels(agent, iters=20):
                 "frac": flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "us_per_launch": us,
                 "note": "timed as 20 back-to-back launches (sustained-MFMA clocks); inside the minibatch, between HBM-bound "
                         "kernels, the same GEMM takes 185-205 us = 126-140 TFLOP/s (profiles/r01_bench_fused_kernel_trace.md)"})
-    # the weight gradient of the 256 x 256 layer as the step runs it: split-K batched GEMM of the library (f32 MFMA)
-    S = fs.wgrad_partials[-1].shape[0]
+    # the weight gradient of the 256 x 256 layer: the library's split-K batched GEMM (f32 MFMA; what use_split_wgrad: false runs)
+    S = 64
     if M % S == 0:
+        lparts = torch.empty(S, C, K, dtype=torch.float32, device=x.device)
         dzv, xv = fs.dz[:M * C].view(S, M // S, C).transpose(1, 2), x.view(S, M // S, K)
-        us = _time_us(lambda: torch.bmm(dzv, xv, out=fs.wgrad_partials[-1]), iters)
-        out.append({"kernel": f"library f32 split-K weight gradient [{C}x{M}]x[{M}x{K}] ({S} slices)", "bound": "mfma",
+        us = _time_us(lambda: torch.bmm(dzv, xv, out=lparts), iters)
+        out.append({"kernel": f"library f32 split-K weight gradient [{C}x{M}]x[{M}x{K}] ({S} slices) - for reference"
+                              + ("" if getattr(fs, "split_wgrad", None) else " (what the step runs)"), "bound": "mfma",
                     "achieved": flops / us / 1e6, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": flops / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, "us_per_launch": us,
-                    "note": "the one GEMM of the update still at the f32 matrix-core rate (90 % pipe occupancy, "
-                            "profiles/r02_update_kernels_pmc.md)"})
+                    "note": "f32-input MFMA (1/16 of the bf16 rate); reads both operands twice (profiles/r02_update_kernels_pmc.md)"})
+        del lparts
+    if getattr(fs, "split_wgrad", None):
+        li = max(fs.split_wgrad)
+        wp = fs.wgrad_partials[li]
+        dzm = fs.dz[:M * C].view(M, C)
+        us = _time_us(lambda: N.check(lib.ag_split_wgrad(dzm.data_ptr(), x.data_ptr(), wp.data_ptr(), M, C, K, wp.shape[0], st),
+                                      "ag_split_wgrad"), iters)
+        out.append({"kernel": f"ag_split_wgrad dW[{C}x{K}] = dZ^T X over {M} rows ({wp.shape[0]} row slices, 6 bf16 MFMAs per f32 "
+                              f"product, f32-accurate), as the step runs it", "bound": "mfma", "achieved": 6.0 * flops / us / 1e6,
+                    "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 6.0 * flops / us / 1e6 / BF16_MFMA_PEAK_TFLOPS,
+                    "us_per_launch": us, "f32_equivalent_tflops": flops / us / 1e6,
+                    "note": "each operand read from HBM once; slice partials summed by ag_sum_rows_multi (fixed order)"})
     if getattr(fs, "split", None):
         sg = next(iter(fs.split.values()))
         sg.prepare()

@@ -24,9 +24,9 @@ int ag_debug_touch_variant(ag_handle h, const float* actions_dev, int mode, void
  * wave, {HW_REG_HW_ID, HW_REG_XCC_ID} into out_dev [ceil(n/64) * 2, 2] u32 (tools/wave_placement.py decodes SIMD / CU / XCC). */
 int ag_debug_wave_placement(ag_handle h, unsigned int* out_dev, void* stream);
 
-/* Scheduling variant of ag_split_gemm / ag_split_gemm_elu_heads (-1 = by size (default); bit 0 = prescribed issue order of LDS
- * reads and MFMAs inside a K chunk, bit 1 = always set (2 x 2 waves), bit 2 = persistent workgroups with the second one of each
- * CU started half a tile late, bit 3 = non-temporal stores of C).  Values without a kernel are refused at launch. */
+/* Row-tile size of ag_split_gemm / ag_split_gemm_elu_heads / ag_split_gemm_input_wgrad: 2 = 128 rows per workgroup (4 waves, two
+ * workgroups per CU), 4 = 256 rows (8 waves, one per CU), -1 = the shipped default.  Also read once from AIRGYM_SPLIT_WM.  Changes
+ * what ag_split_gemm_input_wgrad_rows() returns: set it before a caller sizes its partial buffers. */
 int ag_debug_split_gemm_variant(int variant);
 
 /* ag_split_wgrad: 1 (default) = the issue order of a chunk is prescribed (staging work spread between the MFMAs), 0 = left to

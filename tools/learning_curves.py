@@ -21,7 +21,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 
-def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=None):
+def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=None, env_extra=None):
     class A:
         pass
     A.envs, A.minibatches, A.graph, A.task, A.ctl, A.tuned_gemms = envs, minibatches, 1, "hovering", "rate", 1
@@ -30,6 +30,7 @@ def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=
     params["seed"] = seed
     params["config"]["env_config"]["seed"] = seed
     params["config"].update(extra or {})
+    params["config"]["env_config"].update(env_extra or {})
     torch.manual_seed(seed)
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
     agent = A2CAgent("curve", params)
