@@ -102,13 +102,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // a lane (rows (e & 3) + 8 (e >> 2) + 16 ks + 4 h for lane half h): the B operand (dz1) is formed from the accumulators IN
 // PLACE, no data movement; the A operand (x, pre-split into the same row order) comes from LDS planes built once per tile.
 // Both operands are split three ways like the main product (six MFMAs per step): float32-accurate.
-template <int J, int WM>
+template <int J, int WM, int NDT>
 __device__ __forceinline__ void input_wgrad_tile(const f32x16 (&acc)[8], const float* __restrict__ hcol, const uint4* xp_lane,
                                                  float* mine, int m0, int M, int wm, int khalf, int DIN1) {
-    constexpr int XS = WM * 2 * 32;                          // units per (plane, step) of the x image
-    f32x16 g;
+    constexpr int XS = WM * 2 * 32 * NDT;                    // units per (plane, step) of the x image
+    f32x16 g[NDT];                                           // NDT tiles of 32 input columns (Tracking's 48 + bias column: 2)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g[r] = 0.0f;
+    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[t][r] = 0.0f;
     // activations of step s + PF are requested before step s is worked on (4 steps per column tile: i = s >> 1, ks = s & 1)
     constexpr int PF = 2;
     float ring[PF][8];
@@ -130,29 +132,37 @@ __device__ __forceinline__ void input_wgrad_tile(const f32x16 (&acc)[8], const f
         if (s + PF < 4) AG_IW_FETCH(s + PF);
         uint4 b1, b2, b3;                                   // rows past M need no masking here: their x rows are zero
         split8(make_float4(dz[0], dz[1], dz[2], dz[3]), make_float4(dz[4], dz[5], dz[6], dz[7]), b1, b2, b3);
-        const uint4 ua1 = xp_lane[(0 * 4 + s) * XS], ua2 = xp_lane[(1 * 4 + s) * XS], ua3 = xp_lane[(2 * 4 + s) * XS];
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1), a2 = *reinterpret_cast<const bf16x8*>(&ua2),
-                     a3 = *reinterpret_cast<const bf16x8*>(&ua3);
         const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(&b1), c2 = *reinterpret_cast<const bf16x8*>(&b2),
                      c3 = *reinterpret_cast<const bf16x8*>(&b3);
-        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, c1, g, 0, 0, 0);
-        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c3, g, 0, 0, 0);
-        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c2, g, 0, 0, 0);
-        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c1, g, 0, 0, 0);
-        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c2, g, 0, 0, 0);
-        g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c1, g, 0, 0, 0);
-        asm volatile("" : "+v"(g));                         // this step's products stay in this step (see the head epilogue)
+#pragma unroll
+        for (int t = 0; t < NDT; ++t) {                     // the split dz1 fragment feeds every tile of input columns
+            const uint4 ua1 = xp_lane[(0 * 4 + s) * XS + 32 * t], ua2 = xp_lane[(1 * 4 + s) * XS + 32 * t],
+                        ua3 = xp_lane[(2 * 4 + s) * XS + 32 * t];
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1), a2 = *reinterpret_cast<const bf16x8*>(&ua2),
+                         a3 = *reinterpret_cast<const bf16x8*>(&ua3);
+            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, c1, g[t], 0, 0, 0);
+            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c3, g[t], 0, 0, 0);
+            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c2, g[t], 0, 0, 0);
+            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c1, g[t], 0, 0, 0);
+            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c2, g[t], 0, 0, 0);
+            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c1, g[t], 0, 0, 0);
+            asm volatile("" : "+v"(g[t]));                  // this step's products stay in this step (see the head epilogue)
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef AG_IW_FETCH
 #undef AG_IW_ROW
-    // g: column c = this lane's column of tile J, rows d = (r & 3) + 8 (r >> 2) + 4 h; keep d <= DIN (d = DIN: bias gradient)
-    float* dst = mine + J * 32 * DIN1;
+    // g[t]: column c = this lane's column of tile J, rows d = 32 t + (r & 3) + 8 (r >> 2) + 4 h; keep d <= DIN (d = DIN: bias
+    // gradient).  NDT == 1: `mine` is this lane's row of the whole-tile buffer (column tile J at + J * 32 rows); NDT == 2: of the
+    // per-column-tile buffer.
+    float* dst = mine + (NDT == 1 ? J * 32 * DIN1 : 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int d = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (d < DIN1) dst[d] = g[r];
-    }
+    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (d < DIN1) dst[d] = g[t][r];
+        }
 }
 
 struct SplitEpilogue {
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     constexpr int BPT = B_UNITS / NT;                        // B-plane units copied per thread per chunk (6 or 3)
     static_assert(WM == 2 || WM == 4, "4 or 8 waves");
     static_assert(A1 == 0 || DIN == 0, "one fused epilogue at a time");
-    static_assert((DIN & 1) == 0 && DIN <= 24, "input width: even (packed FMAs), register tile 4 x DIN");
+    static_assert((DIN & 1) == 0 && DIN <= 62, "input width: even, at most two 32-wide tiles with the bias column");
     const float* __restrict__ bias = ep.bias;
     const float* __restrict__ Wh = ep.Wh;
     const float* __restrict__ bh = ep.bh;
@@ -327,16 +337,18 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         }
     } else if constexpr (DIN > 0) {
         constexpr int RW = DIN + 1;                         // reduction row: DIN weight-gradient entries + the bias gradient
-        constexpr int XS = WM * 2 * 32;                     // units per (plane, step)
-        uint4* xp = lds;                                    // [plane 3][step 4][wm WM][h 2][d 32] x 16 B (24 / 48 KB): x, split, in K order
-        float* red = reinterpret_cast<float*>(lds + 3 * 4 * XS);       // [wm WM][BN][RW]
+        constexpr int NDT = (RW + 31) / 32;                 // 32-wide tiles of input columns (1: Hovering's 18; 2: Tracking's 48)
+        constexpr int DW = 32 * NDT;
+        constexpr int XS = WM * 2 * DW;                     // units per (plane, step)
+        uint4* xp = lds;                                    // [plane 3][step 4][wm WM][h 2][d DW] x 16 B: x, split, in K order
+        float* red = reinterpret_cast<float*>(lds + 3 * 4 * XS);       // NDT 1: [wm WM][BN][RW]; NDT 2: [wm WM][wn 2][32][RW] per column tile
         int late = 0;                                       // (opaque zero, as above)
         asm volatile("" : "+s"(late) : : "memory");
         const int m0e = m0 + late;          // opaque too: or the row addresses are formed before the main loop and spilled
         // one unit = the 8 rows of (wm, step, lane half h) for one input column d, as three bf16x8 pieces; d = DIN is the
         // all-ones column that yields the bias gradient, d > DIN and rows past M are zero (which also masks the tail tile)
         for (int u = tid; u < 4 * XS; u += NT) {
-            const int d = u & 31, h = (u >> 5) & 1, w2 = (u >> 6) % WM, st = u / XS;
+            const int d = u % DW, h = (u / DW) & 1, w2 = (u / (2 * DW)) % WM, st = u / XS;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -346,26 +358,51 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
             }
             uint4 p1, p2, p3;
             split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
-            xp[(0 * 4 + st) * XS + (w2 * 2 + h) * 32 + d] = p1;
-            xp[(1 * 4 + st) * XS + (w2 * 2 + h) * 32 + d] = p2;
-            xp[(2 * 4 + st) * XS + (w2 * 2 + h) * 32 + d] = p3;
+            xp[(0 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p1;
+            xp[(1 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p2;
+            xp[(2 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p3;
         }
         __syncthreads();
         const float* hcol = ep.h1 + wn * 128 + l31 + late;
-        const uint4* xp_lane = xp + (wm * 2 + khalf) * 32 + l31;
-        float* mine = red + ((size_t)wm * BN + wn * 128 + l31) * RW;
-        input_wgrad_tile<0, WM>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
-        input_wgrad_tile<1, WM>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
-        input_wgrad_tile<2, WM>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
-        input_wgrad_tile<3, WM>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
-        __syncthreads();
-        // the WM row blocks in a fixed order: deterministic
-        for (int idx = tid; idx < BN * RW; idx += NT) {
-            const int c = idx / RW, d = idx - c * RW;
-            float v = red[idx] + red[BN * RW + idx];
-            if (WM == 4) v = (v + red[2 * BN * RW + idx]) + red[3 * BN * RW + idx];
-            if (d < DIN) ep.dw_partials[((size_t)tile * BN + c) * DIN + d] = v;
-            else ep.db_partials[(size_t)tile * BN + c] = v;
+        const uint4* xp_lane = xp + (wm * 2 + khalf) * DW + l31;
+        if constexpr (NDT == 1) {
+            float* mine = red + ((size_t)wm * BN + wn * 128 + l31) * RW;
+            input_wgrad_tile<0, WM, 1>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+            input_wgrad_tile<1, WM, 1>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+            input_wgrad_tile<2, WM, 1>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+            input_wgrad_tile<3, WM, 1>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);
+            __syncthreads();
+            // the WM row blocks in a fixed order: deterministic
+            for (int idx = tid; idx < BN * RW; idx += NT) {
+                const int c = idx / RW, d = idx - c * RW;
+                float v = red[idx] + red[BN * RW + idx];
+                if (WM == 4) v = (v + red[2 * BN * RW + idx]) + red[3 * BN * RW + idx];
+                if (d < DIN) ep.dw_partials[((size_t)tile * BN + c) * DIN + d] = v;
+                else ep.db_partials[(size_t)tile * BN + c] = v;
+            }
+        } else {
+            // two tiles of input columns: the whole-tile reduction buffer would not fit beside the x image, so the column
+            // tiles are reduced one at a time through a [wm][2 x 32 columns][RW] buffer (same fixed order over the row blocks)
+            float* mine = red + ((size_t)wm * 64 + wn * 32 + l31) * RW;
+#define AG_IW_COLUMN_TILE(J_)                                                                          \
+            do {                                                                                       \
+                input_wgrad_tile<J_, WM, NDT>(acc, hcol, xp_lane, mine, m0e, M, wm, khalf, RW);        \
+                __syncthreads();                                                                       \
+                for (int idx = tid; idx < 64 * RW; idx += NT) {                                        \
+                    const int cj = idx / RW, d = idx - cj * RW;                                        \
+                    const int c = (cj >> 5) * 128 + (J_) * 32 + (cj & 31);                              \
+                    float v = red[idx] + red[64 * RW + idx];                                           \
+                    if (WM == 4) v = (v + red[2 * 64 * RW + idx]) + red[3 * 64 * RW + idx];            \
+                    if (d < DIN) ep.dw_partials[((size_t)tile * BN + c) * DIN + d] = v;                \
+                    else ep.db_partials[(size_t)tile * BN + c] = v;                                    \
+                }                                                                                      \
+                __syncthreads();                                                                       \
+            } while (0)
+            AG_IW_COLUMN_TILE(0);
+            AG_IW_COLUMN_TILE(1);
+            AG_IW_COLUMN_TILE(2);
+            AG_IW_COLUMN_TILE(3);
+#undef AG_IW_COLUMN_TILE
         }
     } else {
 #pragma unroll
@@ -425,7 +462,8 @@ template <int DIN, int WM>
 constexpr size_t split_lds_bytes() {
     size_t stages = (size_t)2 * stage_units(WM * 64) * 16;
     // the first-layer-backward epilogue re-uses the stages for the split x image and the per-row-block reduction buffer
-    size_t epi = DIN > 0 ? (size_t)3 * 4 * (WM * 2 * 32) * 16 + (size_t)WM * BN * (DIN + 1) * 4 : 0;
+    constexpr int ndt = (DIN + 1 + 31) / 32;
+    size_t epi = DIN > 0 ? (size_t)3 * 4 * (WM * 2 * 32 * ndt) * 16 + (size_t)WM * (ndt == 1 ? BN : 64) * (DIN + 1) * 4 : 0;
     return stages > epi ? stages : epi;
 }
 
@@ -472,10 +510,13 @@ extern "C" int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_de
 
 extern "C" int ag_split_gemm_input_wgrad_rows(void) { return g_split_wm * 64; }
 
+// input widths with a fused first-layer backward: Hovering 18 (16 / 20: the neighbouring even widths), Tracking 48
+extern "C" int ag_split_gemm_input_wgrad_supported(int D) { return (D == 16 || D == 18 || D == 20 || D == 48) ? 1 : 0; }
+
 extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
                                          float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream) {
     if (!dZ_dev || !planes_dev || !h1_dev || !x_dev || !dw_partials_dev || !db_partials_dev || M <= 0) return AG_ERR_INVALID_ARG;
-    if (n != BN || k != KDIM || (D != 16 && D != 18 && D != 20)) return AG_ERR_UNSUPPORTED;
+    if (n != BN || k != KDIM || !ag_split_gemm_input_wgrad_supported(D)) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)dZ_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
     SplitEpilogue ep = {};
     ep.h1 = h1_dev; ep.x = x_dev; ep.dw_partials = dw_partials_dev; ep.db_partials = db_partials_dev;
@@ -483,7 +524,8 @@ extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes
     switch (D) {
         case 16: return AG_SG_DISPATCH(AG_SGI(16, 2), AG_SGI(16, 4));
         case 18: return AG_SG_DISPATCH(AG_SGI(18, 2), AG_SGI(18, 4));
-        default: return AG_SG_DISPATCH(AG_SGI(20, 2), AG_SGI(20, 4));
+        case 20: return AG_SG_DISPATCH(AG_SGI(20, 2), AG_SGI(20, 4));
+        default: return AG_SG_DISPATCH(AG_SGI(48, 2), AG_SGI(48, 4));
     }
 #undef AG_SGI
 }

@@ -112,12 +112,13 @@ class FusedMLPStep:
         wrows, irows = self.lib.ag_wgrad_rows_per_block(0), max(1, self.lib.ag_input_wgrad_rows(D))
         self.wg_blocks = (M + wrows - 1) // wrows
         # small weight gradients folded into the ELU' passes (head: always; first layer: D in {16,18,20}, >= 2 layers)
-        self.fuse_input_wgrad = L >= 2 and self.lib.ag_input_wgrad_rows(D) > 0
         # ... and for a [D -> 256 -> 256] trunk the first layer's whole backward rides in the epilogue of the second layer's
-        # dX GEMM (ag_split_gemm_input_wgrad): dh1 / dz1 are never written, one partial per 128-row tile
-        self.fuse_gemm_input_wgrad = (self.fuse_input_wgrad and L == 2 and bool(agent.config.get("fuse_gemm_input_wgrad", True))
+        # dX GEMM (ag_split_gemm_input_wgrad): dh1 / dz1 are never written, one partial per row tile (D = 18: Hovering, 48: Tracking)
+        self.fuse_gemm_input_wgrad = (L == 2 and bool(agent.config.get("fuse_gemm_input_wgrad", True))
                                       and SplitGemm256.applies(self.layers[1][0], agent.config)
-                                      and self.layers[0][0].shape[0] == 256)
+                                      and self.layers[0][0].shape[0] == 256
+                                      and bool(self.lib.ag_split_gemm_input_wgrad_supported(D)))
+        self.fuse_input_wgrad = L >= 2 and (self.lib.ag_input_wgrad_rows(D) > 0 or self.fuse_gemm_input_wgrad)
         if self.fuse_gemm_input_wgrad:
             irows = self.lib.ag_split_gemm_input_wgrad_rows()
         self.in_wg_blocks = (M + irows - 1) // irows

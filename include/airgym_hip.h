@@ -340,7 +340,7 @@ int ag_elu_heads(float* zh_dev, const float* Wh_dev, const float* bh_dev, float*
  *       ag_elu_bwd_input_wgrad computes): dh1 = dZ_dev W stays in registers, is multiplied by ELU'(h1_dev) and reduced against
  *       x_dev [M, D] over each tile of ag_split_gemm_input_wgrad_rows() rows: dw_partials_dev [tiles, 256, D], db_partials_dev
  *       [tiles, 256] (tiles = ceil(M / rows); the caller sums over dim 0, e.g. ag_sum_rows_multi).  Neither dh1 nor dz1 is
- *       written.  D in {16, 18, 20}. */
+ *       written.  D in {16, 18, 20} (Hovering: 18) or 48 (Tracking, tracking.py:202-214): ag_split_gemm_input_wgrad_supported. */
 /*   ag_split_wgrad: the weight gradient of the same layer, dW [256, 256] = dZ_dev^T X_dev (dZ_dev, X_dev: [M, 256] f32 row-major;
  *       autograd's grad_weight of mlp.py:36-39), both operands split three ways on the fly, the contraction running over the
  *       rows.  K = M is cut into `slices` contiguous row ranges, one workgroup each (ag_split_wgrad_slices(M) = one per CU, at
@@ -354,6 +354,7 @@ int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, void* plane
 int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
                   void* stream);
 int ag_split_gemm_input_wgrad_rows(void);
+int ag_split_gemm_input_wgrad_supported(int D);   /* 1 for D in {16, 18, 20, 48} */
 int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
                               float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
 int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,

@@ -388,6 +388,8 @@ def test_hand_scheduled_update_matches_autograd(Handle, task, ctl, units):
     params["network"]["mlp"]["units"] = units
     agent = A2CAgent("t", params)
     assert agent._fused_step is not None, "the bench configuration must take the hand-scheduled path"
+    if units == [256, 256]:     # Hovering's 18-wide and Tracking's 48-wide first layer: backward in the dX GEMM's epilogue
+        assert agent._fused_step.fuse_gemm_input_wgrad and agent._fused_step.split_wgrad == {1}
     agent.init_tensors()
     agent.obs = agent.env_reset()
     agent.epoch_num = 1

@@ -130,8 +130,8 @@ def test_fused_elu_heads_rejects_bad_arguments(lib):
     assert lib.ag_split_gemm_elu_heads(*args, 0, 256, 256, 5, _stream()) != 0
 
 
-@pytest.mark.parametrize("M", [1, 127, 129, 4097, 196608])
-@pytest.mark.parametrize("D", [16, 18, 20])
+@pytest.mark.parametrize("M", [1, 127, 129, 257, 4097, 196608])
+@pytest.mark.parametrize("D", [16, 18, 20, 48])
 def test_fused_first_layer_backward_epilogue(lib, M, D):
     """ag_split_gemm_input_wgrad = ag_split_gemm (dX of layer 2) + ag_elu_bwd_input_wgrad (ELU' + dW1 / db1 partials) in one
     launch, with dh1 never written: summed partials against a float64 evaluation and against the two-launch path."""
@@ -159,16 +159,19 @@ def test_fused_first_layer_backward_epilogue(lib, M, D):
     sb = (dZ.double().abs() @ W.double().abs()).sum(0) + 1e-30
     assert ((dW - dW_ref).abs() / sW).max().item() < 4e-7
     assert ((db - db_ref).abs() / sb).max().item() < 4e-7
-    # the two-launch path it replaces
-    dh32 = torch.empty(M, 256, device="cuda")
-    N.check(lib.ag_split_gemm(dZ.data_ptr(), planes.data_ptr(), None, dh32.data_ptr(), M, 256, 256, _stream()), "ag_split_gemm")
+    # the two-launch path it replaces (Hovering's widths; Tracking's 48 has no stand-alone first-layer kernel)
     r2 = lib.ag_input_wgrad_rows(D)
-    b2 = (M + r2 - 1) // r2
-    dwp2, dbp2 = torch.empty(b2, 256, D, device="cuda"), torch.empty(b2, 256, device="cuda")
-    N.check(lib.ag_elu_bwd_input_wgrad(dh32.data_ptr(), h1.data_ptr(), x.data_ptr(), dwp2.data_ptr(), dbp2.data_ptr(), M, 256, D,
-                                       _stream()), "ag_elu_bwd_input_wgrad")
-    assert ((dwp2.double().sum(0) - dW).abs() / sW).max().item() < 4e-7
-    assert ((dbp2.double().sum(0) - db).abs() / sb).max().item() < 4e-7
+    if r2 > 0:
+        dh32 = torch.empty(M, 256, device="cuda")
+        N.check(lib.ag_split_gemm(dZ.data_ptr(), planes.data_ptr(), None, dh32.data_ptr(), M, 256, 256, _stream()), "ag_split_gemm")
+        b2 = (M + r2 - 1) // r2
+        dwp2, dbp2 = torch.empty(b2, 256, D, device="cuda"), torch.empty(b2, 256, device="cuda")
+        N.check(lib.ag_elu_bwd_input_wgrad(dh32.data_ptr(), h1.data_ptr(), x.data_ptr(), dwp2.data_ptr(), dbp2.data_ptr(), M, 256, D,
+                                           _stream()), "ag_elu_bwd_input_wgrad")
+        assert ((dwp2.double().sum(0) - dW).abs() / sW).max().item() < 4e-7
+        assert ((dbp2.double().sum(0) - db).abs() / sb).max().item() < 4e-7
+    else:
+        assert D == 48 and lib.ag_split_gemm_input_wgrad_supported(D) == 1 and lib.ag_split_gemm_input_wgrad_supported(24) == 0
     # per-tile partials: each tile only sees its own rows (tile t of the tail is partial)
     t = tiles - 1
     sl = slice(t * rows, M)

@@ -40,7 +40,7 @@ def main():
     ref_mean = sd["running_mean_std.running_mean_std.observation.running_mean"][:16].double().cuda()
     ref_std = sd["running_mean_std.running_mean_std.observation.running_var"][:16].double().sqrt().cuda()
     for signs in args.signs:
-        sg = torch.tensor([1.0 if c == "+" else -1.0 for c in signs] + [1.0], device="cuda")
+        sg = torch.tensor([1.0 if c in "+p" else -1.0 for c in signs] + [1.0], device="cuda")      # "+-+" or "pnp"
         env = vecenv.create_vec_env("planning", args.envs, use_image=True, num_envs=args.envs, ctl_mode="rate", seed=0,
                                     sim_device="cuda:0", headless=True)
         obs = env.reset()
