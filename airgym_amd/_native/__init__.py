@@ -184,6 +184,8 @@ SYMBOLS = [
     ("ag_relu_bn_apply", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_reduce", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_dx", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_stats_weighted", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_wgrad_rows_per_block", ctypes.c_int, [ctypes.c_int]),
     ("ag_input_wgrad_rows", ctypes.c_int, [ctypes.c_int]),
     ("ag_sum_rows_groups", ctypes.c_int, []),

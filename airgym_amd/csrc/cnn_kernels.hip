@@ -38,9 +38,12 @@ template <> struct VecT<4> { typedef float4 type; };
 template <> struct VecT<2> { typedef float2 type; };
 template <> struct VecT<1> { typedef float type; };
 
+// `wts` (optional, [N]): per-image multiplicities.  A minibatch that holds image i m_i times (the depth camera runs every 4th env
+// step, so 3 of 4 consecutive rollout samples of an env carry the same image) has the batch statistics of the DISTINCT images
+// weighted by m_i; the update then runs the convolutions on the distinct images only (lib/network/fused_relu_bn.py).
 template <int VEC>
-__global__ __launch_bounds__(256) void relu_bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partials,
-                                                            long long planes, int C, int HW) {
+__global__ __launch_bounds__(256) void relu_bn_stats_kernel(const float* __restrict__ x, const float* __restrict__ wts,
+                                                            float* __restrict__ partials, long long planes, int C, int HW) {
     typedef typename VecT<VEC>::type vec_t;
     __shared__ float acc[4][kMaxC][2];                      // one accumulator set per wave: fixed summation order
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,8 +71,9 @@ __global__ __launch_bounds__(256) void relu_bn_stats_kernel(const float* __restr
         q = wave_sum(q);
         if (lane == 0) {
             const int c = (int)(p % C);
-            acc[wave][c][0] += s;
-            acc[wave][c][1] += q;
+            const float wi = wts ? wts[p / C] : 1.0f;
+            acc[wave][c][0] += wi * s;
+            acc[wave][c][1] += wi * q;
         }
     }
     __syncthreads();
@@ -151,10 +155,13 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_reduce_kernel(const float* __
 }
 
 // coef [C][4] = {mean, invstd, gamma * invstd, 1 / m} ; sums [C][2] = {dbeta, dgamma}
+// With multiplicities (`wts`, see relu_bn_stats_kernel) dy is the gradient SUMMED over the copies of an image and the two mean
+// terms, which every copy receives, are scaled by the image's multiplicity: dx_i = [x > 0] g (dy_i - m_i db / m - m_i xhat dg / m).
 template <int VEC>
 __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ coef, const float* __restrict__ sums,
-                                                             float* __restrict__ dx, long long planes, int C, int HW) {
+                                                             const float* __restrict__ wts, float* __restrict__ dx,
+                                                             long long planes, int C, int HW) {
     typedef typename VecT<VEC>::type vec_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long p0 = (long long)blockIdx.x * kPlanesPerBlock;
@@ -163,7 +170,8 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __rest
         const long long p = p0 + k;
         if (p >= planes) break;
         const int c = (int)(p % C);
-        const float mu = coef[c * 4 + 0], is = coef[c * 4 + 1], gi = coef[c * 4 + 2], rm = coef[c * 4 + 3];
+        const float mu = coef[c * 4 + 0], is = coef[c * 4 + 1], gi = coef[c * 4 + 2];
+        const float rm = coef[c * 4 + 3] * (wts ? wts[p / C] : 1.0f);
         const float db = sums[c * 2 + 0] * rm, dg = sums[c * 2 + 1] * rm;
         const vec_t* gx = reinterpret_cast<const vec_t*>(x + p * HW);
         const vec_t* gd = reinterpret_cast<const vec_t*>(dy + p * HW);
@@ -211,12 +219,17 @@ extern "C" int ag_relu_bn_planes_per_block(void) { return kPlanesPerBlock; }
         else hipLaunchKernelGGL((KERNEL<1>), grid, block, 0, (hipStream_t)stream, __VA_ARGS__);               \
     } while (0)
 
-extern "C" int ag_relu_bn_stats(const float* x_dev, float* partials_dev, int N, int C, int HW, void* stream) {
+extern "C" int ag_relu_bn_stats_weighted(const float* x_dev, const float* weights_dev, float* partials_dev, int N, int C, int HW,
+                                         void* stream) {
     if (!x_dev || !partials_dev) return AG_ERR_INVALID_ARG;
     AG_BN_CHECK(N, C, HW);
     const int w = vec_width(x_dev, nullptr, nullptr, HW);
-    AG_BN_DISPATCH(relu_bn_stats_kernel, w, x_dev, partials_dev, planes, C, HW);
+    AG_BN_DISPATCH(relu_bn_stats_kernel, w, x_dev, weights_dev, partials_dev, planes, C, HW);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_relu_bn_stats(const float* x_dev, float* partials_dev, int N, int C, int HW, void* stream) {
+    return ag_relu_bn_stats_weighted(x_dev, nullptr, partials_dev, N, C, HW, stream);
 }
 
 extern "C" int ag_relu_bn_apply(const float* x_dev, const float* scale_dev, const float* shift_dev, float* y_dev, int N, int C,
@@ -237,11 +250,16 @@ extern "C" int ag_relu_bn_bwd_reduce(const float* dy_dev, const float* x_dev, co
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
-extern "C" int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
-                                 float* dx_dev, int N, int C, int HW, void* stream) {
+extern "C" int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
+                                          const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream) {
     if (!dy_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev) return AG_ERR_INVALID_ARG;
     AG_BN_CHECK(N, C, HW);
     const int w = vec_width(x_dev, dy_dev, dx_dev, HW);
-    AG_BN_DISPATCH(relu_bn_bwd_dx_kernel, w, dy_dev, x_dev, coef_dev, sums_dev, dx_dev, planes, C, HW);
+    AG_BN_DISPATCH(relu_bn_bwd_dx_kernel, w, dy_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, planes, C, HW);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
+                                 float* dx_dev, int N, int C, int HW, void* stream) {
+    return ag_relu_bn_bwd_dx_weighted(dy_dev, x_dev, coef_dev, sums_dev, nullptr, dx_dev, N, C, HW, stream);
 }

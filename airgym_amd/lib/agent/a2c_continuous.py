@@ -66,6 +66,32 @@ def discount_values(fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma
     return mb_advs
 
 
+class DedupFrames:
+    """The images of a flattened rollout batch (env-major: sample b = env * H + t) without their duplicates.
+    `frames` [S, N, ...] are the distinct images of the rollout, `frame_of_step[t]` says which one step t shows (the same for
+    every env: the camera runs on a global cadence).  Slicing [b0:b1] - what PPODataset does for a minibatch - yields the
+    distinct images of those samples, the sample -> image map and the multiplicities."""
+
+    def __init__(self, frames, frame_of_step, horizon):
+        self.frames = frames
+        self.S, self.N = frames.shape[0], frames.shape[1]
+        self.H = horizon
+        self.frame_of_step = torch.tensor(frame_of_step, dtype=torch.long, device=frames.device)
+
+    def __len__(self):
+        return self.N * self.H
+
+    def __getitem__(self, sl):
+        b = torch.arange(sl.start, sl.stop, device=self.frames.device)
+        env = torch.div(b, self.H, rounding_mode="floor")
+        keys = env * self.S + self.frame_of_step[b - env * self.H]          # non-decreasing within an env, envs ascending
+        uniq, inverse, counts = torch.unique_consecutive(keys, return_inverse=True, return_counts=True)
+        u_env = torch.div(uniq, self.S, rounding_mode="floor")
+        flat = self.frames.view((self.S * self.N,) + tuple(self.frames.shape[2:]))
+        return {"image": flat.index_select(0, (uniq - u_env * self.S) * self.N + u_env), "image_inverse": inverse,
+                "image_counts": counts.to(torch.float32)}
+
+
 class FlatAdam:
     """Adam (eps 1e-8, no weight decay unless given) over ONE flat parameter / gradient buffer.
     All state and the learning rate are device tensors: the step is capturable and has no host sync.
@@ -359,6 +385,23 @@ class A2CAgent:
             d = dict(dtype=torch.float64, device=dev)
             # moments of the images rendered during the rollout; merged into the image normaliser at the start of the update
             self._img_moments = [torch.zeros(ishape, **d), torch.zeros(ishape, **d), torch.zeros((), **d)]
+        elif isinstance(self.obs_shape, dict) and self._dedup_ok():
+            # Frame de-duplication (trainable CNN on a camera task): the depth camera renders every 4th env step
+            # (planning.py:153-156, avoid.py:181-185), for every env on the same steps, so the H + 1 rollout slots hold at most
+            # ceil((H + 1) / 4) + 1 DISTINCT images per env.  Only those are stored (`_frames`, with the slot -> frame map on the
+            # host), the rollout runs the CNN once per rendered frame, and the update runs it on the distinct images of a
+            # minibatch with BatchNorm / normaliser statistics weighted by their multiplicities: the same function of the
+            # parameters as the reference's update over all samples (lib/agent/a2c_continuous.py:299-369) at ~1/4 of the
+            # convolution work and 1/3 of the image memory.
+            self._dedup = True
+            smax = (H + 1 + 3) // 4 + 2
+            self.obs_buf = {"observation": torch.zeros((H + 1, N) + tuple(self.obs_shape["observation"]), **f)}
+            # two stores used in turn: the update of rollout k reads store k % 2 while rollout k + 1 fills the other
+            self._frame_stores = [torch.zeros((smax, N) + tuple(self.obs_shape["image"]), **f) for _ in range(2)]
+            self._frames = self._frame_stores[0]
+            self._frame_feat = torch.zeros(N, self.model.feature_dim, **f)
+            self._frame_of_slot = [0] * (H + 1)
+            self._frame_top = 0
         elif isinstance(self.obs_shape, dict):
             self.obs_buf = {k: torch.zeros((H + 1, N) + tuple(shp), **f) for k, shp in self.obs_shape.items()}
         else:
@@ -393,8 +436,26 @@ class A2CAgent:
         if self._fused_rollout is not None and getattr(self, "_restored_noise_counter", None) is not None:
             self._fused_rollout.counter.fill_(int(self._restored_noise_counter))
 
+    def _dedup_ok(self):
+        m = self.model
+        return (bool(self.config.get("dedup_frames", True)) and self._hip_env is not None
+                and getattr(self._hip_env, "image", None) is not None and getattr(m, "has_cnn", False) and not m.separate
+                and "image" in self.obs_shape and str(self.ppo_device).startswith("cuda"))
+
     def _obs_at(self, n):
+        if getattr(self, "_dedup", False):
+            return {"observation": self.obs_buf["observation"][n], "image": self._frames[self._frame_of_slot[n]]}
         return {k: v[n] for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict) else self.obs_buf[n]
+
+    @torch.no_grad()
+    def _new_frame(self, slot, first=False):
+        """The env's camera buffer holds a new image: keep it as the next distinct frame of this rollout and refresh the
+        cached CNN features (policy weights and normalisers are fixed during a rollout)."""
+        self._frame_top = 0 if first else self._frame_top + 1
+        self._frames[self._frame_top].copy_(self._hip_env.image)
+        self._frame_of_slot[slot] = self._frame_top
+        self.model.eval()
+        self._frame_feat.copy_(self.model.cnn_features(self._frames[self._frame_top]))
 
     @torch.no_grad()
     def _encode_current_image(self, n, count_moments=True):
@@ -416,6 +477,11 @@ class A2CAgent:
             cnt.copy_(tot)
 
     def _obs_store(self, n, obs):
+        if getattr(self, "_dedup", False):
+            self.obs_buf["observation"][n].copy_(obs["observation"])
+            if n == 0:        # slot 0 of a rollout: the image the env holds now (after a reset, or the previous rollout's last)
+                self._new_frame(0, first=True)
+            return
         if getattr(self, "_cache_latents", False):
             self.obs_buf["observation"][n].copy_(obs["observation"])
             if "latent" in obs:
@@ -450,7 +516,10 @@ class A2CAgent:
         """One step of play_steps (a2c_base.py:651-695) with every tensor written in place."""
         if self._fused_rollout is not None:
             return self._fused_rollout.step(n)
-        res = self.get_action_values(self._obs_at(n))
+        if getattr(self, "_dedup", False):      # the CNN ran when the frame was rendered
+            res = self.get_action_values({"observation": self.obs_buf["observation"][n], "cnn_features": self._frame_feat})
+        else:
+            res = self.get_action_values(self._obs_at(n))
         self.actions_buf[n].copy_(res["actions"])
         self.neglogpacs_buf[n].copy_(res["neglogpacs"])
         self.values_buf[n].copy_(res["values"])
@@ -465,6 +534,13 @@ class A2CAgent:
                     self._encode_current_image(n + 1)
                 else:
                     self.obs_buf["latent"][n + 1].copy_(self.obs_buf["latent"][n])
+            elif getattr(self, "_dedup", False):   # camera task, trainable CNN: the image is kept only when the camera ran
+                self._hip_env.step_into(env_actions, self.obs_buf["observation"][n + 1], self.raw_rewards_buf[n], None)
+                self.dones_buf[n + 1].copy_(self._hip_env.reset_buf)
+                if self._hip_env.last_step_rendered():
+                    self._new_frame(n + 1)
+                else:
+                    self._frame_of_slot[n + 1] = self._frame_top
             elif isinstance(self.obs_buf, dict):   # Planning: state vector into the slot, image copied from the camera buffer
                 self._hip_env.step_into(env_actions, self.obs_buf["observation"][n + 1], self.raw_rewards_buf[n], None)
                 self.dones_buf[n + 1].copy_(self._hip_env.reset_buf)
@@ -518,7 +594,8 @@ class A2CAgent:
         camera = self._hip_env is not None and getattr(self._hip_env, "image", None) is not None
         graphable = (self.use_hip_graph and str(self.ppo_device).startswith("cuda") and H % 2 == 0
                      and (not camera or H % 4 == 0)
-                     and not self._cache_latents)      # the frozen encoder runs MIOpen's find step: not inside a capture
+                     and not self._cache_latents       # the frozen encoder runs MIOpen's find step: not inside a capture
+                     and not getattr(self, "_dedup", False))
         fr = self._fused_rollout
 
         def rollout():
@@ -551,14 +628,24 @@ class A2CAgent:
             last_values = self.model.denorm_value(heads[:, self.actions_num:self.actions_num + 1])
             mb_advs, mb_returns = fr.gae(last_values)
         else:
-            last_values = self.model({"is_train": False, "obs": self._obs_at(H)})["values"]
+            if getattr(self, "_dedup", False):
+                last_values = self.model({"is_train": False, "obs": {"observation": self.obs_buf["observation"][H],
+                                                                      "cnn_features": self._frame_feat}})["values"]
+            else:
+                last_values = self.model({"is_train": False, "obs": self._obs_at(H)})["values"]
             fdones = self.dones_buf[H].float()
             mb_fdones = self.dones_buf[:H].float()
             mb_advs = self._gae(fdones, last_values, mb_fdones)
             mb_returns = mb_advs + self.values_buf
+        if getattr(self, "_dedup", False):
+            obses = {"observation": swap_and_flatten01(self.obs_buf["observation"][:H]),
+                     "frames": DedupFrames(self._frames, self._frame_of_slot[:H], H)}
+        elif isinstance(self.obs_buf, dict):
+            obses = {k: swap_and_flatten01(v[:H]) for k, v in self.obs_buf.items()}
+        else:
+            obses = swap_and_flatten01(self.obs_buf[:H])
         batch = {
-            "obses": ({k: swap_and_flatten01(v[:H]) for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict)
-                      else swap_and_flatten01(self.obs_buf[:H])),
+            "obses": obses,
             "dones": swap_and_flatten01(self.dones_buf[:H]),
             "actions": swap_and_flatten01(self.actions_buf),
             "neglogpacs": swap_and_flatten01(self.neglogpacs_buf),
@@ -569,7 +656,13 @@ class A2CAgent:
             "played_frames": self.batch_size,
         }
         # the last observation / done flags become slot 0 of the next rollout
-        self._obs_store(0, self._obs_at(H))
+        if getattr(self, "_dedup", False):
+            # the update reads this rollout's frames: the next rollout (and its slot 0, the image the env holds now) uses the other store
+            self._frames = self._frame_stores[1] if self._frames is self._frame_stores[0] else self._frame_stores[0]
+            self.obs_buf["observation"][0].copy_(self.obs_buf["observation"][H])
+            self._new_frame(0, first=True)
+        else:
+            self._obs_store(0, self._obs_at(H))
         self.dones_buf[0].copy_(self.dones_buf[H])
         return batch
 

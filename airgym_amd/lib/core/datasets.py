@@ -31,5 +31,14 @@ class PPODataset:
         for k, v in self.values_dict.items():
             if v is None:
                 continue
-            out[k] = {kd: vd[start:end] for kd, vd in v.items()} if isinstance(v, dict) else v[start:end]
+            if isinstance(v, dict):
+                out[k] = {}
+                for kd, vd in v.items():
+                    piece = vd[start:end]
+                    if isinstance(piece, dict):      # de-duplicated frames: {image, image_inverse, image_counts} of this slice
+                        out[k].update(piece)
+                    else:
+                        out[k][kd] = piece
+            else:
+                out[k] = v[start:end]
         return out

@@ -22,10 +22,26 @@ class RunningMeanStd(nn.Module):
         self.register_buffer("count", torch.ones((), dtype=torch.float64))
 
     @torch.no_grad()
-    def update(self, x, group=None):
+    def update(self, x, group=None, weights=None):
         """Merge the moments of batch x ([B, ...]).  With `group` (torch.distributed) the batch moments
         are first combined across ranks so that every replica keeps identical statistics (the reference
-        lets them drift)."""
+        lets them drift).  weights [B] (optional): row i stands for weights[i] identical rows
+        (frame de-duplication of the depth images): the moments are those of the expanded batch."""
+        if weights is not None:
+            wv = weights.to(device=x.device, dtype=torch.float64).view(-1, *([1] * (x.dim() - 1)))
+            n = wv.sum()
+            mean = (wv * x).sum(0) / n
+            var = (wv * (x - mean) ** 2).sum(0) / torch.clamp(n - 1.0, min=1.0)      # unbiased, like x.var(0) of the expansion
+            if group is not None:
+                import torch.distributed as dist
+                if dist.get_world_size(group) > 1:
+                    packed = torch.cat(((mean * n).reshape(-1), ((var * (n - 1.0)) + n * mean * mean).reshape(-1), n.reshape(1)))
+                    dist.all_reduce(packed, group=group)
+                    k = mean.numel()
+                    n = packed[-1]
+                    mean = (packed[:k] / n).view_as(mean)
+                    var = ((packed[k:2 * k].view_as(var) - n * mean * mean) / torch.clamp(n - 1.0, min=1.0))
+            return self.merge_moments(mean, var, n)
         if group is None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] >= 2 \
                 and 0 < x[0].numel() <= 256:
             return self._update_hip(x)

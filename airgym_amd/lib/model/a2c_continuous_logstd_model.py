@@ -103,12 +103,12 @@ class ModelA2CContinuousLogStd(nn.Module):
         self.fixed_sigma = space.get("fixed_sigma", True)
 
     # ---- normalisers (base_model.py:21-35)
-    def _norm(self, rms, x):
+    def _norm(self, rms, x, weights=None):
         if not self.normalize_input:
             return x
         with torch.no_grad():
             if self.update_stats:
-                rms.update(x.detach(), self.stats_group)
+                rms.update(x.detach(), self.stats_group, weights) if weights is not None else rms.update(x.detach(), self.stats_group)
             mean = rms.running_mean.float()
             std = torch.sqrt(rms.running_var.float() + rms.epsilon)
         return torch.clamp((x - mean) / std, min=-5.0, max=5.0)      # running_mean_std.py:78-79
@@ -116,11 +116,18 @@ class ModelA2CContinuousLogStd(nn.Module):
     def norm_obs(self, observation):
         return self._norm(self.running_mean_std, observation) if self.normalize_input else observation
 
-    def norm_image(self, image):
-        return self._norm(self.running_mean_std.running_mean_std["image"], image) if self.normalize_input else image
+    def norm_image(self, image, weights=None):
+        return self._norm(self.running_mean_std.running_mean_std["image"], image, weights) if self.normalize_input else image
 
     def norm_observation(self, observation):
         return self._norm(self.running_mean_std.running_mean_std["observation"], observation) if self.normalize_input else observation
+
+    @torch.no_grad()
+    def cnn_features(self, image):
+        """Inference-time CNN features of a batch of images (BatchNorm on its running statistics, the image normaliser as it
+        is now): what the rollout caches per rendered frame.  Shared-trunk models only."""
+        assert self.has_cnn and not self.separate
+        return self.actor_cnn(self.norm_image(image))
 
     def encode_image(self, image):
         """Frozen-VAE features of a batch of depth images, normalised with the image statistics as they are NOW."""
@@ -151,12 +158,24 @@ class ModelA2CContinuousLogStd(nn.Module):
             a_out = self.actor_mlp(a_in)
             c_out = self.critic_mlp(a_in) if self.separate else a_out
         elif self.dict_obs:
-            normed_image = self.norm_image(obs["image"])
-            a_feat = self.actor_cnn(normed_image)
+            # Frame de-duplication (agent: dedup_frames): obs["image"] holds the U DISTINCT images of the minibatch,
+            # obs["image_inverse"] [B] maps every sample to its image and obs["image_counts"] [U] is how often each occurs (the
+            # depth camera renders every 4th env step, planning.py:153-156).  The CNN runs on the distinct images with the
+            # batch statistics weighted by the counts and the features are gathered back per sample: the same function of the
+            # parameters as the reference's forward over all B images, at about a quarter of the convolution work.
+            inverse, counts = obs.get("image_inverse"), obs.get("image_counts")
+            if "cnn_features" in obs:       # rollout: features computed when the image was rendered (weights are fixed there)
+                a_feat = c_feat = obs["cnn_features"]
+            else:
+                normed_image = self.norm_image(obs["image"], counts)
+                a_feat = self.actor_cnn(normed_image, counts)
+                c_feat = self.critic_cnn(normed_image, counts) if self.separate else None
+                if inverse is not None:
+                    a_feat = a_feat.index_select(0, inverse)
+                    c_feat = c_feat.index_select(0, inverse) if c_feat is not None else None
             a_in = self.norm_observation(torch.cat((obs["observation"], a_feat), dim=-1))
             a_out = self.actor_mlp(a_in)
             if self.separate:
-                c_feat = self.critic_cnn(normed_image)
                 c_out = self.critic_mlp(self.norm_observation(torch.cat((obs["observation"], c_feat), dim=-1)))
             else:
                 c_out = a_out

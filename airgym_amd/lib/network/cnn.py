@@ -16,16 +16,21 @@ class CNNFeatureExtractor(nn.Module):
         self.fc = nn.Linear(64, feature_dim)
         self.fused_relu_bn = True       # False: the plain torch modules (MIOpen batch norm), e.g. for A/B timing
 
-    def forward(self, x):
-        if x.is_cuda and self.fused_relu_bn:
+    def forward(self, x, weights=None):
+        """weights [N] (optional, training): image i stands for weights[i] identical images of the minibatch (frame
+        de-duplication, see fused_relu_bn.relu_batchnorm): BatchNorm statistics are those of the full minibatch."""
+        if (x.is_cuda and self.fused_relu_bn) or weights is not None:
             # ReLU + BatchNorm2d pairs run as one node on csrc/cnn_kernels.hip (the modules stay for the state dict)
-            from airgym_amd.lib.network.fused_relu_bn import relu_batchnorm, usable
+            from airgym_amd.lib.network.fused_relu_bn import relu_batchnorm, relu_batchnorm_torch, usable
             layers = list(self.features)
             i = 0
             while i < len(layers):
-                if (isinstance(layers[i], nn.ReLU) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d)
-                        and usable(x, layers[i + 1]) and (layers[i + 1].training or not torch.is_grad_enabled())):
-                    x = relu_batchnorm(x, layers[i + 1])
+                if isinstance(layers[i], nn.ReLU) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d):
+                    bn = layers[i + 1]
+                    if (x.is_cuda and self.fused_relu_bn and usable(x, bn) and (bn.training or not torch.is_grad_enabled())):
+                        x = relu_batchnorm(x, bn, weights if bn.training else None)
+                    else:
+                        x = relu_batchnorm_torch(x, bn, weights)
                     i += 2
                 else:
                     x = layers[i](x)

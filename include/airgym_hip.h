@@ -369,7 +369,13 @@ int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const fl
  *                          running statistics this is the eval-mode forward).
  *   ag_relu_bn_bwd_reduce: partials_dev [blocks, C, 2] = per-channel (sum dy, sum dy * xhat), xhat = (relu(x) - mean) invstd.
  *   ag_relu_bn_bwd_dx    : dx = [x > 0] coef[c][2] (dy - sums[c][0] coef[c][3] - xhat sums[c][1] coef[c][3]);
- *                          coef_dev [C, 4] = {mean, invstd, gamma invstd, 1 / (N HW)}, sums_dev [C, 2] = {dbeta, dgamma}. */
+ *                          coef_dev [C, 4] = {mean, invstd, gamma invstd, 1 / (N HW)}, sums_dev [C, 2] = {dbeta, dgamma}.
+ *   ag_relu_bn_stats_weighted / ag_relu_bn_bwd_dx_weighted: the same with per-image multiplicities weights_dev [N] (NULL = 1):
+ *                          a minibatch that holds image i m_i times - the depth camera runs every 4th env step
+ *                          (planning.py:153-156), so consecutive rollout samples of an env share their image - has the batch
+ *                          statistics of its DISTINCT images weighted by m_i; in the backward dy is the gradient summed over the
+ *                          copies and the two mean terms are scaled by m_i (coef[c][3] = 1 / (sum_i m_i HW)).  Same result as
+ *                          the reference's computation on the full minibatch, on 1/4 of the images. */
 int ag_relu_bn_planes_per_block(void);
 int ag_relu_bn_stats(const float* x_dev, float* partials_dev, int N, int C, int HW, void* stream);
 int ag_relu_bn_apply(const float* x_dev, const float* scale_dev, const float* shift_dev, float* y_dev, int N, int C, int HW,
@@ -378,6 +384,10 @@ int ag_relu_bn_bwd_reduce(const float* dy_dev, const float* x_dev, const float* 
                           float* partials_dev, int N, int C, int HW, void* stream);
 int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev, float* dx_dev,
                       int N, int C, int HW, void* stream);
+int ag_relu_bn_stats_weighted(const float* x_dev, const float* weights_dev, float* partials_dev, int N, int C, int HW,
+                              void* stream);
+int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
+                               const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream);
 
 /* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block(which) rows
  * (ceil(M / rows) blocks); the caller reduces them over dim 0.

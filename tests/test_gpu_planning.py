@@ -165,7 +165,7 @@ def test_drop_in_api_and_ppo_epoch(Handle):
     before = agent.flat_param.clone()
     agent.train()
     assert agent.epoch_num == 1 and torch.isfinite(agent.flat_param).all() and not torch.equal(before, agent.flat_param)
-    assert agent.obs_buf["image"].abs().sum() > 0          # rendered images reached the rollout buffer
+    assert agent._dedup and agent._frame_stores[0].abs().sum() > 0      # rendered frames reached the rollout's frame store
 
 
 def test_golden_observations_reward_done(Handle, golden):
@@ -413,3 +413,108 @@ def test_last_step_rendered_follows_the_camera_schedule(Handle):
     with pytest.raises(RuntimeError):
         b.last_step_rendered()
     b.close()
+
+
+def _cnn_agent(envs, dedup, horizon=8, seed=3, minibatches=3):
+    import os
+    import yaml
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
+    c = params["config"]
+    c.update(num_actors=envs, horizon_length=horizon, mini_epochs=2, minibatch_size=envs * horizon // minibatches,
+             device="cuda:0", max_epochs=-1, write_summaries=False, print_stats=False, save_frequency=0,
+             save_best_after=10 ** 9, dedup_frames=dedup, use_hip_graph=False)
+    c["env_config"] = {"use_image": True, "num_envs": envs, "ctl_mode": "rate", "seed": seed, "sim_device": "cuda:0",
+                       "headless": True}
+    params["seed"] = seed
+    torch.manual_seed(seed)
+    agent = A2CAgent("dedup_test", params)
+    agent.init_tensors()
+    torch.manual_seed(seed + 1)
+    agent.obs = agent.env_reset()
+    return agent
+
+
+def test_weighted_relu_batchnorm_kernels():
+    """ReLU + BatchNorm2d with per-image multiplicities on csrc/cnn_kernels.hip == the same layer applied to the expanded
+    batch (every image repeated weights[i] times, upstream gradients of the copies summed): outputs, running statistics,
+    input / gamma / beta gradients, against a float64 evaluation."""
+    from airgym_amd.lib.network.fused_relu_bn import relu_batchnorm
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for (n, c, h, w) in [(13, 16, 53, 30), (9, 64, 27, 15), (5, 32, 7, 3)]:
+        x = torch.randn(n, c, h, w, device="cuda", generator=g)
+        cnt = torch.randint(1, 5, (n,), device="cuda", generator=g)
+        inv = torch.repeat_interleave(torch.arange(n, device="cuda"), cnt)
+        up = torch.randn(int(cnt.sum()), c, h, w, device="cuda", generator=g)        # one upstream gradient per COPY
+        # float64 reference on the expanded batch
+        bn64 = torch.nn.BatchNorm2d(c).cuda().double()
+        with torch.no_grad():
+            bn64.weight.uniform_(0.5, 1.5); bn64.bias.uniform_(-0.5, 0.5)
+        x64 = x.double().requires_grad_(True)
+        y64 = bn64(torch.relu(x64[inv]))
+        (y64 * up.double()).sum().backward()
+        # the HIP node on the distinct images, upstream gradient summed over the copies
+        bn = torch.nn.BatchNorm2d(c).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(bn64.weight); bn.bias.copy_(bn64.bias)
+        xg = x.clone().requires_grad_(True)
+        y = relu_batchnorm(xg, bn, cnt.float())
+        gsum = torch.zeros_like(x).index_add_(0, inv, up)
+        (y * gsum).sum().backward()
+        assert torch.allclose(y.double()[inv], y64, atol=2e-5)
+        assert torch.allclose(bn.running_mean.double(), bn64.running_mean, atol=1e-6)
+        assert torch.allclose(bn.running_var.double(), bn64.running_var, atol=1e-6)
+        sc = x64.grad.abs().max().item()
+        assert (xg.grad.double() - x64.grad).abs().max().item() <= 2e-5 * sc + 1e-6
+        assert torch.allclose(bn.weight.grad.double(), bn64.weight.grad, rtol=1e-4, atol=1e-3 * bn64.weight.grad.abs().max().item())
+        assert torch.allclose(bn.bias.grad.double(), bn64.bias.grad, rtol=1e-4, atol=1e-3 * bn64.bias.grad.abs().max().item())
+
+
+def test_frame_dedup_is_the_same_update_on_a_quarter_of_the_images():
+    """dedup_frames (default for camera tasks with the trainable CNN): the rollout keeps only the rendered frames and runs the
+    CNN once per frame; a minibatch runs the CNN on its DISTINCT images with statistics weighted by their multiplicities.
+    Against dedup_frames: false (every sample's image stored and convolved, as the reference does): identical rollouts, and
+    the same loss, the same gradient of every parameter and the same normaliser / BatchNorm statistics for a minibatch."""
+    out = []
+    for dedup in (True, False):
+        agent = _cnn_agent(48, dedup, horizon=8, seed=5, minibatches=3)      # 128-sample minibatches cut through env trajectories
+        assert bool(getattr(agent, "_dedup", False)) == dedup
+        calls = []
+        cnn = agent.model.actor_cnn
+        orig = cnn.forward
+        cnn.forward = lambda x, weights=None: (calls.append(x.shape[0]), orig(x, weights))[1]
+        torch.manual_seed(11)
+        batch = agent.play_steps()
+        rollout_calls = list(calls)
+        agent.model.train()
+        agent.curr_frames = batch.pop("played_frames")
+        agent.prepare_dataset(batch)
+        agent.model.running_mean_std.eval()
+        agent.model.update_stats = True
+        calls.clear()
+        mb = agent.dataset[1]
+        a, c, e, b_, _, _ = agent._loss_and_backward(mb)
+        out.append({"dedup": dedup, "actions": batch["actions"].clone(), "values": batch["values"].clone(),
+                    "grad": agent.flat_grad.clone(), "loss": (float(a), float(c)), "rollout_calls": rollout_calls,
+                    "update_images": list(calls),
+                    "img_mean": agent.model.running_mean_std.running_mean_std["image"].running_mean.clone(),
+                    "img_count": float(agent.model.running_mean_std.running_mean_std["image"].count),
+                    "bn": [m.running_var.clone() for m in agent.model.actor_cnn.features if isinstance(m, torch.nn.BatchNorm2d)],
+                    "mem": sum(v.numel() for v in (agent._frame_stores if dedup else [agent.obs_buf["image"]]))})
+        agent.vec_env.env.hip.close()
+    d, f = out
+    # the rollouts are the same rollout (same policy outputs from cached vs recomputed features)
+    assert torch.allclose(d["actions"], f["actions"], atol=1e-5) and torch.allclose(d["values"], f["values"], atol=1e-4)
+    # CNN work: per rendered frame in the rollout (2-3 of 8 steps + slot 0) instead of per step; ~1/3 of the images in the update
+    assert len(d["rollout_calls"]) <= 4 and len(f["rollout_calls"]) >= 8
+    assert d["update_images"][0] < 0.5 * f["update_images"][0], (d["update_images"], f["update_images"])
+    # the minibatch: same losses, same gradients, same statistics
+    assert abs(d["loss"][0] - f["loss"][0]) <= 1e-5 and abs(d["loss"][1] - f["loss"][1]) <= 1e-4 * max(1.0, abs(f["loss"][1]))
+    scale = f["grad"][:-1].abs().max().item()
+    assert (d["grad"] - f["grad"])[:-1].abs().max().item() <= 2e-4 * scale, ((d["grad"] - f["grad"]).abs().max().item(), scale)
+    assert d["img_count"] == f["img_count"] and torch.allclose(d["img_mean"], f["img_mean"], atol=1e-6)
+    for x, y in zip(d["bn"], f["bn"]):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-6)
+    # image memory: two stores of ceil((H + 1) / 4) + 2 frames instead of H + 1 images per env (H = 24: 18 vs 25; this H = 8 test: 10 vs 9)
+    assert d["mem"] == 2 * ((8 + 1 + 3) // 4 + 2) * 48 * 212 * 120 and f["mem"] == 9 * 48 * 212 * 120
