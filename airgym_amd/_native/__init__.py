@@ -28,6 +28,7 @@ AG_NUM_REWARD_TERMS = 11
 
 AG_ERR_UNKNOWN_TASK = -2
 AG_ERR_UNKNOWN_CTL = -3
+AG_ERR_UNSUPPORTED = -6
 
 # order of ag_buffers.reward_terms (include/airgym_hip.h)
 REWARD_TERM_NAMES = {
@@ -186,6 +187,15 @@ SYMBOLS = [
     ("ag_relu_bn_bwd_dx", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_stats_weighted", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_cnn_conv_workspace_floats", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    ("ag_cnn_conv1_fwd", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, _P]),
+    ("ag_cnn_conv1_wgrad_partials", ctypes.c_int, [ctypes.c_int]),
+    ("ag_cnn_conv1_wgrad", ctypes.c_int, [_P, _P, _P, ctypes.c_int, _P]),
+    ("ag_cnn_conv_supported", ctypes.c_int, [ctypes.c_int] * 4),
+    ("ag_cnn_conv_fwd", ctypes.c_int, [_P] * 6 + [ctypes.c_int] * 5 + [_P, _P]),
+    ("ag_cnn_conv_dgrad", ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
+    ("ag_cnn_conv_wgrad_partials", ctypes.c_int, [ctypes.c_int] * 5),
+    ("ag_cnn_conv_wgrad", ctypes.c_int, [_P] * 5 + [ctypes.c_int] * 5 + [_P]),
     ("ag_wgrad_rows_per_block", ctypes.c_int, [ctypes.c_int]),
     ("ag_input_wgrad_rows", ctypes.c_int, [ctypes.c_int]),
     ("ag_sum_rows_groups", ctypes.c_int, []),

@@ -1,0 +1,644 @@
+// conv_kernels.hip - the three stride-2 convolutions of the depth-image feature extractor of the Planning policy, forward,
+// input gradient and weight gradient, on NCHW float32 tensors as torch holds them
+// (reference: lib/network/cnn.py:3-33: Conv2d(1,16,5,s2,p2) -> Conv2d(16,32,3,s2,p1) -> Conv2d(32,64,3,s2,p1) on (1,212,120) images).
+//
+// Why: with the library (MIOpen fp32) every convolution call of a PPO minibatch is an NHWC implicit GEMM wrapped in
+// NCHW<->NHWC transposes of 0.5 - 1.9 GB activations; the transposes alone are 8.6 ms of a 31.7 ms minibatch step and the
+// kernels another 12.6 ms (profiles/r03_planning_cnn_dedup_kernel_trace.md).  These kernels read and write NCHW directly.
+//
+// Arithmetic: exact float32.  The two 3x3 layers run on the f32-input matrix instruction v_mfma_f32_16x16x4_f32 (each product
+// and accumulation is an fmaf; 157 TFLOP/s peak = the f32 vector rate, with no VALU issue slots spent on it); the 5x5 first
+// layer has one input channel and 16 outputs, is bound by the 1.9 GB it writes, and its forward runs on the vector ALU with the
+// weights in scalar registers; its weight gradient (K = all output pixels) runs on the same MFMA.
+//
+// Common scheme of the stride-2 kernels: a workgroup stages a band of input rows in LDS with the columns DE-INTERLEAVED by
+// parity (c = ix + pad; E[j] = column 2j, O[j] = column 2j + 1), so that the stride-2 taps of 16 neighbouring output pixels are
+// 16 consecutive floats of E or O (conflict-free ds_read_b32, the 16x16x4 operand layout: lane l supplies element
+// [l & 15][k = l >> 4]).  Plane / row strides are chosen so that the two 16-lane quarters of a 32-lane LDS group fall into
+// different banks (stride = 16 mod 32, or odd strides with a +16 quarter offset).  ReLU + BatchNorm of the PREVIOUS layer can be
+// applied while staging (y = max(x, 0) * scale[c] + shift[c]; padding stays 0), so the normalised activation never exists in HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/airgym_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define AG_MFMA4(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+
+constexpr int pad16mod32(int v) { return v + ((16 - (v % 32)) + 32) % 32; }
+constexpr int make_odd(int v) { return v | 1; }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// weight packing (tiny; once per call)
+//   forward : wp[ch][tap][kk][q][co] = w[co][ci = 8 ch + 4 kk + q][tap]       (one LDS row per (tap, k-step, lane quarter))
+//   dgrad   : wd[ch][tap][c][ci]     = w[co = 16 ch + c][ci][tap]
+//   conv1   : w1[tap][co]            = w[co][0][tap]
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int cin, int cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * cin * cout) return;
+    const int co = i % cout;
+    int r = i / cout;
+    const int q = r % 4; r /= 4;
+    const int kk = r % 2; r /= 2;
+    const int tap = r % 9;
+    const int ch = r / 9;
+    wp[i] = w[((size_t)co * cin + (8 * ch + 4 * kk + q)) * 9 + tap];
+}
+
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int cin, int cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * cin * cout) return;
+    const int ci = i % cin;
+    int r = i / cin;
+    const int c = r % 16; r /= 16;
+    const int tap = r % 9;
+    const int ch = r / 9;
+    wd[i] = w[((size_t)(16 * ch + c) * cin + ci) * 9 + tap];
+}
+
+__global__ void pack_conv1_kernel(const float* __restrict__ w, float* __restrict__ w1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 400) return;
+    w1[i] = w[(i % 16) * 25 + i / 16];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// forward of a 3x3 / stride 2 / pad 1 layer.  Workgroup = (image, band of 2 WAVES output rows); wave w owns output rows
+// 2w, 2w + 1 of the band, all COUT channels: D[co][pixel] tiles of 16 x 16, K = 8 input channels per LDS chunk x 9 taps.
+template <int CIN, int COUT, int HIN, int WIN, int WAVES, bool APPLY>
+__global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, float* __restrict__ y, int bands) {
+    constexpr int HO = (HIN - 1) / 2 + 1, WO = WIN / 2;
+    constexpr int NT = WAVES * 64, ROWS = 2 * WAVES, IN_ROWS = 2 * ROWS + 1;
+    constexpr int NBT = (WO + 15) / 16, RT = COUT / 16;
+    constexpr int EO = 16 * NBT + 1;          // E[0 .. 16 NBT]: E[0] is the left padding, E[j + 1] = column 2j + 1
+    constexpr int RS = EO + 16 * NBT;         // O[0 .. 16 NBT - 1]: O[j] = column 2j
+    constexpr int PS = pad16mod32(IN_ROWS * RS);
+    constexpr int QS = COUT + 16;             // = 16 mod 32 for COUT = 32, 64
+    constexpr int W2 = WIN / 2;
+    static_assert(WIN % 2 == 0 && COUT % 16 == 0 && CIN % 8 == 0, "shape");
+    __shared__ __attribute__((aligned(16))) float s_in[8 * PS + 64];
+    __shared__ __attribute__((aligned(16))) float s_w[72 * QS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
+    const int oy0 = band * ROWS;
+    const float* xin = x + (size_t)n * CIN * HIN * WIN;
+
+    f32x4 acc[2][NBT][RT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[r][bt][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < CIN / 8; ++ch) {
+        __syncthreads();
+        for (int u = tid; u < 8 * IN_ROWS * W2; u += NT) {
+            const int p = u / (IN_ROWS * W2), rem = u - p * (IN_ROWS * W2);
+            const int row = rem / W2, j = rem - row * W2;
+            const int iy = 2 * oy0 - 1 + row, ci = ch * 8 + p;
+            float2 v = make_float2(0.f, 0.f);
+            if (iy >= 0 && iy < HIN) {
+                v = *reinterpret_cast<const float2*>(xin + ((size_t)ci * HIN + iy) * WIN + 2 * j);
+                if (APPLY) {
+                    const float sc = scale[ci], sh = shift[ci];
+                    v.x = fmaxf(v.x, 0.f) * sc + sh;
+                    v.y = fmaxf(v.y, 0.f) * sc + sh;
+                }
+            }
+            float* rowp = s_in + p * PS + row * RS;
+            rowp[EO + j] = v.x;
+            rowp[j + 1] = v.y;
+            if (j == 0) rowp[0] = 0.f;
+        }
+        {
+            const float4* wsrc = reinterpret_cast<const float4*>(wp + (size_t)ch * 72 * COUT);
+            for (int u = tid; u < 72 * COUT / 4; u += NT) {
+                const int r = u / (COUT / 4), c4 = u - r * (COUT / 4);
+                *reinterpret_cast<float4*>(s_w + r * QS + 4 * c4) = wsrc[u];
+            }
+        }
+        __syncthreads();
+        const float* bb = s_in + q * PS + (4 * wave) * RS + m;
+        const float* ab = s_w + q * QS + m;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int xo = (kx == 1 ? EO : 0) + (kx == 2 ? 1 : 0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                float a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[rt] = ab[((tap * 2 + kk) * 4) * QS + 16 * rt];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int bt = 0; bt < NBT; ++bt) {
+                        const float b = bb[(4 * kk) * PS + (2 * r + ky) * RS + xo + 16 * bt];
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) acc[r][bt][rt] = AG_MFMA4(a[rt], b, acc[r][bt][rt]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + 2 * wave + r;
+        if (oy >= HO) continue;
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) {
+            const int ox = 16 * bt + m;
+            if (ox >= WO) continue;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = 16 * rt + 4 * q + i;
+                    y[(((size_t)n * COUT + co) * HO + oy) * WO + ox] = acc[r][bt][rt][i] + bias[co];
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// input gradient of a 3x3 / stride 2 / pad 1 layer: din[ci][iy][ix] = sum_{co,ky,kx} dz[co][oy][ox] w[co][ci][ky][kx] with
+// iy = 2 oy + ky - 1, ix = 2 ox + kx - 1.  Output pixels split into four parity classes (iy = 2a + py, ix = 2b + px):
+//   py = 0: ky = 1, oy = a;   py = 1: ky = 0, oy = a + 1  and  ky = 2, oy = a        (the same in x)
+// so every tap reads dz at (a + dy, b + dx), dy, dx in {0, 1}: UNIT-stride reads, no de-interleaving; a lane holds the px = 0
+// and px = 1 results of its b and stores them as one float2 (rows of din are written contiguously).
+// D[ci][b] tiles of 16 x 16, K = 16 output channels per LDS chunk x the taps of the class.  Wave w owns a-rows 2w, 2w + 1.
+template <int CIN, int COUT, int HIN, int WIN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wd,
+                                                                  float* __restrict__ dx, int bands) {
+    constexpr int HO = (HIN - 1) / 2 + 1, WO = WIN / 2;
+    constexpr int NT = WAVES * 64, AROWS = 2 * WAVES, ZR = AROWS + 1;
+    constexpr int NBT = (WO + 15) / 16, RT = CIN / 16;
+    constexpr int RSZ = 16 * NBT + 1;
+    constexpr int PSZ = pad16mod32(ZR * RSZ);
+    constexpr int CINP = (CIN == 16) ? 16 : CIN + 16;
+    static_assert(CIN % 16 == 0 && COUT % 16 == 0, "shape");
+    __shared__ __attribute__((aligned(16))) float s_z[16 * PSZ + 32];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * 16 * CINP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
+    const int a0 = band * AROWS;
+    const float* zin = dz + (size_t)n * COUT * HO * WO;
+
+    f32x4 acc[2][2][2][RT][NBT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int bt = 0; bt < NBT; ++bt) acc[r][py][px][rt][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < COUT / 16; ++ch) {
+        __syncthreads();
+        for (int u = tid; u < 16 * ZR * RSZ; u += NT) {
+            const int c = u / (ZR * RSZ), rem = u - c * (ZR * RSZ);
+            const int lr = rem / RSZ, col = rem - lr * RSZ;
+            const int a = a0 + lr;
+            float v = 0.f;
+            if (a < HO && col < WO) v = zin[((size_t)(ch * 16 + c) * HO + a) * WO + col];
+            s_z[c * PSZ + lr * RSZ + col] = v;
+        }
+        {
+            const float4* wsrc = reinterpret_cast<const float4*>(wd + (size_t)ch * 9 * 16 * CIN);
+            for (int u = tid; u < 9 * 16 * CIN / 4; u += NT) {
+                const int r = u / (CIN / 4), c4 = u - r * (CIN / 4);
+                *reinterpret_cast<float4*>(s_w + r * CINP + 4 * c4) = wsrc[u];
+            }
+        }
+        __syncthreads();
+        const float* zb = s_z + q * PSZ + (2 * wave) * RSZ + m;
+        const float* ab = s_w + q * CINP + m;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float B[3][2][NBT];
+#pragma unroll
+            for (int ro = 0; ro < 3; ++ro)
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int bt = 0; bt < NBT; ++bt) B[ro][d][bt] = zb[(4 * s) * PSZ + ro * RSZ + 16 * bt + d];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const int py = (ky != 1), dy = (ky == 0), px = (kx != 1), dxx = (kx == 0);
+                float a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[rt] = ab[(tap * 16 + 4 * s) * CINP + 16 * rt];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int bt = 0; bt < NBT; ++bt)
+                            acc[r][py][px][rt][bt] = AG_MFMA4(a[rt], B[r + dy][dxx][bt], acc[r][py][px][rt][bt]);
+            }
+        }
+    }
+    float* dout = dx + (size_t)n * CIN * HIN * WIN;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int a = a0 + 2 * wave + r;
+        if (a >= HO) continue;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const int iy = 2 * a + py;
+            if (iy >= HIN) continue;
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt) {
+                const int b = 16 * bt + m;
+                if (b >= WO) continue;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ci = 16 * rt + 4 * q + i;
+                        *reinterpret_cast<float2*>(dout + ((size_t)ci * HIN + iy) * WIN + 2 * b) =
+                            make_float2(acc[r][py][0][rt][bt][i], acc[r][py][1][rt][bt][i]);
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// weight gradient of a 3x3 / stride 2 / pad 1 layer: dw[co][ci][ky][kx] = sum_{n,oy,ox} dz[co][oy][ox] in[ci][2oy+ky-1][2ox+kx-1],
+// db[co] = sum dz.  D[co][ci] tiles of 16 x 16 per tap, K = output pixels (4 per instruction, one per lane quarter).  Six waves:
+// wave w owns kernel row ky = w >> 1 (its three kx taps) and half of the co tiles (w & 1); all waves walk the same pixels of
+// a band of 4 output rows.  Workgroups are persistent: each accumulates its (image, band) items in registers and writes ONE
+// partial [COUT*CIN*9 + COUT]; the caller sums the partials (fixed order -> deterministic).
+// Pixel <-> quarter map (chosen for the bank rule): WO > 16 (30 wide): quarter = (row & 1, half) - rows 2r'+(q>>1), ox = j + 16 (q&1);
+// WO <= 16 (15 wide): quarter = row, ox = j.  Pixels ox >= WO have dz = 0 in LDS (and finite input values).
+template <int CIN, int COUT, int HIN, int WIN, bool APPLY>
+__global__ __launch_bounds__(384) void conv_s2_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ partials, int items, int bands) {
+    constexpr int HO = (HIN - 1) / 2 + 1, WO = WIN / 2;
+    constexpr int NT = 384, R = 4, IN_ROWS = 2 * R + 1;
+    constexpr bool WIDE = (WO > 16);
+    constexpr int RT = COUT / 16, CT = CIN / 16, RTW = RT / 2;
+    constexpr int RSZ = WIDE ? 32 : 16, PSZ = R * RSZ + 1;
+    constexpr int EO = WIDE ? 33 : 17, RS = WIDE ? 65 : 40;
+    constexpr int PS = make_odd(IN_ROWS * RS);
+    constexpr int W2 = WIN / 2;
+    constexpr int PLEN = COUT * CIN * 9 + COUT;
+    static_assert(RT % 2 == 0, "row tiles split over two wave groups");
+    __shared__ __attribute__((aligned(16))) float s_in[CIN * PS + 32];
+    __shared__ __attribute__((aligned(16))) float s_z[COUT * PSZ + 32];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
+    const int ky = wave >> 1, rg = wave & 1;
+
+    for (int u = tid; u < CIN * PS + 32; u += NT) s_in[u] = 0.f;
+    for (int u = tid; u < COUT * PSZ + 32; u += NT) s_z[u] = 0.f;
+
+    f32x4 acc[RTW][3][CT], accb[RTW];
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt) {
+        accb[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[rt][kx][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int aq = WIDE ? (q >> 1) * RSZ + 16 * (q & 1) : q * RSZ;
+    const int bq = WIDE ? (q >> 1) * 2 * RS + 16 * (q & 1) : q * 2 * RS;
+    const float* ab = s_z + (16 * rg * RTW + m) * PSZ + aq;
+    const float* bb = s_in + m * PS + bq + ky * RS;
+
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int n = item / bands, band = item - n * bands;
+        const int oy0 = band * R;
+        __syncthreads();
+        {
+            const float* zin = dz + (size_t)n * COUT * HO * WO;
+            for (int u = tid; u < COUT * R * WO; u += NT) {
+                const int co = u / (R * WO), rem = u - co * (R * WO);
+                const int lr = rem / WO, ox = rem - lr * WO;
+                const int oy = oy0 + lr;
+                s_z[co * PSZ + lr * RSZ + ox] = (oy < HO) ? zin[((size_t)co * HO + oy) * WO + ox] : 0.f;
+            }
+            const float* xin = x + (size_t)n * CIN * HIN * WIN;
+            for (int u = tid; u < CIN * IN_ROWS * W2; u += NT) {
+                const int ci = u / (IN_ROWS * W2), rem = u - ci * (IN_ROWS * W2);
+                const int row = rem / W2, j = rem - row * W2;
+                const int iy = 2 * oy0 - 1 + row;
+                float2 v = make_float2(0.f, 0.f);
+                if (iy >= 0 && iy < HIN) {
+                    v = *reinterpret_cast<const float2*>(xin + ((size_t)ci * HIN + iy) * WIN + 2 * j);
+                    if (APPLY) {
+                        const float sc = scale[ci], sh = shift[ci];
+                        v.x = fmaxf(v.x, 0.f) * sc + sh;
+                        v.y = fmaxf(v.y, 0.f) * sc + sh;
+                    }
+                }
+                float* rowp = s_in + ci * PS + row * RS;
+                rowp[EO + j] = v.x;
+                rowp[j + 1] = v.y;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rp = 0; rp < (WIDE ? 2 : 1); ++rp) {
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                float a[RTW];
+#pragma unroll
+                for (int rt = 0; rt < RTW; ++rt) a[rt] = ab[(16 * rt) * PSZ + rp * 2 * RSZ + j];
+                float b[3][CT];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        b[kx][ct] = bb[(16 * ct) * PS + rp * 4 * RS + (kx == 1 ? EO : 0) + (kx == 2 ? 1 : 0) + j];
+#pragma unroll
+                for (int rt = 0; rt < RTW; ++rt) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) acc[rt][kx][ct] = AG_MFMA4(a[rt], b[kx][ct], acc[rt][kx][ct]);
+                    if (ky == 0) accb[rt] = AG_MFMA4(a[rt], 1.0f, accb[rt]);
+                }
+            }
+        }
+    }
+    float* part = partials + (size_t)blockIdx.x * PLEN;
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = 16 * (rg * RTW + rt) + 4 * q + i;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) part[((size_t)(co * CIN + 16 * ct + m) * 3 + ky) * 3 + kx] = acc[rt][kx][ct][i];
+            if (ky == 0 && m == 0) part[COUT * CIN * 9 + co] = accb[rt][i];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// first layer, forward: Conv2d(1, 16, 5, stride 2, pad 2) on (212, 120) -> (16, 106, 60).  One lane per output pixel of a row
+// (60 of 64 lanes), 16 accumulators per row, two rows per wave; the 400 weights are wave-uniform (scalar loads, [tap][co]).
+// Bound: the 1.93 GB of output per 4 750 images.
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int bands) {
+    constexpr int HIN = 212, WIN = 120, HO = 106, WO = 60, ROWS = 8, IN_ROWS = 2 * ROWS + 3, EO = 66, RS = 132;
+    __shared__ __attribute__((aligned(16))) float s_in[IN_ROWS * RS + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
+    const int oy0 = band * ROWS;
+    const float* xin = x + (size_t)n * HIN * WIN;
+    for (int u = tid; u < IN_ROWS * (WIN / 2); u += 256) {
+        const int row = u / (WIN / 2), j = u - row * (WIN / 2);
+        const int iy = 2 * oy0 - 2 + row;
+        float2 v = make_float2(0.f, 0.f);
+        if (iy >= 0 && iy < HIN) v = *reinterpret_cast<const float2*>(xin + (size_t)iy * WIN + 2 * j);
+        float* rowp = s_in + row * RS;
+        rowp[j + 1] = v.x;            // c = ix + 2 = 2j + 2
+        rowp[EO + j + 1] = v.y;       // c = 2j + 3
+        if (j == 0) { rowp[0] = 0.f; rowp[EO] = 0.f; rowp[WIN / 2 + 1] = 0.f; rowp[EO + WIN / 2 + 1] = 0.f; }
+    }
+    __syncthreads();
+    float acc[2][16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) { acc[0][co] = bias[co]; acc[1][co] = acc[0][co]; }
+    const float* p0 = s_in + (4 * wave) * RS + lane;
+#pragma unroll 1
+    for (int ky = 0; ky < 5; ++ky)            // not unrolled: 80 weights (scalar registers) live per kernel row, not 400
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const int off = (kx & 1) ? EO + (kx >> 1) : (kx >> 1);
+            const float v0 = p0[ky * RS + off], v1 = p0[(2 + ky) * RS + off];
+#pragma unroll
+            for (int co = 0; co < 16; ++co) {
+                const float wv = w1[(ky * 5 + kx) * 16 + co];
+                acc[0][co] = fmaf(wv, v0, acc[0][co]);
+                acc[1][co] = fmaf(wv, v1, acc[1][co]);
+            }
+        }
+    if (lane >= WO) return;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + 2 * wave + r;
+        if (oy >= HO) continue;
+#pragma unroll
+        for (int co = 0; co < 16; ++co) y[(((size_t)n * 16 + co) * HO + oy) * WO + lane] = acc[r][co];
+    }
+}
+
+// first layer, weight gradient: dw[co][tap] = sum_{n,oy,ox} dz[co][oy][ox] in[2oy+ky-2][2ox+kx-2]; D[co][tap] = two 16 x 16 tiles
+// (taps 0-15, 16-24; column 25 of the second tile is the constant 1 -> db[co]), K = pixels: ox = 4j + quarter.
+// Four waves split the 8 rows of a band; persistent workgroups, one partial [16][32] each.
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                         float* __restrict__ partials, int items, int bands) {
+    constexpr int HIN = 212, WIN = 120, HO = 106, WO = 60, ROWS = 8, IN_ROWS = 2 * ROWS + 3;
+    constexpr int EO = 68, RS = 136, PSZ = 482;     // RS = 8, EO = 4, PSZ = 2 (mod 32): conflict-free operand reads
+    __shared__ __attribute__((aligned(16))) float s_in[IN_ROWS * RS + 8];
+    __shared__ __attribute__((aligned(16))) float s_z[16 * PSZ + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
+    for (int u = tid; u < IN_ROWS * RS + 8; u += 256) s_in[u] = 0.f;
+    for (int u = tid; u < 16 * PSZ + 8; u += 256) s_z[u] = 0.f;
+    int boff[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tap = m + 16 * t, kyy = tap / 5, kxx = tap - 5 * kyy;
+        boff[t] = (tap < 25) ? kyy * RS + (kxx & 1) * EO + (kxx >> 1) + q : 0;
+    }
+    const bool t1_data = (m + 16) < 25;
+    const float t1_const = (m + 16 == 25) ? 1.f : 0.f;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int n = item / bands, band = item - n * bands;
+        const int oy0 = band * ROWS;
+        __syncthreads();
+        const float* zin = dz + (size_t)n * 16 * HO * WO;
+        for (int u = tid; u < 16 * ROWS * (WO / 2); u += 256) {
+            const int co = u / (ROWS * (WO / 2)), rem = u - co * (ROWS * (WO / 2));
+            const int lr = rem / (WO / 2), j = rem - lr * (WO / 2);
+            const int oy = oy0 + lr;
+            float2 v = make_float2(0.f, 0.f);
+            if (oy < HO) v = *reinterpret_cast<const float2*>(zin + ((size_t)co * HO + oy) * WO + 2 * j);
+            *reinterpret_cast<float2*>(s_z + co * PSZ + lr * WO + 2 * j) = v;
+        }
+        const float* xin = x + (size_t)n * HIN * WIN;
+        for (int u = tid; u < IN_ROWS * (WIN / 2); u += 256) {
+            const int row = u / (WIN / 2), j = u - row * (WIN / 2);
+            const int iy = 2 * oy0 - 2 + row;
+            float2 v = make_float2(0.f, 0.f);
+            if (iy >= 0 && iy < HIN) v = *reinterpret_cast<const float2*>(xin + (size_t)iy * WIN + 2 * j);
+            s_in[row * RS + j + 1] = v.x;
+            s_in[row * RS + EO + j + 1] = v.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int lr = 2 * wave + rr;
+            const float* ap = s_z + m * PSZ + lr * WO + q;
+            const float* bp = s_in + (2 * lr) * RS;
+#pragma unroll 5
+            for (int j = 0; j < 15; ++j) {
+                const float a = ap[4 * j];
+                const float b0 = bp[boff[0] + 4 * j];
+                float b1 = bp[boff[1] + 4 * j];
+                b1 = t1_data ? b1 : t1_const;
+                acc0 = AG_MFMA4(a, b0, acc0);
+                acc1 = AG_MFMA4(a, b1, acc1);
+            }
+        }
+    }
+    // cross-wave sum through LDS (s_z is free after the last barrier below)
+    __syncthreads();
+    float* red = s_z;     // [4 waves][16 co][32 taps]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        red[(wave * 16 + 4 * q + i) * 32 + m] = acc0[i];
+        red[(wave * 16 + 4 * q + i) * 32 + 16 + m] = acc1[i];
+    }
+    __syncthreads();
+    for (int u = tid; u < 512; u += 256)
+        partials[(size_t)blockIdx.x * 512 + u] = red[u] + red[512 + u] + red[1024 + u] + red[1536 + u];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct Shape { int cin, cout, hin, win; };
+constexpr Shape kL2 = {16, 32, 106, 60}, kL3 = {32, 64, 53, 30};
+inline int layer_of(int cin, int cout, int hin, int win) {
+    if (cin == kL2.cin && cout == kL2.cout && hin == kL2.hin && win == kL2.win) return 2;
+    if (cin == kL3.cin && cout == kL3.cout && hin == kL3.hin && win == kL3.win) return 3;
+    return 0;
+}
+constexpr int kL2Waves = 4, kL3Waves = 7;          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1)
+constexpr int kWgradWorkgroups = 512;              // persistent: two per CU
+
+}  // namespace
+
+#define AG_CONV_LAUNCH_OK() (hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP)
+
+extern "C" int ag_cnn_conv_workspace_floats(int cin, int cout) {
+    if (cin == 1 && cout == 16) return 400;
+    return 9 * cin * cout;
+}
+
+extern "C" int ag_cnn_conv1_fwd(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int n,
+                                float* workspace_dev, void* stream) {
+    if (!x_dev || !w_dev || !b_dev || !y_dev || !workspace_dev || n <= 0) return AG_ERR_INVALID_ARG;
+    const int bands = (106 + 7) / 8;
+    if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_conv1_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev);
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(n * bands), dim3(256), 0, (hipStream_t)stream, x_dev, workspace_dev, b_dev, y_dev,
+                       bands);
+    return AG_CONV_LAUNCH_OK();
+}
+
+extern "C" int ag_cnn_conv1_wgrad_partials(int n) {
+    const long long items = (long long)n * ((106 + 7) / 8);
+    return (int)(items < 768 ? items : 768);       // three workgroups per CU
+}
+
+extern "C" int ag_cnn_conv1_wgrad(const float* dz_dev, const float* x_dev, float* partials_dev, int n, void* stream) {
+    if (!dz_dev || !x_dev || !partials_dev || n <= 0) return AG_ERR_INVALID_ARG;
+    const int bands = (106 + 7) / 8;
+    if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+    const int g = ag_cnn_conv1_wgrad_partials(n);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dz_dev, x_dev, partials_dev, n * bands, bands);
+    return AG_CONV_LAUNCH_OK();
+}
+
+extern "C" int ag_cnn_conv_supported(int cin, int cout, int hin, int win) { return layer_of(cin, cout, hin, win) != 0; }
+
+extern "C" int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev,
+                               const float* b_dev, float* y_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev,
+                               void* stream) {
+    if (!x_dev || !w_dev || !b_dev || !y_dev || !workspace_dev || n <= 0 || (!scale_dev) != (!shift_dev)) return AG_ERR_INVALID_ARG;
+    const int layer = layer_of(cin, cout, hin, win);
+    if (!layer) return AG_ERR_UNSUPPORTED;
+    const int tot = 9 * cin * cout;
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, cin, cout);
+    const bool apply = scale_dev != nullptr;
+    if (layer == 2) {
+        const int bands = (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
+        if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+        if (apply)
+            hipLaunchKernelGGL((conv_s2_fwd_kernel<16, 32, 106, 60, kL2Waves, true>), dim3(n * bands), dim3(kL2Waves * 64), 0,
+                               (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, bands);
+        else
+            hipLaunchKernelGGL((conv_s2_fwd_kernel<16, 32, 106, 60, kL2Waves, false>), dim3(n * bands), dim3(kL2Waves * 64), 0,
+                               (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, bands);
+    } else {
+        const int bands = (27 + 2 * kL3Waves - 1) / (2 * kL3Waves);
+        if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+        if (apply)
+            hipLaunchKernelGGL((conv_s2_fwd_kernel<32, 64, 53, 30, kL3Waves, true>), dim3(n * bands), dim3(kL3Waves * 64), 0,
+                               (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, bands);
+        else
+            hipLaunchKernelGGL((conv_s2_fwd_kernel<32, 64, 53, 30, kL3Waves, false>), dim3(n * bands), dim3(kL3Waves * 64), 0,
+                               (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, bands);
+    }
+    return AG_CONV_LAUNCH_OK();
+}
+
+extern "C" int ag_cnn_conv_dgrad(const float* dz_dev, const float* w_dev, float* dx_dev, int n, int cin, int cout, int hin, int win,
+                                 float* workspace_dev, void* stream) {
+    if (!dz_dev || !w_dev || !dx_dev || !workspace_dev || n <= 0) return AG_ERR_INVALID_ARG;
+    const int layer = layer_of(cin, cout, hin, win);
+    if (!layer) return AG_ERR_UNSUPPORTED;
+    const int tot = 9 * cin * cout;
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, cin, cout);
+    if (layer == 2) {
+        const int bands = (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
+        if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((conv_s2_dgrad_kernel<16, 32, 106, 60, kL2Waves>), dim3(n * bands), dim3(kL2Waves * 64), 0,
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands);
+    } else {
+        const int bands = (27 + 2 * kL3Waves - 1) / (2 * kL3Waves);
+        if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((conv_s2_dgrad_kernel<32, 64, 53, 30, kL3Waves>), dim3(n * bands), dim3(kL3Waves * 64), 0,
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands);
+    }
+    return AG_CONV_LAUNCH_OK();
+}
+
+extern "C" int ag_cnn_conv_wgrad_partials(int n, int cin, int cout, int hin, int win) {
+    const int layer = layer_of(cin, cout, hin, win);
+    if (!layer) return AG_ERR_UNSUPPORTED;
+    const int ho = (hin - 1) / 2 + 1;
+    const long long items = (long long)n * ((ho + 3) / 4);
+    return (int)(items < kWgradWorkgroups ? items : kWgradWorkgroups);
+}
+
+extern "C" int ag_cnn_conv_wgrad(const float* dz_dev, const float* x_dev, const float* scale_dev, const float* shift_dev,
+                                 float* partials_dev, int n, int cin, int cout, int hin, int win, void* stream) {
+    if (!dz_dev || !x_dev || !partials_dev || n <= 0 || (!scale_dev) != (!shift_dev)) return AG_ERR_INVALID_ARG;
+    const int layer = layer_of(cin, cout, hin, win);
+    if (!layer) return AG_ERR_UNSUPPORTED;
+    const int ho = (hin - 1) / 2 + 1, bands = (ho + 3) / 4;
+    if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+    const int g = ag_cnn_conv_wgrad_partials(n, cin, cout, hin, win);
+    const bool apply = scale_dev != nullptr;
+    const dim3 grid(g), block(384);
+    if (layer == 2) {
+        if (apply) hipLaunchKernelGGL((conv_s2_wgrad_kernel<16, 32, 106, 60, true>), grid, block, 0, (hipStream_t)stream, dz_dev, x_dev,
+                                      scale_dev, shift_dev, partials_dev, n * bands, bands);
+        else hipLaunchKernelGGL((conv_s2_wgrad_kernel<16, 32, 106, 60, false>), grid, block, 0, (hipStream_t)stream, dz_dev, x_dev,
+                                scale_dev, shift_dev, partials_dev, n * bands, bands);
+    } else {
+        if (apply) hipLaunchKernelGGL((conv_s2_wgrad_kernel<32, 64, 53, 30, true>), grid, block, 0, (hipStream_t)stream, dz_dev, x_dev,
+                                      scale_dev, shift_dev, partials_dev, n * bands, bands);
+        else hipLaunchKernelGGL((conv_s2_wgrad_kernel<32, 64, 53, 30, false>), grid, block, 0, (hipStream_t)stream, dz_dev, x_dev,
+                                scale_dev, shift_dev, partials_dev, n * bands, bands);
+    }
+    return AG_CONV_LAUNCH_OK();
+}

@@ -389,6 +389,35 @@ int ag_relu_bn_stats_weighted(const float* x_dev, const float* weights_dev, floa
 int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                                const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream);
 
+/* The three stride-2 convolutions of the same feature extractor (reference: lib/network/cnn.py:11-13 - nn.Conv2d(1, 16, 5, 2, 2),
+ * nn.Conv2d(16, 32, 3, 2, 1), nn.Conv2d(32, 64, 3, 2, 1) on (1, 212, 120) images; they replace torch's conv2d / MIOpen for exactly
+ * these shapes) - airgym_amd/csrc/conv_kernels.hip.  All tensors NCHW float32 as torch holds them, weights [COUT][CIN][k][k], exact
+ * float32 arithmetic (f32-input MFMA / fmaf).  n = images.  AG_ERR_UNSUPPORTED for any other shape.
+ *   ag_cnn_conv1_fwd      : y [n,16,106,60] = conv(x [n,1,212,120], w [16,1,5,5]) + b.
+ *   ag_cnn_conv1_wgrad    : partials_dev [ag_cnn_conv1_wgrad_partials(n)][16][32]: columns 0-24 = dw[co][tap], column 25 = db[co]
+ *                           (26-31 zero); the caller sums over dim 0 (fixed order -> deterministic).
+ *   ag_cnn_conv_supported : 1 for (cin, cout, hin, win) in {(16, 32, 106, 60), (32, 64, 53, 30)} (3x3, stride 2, pad 1).
+ *   ag_cnn_conv_fwd       : y [n,cout,ho,wo] = conv(in, w) + b with in = x, or, with scale_dev / shift_dev [cin] given,
+ *                           in = relu(x) * scale[c] + shift[c] - the previous layer's ReLU + BatchNorm applied while the input is
+ *                           staged, so that activation is never written to memory.
+ *   ag_cnn_conv_dgrad     : dx [n,cin,hin,win] = gradient of the layer's input (w.r.t. `in` above) from dz [n,cout,ho,wo].
+ *   ag_cnn_conv_wgrad     : partials_dev [ag_cnn_conv_wgrad_partials(...)][cout*cin*9 + cout]: dw [cout][cin][3][3] then db [cout];
+ *                           x / scale / shift as in ag_cnn_conv_fwd.
+ * workspace_dev: ag_cnn_conv_workspace_floats(cin, cout) floats (the weights re-laid out for the kernel, rebuilt every call). */
+int ag_cnn_conv_workspace_floats(int cin, int cout);
+int ag_cnn_conv1_fwd(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int n, float* workspace_dev,
+                     void* stream);
+int ag_cnn_conv1_wgrad_partials(int n);
+int ag_cnn_conv1_wgrad(const float* dz_dev, const float* x_dev, float* partials_dev, int n, void* stream);
+int ag_cnn_conv_supported(int cin, int cout, int hin, int win);
+int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev, const float* b_dev,
+                    float* y_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev, void* stream);
+int ag_cnn_conv_dgrad(const float* dz_dev, const float* w_dev, float* dx_dev, int n, int cin, int cout, int hin, int win,
+                      float* workspace_dev, void* stream);
+int ag_cnn_conv_wgrad_partials(int n, int cin, int cout, int hin, int win);
+int ag_cnn_conv_wgrad(const float* dz_dev, const float* x_dev, const float* scale_dev, const float* shift_dev,
+                      float* partials_dev, int n, int cin, int cout, int hin, int win, void* stream);
+
 /* Backward edges with the small weight gradients folded in.  Partials are per block of ag_wgrad_rows_per_block(which) rows
  * (ceil(M / rows) blocks); the caller reduces them over dim 0.
  *   ag_heads_bwd_elu_wgrad: dz = (d_heads Wh) * ELU'(h) (the head's dX formed inside the ELU' pass), plus dwh_partials_dev [blocks, A1, C] of dWh[a,c] = sum_m d_heads[m,a] h[m,c];

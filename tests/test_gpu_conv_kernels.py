@@ -1,0 +1,111 @@
+"""csrc/conv_kernels.hip against torch's conv2d evaluated in float64 on the CPU (reference modules: lib/network/cnn.py:11-13).
+
+Tolerance: the kernels are exact float32 (f32-input MFMA / fmaf) in their own summation order, so the error against float64 is
+float32 rounding over K terms: 2e-5 of the tensor's scale for the forward and the input gradient (K <= 288), 1e-4 for the weight
+gradients (K = every output pixel of every image)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+LAYERS = {
+    "conv1": dict(cin=1, cout=16, k=5, hin=212, win=120),
+    "conv2": dict(cin=16, cout=32, k=3, hin=106, win=60),
+    "conv3": dict(cin=32, cout=64, k=3, hin=53, win=30),
+}
+
+
+def _close(got, ref, tol, what):
+    scale = ref.abs().max().item()
+    err = (got.double().cpu() - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max error {err:.3e} against scale {scale:.3e} (tolerance {tol:g})"
+
+
+def _layer(name, seed):
+    c = LAYERS[name]
+    g = torch.Generator().manual_seed(seed)
+    conv = nn.Conv2d(c["cin"], c["cout"], c["k"], stride=2, padding=c["k"] // 2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.3)
+        conv.bias.copy_(torch.randn(conv.bias.shape, generator=g))
+    return c, conv, g
+
+
+@pytest.mark.parametrize("name", ["conv1", "conv2", "conv3"])
+@pytest.mark.parametrize("n", [1, 5])
+def test_forward_and_gradients_match_float64(name, n):
+    from airgym_amd.lib.network import hip_conv
+    c, conv, g = _layer(name, 3)
+    x = torch.randn(n, c["cin"], c["hin"], c["win"], generator=g)
+    ref_conv = nn.Conv2d(c["cin"], c["cout"], c["k"], stride=2, padding=c["k"] // 2).double()
+    ref_conv.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    xr = x.double().requires_grad_(c["cin"] > 1)
+    yr = ref_conv(xr)
+    dy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(dy)
+
+    conv = conv.cuda()
+    xg = x.cuda().requires_grad_(c["cin"] > 1)
+    assert hip_conv.supported(xg, conv)
+    y = hip_conv.conv2d(xg, conv)
+    assert y.shape == yr.shape
+    _close(y.detach(), yr.detach(), 2e-5, name + " forward")
+    y.backward(dy.float().cuda())
+    _close(conv.weight.grad, ref_conv.weight.grad, 1e-4, name + " weight gradient")
+    _close(conv.bias.grad, ref_conv.bias.grad, 1e-4, name + " bias gradient")
+    if c["cin"] > 1:
+        _close(xg.grad, xr.grad, 2e-5, name + " input gradient")
+
+
+@pytest.mark.parametrize("name", ["conv2", "conv3"])
+def test_previous_relu_batchnorm_applied_while_staging(name):
+    """scale / shift given: the layer convolves relu(x) * scale[c] + shift[c] (padding stays zero) without that tensor existing."""
+    import ctypes
+    from airgym_amd import _native as N
+    lib = N.load()
+    c, conv, g = _layer(name, 5)
+    n = 3
+    x = torch.randn(n, c["cin"], c["hin"], c["win"], generator=g)
+    scale = torch.rand(c["cin"], generator=g) + 0.5
+    shift = torch.randn(c["cin"], generator=g)
+    act = torch.relu(x.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    yr = F.conv2d(act, conv.weight.double(), conv.bias.double(), stride=2, padding=1)
+    dy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    w64 = conv.weight.double().detach().requires_grad_(True)
+    b64 = conv.bias.double().detach().requires_grad_(True)
+    F.conv2d(act, w64, b64, stride=2, padding=1).backward(dy)
+
+    dev = torch.device("cuda")
+    xg, sc, sh = x.to(dev), scale.to(dev), shift.to(dev)
+    w, b = conv.weight.detach().to(dev).contiguous(), conv.bias.detach().to(dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y = torch.empty(yr.shape, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.ag_cnn_conv_workspace_floats(c["cin"], c["cout"]), dtype=torch.float32, device=dev)
+    N.check(lib.ag_cnn_conv_fwd(xg.data_ptr(), sc.data_ptr(), sh.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, c["cin"],
+                                c["cout"], c["hin"], c["win"], ws.data_ptr(), stream), "fwd")
+    _close(y, yr.detach(), 2e-5, name + " forward with the previous layer's ReLU + BatchNorm")
+    gparts = lib.ag_cnn_conv_wgrad_partials(n, c["cin"], c["cout"], c["hin"], c["win"])
+    plen = c["cout"] * c["cin"] * 9 + c["cout"]
+    partials = torch.empty(gparts, plen, dtype=torch.float32, device=dev)
+    dyg = dy.float().to(dev)
+    N.check(lib.ag_cnn_conv_wgrad(dyg.data_ptr(), xg.data_ptr(), sc.data_ptr(), sh.data_ptr(), partials.data_ptr(), n, c["cin"],
+                                  c["cout"], c["hin"], c["win"], stream), "wgrad")
+    s = partials.sum(0)
+    _close(s[:plen - c["cout"]].reshape(w.shape), w64.grad, 1e-4, name + " weight gradient with ReLU + BatchNorm")
+    _close(s[plen - c["cout"]:], b64.grad, 1e-4, name + " bias gradient")
+
+
+def test_unsupported_shapes_are_refused():
+    from airgym_amd import _native as N
+    from airgym_amd.lib.network import hip_conv
+    lib = N.load()
+    assert not lib.ag_cnn_conv_supported(16, 32, 100, 60)
+    conv = nn.Conv2d(16, 32, 3, stride=2, padding=1).cuda()
+    assert not hip_conv.supported(torch.zeros(2, 16, 100, 60, device="cuda"), conv)
+    assert hip_conv.supported(torch.zeros(2, 16, 106, 60, device="cuda"), conv)
+    assert not hip_conv.supported(torch.zeros(2, 16, 106, 60), conv.cpu())
+    ws = torch.zeros(16, device="cuda")
+    assert lib.ag_cnn_conv_fwd(ws.data_ptr(), None, None, ws.data_ptr(), ws.data_ptr(), ws.data_ptr(), 1, 16, 32, 100, 60,
+                               ws.data_ptr(), None) == N.AG_ERR_UNSUPPORTED
