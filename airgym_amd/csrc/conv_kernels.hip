@@ -82,6 +82,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
     static_assert(WIN % 2 == 0 && COUT % 16 == 0 && CIN % 8 == 0, "shape");
     __shared__ __attribute__((aligned(16))) float s_in[8 * PS + 64];
     __shared__ __attribute__((aligned(16))) float s_w[72 * QS];
+    __shared__ float s_ss[2 * CIN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
     const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
@@ -96,17 +97,46 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[r][bt][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int ch = 0; ch < CIN / 8; ++ch) {
-        __syncthreads();
-        for (int u = tid; u < 8 * IN_ROWS * W2; u += NT) {
+    // staging through registers: the loads of chunk ch + 1 are issued before the MFMA loop of chunk ch and land in LDS after it
+    constexpr int IN_UNITS = 8 * IN_ROWS * W2, IN_IT = (IN_UNITS + NT - 1) / NT;
+    constexpr int W_UNITS = 72 * COUT / 4, W_IT = (W_UNITS + NT - 1) / NT;
+    float2 vin[IN_IT];
+    float4 vw[W_IT];
+    auto fetch = [&](int ch) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int u = t + it * NT;
             const int p = u / (IN_ROWS * W2), rem = u - p * (IN_ROWS * W2);
             const int row = rem / W2, j = rem - row * W2;
-            const int iy = 2 * oy0 - 1 + row, ci = ch * 8 + p;
-            float2 v = make_float2(0.f, 0.f);
-            if (iy >= 0 && iy < HIN) {
-                v = *reinterpret_cast<const float2*>(xin + ((size_t)ci * HIN + iy) * WIN + 2 * j);
-                if (APPLY) {
-                    const float sc = scale[ci], sh = shift[ci];
+            const int iy = 2 * oy0 - 1 + row;
+            vin[it] = make_float2(0.f, 0.f);
+            if (u < IN_UNITS && iy >= 0 && iy < HIN)
+                vin[it] = *reinterpret_cast<const float2*>(xin + (unsigned)(((ch * 8 + p) * HIN + iy) * WIN + 2 * j));
+        }
+        const float4* wsrc = reinterpret_cast<const float4*>(wp + (size_t)ch * 72 * COUT);
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int u = t + it * NT;
+            vw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < W_UNITS) vw[it] = wsrc[u];
+        }
+    };
+    auto stash = [&](int ch) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int u = t + it * NT;
+            if (u >= IN_UNITS) continue;
+            const int p = u / (IN_ROWS * W2), rem = u - p * (IN_ROWS * W2);
+            const int row = rem / W2, j = rem - row * W2;
+            float2 v = vin[it];
+            if (APPLY) {
+                const int iy = 2 * oy0 - 1 + row;
+                if (iy >= 0 && iy < HIN) {
+                    const float sc = s_ss[ch * 8 + p], sh = s_ss[CIN + ch * 8 + p];
                     v.x = fmaxf(v.x, 0.f) * sc + sh;
                     v.y = fmaxf(v.y, 0.f) * sc + sh;
                 }
@@ -116,14 +146,23 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
             rowp[j + 1] = v.y;
             if (j == 0) rowp[0] = 0.f;
         }
-        {
-            const float4* wsrc = reinterpret_cast<const float4*>(wp + (size_t)ch * 72 * COUT);
-            for (int u = tid; u < 72 * COUT / 4; u += NT) {
-                const int r = u / (COUT / 4), c4 = u - r * (COUT / 4);
-                *reinterpret_cast<float4*>(s_w + r * QS + 4 * c4) = wsrc[u];
-            }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int u = t + it * NT;
+            if (u >= W_UNITS) continue;
+            const int r = u / (COUT / 4), c4 = u - r * (COUT / 4);
+            *reinterpret_cast<float4*>(s_w + r * QS + 4 * c4) = vw[it];
         }
+    };
+    if (APPLY) {
+        for (int u = tid; u < CIN; u += NT) { s_ss[u] = scale[u]; s_ss[CIN + u] = shift[u]; }
+    }
+    fetch(0);
+    for (int ch = 0; ch < CIN / 8; ++ch) {
         __syncthreads();
+        stash(ch);
+        __syncthreads();
+        if (ch + 1 < CIN / 8) fetch(ch + 1);
         const float* bb = s_in + q * PS + (4 * wave) * RS + m;
         const float* ab = s_w + q * QS + m;
 #pragma unroll
@@ -202,24 +241,54 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
 #pragma unroll
                     for (int bt = 0; bt < NBT; ++bt) acc[r][py][px][rt][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int ch = 0; ch < COUT / 16; ++ch) {
-        __syncthreads();
-        for (int u = tid; u < 16 * ZR * RSZ; u += NT) {
+    constexpr int Z_UNITS = 16 * ZR * RSZ, Z_IT = (Z_UNITS + NT - 1) / NT;
+    constexpr int W_UNITS = 9 * 16 * CIN / 4, W_IT = (W_UNITS + NT - 1) / NT;
+    float vz[Z_IT];
+    float4 vw[W_IT];
+    auto fetch = [&](int ch) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int it = 0; it < Z_IT; ++it) {
+            const int u = t + it * NT;
             const int c = u / (ZR * RSZ), rem = u - c * (ZR * RSZ);
             const int lr = rem / RSZ, col = rem - lr * RSZ;
             const int a = a0 + lr;
-            float v = 0.f;
-            if (a < HO && col < WO) v = zin[((size_t)(ch * 16 + c) * HO + a) * WO + col];
-            s_z[c * PSZ + lr * RSZ + col] = v;
+            vz[it] = 0.f;
+            if (u < Z_UNITS && a < HO && col < WO) vz[it] = zin[(unsigned)(((ch * 16 + c) * HO + a) * WO + col)];
         }
-        {
-            const float4* wsrc = reinterpret_cast<const float4*>(wd + (size_t)ch * 9 * 16 * CIN);
-            for (int u = tid; u < 9 * 16 * CIN / 4; u += NT) {
-                const int r = u / (CIN / 4), c4 = u - r * (CIN / 4);
-                *reinterpret_cast<float4*>(s_w + r * CINP + 4 * c4) = wsrc[u];
-            }
+        const float4* wsrc = reinterpret_cast<const float4*>(wd + (size_t)ch * 9 * 16 * CIN);
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int u = t + it * NT;
+            vw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < W_UNITS) vw[it] = wsrc[u];
         }
+    };
+    auto stash = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int it = 0; it < Z_IT; ++it) {
+            const int u = t + it * NT;
+            if (u >= Z_UNITS) continue;
+            const int c = u / (ZR * RSZ), rem = u - c * (ZR * RSZ);
+            s_z[c * PSZ + rem] = vz[it];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int u = t + it * NT;
+            if (u >= W_UNITS) continue;
+            const int r = u / (CIN / 4), c4 = u - r * (CIN / 4);
+            *reinterpret_cast<float4*>(s_w + r * CINP + 4 * c4) = vw[it];
+        }
+    };
+    fetch(0);
+    for (int ch = 0; ch < COUT / 16; ++ch) {
         __syncthreads();
+        stash();
+        __syncthreads();
+        if (ch + 1 < COUT / 16) fetch(ch + 1);
         const float* zb = s_z + q * PSZ + (2 * wave) * RSZ + m;
         const float* ab = s_w + q * CINP + m;
 #pragma unroll
@@ -298,6 +367,7 @@ __global__ __launch_bounds__(384) void conv_s2_wgrad_kernel(const float* __restr
     static_assert(RT % 2 == 0, "row tiles split over two wave groups");
     __shared__ __attribute__((aligned(16))) float s_in[CIN * PS + 32];
     __shared__ __attribute__((aligned(16))) float s_z[COUT * PSZ + 32];
+    __shared__ float s_ss[2 * CIN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
     const int ky = wave >> 1, rg = wave & 1;
@@ -319,38 +389,79 @@ __global__ __launch_bounds__(384) void conv_s2_wgrad_kernel(const float* __restr
     const float* ab = s_z + (16 * rg * RTW + m) * PSZ + aq;
     const float* bb = s_in + m * PS + bq + ky * RS;
 
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    constexpr int Z_UNITS = COUT * R * WO, Z_IT = (Z_UNITS + NT - 1) / NT;
+    constexpr int IN_UNITS = CIN * IN_ROWS * W2, IN_IT = (IN_UNITS + NT - 1) / NT;
+    float vz[Z_IT];
+    float2 vin[IN_IT];
+    auto fetch = [&](int item) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
         const int n = item / bands, band = item - n * bands;
         const int oy0 = band * R;
-        __syncthreads();
-        {
-            const float* zin = dz + (size_t)n * COUT * HO * WO;
-            for (int u = tid; u < COUT * R * WO; u += NT) {
-                const int co = u / (R * WO), rem = u - co * (R * WO);
-                const int lr = rem / WO, ox = rem - lr * WO;
-                const int oy = oy0 + lr;
-                s_z[co * PSZ + lr * RSZ + ox] = (oy < HO) ? zin[((size_t)co * HO + oy) * WO + ox] : 0.f;
-            }
-            const float* xin = x + (size_t)n * CIN * HIN * WIN;
-            for (int u = tid; u < CIN * IN_ROWS * W2; u += NT) {
-                const int ci = u / (IN_ROWS * W2), rem = u - ci * (IN_ROWS * W2);
-                const int row = rem / W2, j = rem - row * W2;
-                const int iy = 2 * oy0 - 1 + row;
-                float2 v = make_float2(0.f, 0.f);
-                if (iy >= 0 && iy < HIN) {
-                    v = *reinterpret_cast<const float2*>(xin + ((size_t)ci * HIN + iy) * WIN + 2 * j);
-                    if (APPLY) {
-                        const float sc = scale[ci], sh = shift[ci];
-                        v.x = fmaxf(v.x, 0.f) * sc + sh;
-                        v.y = fmaxf(v.y, 0.f) * sc + sh;
-                    }
-                }
-                float* rowp = s_in + ci * PS + row * RS;
-                rowp[EO + j] = v.x;
-                rowp[j + 1] = v.y;
-            }
+        const float* zin = dz + (size_t)n * COUT * HO * WO;
+#pragma unroll
+        for (int it = 0; it < Z_IT; ++it) {
+            const int u = t + it * NT;
+            const int co = u / (R * WO), rem = u - co * (R * WO);
+            const int lr = rem / WO, ox = rem - lr * WO;
+            const int oy = oy0 + lr;
+            vz[it] = 0.f;
+            if (u < Z_UNITS && oy < HO) vz[it] = zin[(unsigned)((co * HO + oy) * WO + ox)];
         }
+        const float* xin = x + (size_t)n * CIN * HIN * WIN;
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int u = t + it * NT;
+            const int ci = u / (IN_ROWS * W2), rem = u - ci * (IN_ROWS * W2);
+            const int row = rem / W2, j = rem - row * W2;
+            const int iy = 2 * oy0 - 1 + row;
+            vin[it] = make_float2(0.f, 0.f);
+            if (u < IN_UNITS && iy >= 0 && iy < HIN)
+                vin[it] = *reinterpret_cast<const float2*>(xin + (unsigned)((ci * HIN + iy) * WIN + 2 * j));
+        }
+    };
+    auto stash = [&](int item) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int band = item % bands;
+        const int oy0 = band * R;
+#pragma unroll
+        for (int it = 0; it < Z_IT; ++it) {
+            const int u = t + it * NT;
+            if (u >= Z_UNITS) continue;
+            const int co = u / (R * WO), rem = u - co * (R * WO);
+            const int lr = rem / WO, ox = rem - lr * WO;
+            s_z[co * PSZ + lr * RSZ + ox] = vz[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int u = t + it * NT;
+            if (u >= IN_UNITS) continue;
+            const int ci = u / (IN_ROWS * W2), rem = u - ci * (IN_ROWS * W2);
+            const int row = rem / W2, j = rem - row * W2;
+            float2 v = vin[it];
+            if (APPLY) {
+                const int iy = 2 * oy0 - 1 + row;
+                if (iy >= 0 && iy < HIN) {
+                    const float sc = s_ss[ci], sh = s_ss[CIN + ci];
+                    v.x = fmaxf(v.x, 0.f) * sc + sh;
+                    v.y = fmaxf(v.y, 0.f) * sc + sh;
+                }
+            }
+            float* rowp = s_in + ci * PS + row * RS;
+            rowp[EO + j] = v.x;
+            rowp[j + 1] = v.y;
+        }
+    };
+    if (APPLY) {
+        for (int u = tid; u < CIN; u += NT) { s_ss[u] = scale[u]; s_ss[CIN + u] = shift[u]; }
+    }
+    fetch(blockIdx.x);
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
         __syncthreads();
+        stash(item);
+        __syncthreads();
+        if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
 #pragma unroll
         for (int rp = 0; rp < (WIDE ? 2 : 1); ++rp) {
 #pragma unroll 4
@@ -401,14 +512,25 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
     const int oy0 = band * ROWS;
     const float* xin = x + (size_t)n * HIN * WIN;
-    for (int u = tid; u < IN_ROWS * (WIN / 2); u += 256) {
+    constexpr int IN_UNITS = IN_ROWS * (WIN / 2), IN_IT = (IN_UNITS + 255) / 256;
+    float2 vin[IN_IT];
+    const int t = tid;
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+        const int u = t + it * 256;
         const int row = u / (WIN / 2), j = u - row * (WIN / 2);
         const int iy = 2 * oy0 - 2 + row;
-        float2 v = make_float2(0.f, 0.f);
-        if (iy >= 0 && iy < HIN) v = *reinterpret_cast<const float2*>(xin + (size_t)iy * WIN + 2 * j);
+        vin[it] = make_float2(0.f, 0.f);
+        if (u < IN_UNITS && iy >= 0 && iy < HIN) vin[it] = *reinterpret_cast<const float2*>(xin + (unsigned)(iy * WIN + 2 * j));
+    }
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+        const int u = t + it * 256;
+        if (u >= IN_UNITS) continue;
+        const int row = u / (WIN / 2), j = u - row * (WIN / 2);
         float* rowp = s_in + row * RS;
-        rowp[j + 1] = v.x;            // c = ix + 2 = 2j + 2
-        rowp[EO + j + 1] = v.y;       // c = 2j + 3
+        rowp[j + 1] = vin[it].x;            // c = ix + 2 = 2j + 2
+        rowp[EO + j + 1] = vin[it].y;       // c = 2j + 3
         if (j == 0) { rowp[0] = 0.f; rowp[EO] = 0.f; rowp[WIN / 2 + 1] = 0.f; rowp[EO + WIN / 2 + 1] = 0.f; }
     }
     __syncthreads();
@@ -460,29 +582,58 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     const bool t1_data = (m + 16) < 25;
     const float t1_const = (m + 16 == 25) ? 1.f : 0.f;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    constexpr int Z_UNITS = 16 * ROWS * (WO / 2), Z_IT = (Z_UNITS + 255) / 256;
+    constexpr int IN_UNITS = IN_ROWS * (WIN / 2), IN_IT = (IN_UNITS + 255) / 256;
+    float2 vz[Z_IT], vin[IN_IT];
+    auto fetch = [&](int item) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
         const int n = item / bands, band = item - n * bands;
         const int oy0 = band * ROWS;
-        __syncthreads();
         const float* zin = dz + (size_t)n * 16 * HO * WO;
-        for (int u = tid; u < 16 * ROWS * (WO / 2); u += 256) {
+#pragma unroll
+        for (int it = 0; it < Z_IT; ++it) {
+            const int u = t + it * 256;
             const int co = u / (ROWS * (WO / 2)), rem = u - co * (ROWS * (WO / 2));
             const int lr = rem / (WO / 2), j = rem - lr * (WO / 2);
-            const int oy = oy0 + lr;
-            float2 v = make_float2(0.f, 0.f);
-            if (oy < HO) v = *reinterpret_cast<const float2*>(zin + ((size_t)co * HO + oy) * WO + 2 * j);
-            *reinterpret_cast<float2*>(s_z + co * PSZ + lr * WO + 2 * j) = v;
+            vz[it] = make_float2(0.f, 0.f);
+            if (u < Z_UNITS && oy0 + lr < HO) vz[it] = *reinterpret_cast<const float2*>(zin + (unsigned)((co * HO + oy0 + lr) * WO + 2 * j));
         }
         const float* xin = x + (size_t)n * HIN * WIN;
-        for (int u = tid; u < IN_ROWS * (WIN / 2); u += 256) {
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int u = t + it * 256;
             const int row = u / (WIN / 2), j = u - row * (WIN / 2);
             const int iy = 2 * oy0 - 2 + row;
-            float2 v = make_float2(0.f, 0.f);
-            if (iy >= 0 && iy < HIN) v = *reinterpret_cast<const float2*>(xin + (size_t)iy * WIN + 2 * j);
-            s_in[row * RS + j + 1] = v.x;
-            s_in[row * RS + EO + j + 1] = v.y;
+            vin[it] = make_float2(0.f, 0.f);
+            if (u < IN_UNITS && iy >= 0 && iy < HIN) vin[it] = *reinterpret_cast<const float2*>(xin + (unsigned)(iy * WIN + 2 * j));
         }
+    };
+    auto stash = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int it = 0; it < Z_IT; ++it) {
+            const int u = t + it * 256;
+            if (u >= Z_UNITS) continue;
+            const int co = u / (ROWS * (WO / 2)), rem = u - co * (ROWS * (WO / 2));
+            *reinterpret_cast<float2*>(s_z + co * PSZ + 2 * rem) = vz[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int u = t + it * 256;
+            if (u >= IN_UNITS) continue;
+            const int row = u / (WIN / 2), j = u - row * (WIN / 2);
+            s_in[row * RS + j + 1] = vin[it].x;
+            s_in[row * RS + EO + j + 1] = vin[it].y;
+        }
+    };
+    fetch(blockIdx.x);
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
         __syncthreads();
+        stash();
+        __syncthreads();
+        if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int lr = 2 * wave + rr;

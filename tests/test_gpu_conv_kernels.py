@@ -109,3 +109,26 @@ def test_unsupported_shapes_are_refused():
     ws = torch.zeros(16, device="cuda")
     assert lib.ag_cnn_conv_fwd(ws.data_ptr(), None, None, ws.data_ptr(), ws.data_ptr(), ws.data_ptr(), 1, 16, 32, 100, 60,
                                ws.data_ptr(), None) == N.AG_ERR_UNSUPPORTED
+
+
+def test_feature_extractor_is_the_same_function_with_and_without_the_kernels():
+    """CNNFeatureExtractor (training mode, batch statistics) through csrc/conv_kernels.hip against the same module on torch's
+    conv2d: features, parameter gradients and BatchNorm running statistics."""
+    import copy
+    from airgym_amd.lib.network.cnn import CNNFeatureExtractor
+    torch.manual_seed(1)
+    a = CNNFeatureExtractor(12).cuda().train()
+    b = copy.deepcopy(a)
+    b.hip_convs = False
+    x = torch.rand(6, 1, 212, 120, device="cuda")
+    g = torch.randn(6, 12, device="cuda")
+    fa, fb = a(x), b(x)
+    fa.backward(g)
+    fb.backward(g)
+    scale = fb.abs().max().item()
+    assert (fa - fb).abs().max().item() <= 2e-4 * scale
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        s = pb.grad.abs().max().item()
+        assert (pa.grad - pb.grad).abs().max().item() <= 5e-4 * s + 1e-7, name
+    for (name, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-4, atol=1e-6), name
