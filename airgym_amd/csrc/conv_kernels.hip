@@ -27,6 +27,41 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AG_MFMA4(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 
+// experiments build only (tools/): -DAG_CONV_EXP=1 weight gradient without its MFMA loop, =2 without staging after the first item
+#if defined(AG_EXPERIMENTS) && defined(AG_CONV_EXP)
+constexpr int kConvExp = AG_CONV_EXP;
+#else
+constexpr int kConvExp = 0;
+#endif
+
+// Staging loads go through buffer descriptors: a 32-bit byte offset per lane and hardware bounds checking - an out-of-range
+// offset (kOob) returns 0, which is how padding rows, band tails and tail units are produced without a branch per load.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_of(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_f1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ float2 buf_f2(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+}
+// the same with a wave-uniform byte offset added by the hardware (soffset; not part of the bounds check, so kOob stays out of range)
+__device__ __forceinline__ float buf_f1(__amdgpu_buffer_rsrc_t r, unsigned off, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
+}
+__device__ __forceinline__ float2 buf_f2(__amdgpu_buffer_rsrc_t r, unsigned off, int soff) {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
+}
+__device__ __forceinline__ float4 buf_f4(__amdgpu_buffer_rsrc_t r, unsigned off, int soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0));
+}
+__device__ __forceinline__ float4 buf_f4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
 constexpr int pad16mod32(int v) { return v + ((16 - (v % 32)) + 32) % 32; }
 constexpr int make_odd(int v) { return v | 1; }
 
@@ -102,6 +137,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
     constexpr int W_UNITS = 72 * COUT / 4, W_IT = (W_UNITS + NT - 1) / NT;
     float2 vin[IN_IT];
     float4 vw[W_IT];
+    const __amdgpu_buffer_rsrc_t rx = buf_of(xin, CIN * HIN * WIN * 4), rw = buf_of(wp, 9 * CIN * COUT * 4);
     auto fetch = [&](int ch) {
         int t = tid;
         asm volatile("" : "+v"(t));
@@ -111,16 +147,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
             const int p = u / (IN_ROWS * W2), rem = u - p * (IN_ROWS * W2);
             const int row = rem / W2, j = rem - row * W2;
             const int iy = 2 * oy0 - 1 + row;
-            vin[it] = make_float2(0.f, 0.f);
-            if (u < IN_UNITS && iy >= 0 && iy < HIN)
-                vin[it] = *reinterpret_cast<const float2*>(xin + (unsigned)(((ch * 8 + p) * HIN + iy) * WIN + 2 * j));
+            const bool ok = u < IN_UNITS && iy >= 0 && iy < HIN;
+            vin[it] = buf_f2(rx, ok ? (unsigned)((((ch * 8 + p) * HIN + iy) * WIN + 2 * j) * 4) : kOob);
         }
-        const float4* wsrc = reinterpret_cast<const float4*>(wp + (size_t)ch * 72 * COUT);
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int u = t + it * NT;
-            vw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < W_UNITS) vw[it] = wsrc[u];
+            vw[it] = buf_f4(rw, u < W_UNITS ? (unsigned)((ch * 72 * COUT + 4 * u) * 4) : kOob);
         }
     };
     auto stash = [&](int ch) {
@@ -245,6 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
     constexpr int W_UNITS = 9 * 16 * CIN / 4, W_IT = (W_UNITS + NT - 1) / NT;
     float vz[Z_IT];
     float4 vw[W_IT];
+    const __amdgpu_buffer_rsrc_t rz = buf_of(zin, COUT * HO * WO * 4), rw = buf_of(wd, 9 * CIN * COUT * 4);
     auto fetch = [&](int ch) {
         int t = tid;
         asm volatile("" : "+v"(t));
@@ -254,15 +288,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
             const int c = u / (ZR * RSZ), rem = u - c * (ZR * RSZ);
             const int lr = rem / RSZ, col = rem - lr * RSZ;
             const int a = a0 + lr;
-            vz[it] = 0.f;
-            if (u < Z_UNITS && a < HO && col < WO) vz[it] = zin[(unsigned)(((ch * 16 + c) * HO + a) * WO + col)];
+            const bool ok = u < Z_UNITS && a < HO && col < WO;
+            vz[it] = buf_f1(rz, ok ? (unsigned)((((ch * 16 + c) * HO + a) * WO + col) * 4) : kOob);
         }
-        const float4* wsrc = reinterpret_cast<const float4*>(wd + (size_t)ch * 9 * 16 * CIN);
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int u = t + it * NT;
-            vw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < W_UNITS) vw[it] = wsrc[u];
+            vw[it] = buf_f4(rw, u < W_UNITS ? (unsigned)((ch * 9 * 16 * CIN + 4 * u) * 4) : kOob);
         }
     };
     auto stash = [&]() {
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
 // Pixel <-> quarter map (chosen for the bank rule): WO > 16 (30 wide): quarter = (row & 1, half) - rows 2r'+(q>>1), ox = j + 16 (q&1);
 // WO <= 16 (15 wide): quarter = row, ox = j.  Pixels ox >= WO have dz = 0 in LDS (and finite input values).
 template <int CIN, int COUT, int HIN, int WIN, bool APPLY>
-__global__ __launch_bounds__(384) void conv_s2_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+__global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            float* __restrict__ partials, int items, int bands) {
     constexpr int HO = (HIN - 1) / 2 + 1, WO = WIN / 2;
@@ -389,68 +421,77 @@ __global__ __launch_bounds__(384) void conv_s2_wgrad_kernel(const float* __restr
     const float* ab = s_z + (16 * rg * RTW + m) * PSZ + aq;
     const float* bb = s_in + m * PS + bq + ky * RS;
 
-    constexpr int Z_UNITS = COUT * R * WO, Z_IT = (Z_UNITS + NT - 1) / NT;
-    constexpr int IN_UNITS = CIN * IN_ROWS * W2, IN_IT = (IN_UNITS + NT - 1) / NT;
-    float vz[Z_IT];
+    // Staging, slot-major: a thread owns ONE position of a plane (input: (row, column pair) of the band; dz: (row, column) of the
+    // band) and walks the planes - every address is (per-thread base, computed once per item) + (plane step: a constant scalar
+    // offset of the load / an immediate offset of the LDS store), so staging costs no address arithmetic per element.
+    constexpr int SLOTS_IN = IN_ROWS * W2;               // 270 / 135 float2 per input plane
+    constexpr int PG = NT / SLOTS_IN;                    // plane groups walking in parallel: 1 / 2
+    constexpr int IN_IT = CIN / PG;
+    static_assert(CIN % PG == 0, "planes split evenly over the plane groups");
+    const int ipg = tid / SLOTS_IN, islot = tid - ipg * SLOTS_IN;
+    const int irow = islot / W2, ij = islot - irow * W2;
+    const bool in_act = tid < PG * SLOTS_IN;
+    float* const in_dst = s_in + ipg * PS + irow * RS + ij;
+    constexpr int ZV = WIDE ? 2 : 1;                     // dz row width 30: float2 units; 15: single floats (rows are 4-byte aligned)
+    constexpr int SLOTS_Z = R * WO / ZV;                 // 60 per dz plane
+    constexpr int ZG = NT / 64;                          // 6 plane groups of 64 threads (60 active)
+    constexpr int Z_IT = (COUT + ZG - 1) / ZG;
+    static_assert(SLOTS_Z <= 64, "one dz slot per lane");
+    const int zg = tid >> 6, zslot = tid & 63;
+    const int zlr = zslot / (WO / ZV), zc = (zslot - zlr * (WO / ZV)) * ZV;
+    float* const z_dst = s_z + zg * PSZ + zlr * RSZ + zc;
     float2 vin[IN_IT];
+    float vz[Z_IT][ZV];
     auto fetch = [&](int item) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
         const int n = item / bands, band = item - n * bands;
         const int oy0 = band * R;
-        const float* zin = dz + (size_t)n * COUT * HO * WO;
+        const __amdgpu_buffer_rsrc_t rz = buf_of(dz + (size_t)n * COUT * HO * WO, COUT * HO * WO * 4);
+        const __amdgpu_buffer_rsrc_t rx = buf_of(x + (size_t)n * CIN * HIN * WIN, CIN * HIN * WIN * 4);
+        const int iy = 2 * oy0 - 1 + irow;
+        const unsigned xoff = (in_act && iy >= 0 && iy < HIN) ? (unsigned)(((ipg * HIN + iy) * WIN + 2 * ij) * 4) : kOob;
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) vin[it] = buf_f2(rx, xoff, it * PG * HIN * WIN * 4);
+        const unsigned zoff = (zslot < SLOTS_Z && oy0 + zlr < HO) ? (unsigned)(((zg * HO + oy0 + zlr) * WO + zc) * 4) : kOob;
 #pragma unroll
         for (int it = 0; it < Z_IT; ++it) {
-            const int u = t + it * NT;
-            const int co = u / (R * WO), rem = u - co * (R * WO);
-            const int lr = rem / WO, ox = rem - lr * WO;
-            const int oy = oy0 + lr;
-            vz[it] = 0.f;
-            if (u < Z_UNITS && oy < HO) vz[it] = zin[(unsigned)((co * HO + oy) * WO + ox)];
-        }
-        const float* xin = x + (size_t)n * CIN * HIN * WIN;
-#pragma unroll
-        for (int it = 0; it < IN_IT; ++it) {
-            const int u = t + it * NT;
-            const int ci = u / (IN_ROWS * W2), rem = u - ci * (IN_ROWS * W2);
-            const int row = rem / W2, j = rem - row * W2;
-            const int iy = 2 * oy0 - 1 + row;
-            vin[it] = make_float2(0.f, 0.f);
-            if (u < IN_UNITS && iy >= 0 && iy < HIN)
-                vin[it] = *reinterpret_cast<const float2*>(xin + (unsigned)((ci * HIN + iy) * WIN + 2 * j));
+            const unsigned o = (it * ZG + ZG <= COUT || zg + it * ZG < COUT) ? zoff : kOob;
+            if (ZV == 2) {
+                const float2 v = buf_f2(rz, o, it * ZG * HO * WO * 4);
+                vz[it][0] = v.x;
+                vz[it][ZV - 1] = v.y;
+            } else {
+                vz[it][0] = buf_f1(rz, o, it * ZG * HO * WO * 4);
+            }
         }
     };
     auto stash = [&](int item) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
         const int band = item % bands;
         const int oy0 = band * R;
+        if (in_act) {
+            const int iy = 2 * oy0 - 1 + irow;
+            const bool inside = iy >= 0 && iy < HIN;
 #pragma unroll
-        for (int it = 0; it < Z_IT; ++it) {
-            const int u = t + it * NT;
-            if (u >= Z_UNITS) continue;
-            const int co = u / (R * WO), rem = u - co * (R * WO);
-            const int lr = rem / WO, ox = rem - lr * WO;
-            s_z[co * PSZ + lr * RSZ + ox] = vz[it];
+            for (int it = 0; it < IN_IT; ++it) {
+                float2 v = vin[it];
+                if (APPLY) {
+                    if (inside) {
+                        const float sc = s_ss[ipg + it * PG], sh = s_ss[CIN + ipg + it * PG];
+                        v.x = fmaxf(v.x, 0.f) * sc + sh;
+                        v.y = fmaxf(v.y, 0.f) * sc + sh;
+                    }
+                }
+                in_dst[it * PG * PS + EO] = v.x;
+                in_dst[it * PG * PS + 1] = v.y;
+            }
         }
+        if (zslot < SLOTS_Z) {
 #pragma unroll
-        for (int it = 0; it < IN_IT; ++it) {
-            const int u = t + it * NT;
-            if (u >= IN_UNITS) continue;
-            const int ci = u / (IN_ROWS * W2), rem = u - ci * (IN_ROWS * W2);
-            const int row = rem / W2, j = rem - row * W2;
-            float2 v = vin[it];
-            if (APPLY) {
-                const int iy = 2 * oy0 - 1 + row;
-                if (iy >= 0 && iy < HIN) {
-                    const float sc = s_ss[ci], sh = s_ss[CIN + ci];
-                    v.x = fmaxf(v.x, 0.f) * sc + sh;
-                    v.y = fmaxf(v.y, 0.f) * sc + sh;
+            for (int it = 0; it < Z_IT; ++it) {
+                if (it * ZG + ZG <= COUT || zg + it * ZG < COUT) {
+                    z_dst[it * ZG * PSZ] = vz[it][0];
+                    if (ZV == 2) z_dst[it * ZG * PSZ + 1] = vz[it][ZV - 1];
                 }
             }
-            float* rowp = s_in + ci * PS + row * RS;
-            rowp[EO + j] = v.x;
-            rowp[j + 1] = v.y;
         }
     };
     if (APPLY) {
@@ -459,9 +500,10 @@ __global__ __launch_bounds__(384) void conv_s2_wgrad_kernel(const float* __restr
     fetch(blockIdx.x);
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         __syncthreads();
-        stash(item);
+        if (!(kConvExp & 2) || item == (int)blockIdx.x) stash(item);
         __syncthreads();
-        if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
+        if (!(kConvExp & 2) && item + (int)gridDim.x < items) fetch(item + gridDim.x);
+        if (kConvExp & 1) { acc[0][0][0][0] += s_in[tid] + s_z[tid]; continue; }      // keeps the staging alive
 #pragma unroll
         for (int rp = 0; rp < (WIDE ? 2 : 1); ++rp) {
 #pragma unroll 4
@@ -515,13 +557,13 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     constexpr int IN_UNITS = IN_ROWS * (WIN / 2), IN_IT = (IN_UNITS + 255) / 256;
     float2 vin[IN_IT];
     const int t = tid;
+    const __amdgpu_buffer_rsrc_t rx = buf_of(xin, HIN * WIN * 4);
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
         const int u = t + it * 256;
         const int row = u / (WIN / 2), j = u - row * (WIN / 2);
         const int iy = 2 * oy0 - 2 + row;
-        vin[it] = make_float2(0.f, 0.f);
-        if (u < IN_UNITS && iy >= 0 && iy < HIN) vin[it] = *reinterpret_cast<const float2*>(xin + (unsigned)(iy * WIN + 2 * j));
+        vin[it] = buf_f2(rx, (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob);
     }
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
@@ -590,23 +632,21 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
         asm volatile("" : "+v"(t));
         const int n = item / bands, band = item - n * bands;
         const int oy0 = band * ROWS;
-        const float* zin = dz + (size_t)n * 16 * HO * WO;
+        const __amdgpu_buffer_rsrc_t rz = buf_of(dz + (size_t)n * 16 * HO * WO, 16 * HO * WO * 4);
+        const __amdgpu_buffer_rsrc_t rx = buf_of(x + (size_t)n * HIN * WIN, HIN * WIN * 4);
 #pragma unroll
         for (int it = 0; it < Z_IT; ++it) {
             const int u = t + it * 256;
             const int co = u / (ROWS * (WO / 2)), rem = u - co * (ROWS * (WO / 2));
             const int lr = rem / (WO / 2), j = rem - lr * (WO / 2);
-            vz[it] = make_float2(0.f, 0.f);
-            if (u < Z_UNITS && oy0 + lr < HO) vz[it] = *reinterpret_cast<const float2*>(zin + (unsigned)((co * HO + oy0 + lr) * WO + 2 * j));
+            vz[it] = buf_f2(rz, (u < Z_UNITS && oy0 + lr < HO) ? (unsigned)(((co * HO + oy0 + lr) * WO + 2 * j) * 4) : kOob);
         }
-        const float* xin = x + (size_t)n * HIN * WIN;
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
             const int u = t + it * 256;
             const int row = u / (WIN / 2), j = u - row * (WIN / 2);
             const int iy = 2 * oy0 - 2 + row;
-            vin[it] = make_float2(0.f, 0.f);
-            if (u < IN_UNITS && iy >= 0 && iy < HIN) vin[it] = *reinterpret_cast<const float2*>(xin + (unsigned)(iy * WIN + 2 * j));
+            vin[it] = buf_f2(rx, (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob);
         }
     };
     auto stash = [&]() {
