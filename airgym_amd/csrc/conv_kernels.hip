@@ -132,60 +132,68 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[r][bt][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // staging through registers: the loads of chunk ch + 1 are issued before the MFMA loop of chunk ch and land in LDS after it
-    constexpr int IN_UNITS = 8 * IN_ROWS * W2, IN_IT = (IN_UNITS + NT - 1) / NT;
+    // Staging through registers, slot-major (see the weight-gradient kernel): the loads of chunk ch + 1 are issued before the
+    // MFMA loop of chunk ch and land in LDS after it; a thread owns NS (row, column pair) positions and walks the 8 planes.
+    constexpr int SLOTS = IN_ROWS * W2, NS = (SLOTS + NT - 1) / NT;
     constexpr int W_UNITS = 72 * COUT / 4, W_IT = (W_UNITS + NT - 1) / NT;
-    float2 vin[IN_IT];
+    float2 vin[NS][8];
     float4 vw[W_IT];
     const __amdgpu_buffer_rsrc_t rx = buf_of(xin, CIN * HIN * WIN * 4), rw = buf_of(wp, 9 * CIN * COUT * 4);
+    unsigned xoff[NS];
+    float* in_dst[NS];
+    bool in_act[NS], in_inside[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int sl = tid + k * NT;
+        const int row = sl / W2, j = sl - row * W2;
+        const int iy = 2 * oy0 - 1 + row;
+        in_act[k] = sl < SLOTS;
+        in_inside[k] = in_act[k] && iy >= 0 && iy < HIN;
+        xoff[k] = in_inside[k] ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob;
+        in_dst[k] = s_in + row * RS + j;
+        if (in_act[k] && j == 0) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) in_dst[k][p * PS] = 0.f;       // E[0]: the left padding column, never overwritten
+        }
+    }
+    unsigned woff[W_IT];
+    float* w_dst[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int u = tid + it * NT;
+        const int r = u / (COUT / 4), c4 = u - r * (COUT / 4);
+        woff[it] = u < W_UNITS ? (unsigned)(u * 16) : kOob;
+        w_dst[it] = s_w + r * QS + 4 * c4;
+    }
     auto fetch = [&](int ch) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
 #pragma unroll
-        for (int it = 0; it < IN_IT; ++it) {
-            const int u = t + it * NT;
-            const int p = u / (IN_ROWS * W2), rem = u - p * (IN_ROWS * W2);
-            const int row = rem / W2, j = rem - row * W2;
-            const int iy = 2 * oy0 - 1 + row;
-            const bool ok = u < IN_UNITS && iy >= 0 && iy < HIN;
-            vin[it] = buf_f2(rx, ok ? (unsigned)((((ch * 8 + p) * HIN + iy) * WIN + 2 * j) * 4) : kOob);
-        }
+        for (int k = 0; k < NS; ++k)
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int u = t + it * NT;
-            vw[it] = buf_f4(rw, u < W_UNITS ? (unsigned)((ch * 72 * COUT + 4 * u) * 4) : kOob);
-        }
+            for (int p = 0; p < 8; ++p) vin[k][p] = buf_f2(rx, xoff[k], (ch * 8 + p) * (HIN * WIN * 4));
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) vw[it] = buf_f4(rw, woff[it], ch * (72 * COUT * 4));
     };
     auto stash = [&](int ch) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
 #pragma unroll
-        for (int it = 0; it < IN_IT; ++it) {
-            const int u = t + it * NT;
-            if (u >= IN_UNITS) continue;
-            const int p = u / (IN_ROWS * W2), rem = u - p * (IN_ROWS * W2);
-            const int row = rem / W2, j = rem - row * W2;
-            float2 v = vin[it];
-            if (APPLY) {
-                const int iy = 2 * oy0 - 1 + row;
-                if (iy >= 0 && iy < HIN) {
-                    const float sc = s_ss[ch * 8 + p], sh = s_ss[CIN + ch * 8 + p];
-                    v.x = fmaxf(v.x, 0.f) * sc + sh;
-                    v.y = fmaxf(v.y, 0.f) * sc + sh;
+        for (int k = 0; k < NS; ++k) {
+            if (!in_act[k]) continue;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float2 v = vin[k][p];
+                if (APPLY) {
+                    if (in_inside[k]) {
+                        const float sc = s_ss[ch * 8 + p], sh = s_ss[CIN + ch * 8 + p];
+                        v.x = fmaxf(v.x, 0.f) * sc + sh;
+                        v.y = fmaxf(v.y, 0.f) * sc + sh;
+                    }
                 }
+                in_dst[k][p * PS + EO] = v.x;
+                in_dst[k][p * PS + 1] = v.y;
             }
-            float* rowp = s_in + p * PS + row * RS;
-            rowp[EO + j] = v.x;
-            rowp[j + 1] = v.y;
-            if (j == 0) rowp[0] = 0.f;
         }
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int u = t + it * NT;
-            if (u >= W_UNITS) continue;
-            const int r = u / (COUT / 4), c4 = u - r * (COUT / 4);
-            *reinterpret_cast<float4*>(s_w + r * QS + 4 * c4) = vw[it];
-        }
+        for (int it = 0; it < W_IT; ++it)
+            if (tid + it * NT < W_UNITS) *reinterpret_cast<float4*>(w_dst[it]) = vw[it];
     };
     if (APPLY) {
         for (int u = tid; u < CIN; u += NT) { s_ss[u] = scale[u]; s_ss[CIN + u] = shift[u]; }
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
         stash(ch);
         __syncthreads();
         if (ch + 1 < CIN / 8) fetch(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
         const float* bb = s_in + q * PS + (4 * wave) * RS + m;
         const float* ab = s_w + q * QS + m;
 #pragma unroll
@@ -274,46 +283,54 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
 #pragma unroll
                     for (int bt = 0; bt < NBT; ++bt) acc[r][py][px][rt][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int Z_UNITS = 16 * ZR * RSZ, Z_IT = (Z_UNITS + NT - 1) / NT;
+    // Staging, slot-major: a thread owns one (row, column [pair]) position of the dz band and walks the 16 planes of a chunk.
+    // Only positions inside the tensor are staged; the zero column / rows behind them are written once, here.
+    constexpr int ZV = (WO % 2 == 0) ? 2 : 1;
+    constexpr int SLOTS = ZR * (WO / ZV);
+    static_assert(SLOTS <= NT, "one dz slot per thread");
     constexpr int W_UNITS = 9 * 16 * CIN / 4, W_IT = (W_UNITS + NT - 1) / NT;
-    float vz[Z_IT];
-    float4 vw[W_IT];
+    for (int u = tid; u < 16 * PSZ + 32; u += NT) s_z[u] = 0.f;
+    const int zlr = tid / (WO / ZV), zc = (tid - zlr * (WO / ZV)) * ZV;
+    const bool z_act = tid < SLOTS;
+    const unsigned zoff = (z_act && a0 + zlr < HO) ? (unsigned)(((a0 + zlr) * WO + zc) * 4) : kOob;
+    float* const z_dst = s_z + zlr * RSZ + zc;
     const __amdgpu_buffer_rsrc_t rz = buf_of(zin, COUT * HO * WO * 4), rw = buf_of(wd, 9 * CIN * COUT * 4);
+    float vz[16][ZV];
+    float4 vw[W_IT];
+    unsigned woff[W_IT];
+    float* w_dst[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int u = tid + it * NT;
+        const int r = u / (CIN / 4), c4 = u - r * (CIN / 4);
+        woff[it] = u < W_UNITS ? (unsigned)(u * 16) : kOob;
+        w_dst[it] = s_w + r * CINP + 4 * c4;
+    }
     auto fetch = [&](int ch) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
 #pragma unroll
-        for (int it = 0; it < Z_IT; ++it) {
-            const int u = t + it * NT;
-            const int c = u / (ZR * RSZ), rem = u - c * (ZR * RSZ);
-            const int lr = rem / RSZ, col = rem - lr * RSZ;
-            const int a = a0 + lr;
-            const bool ok = u < Z_UNITS && a < HO && col < WO;
-            vz[it] = buf_f1(rz, ok ? (unsigned)((((ch * 16 + c) * HO + a) * WO + col) * 4) : kOob);
+        for (int p = 0; p < 16; ++p) {
+            if (ZV == 2) {
+                const float2 v = buf_f2(rz, zoff, (ch * 16 + p) * (HO * WO * 4));
+                vz[p][0] = v.x;
+                vz[p][ZV - 1] = v.y;
+            } else {
+                vz[p][0] = buf_f1(rz, zoff, (ch * 16 + p) * (HO * WO * 4));
+            }
         }
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int u = t + it * NT;
-            vw[it] = buf_f4(rw, u < W_UNITS ? (unsigned)((ch * 9 * 16 * CIN + 4 * u) * 4) : kOob);
-        }
+        for (int it = 0; it < W_IT; ++it) vw[it] = buf_f4(rw, woff[it], ch * (9 * 16 * CIN * 4));
     };
     auto stash = [&]() {
-        int t = tid;
-        asm volatile("" : "+v"(t));
+        if (z_act) {
 #pragma unroll
-        for (int it = 0; it < Z_IT; ++it) {
-            const int u = t + it * NT;
-            if (u >= Z_UNITS) continue;
-            const int c = u / (ZR * RSZ), rem = u - c * (ZR * RSZ);
-            s_z[c * PSZ + rem] = vz[it];
+            for (int p = 0; p < 16; ++p) {
+                z_dst[p * PSZ] = vz[p][0];
+                if (ZV == 2) z_dst[p * PSZ + 1] = vz[p][ZV - 1];
+            }
         }
 #pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int u = t + it * NT;
-            if (u >= W_UNITS) continue;
-            const int r = u / (CIN / 4), c4 = u - r * (CIN / 4);
-            *reinterpret_cast<float4*>(s_w + r * CINP + 4 * c4) = vw[it];
-        }
+        for (int it = 0; it < W_IT; ++it)
+            if (tid + it * NT < W_UNITS) *reinterpret_cast<float4*>(w_dst[it]) = vw[it];
     };
     fetch(0);
     for (int ch = 0; ch < COUT / 16; ++ch) {
@@ -321,6 +338,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
         stash();
         __syncthreads();
         if (ch + 1 < COUT / 16) fetch(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
         const float* zb = s_z + q * PSZ + (2 * wave) * RSZ + m;
         const float* ab = s_w + q * CINP + m;
 #pragma unroll
@@ -503,6 +521,7 @@ __global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __re
         if (!(kConvExp & 2) || item == (int)blockIdx.x) stash(item);
         __syncthreads();
         if (!(kConvExp & 2) && item + (int)gridDim.x < items) fetch(item + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
         if (kConvExp & 1) { acc[0][0][0][0] += s_in[tid] + s_z[tid]; continue; }      // keeps the staging alive
 #pragma unroll
         for (int rp = 0; rp < (WIDE ? 2 : 1); ++rp) {
@@ -624,44 +643,39 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     const bool t1_data = (m + 16) < 25;
     const float t1_const = (m + 16 == 25) ? 1.f : 0.f;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int Z_UNITS = 16 * ROWS * (WO / 2), Z_IT = (Z_UNITS + 255) / 256;
+    // staging: dz slot-major (a thread owns one (row, column pair) of the band and walks the 16 channel planes); the input band is
+    // one plane of 19 rows, five column pairs per thread
+    constexpr int Z_SLOTS = ROWS * (WO / 2);
+    static_assert(Z_SLOTS <= 256, "one dz slot per thread");
     constexpr int IN_UNITS = IN_ROWS * (WIN / 2), IN_IT = (IN_UNITS + 255) / 256;
-    float2 vz[Z_IT], vin[IN_IT];
+    const int zlr = tid / (WO / 2), zj = tid - zlr * (WO / 2);
+    const bool z_act = tid < Z_SLOTS;
+    float* const z_dst = s_z + zlr * WO + 2 * zj;
+    float2 vz[16], vin[IN_IT];
     auto fetch = [&](int item) {
-        int t = tid;
-        asm volatile("" : "+v"(t));
         const int n = item / bands, band = item - n * bands;
         const int oy0 = band * ROWS;
         const __amdgpu_buffer_rsrc_t rz = buf_of(dz + (size_t)n * 16 * HO * WO, 16 * HO * WO * 4);
         const __amdgpu_buffer_rsrc_t rx = buf_of(x + (size_t)n * HIN * WIN, HIN * WIN * 4);
+        const unsigned zoff = (z_act && oy0 + zlr < HO) ? (unsigned)(((oy0 + zlr) * WO + 2 * zj) * 4) : kOob;
 #pragma unroll
-        for (int it = 0; it < Z_IT; ++it) {
-            const int u = t + it * 256;
-            const int co = u / (ROWS * (WO / 2)), rem = u - co * (ROWS * (WO / 2));
-            const int lr = rem / (WO / 2), j = rem - lr * (WO / 2);
-            vz[it] = buf_f2(rz, (u < Z_UNITS && oy0 + lr < HO) ? (unsigned)(((co * HO + oy0 + lr) * WO + 2 * j) * 4) : kOob);
-        }
+        for (int co = 0; co < 16; ++co) vz[co] = buf_f2(rz, zoff, co * (HO * WO * 4));
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
-            const int u = t + it * 256;
+            const int u = tid + it * 256;
             const int row = u / (WIN / 2), j = u - row * (WIN / 2);
             const int iy = 2 * oy0 - 2 + row;
             vin[it] = buf_f2(rx, (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob);
         }
     };
     auto stash = [&]() {
-        int t = tid;
-        asm volatile("" : "+v"(t));
+        if (z_act) {
 #pragma unroll
-        for (int it = 0; it < Z_IT; ++it) {
-            const int u = t + it * 256;
-            if (u >= Z_UNITS) continue;
-            const int co = u / (ROWS * (WO / 2)), rem = u - co * (ROWS * (WO / 2));
-            *reinterpret_cast<float2*>(s_z + co * PSZ + 2 * rem) = vz[it];
+            for (int co = 0; co < 16; ++co) *reinterpret_cast<float2*>(z_dst + co * PSZ) = vz[co];
         }
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
-            const int u = t + it * 256;
+            const int u = tid + it * 256;
             if (u >= IN_UNITS) continue;
             const int row = u / (WIN / 2), j = u - row * (WIN / 2);
             s_in[row * RS + j + 1] = vin[it].x;
@@ -674,6 +688,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
         stash();
         __syncthreads();
         if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int lr = 2 * wave + rr;
