@@ -187,6 +187,8 @@ SYMBOLS = [
     ("ag_relu_bn_bwd_dx", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_stats_weighted", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_plane_sums", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_bwd_dx_plane", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_cnn_conv_workspace_floats", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     ("ag_cnn_conv1_fwd", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, _P, _P]),
     ("ag_cnn_conv1_wgrad_partials", ctypes.c_int, [ctypes.c_int]),

@@ -376,6 +376,10 @@ int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const fl
  *                          statistics of its DISTINCT images weighted by m_i; in the backward dy is the gradient summed over the
  *                          copies and the two mean terms are scaled by m_i (coef[c][3] = 1 / (sum_i m_i HW)).  Same result as
  *                          the reference's computation on the full minibatch, on 1/4 of the images. */
+/*   ag_relu_plane_sums   : out_dev [N * C, 2] = per-PLANE (sum relu(x), sum relu(x)^2).  The extractor's last BatchNorm is followed by
+ *                          AdaptiveAvgPool2d((1, 1)) (cnn.py:14): batch statistics and pooled features both follow from these sums
+ *                          (mean_hw(relu(x) scale + shift) = scale S1 / HW + shift); the normalised tensor is never formed.
+ *   ag_relu_bn_bwd_dx_plane: ag_relu_bn_bwd_dx_weighted with dy constant over each plane, dyp_dev [N * C] (the pool's backward). */
 int ag_relu_bn_planes_per_block(void);
 int ag_relu_bn_stats(const float* x_dev, float* partials_dev, int N, int C, int HW, void* stream);
 int ag_relu_bn_apply(const float* x_dev, const float* scale_dev, const float* shift_dev, float* y_dev, int N, int C, int HW,
@@ -388,6 +392,9 @@ int ag_relu_bn_stats_weighted(const float* x_dev, const float* weights_dev, floa
                               void* stream);
 int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                                const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream);
+int ag_relu_plane_sums(const float* x_dev, float* out_dev, int N, int C, int HW, void* stream);
+int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
+                            const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream);
 
 /* The three stride-2 convolutions of the same feature extractor (reference: lib/network/cnn.py:11-13 - nn.Conv2d(1, 16, 5, 2, 2),
  * nn.Conv2d(16, 32, 3, 2, 1), nn.Conv2d(32, 64, 3, 2, 1) on (1, 212, 120) images; they replace torch's conv2d / MIOpen for exactly

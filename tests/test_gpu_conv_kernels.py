@@ -132,3 +132,39 @@ def test_feature_extractor_is_the_same_function_with_and_without_the_kernels():
         assert (pa.grad - pb.grad).abs().max().item() <= 5e-4 * s + 1e-7, name
     for (name, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-4, atol=1e-6), name
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_fused_trunk_is_the_layer_sequence(weighted):
+    """lib/network/fused_cnn.py (one autograd node; the ReLU + BatchNorm outputs never written) against the same extractor layer by
+    layer on torch's conv2d: features, every parameter gradient, running statistics; with and without image multiplicities."""
+    import copy
+    from airgym_amd.lib.network.cnn import CNNFeatureExtractor
+    torch.manual_seed(2)
+    a = CNNFeatureExtractor(12).cuda().train()
+    with torch.no_grad():
+        for mod in a.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_()
+    b = copy.deepcopy(a)
+    b.fused_trunk = False
+    b.hip_convs = False
+    x = torch.rand(7, 1, 212, 120, device="cuda")
+    w = torch.tensor([1., 4., 2., 1., 3., 4., 1.], device="cuda") if weighted else None
+    g = torch.randn(7, 12, device="cuda")
+    fa, fb = a(x, w), b(x, w)
+    fa.backward(g)
+    fb.backward(g)
+    scale = fb.abs().max().item()
+    assert (fa - fb).abs().max().item() <= 2e-4 * scale
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        s = pb.grad.abs().max().item()
+        assert (pa.grad - pb.grad).abs().max().item() <= 1e-3 * s + 1e-6, (name, (pa.grad - pb.grad).abs().max().item(), s)
+    for (name, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-4, atol=1e-6), name
+    # eval mode (running statistics), no gradient: the rollout's path
+    a.eval(), b.eval()
+    with torch.no_grad():
+        ea, eb = a(x), b(x)
+    assert (ea - eb).abs().max().item() <= 2e-4 * eb.abs().max().item()
