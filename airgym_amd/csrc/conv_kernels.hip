@@ -201,10 +201,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
     fetch(0);
     for (int ch = 0; ch < CIN / 8; ++ch) {
         __syncthreads();
-        stash(ch);
+        if (!(kConvExp & 8) || ch == 0) stash(ch);
         __syncthreads();
-        if (ch + 1 < CIN / 8) fetch(ch + 1);
+        if (!(kConvExp & 8) && ch + 1 < CIN / 8) fetch(ch + 1);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
+        if (kConvExp & 4) { acc[0][0][0][0] += s_in[tid] + s_w[tid]; continue; }
         const float* bb = s_in + q * PS + (4 * wave) * RS + m;
         const float* ab = s_w + q * QS + m;
 #pragma unroll
@@ -226,6 +227,17 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
                     }
             }
         }
+    }
+    if (kConvExp & 16) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) t += acc[r][bt][rt][0] + acc[r][bt][rt][1] + acc[r][bt][rt][2] + acc[r][bt][rt][3];
+        if (t == 12345.f) y[0] = t;
+        return;
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -335,10 +347,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
     fetch(0);
     for (int ch = 0; ch < COUT / 16; ++ch) {
         __syncthreads();
-        stash();
+        if (!(kConvExp & 8) || ch == 0) stash();
         __syncthreads();
-        if (ch + 1 < COUT / 16) fetch(ch + 1);
+        if (!(kConvExp & 8) && ch + 1 < COUT / 16) fetch(ch + 1);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
+        if (kConvExp & 4) { acc[0][0][0][0][0][0] += s_z[tid] + s_w[tid]; continue; }
         const float* zb = s_z + q * PSZ + (2 * wave) * RSZ + m;
         const float* ab = s_w + q * CINP + m;
 #pragma unroll
@@ -565,7 +578,12 @@ __global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __re
 // first layer, forward: Conv2d(1, 16, 5, stride 2, pad 2) on (212, 120) -> (16, 106, 60).  One lane per output pixel of a row
 // (60 of 64 lanes), 16 accumulators per row, two rows per wave; the 400 weights are wave-uniform (scalar loads, [tap][co]).
 // Bound: the 1.93 GB of output per 4 750 images.
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+// NORM: the image normaliser of the policy (clamp((x - mean) / std, -5, 5) with per-pixel statistics, model
+// a2c_continuous_logstd_model.py:106-114 / running_mean_std.py:78-79) applied while the band is staged: the kernels take the RAW
+// image and the normalised copy is never written (mean / std are 100 KB each and stay in L2).
+template <bool NORM>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nmean,
+                                                       const float* __restrict__ nstd, const float* __restrict__ w1,
                                                        const float* __restrict__ bias, float* __restrict__ y, int bands) {
     constexpr int HIN = 212, WIN = 120, HO = 106, WO = 60, ROWS = 8, IN_ROWS = 2 * ROWS + 3, EO = 66, RS = 132;
     __shared__ __attribute__((aligned(16))) float s_in[IN_ROWS * RS + 8];
@@ -574,15 +592,18 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const int oy0 = band * ROWS;
     const float* xin = x + (size_t)n * HIN * WIN;
     constexpr int IN_UNITS = IN_ROWS * (WIN / 2), IN_IT = (IN_UNITS + 255) / 256;
-    float2 vin[IN_IT];
+    float2 vin[IN_IT], vm[NORM ? IN_IT : 1], vs[NORM ? IN_IT : 1];
     const int t = tid;
     const __amdgpu_buffer_rsrc_t rx = buf_of(xin, HIN * WIN * 4);
+    const __amdgpu_buffer_rsrc_t rm = buf_of(NORM ? nmean : x, HIN * WIN * 4), rs = buf_of(NORM ? nstd : x, HIN * WIN * 4);
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
         const int u = t + it * 256;
         const int row = u / (WIN / 2), j = u - row * (WIN / 2);
         const int iy = 2 * oy0 - 2 + row;
-        vin[it] = buf_f2(rx, (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob);
+        const unsigned off = (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob;
+        vin[it] = buf_f2(rx, off);
+        if (NORM) { vm[it] = buf_f2(rm, off); vs[it] = buf_f2(rs, off); }
     }
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
@@ -590,8 +611,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         if (u >= IN_UNITS) continue;
         const int row = u / (WIN / 2), j = u - row * (WIN / 2);
         float* rowp = s_in + row * RS;
-        rowp[j + 1] = vin[it].x;            // c = ix + 2 = 2j + 2
-        rowp[EO + j + 1] = vin[it].y;       // c = 2j + 3
+        float2 v = vin[it];
+        if (NORM) {
+            const int iy = 2 * oy0 - 2 + row;
+            if (iy >= 0 && iy < HIN) {
+                v.x = fminf(fmaxf((v.x - vm[it].x) / vs[it].x, -5.f), 5.f);
+                v.y = fminf(fmaxf((v.y - vm[it].y) / vs[it].y, -5.f), 5.f);
+            }
+        }
+        rowp[j + 1] = v.x;            // c = ix + 2 = 2j + 2
+        rowp[EO + j + 1] = v.y;       // c = 2j + 3
         if (j == 0) { rowp[0] = 0.f; rowp[EO] = 0.f; rowp[WIN / 2 + 1] = 0.f; rowp[EO + WIN / 2 + 1] = 0.f; }
     }
     __syncthreads();
@@ -625,12 +654,20 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // first layer, weight gradient: dw[co][tap] = sum_{n,oy,ox} dz[co][oy][ox] in[2oy+ky-2][2ox+kx-2]; D[co][tap] = two 16 x 16 tiles
 // (taps 0-15, 16-24; column 25 of the second tile is the constant 1 -> db[co]), K = pixels: ox = 4j + quarter.
 // Four waves split the 8 rows of a band; persistent workgroups, one partial [16][32] each.
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
-                                                         float* __restrict__ partials, int items, int bands) {
+// BNBWD: dz is not read but formed while staging from the gradient dy of the layer's ReLU + BatchNorm output and the layer's own
+// output x1 (ag_relu_bn_bwd_dx's arithmetic folded per channel: dz = [x1 > 0] (A dy + m_i (B x1 + C)), tab[c] = {A, B, C, 0},
+// m_i = image multiplicity) - the 1.9 GB gradient of the first convolution's output is never written.  NORM: see conv1_fwd_kernel.
+template <bool NORM, bool BNBWD>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x1,
+                                                         const float* __restrict__ tab, const float* __restrict__ wts,
+                                                         const float* __restrict__ x, const float* __restrict__ nmean,
+                                                         const float* __restrict__ nstd, float* __restrict__ partials, int items,
+                                                         int bands) {
     constexpr int HIN = 212, WIN = 120, HO = 106, WO = 60, ROWS = 8, IN_ROWS = 2 * ROWS + 3;
     constexpr int EO = 68, RS = 136, PSZ = 482;     // RS = 8, EO = 4, PSZ = 2 (mod 32): conflict-free operand reads
     __shared__ __attribute__((aligned(16))) float s_in[IN_ROWS * RS + 8];
     __shared__ __attribute__((aligned(16))) float s_z[16 * PSZ + 8];
+    __shared__ float s_tab[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
     for (int u = tid; u < IN_ROWS * RS + 8; u += 256) s_in[u] = 0.f;
     for (int u = tid; u < 16 * PSZ + 8; u += 256) s_z[u] = 0.f;
@@ -651,41 +688,71 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     const int zlr = tid / (WO / 2), zj = tid - zlr * (WO / 2);
     const bool z_act = tid < Z_SLOTS;
     float* const z_dst = s_z + zlr * WO + 2 * zj;
-    float2 vz[16], vin[IN_IT];
+    float2 vz[16], vx[BNBWD ? 16 : 1], vin[IN_IT], vm[NORM ? IN_IT : 1], vs[NORM ? IN_IT : 1];
+    const __amdgpu_buffer_rsrc_t rm = buf_of(NORM ? nmean : x, HIN * WIN * 4), rs = buf_of(NORM ? nstd : x, HIN * WIN * 4);
+    if (BNBWD) {
+        if (tid < 64) s_tab[tid] = tab[tid];
+    }
     auto fetch = [&](int item) {
         const int n = item / bands, band = item - n * bands;
         const int oy0 = band * ROWS;
         const __amdgpu_buffer_rsrc_t rz = buf_of(dz + (size_t)n * 16 * HO * WO, 16 * HO * WO * 4);
+        const __amdgpu_buffer_rsrc_t rz1 = buf_of((BNBWD ? x1 : dz) + (size_t)n * 16 * HO * WO, 16 * HO * WO * 4);
         const __amdgpu_buffer_rsrc_t rx = buf_of(x + (size_t)n * HIN * WIN, HIN * WIN * 4);
         const unsigned zoff = (z_act && oy0 + zlr < HO) ? (unsigned)(((oy0 + zlr) * WO + 2 * zj) * 4) : kOob;
 #pragma unroll
-        for (int co = 0; co < 16; ++co) vz[co] = buf_f2(rz, zoff, co * (HO * WO * 4));
+        for (int co = 0; co < 16; ++co) {
+            vz[co] = buf_f2(rz, zoff, co * (HO * WO * 4));
+            if (BNBWD) vx[co] = buf_f2(rz1, zoff, co * (HO * WO * 4));
+        }
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
             const int u = tid + it * 256;
             const int row = u / (WIN / 2), j = u - row * (WIN / 2);
             const int iy = 2 * oy0 - 2 + row;
-            vin[it] = buf_f2(rx, (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob);
+            const unsigned off = (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob;
+            vin[it] = buf_f2(rx, off);
+            if (NORM) { vm[it] = buf_f2(rm, off); vs[it] = buf_f2(rs, off); }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](int item) {
+        const int n = item / bands, band = item - n * bands;
+        const int oy0 = band * ROWS;
         if (z_act) {
+            const float wi = (BNBWD && wts) ? wts[n] : 1.0f;
 #pragma unroll
-            for (int co = 0; co < 16; ++co) *reinterpret_cast<float2*>(z_dst + co * PSZ) = vz[co];
+            for (int co = 0; co < 16; ++co) {
+                float2 v = vz[co];
+                if (BNBWD) {
+                    const float a = s_tab[co * 4 + 0], b = s_tab[co * 4 + 1], c = s_tab[co * 4 + 2];
+                    const float2 xv = vx[co];
+                    v.x = xv.x > 0.f ? fmaf(v.x, a, wi * fmaf(xv.x, b, c)) : 0.f;
+                    v.y = xv.y > 0.f ? fmaf(v.y, a, wi * fmaf(xv.y, b, c)) : 0.f;
+                }
+                *reinterpret_cast<float2*>(z_dst + co * PSZ) = v;
+            }
         }
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
             const int u = tid + it * 256;
             if (u >= IN_UNITS) continue;
             const int row = u / (WIN / 2), j = u - row * (WIN / 2);
-            s_in[row * RS + j + 1] = vin[it].x;
-            s_in[row * RS + EO + j + 1] = vin[it].y;
+            float2 v = vin[it];
+            if (NORM) {
+                const int iy = 2 * oy0 - 2 + row;
+                if (iy >= 0 && iy < HIN) {
+                    v.x = fminf(fmaxf((v.x - vm[it].x) / vs[it].x, -5.f), 5.f);
+                    v.y = fminf(fmaxf((v.y - vm[it].y) / vs[it].y, -5.f), 5.f);
+                }
+            }
+            s_in[row * RS + j + 1] = v.x;
+            s_in[row * RS + EO + j + 1] = v.y;
         }
     };
     fetch(blockIdx.x);
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         __syncthreads();
-        stash();
+        stash(item);
         __syncthreads();
         if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
@@ -738,14 +805,18 @@ extern "C" int ag_cnn_conv_workspace_floats(int cin, int cout) {
     return 9 * cin * cout;
 }
 
-extern "C" int ag_cnn_conv1_fwd(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int n,
-                                float* workspace_dev, void* stream) {
-    if (!x_dev || !w_dev || !b_dev || !y_dev || !workspace_dev || n <= 0) return AG_ERR_INVALID_ARG;
+extern "C" int ag_cnn_conv1_fwd(const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, const float* w_dev,
+                                const float* b_dev, float* y_dev, int n, float* workspace_dev, void* stream) {
+    if (!x_dev || !w_dev || !b_dev || !y_dev || !workspace_dev || n <= 0 || (!norm_mean_dev) != (!norm_std_dev)) return AG_ERR_INVALID_ARG;
     const int bands = (106 + 7) / 8;
     if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_conv1_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev);
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(n * bands), dim3(256), 0, (hipStream_t)stream, x_dev, workspace_dev, b_dev, y_dev,
-                       bands);
+    if (norm_mean_dev)
+        hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(n * bands), dim3(256), 0, (hipStream_t)stream, x_dev, norm_mean_dev, norm_std_dev,
+                           workspace_dev, b_dev, y_dev, bands);
+    else
+        hipLaunchKernelGGL(conv1_fwd_kernel<false>, dim3(n * bands), dim3(256), 0, (hipStream_t)stream, x_dev, norm_mean_dev,
+                           norm_std_dev, workspace_dev, b_dev, y_dev, bands);
     return AG_CONV_LAUNCH_OK();
 }
 
@@ -754,12 +825,23 @@ extern "C" int ag_cnn_conv1_wgrad_partials(int n) {
     return (int)(items < 768 ? items : 768);       // three workgroups per CU
 }
 
-extern "C" int ag_cnn_conv1_wgrad(const float* dz_dev, const float* x_dev, float* partials_dev, int n, void* stream) {
-    if (!dz_dev || !x_dev || !partials_dev || n <= 0) return AG_ERR_INVALID_ARG;
+extern "C" int ag_cnn_conv1_wgrad(const float* dz_dev, const float* bn_x_dev, const float* bn_tab_dev, const float* weights_dev,
+                                  const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, float* partials_dev, int n,
+                                  void* stream) {
+    if (!dz_dev || !x_dev || !partials_dev || n <= 0 || (!norm_mean_dev) != (!norm_std_dev) || (!bn_x_dev) != (!bn_tab_dev))
+        return AG_ERR_INVALID_ARG;
     const int bands = (106 + 7) / 8;
     if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
-    const int g = ag_cnn_conv1_wgrad_partials(n);
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, dz_dev, x_dev, partials_dev, n * bands, bands);
+    const dim3 grid(ag_cnn_conv1_wgrad_partials(n)), block(256);
+    const bool norm = norm_mean_dev != nullptr, bn = bn_x_dev != nullptr;
+#define AG_C1W(NORM_, BN_)                                                                                                        \
+    hipLaunchKernelGGL((conv1_wgrad_kernel<NORM_, BN_>), grid, block, 0, (hipStream_t)stream, dz_dev, bn_x_dev, bn_tab_dev, weights_dev, \
+                       x_dev, norm_mean_dev, norm_std_dev, partials_dev, n * bands, bands)
+    if (norm && bn) AG_C1W(true, true);
+    else if (norm) AG_C1W(true, false);
+    else if (bn) AG_C1W(false, true);
+    else AG_C1W(false, false);
+#undef AG_C1W
     return AG_CONV_LAUNCH_OK();
 }
 

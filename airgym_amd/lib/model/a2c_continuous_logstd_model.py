@@ -119,6 +119,18 @@ class ModelA2CContinuousLogStd(nn.Module):
     def norm_image(self, image, weights=None):
         return self._norm(self.running_mean_std.running_mean_std["image"], image, weights) if self.normalize_input else image
 
+    def image_norm(self, image, weights=None):
+        """The image normaliser as (mean, std) per pixel instead of a normalised copy of `image` (None when inputs are not
+        normalised): the CNN's first convolution applies clamp((x - mean) / std, -5, 5) while it reads the raw image
+        (lib/network/cnn.py forward(..., norm)).  The statistics are updated exactly where norm_image would update them."""
+        if not self.normalize_input:
+            return None
+        rms = self.running_mean_std.running_mean_std["image"]
+        with torch.no_grad():
+            if self.update_stats:
+                rms.update(image.detach(), self.stats_group, weights) if weights is not None else rms.update(image.detach(), self.stats_group)
+            return rms.running_mean.float(), torch.sqrt(rms.running_var.float() + rms.epsilon)
+
     def norm_observation(self, observation):
         return self._norm(self.running_mean_std.running_mean_std["observation"], observation) if self.normalize_input else observation
 
@@ -127,7 +139,7 @@ class ModelA2CContinuousLogStd(nn.Module):
         """Inference-time CNN features of a batch of images (BatchNorm on its running statistics, the image normaliser as it
         is now): what the rollout caches per rendered frame.  Shared-trunk models only."""
         assert self.has_cnn and not self.separate
-        return self.actor_cnn(self.norm_image(image))
+        return self.actor_cnn(image, None, self.image_norm(image))
 
     def encode_image(self, image):
         """Frozen-VAE features of a batch of depth images, normalised with the image statistics as they are NOW."""
@@ -167,9 +179,9 @@ class ModelA2CContinuousLogStd(nn.Module):
             if "cnn_features" in obs:       # rollout: features computed when the image was rendered (weights are fixed there)
                 a_feat = c_feat = obs["cnn_features"]
             else:
-                normed_image = self.norm_image(obs["image"], counts)
-                a_feat = self.actor_cnn(normed_image, counts)
-                c_feat = self.critic_cnn(normed_image, counts) if self.separate else None
+                norm = self.image_norm(obs["image"], counts)
+                a_feat = self.actor_cnn(obs["image"], counts, norm)
+                c_feat = self.critic_cnn(obs["image"], counts, norm) if self.separate else None
                 if inverse is not None:
                     a_feat = a_feat.index_select(0, inverse)
                     c_feat = c_feat.index_select(0, inverse) if c_feat is not None else None

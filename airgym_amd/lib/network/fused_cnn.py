@@ -45,12 +45,16 @@ def usable(x, features):
 
 
 # ---------------------------------------------------------------- kernel wrappers
-def _conv1_fwd(lib, img, w, b):
+def _norm_ptrs(norm):
+    return (norm[0].data_ptr(), norm[1].data_ptr()) if norm is not None else (None, None)
+
+
+def _conv1_fwd(lib, img, norm, w, b):
     n = img.shape[0]
     y = torch.empty(n, 16, 106, 60, dtype=torch.float32, device=img.device)
     ws = torch.empty(lib.ag_cnn_conv_workspace_floats(1, 16), dtype=torch.float32, device=img.device)
-    N.check(lib.ag_cnn_conv1_fwd(img.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, ws.data_ptr(), _stream(img)),
-            "ag_cnn_conv1_fwd")
+    N.check(lib.ag_cnn_conv1_fwd(img.data_ptr(), *_norm_ptrs(norm), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, ws.data_ptr(),
+                                 _stream(img)), "ag_cnn_conv1_fwd")
     return y
 
 
@@ -84,11 +88,14 @@ def _conv_wgrad(lib, dz, x, scale, shift, cout):
     return s[:cout * cin * 9].reshape(cout, cin, 3, 3), s[cout * cin * 9:]
 
 
-def _conv1_wgrad(lib, dz, img):
+def _conv1_wgrad(lib, dy, x1, tab, weights, img, norm):
+    """Weight / bias gradient of the first convolution from the gradient dy of its ReLU + BatchNorm output (the BatchNorm backward
+    is folded into the kernel's staging: tab [16, 4], see ag_cnn_conv1_wgrad)."""
     n = img.shape[0]
     g = lib.ag_cnn_conv1_wgrad_partials(n)
     partials = torch.empty(g, 16, 32, dtype=torch.float32, device=img.device)
-    N.check(lib.ag_cnn_conv1_wgrad(dz.data_ptr(), img.data_ptr(), partials.data_ptr(), n, _stream(img)), "ag_cnn_conv1_wgrad")
+    N.check(lib.ag_cnn_conv1_wgrad(dy.data_ptr(), x1.data_ptr(), tab.data_ptr(), _wptr(weights), img.data_ptr(), *_norm_ptrs(norm),
+                                   partials.data_ptr(), n, _stream(img)), "ag_cnn_conv1_wgrad")
     s = partials.sum(0)
     return s[:, :25].reshape(16, 1, 5, 5), s[:, 25]
 
@@ -131,13 +138,19 @@ def _coefficients(sums, m, bn, training):
     return mean.float(), invstd.float(), scale.float().contiguous(), shift.float().contiguous()
 
 
-def _bn_backward(lib, dy, x, mean, invstd, gamma, m, weights):
-    """ReLU + BatchNorm backward of a layer whose output gradient dy is a tensor: returns (dx written over dy, dgamma, dbeta)."""
+def _bn_reduce(lib, dy, x, mean, invstd):
+    """float32 [C, 2] = (dbeta, dgamma) of ReLU + BatchNorm from the gradient dy of its output and the layer's own output x."""
     n, c, h, w = x.shape
     partials = torch.empty(_blocks(lib, n, c), c, 2, dtype=torch.float32, device=x.device)
     N.check(lib.ag_relu_bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(), n, c,
                                       h * w, _stream(x)), "ag_relu_bn_bwd_reduce")
-    sums = partials.sum(0, dtype=torch.float64).float().contiguous()
+    return partials.sum(0, dtype=torch.float64).float().contiguous()
+
+
+def _bn_backward(lib, dy, x, mean, invstd, gamma, m, weights):
+    """ReLU + BatchNorm backward of a layer whose output gradient dy is a tensor: returns (dx written over dy, dgamma, dbeta)."""
+    n, c, h, w = x.shape
+    sums = _bn_reduce(lib, dy, x, mean, invstd)
     coef = torch.stack((mean, invstd, gamma.detach() * invstd, torch.full_like(mean, 1.0 / m)), dim=1).contiguous()
     N.check(lib.ag_relu_bn_bwd_dx_weighted(dy.data_ptr(), x.data_ptr(), coef.data_ptr(), sums.data_ptr(), _wptr(weights),
                                            dy.data_ptr(), n, c, h * w, _stream(x)), "ag_relu_bn_bwd_dx")
@@ -146,7 +159,7 @@ def _bn_backward(lib, dy, x, mean, invstd, gamma, m, weights):
 
 class _Trunk(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, weights, bns, training, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
+    def forward(ctx, img, weights, bns, training, norm, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
         lib = N.load()
         img = img.contiguous()
         n = img.shape[0]
@@ -157,7 +170,10 @@ class _Trunk(torch.autograd.Function):
         else:
             wsum = float(n)
         w1, w2, w3 = w1.contiguous(), w2.contiguous(), w3.contiguous()
-        x1 = _conv1_fwd(lib, img, w1, b1)
+        if norm is not None:
+            norm = tuple(t.to(device=img.device, dtype=torch.float32).contiguous().view(-1) for t in norm)
+            assert norm[0].numel() == 212 * 120 and norm[1].numel() == 212 * 120
+        x1 = _conv1_fwd(lib, img, norm, w1, b1)
         mean1, invstd1, sc1, sh1 = _coefficients(_channel_sums(lib, x1, weights) if training else None, wsum * _HW[0], bns[0], training)
         x2 = _conv_fwd(lib, x1, sc1, sh1, w2, b2)
         mean2, invstd2, sc2, sh2 = _coefficients(_channel_sums(lib, x2, weights) if training else None, wsum * _HW[1], bns[1], training)
@@ -171,6 +187,7 @@ class _Trunk(torch.autograd.Function):
         pooled = ps[:, :, 0] * (sc3 / _HW[2]) + sh3
         ctx.wsum = wsum
         ctx.has_weights = weights is not None
+        ctx.norm = norm
         ctx.save_for_backward(img, x1, x2, x3, ps, weights if weights is not None else img.new_empty(0), w2, w3, g1, g2, g3,
                               mean1, invstd1, sc1, sh1, mean2, invstd2, sc2, sh2, mean3, invstd3)
         return pooled
@@ -201,15 +218,20 @@ class _Trunk(torch.autograd.Function):
         dw2, db2 = _conv_wgrad(lib, dx2, x1, sc1, sh1, 32)
         dy1 = _conv_dgrad(lib, dx2, w2, x1)
         del dx2, dy2
-        dx1, dgamma1, dbeta1 = _bn_backward(lib, dy1, x1, mean1, invstd1, g1, m1, weights)
-        dw1, db1 = _conv1_wgrad(lib, dx1, img)
-        return (None, None, None, None, dw1, db1, dgamma1, dbeta1, dw2, db2, dgamma2, dbeta2, dw3, db3,
+        # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)
+        sums1 = _bn_reduce(lib, dy1, x1, mean1, invstd1)
+        a = g1.detach() * invstd1
+        tab = torch.stack((a, -a * invstd1 * sums1[:, 1] / m1, a * (invstd1 * mean1 * sums1[:, 1] - sums1[:, 0]) / m1,
+                           torch.zeros_like(a)), dim=1).contiguous()
+        dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab, weights, img, ctx.norm)
+        return (None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, dgamma2, dbeta2, dw3, db3,
                 sums3[:, 1].clone(), sums3[:, 0].clone())
 
 
-def trunk(x, features, weights=None):
+def trunk(x, features, weights=None, norm=None):
     """`features(x)` flattened to [N, 64] (the caller has checked `usable(x, features)`): batch statistics when the BatchNorm
-    layers are in training mode (all three must agree), running statistics otherwise."""
+    layers are in training mode (all three must agree), running statistics otherwise.  norm = (mean, std) (optional, per-pixel
+    [212 * 120]): x is the RAW image and the first convolution normalises it, clamp((x - mean) / std, -5, 5), while staging."""
     layers = list(features)
     convs, bns = (layers[0], layers[3], layers[6]), (layers[2], layers[5], layers[8])
     training = bns[0].training
@@ -219,4 +241,4 @@ def trunk(x, features, weights=None):
     args = []
     for conv, bn in zip(convs, bns):
         args += [conv.weight, conv.bias, bn.weight, bn.bias]
-    return _Trunk.apply(x, weights if training else None, bns, training, *args)
+    return _Trunk.apply(x, weights if training else None, bns, training, norm, *args)

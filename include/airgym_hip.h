@@ -400,9 +400,15 @@ int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const floa
  * nn.Conv2d(16, 32, 3, 2, 1), nn.Conv2d(32, 64, 3, 2, 1) on (1, 212, 120) images; they replace torch's conv2d / MIOpen for exactly
  * these shapes) - airgym_amd/csrc/conv_kernels.hip.  All tensors NCHW float32 as torch holds them, weights [COUT][CIN][k][k], exact
  * float32 arithmetic (f32-input MFMA / fmaf).  n = images.  AG_ERR_UNSUPPORTED for any other shape.
- *   ag_cnn_conv1_fwd      : y [n,16,106,60] = conv(x [n,1,212,120], w [16,1,5,5]) + b.
+ *   ag_cnn_conv1_fwd      : y [n,16,106,60] = conv(in, w [16,1,5,5]) + b with in = x [n,1,212,120], or, with norm_mean_dev /
+ *                           norm_std_dev [212*120] given, in = clamp((x - mean) / std, -5, 5): the policy's image normaliser
+ *                           (running_mean_std.py:78-79, per-pixel statistics) applied while the image is staged.
  *   ag_cnn_conv1_wgrad    : partials_dev [ag_cnn_conv1_wgrad_partials(n)][16][32]: columns 0-24 = dw[co][tap], column 25 = db[co]
- *                           (26-31 zero); the caller sums over dim 0 (fixed order -> deterministic).
+ *                           (26-31 zero); the caller sums over dim 0 (fixed order -> deterministic).  x / norm_* as in the forward.
+ *                           With bn_x_dev (the layer's own output x1 [n,16,106,60]) and bn_tab_dev [16][4] = {A, B, C, 0} per channel,
+ *                           dz_dev is the gradient of the layer's ReLU + BatchNorm OUTPUT and the ReLU + BatchNorm backward is
+ *                           folded in: dz = [x1 > 0] (A dy + m_i (B x1 + C)), m_i = weights_dev[i] (NULL = 1) - ag_relu_bn_bwd_dx's
+ *                           arithmetic with A = gamma invstd, B = -A invstd dgamma / m, C = A (invstd mean dgamma - dbeta) / m.
  *   ag_cnn_conv_supported : 1 for (cin, cout, hin, win) in {(16, 32, 106, 60), (32, 64, 53, 30)} (3x3, stride 2, pad 1).
  *   ag_cnn_conv_fwd       : y [n,cout,ho,wo] = conv(in, w) + b with in = x, or, with scale_dev / shift_dev [cin] given,
  *                           in = relu(x) * scale[c] + shift[c] - the previous layer's ReLU + BatchNorm applied while the input is
@@ -412,10 +418,12 @@ int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const floa
  *                           x / scale / shift as in ag_cnn_conv_fwd.
  * workspace_dev: ag_cnn_conv_workspace_floats(cin, cout) floats (the weights re-laid out for the kernel, rebuilt every call). */
 int ag_cnn_conv_workspace_floats(int cin, int cout);
-int ag_cnn_conv1_fwd(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int n, float* workspace_dev,
-                     void* stream);
+int ag_cnn_conv1_fwd(const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, const float* w_dev,
+                     const float* b_dev, float* y_dev, int n, float* workspace_dev, void* stream);
 int ag_cnn_conv1_wgrad_partials(int n);
-int ag_cnn_conv1_wgrad(const float* dz_dev, const float* x_dev, float* partials_dev, int n, void* stream);
+int ag_cnn_conv1_wgrad(const float* dz_dev, const float* bn_x_dev, const float* bn_tab_dev, const float* weights_dev,
+                       const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, float* partials_dev, int n,
+                       void* stream);
 int ag_cnn_conv_supported(int cin, int cout, int hin, int win);
 int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev, const float* b_dev,
                     float* y_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev, void* stream);

@@ -153,7 +153,9 @@ def test_fused_trunk_is_the_layer_sequence(weighted):
     x = torch.rand(7, 1, 212, 120, device="cuda")
     w = torch.tensor([1., 4., 2., 1., 3., 4., 1.], device="cuda") if weighted else None
     g = torch.randn(7, 12, device="cuda")
-    fa, fb = a(x, w), b(x, w)
+    # raw image + the input normaliser's per-pixel statistics (some pixels far enough out to hit the +-5 clamp)
+    norm = (torch.rand(212 * 120, device="cuda"), torch.rand(212 * 120, device="cuda") * 0.3 + 0.02) if weighted else None
+    fa, fb = a(x, w, norm), b(x, w, norm)
     fa.backward(g)
     fb.backward(g)
     scale = fb.abs().max().item()
@@ -166,5 +168,5 @@ def test_fused_trunk_is_the_layer_sequence(weighted):
     # eval mode (running statistics), no gradient: the rollout's path
     a.eval(), b.eval()
     with torch.no_grad():
-        ea, eb = a(x), b(x)
+        ea, eb = a(x, None, norm), b(x, None, norm)
     assert (ea - eb).abs().max().item() <= 2e-4 * eb.abs().max().item()
