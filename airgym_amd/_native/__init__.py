@@ -187,14 +187,14 @@ SYMBOLS = [
     ("ag_relu_bn_bwd_dx", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_stats_weighted", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    ("ag_relu_plane_sums", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_dx_plane", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_cnn_conv_workspace_floats", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
-    ("ag_cnn_conv1_fwd", ctypes.c_int, [_P] * 6 + [ctypes.c_int, _P, _P]),
+    ("ag_cnn_conv1_fwd", ctypes.c_int, [_P] * 7 + [ctypes.c_int, _P, _P]),
     ("ag_cnn_conv1_wgrad_partials", ctypes.c_int, [ctypes.c_int]),
     ("ag_cnn_conv1_wgrad", ctypes.c_int, [_P] * 8 + [ctypes.c_int, _P]),
     ("ag_cnn_conv_supported", ctypes.c_int, [ctypes.c_int] * 4),
-    ("ag_cnn_conv_fwd", ctypes.c_int, [_P] * 6 + [ctypes.c_int] * 5 + [_P, _P]),
+    ("ag_cnn_conv_fwd_bands", ctypes.c_int, [ctypes.c_int] * 4),
+    ("ag_cnn_conv_fwd", ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 5 + [_P, _P]),
     ("ag_cnn_conv_dgrad", ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
     ("ag_cnn_conv_wgrad_partials", ctypes.c_int, [ctypes.c_int] * 5),
     ("ag_cnn_conv_wgrad", ctypes.c_int, [_P] * 5 + [ctypes.c_int] * 5 + [_P]),

@@ -193,43 +193,10 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __rest
     }
 }
 
-// Last layer of the extractor: BatchNorm is followed by a global average pool (AdaptiveAvgPool2d((1, 1)), cnn.py:14), so the
-// layer's output is only ever needed as plane means.  relu_plane_sums: out[plane] = (sum relu(x), sum relu(x)^2) - from these
-// the caller forms the batch statistics (weighted sums over images) AND the pooled features
-// (mean_hw(relu(x) scale + shift) = scale S1 / HW + shift); the normalised [N, C, H, W] tensor is never formed.
-template <int VEC>
-__global__ __launch_bounds__(256) void relu_plane_sums_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                              long long planes, int HW) {
-    typedef typename VecT<VEC>::type vec_t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long p0 = (long long)blockIdx.x * kPlanesPerBlock;
-    const int nvec = HW / VEC;
-    for (int k = wave; k < kPlanesPerBlock; k += 4) {
-        const long long p = p0 + k;
-        if (p >= planes) break;
-        const vec_t* src = reinterpret_cast<const vec_t*>(x + p * HW);
-        float s = 0.0f, q = 0.0f;
-#pragma unroll 2
-        for (int i = lane; i < nvec; i += 64) {
-            const vec_t v = src[i];
-            const float* f = reinterpret_cast<const float*>(&v);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float r = fmaxf(f[e], 0.0f);
-                s += r;
-                q = fmaf(r, r, q);
-            }
-        }
-        s = wave_sum(s);
-        q = wave_sum(q);
-        if (lane == 0) {
-            out[p * 2 + 0] = s;
-            out[p * 2 + 1] = q;
-        }
-    }
-}
-
-// ... and its backward: the gradient of the pooled output reaches every pixel of a plane as the same number dyp[plane] (already
+// Last layer of the extractor: BatchNorm is followed by a global average pool (AdaptiveAvgPool2d((1, 1)), cnn.py:14), so the layer's
+// output is only needed as plane means, which follow from the per-plane sums of relu(x) that the convolution's epilogue emits
+// (conv_kernels.hip, `stats`): mean_hw(relu(x) scale + shift) = scale S1 / HW + shift.  The backward of that pool:
+// the gradient of the pooled output reaches every pixel of a plane as the same number dyp[plane] (already
 // divided by HW by the caller), so relu_bn_bwd_dx needs no dy tensor: dx = [x > 0] g (dyp - m_i db / m - m_i xhat dg / m).
 template <int VEC>
 __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* __restrict__ dyp, const float* __restrict__ x,
@@ -333,14 +300,6 @@ extern "C" int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_de
 extern "C" int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                                  float* dx_dev, int N, int C, int HW, void* stream) {
     return ag_relu_bn_bwd_dx_weighted(dy_dev, x_dev, coef_dev, sums_dev, nullptr, dx_dev, N, C, HW, stream);
-}
-
-extern "C" int ag_relu_plane_sums(const float* x_dev, float* out_dev, int N, int C, int HW, void* stream) {
-    if (!x_dev || !out_dev) return AG_ERR_INVALID_ARG;
-    AG_BN_CHECK(N, C, HW);
-    const int w = vec_width(x_dev, nullptr, nullptr, HW);
-    AG_BN_DISPATCH(relu_plane_sums_kernel, w, x_dev, out_dev, planes, HW);
-    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
 extern "C" int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,

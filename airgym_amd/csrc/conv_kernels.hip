@@ -62,6 +62,15 @@ __device__ __forceinline__ float4 buf_f4(__amdgpu_buffer_rsrc_t r, unsigned off)
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
+// sum over the 16 lanes of a DPP row (a lane quarter), result in every lane of the row; fixed order
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
 constexpr int pad16mod32(int v) { return v + ((16 - (v % 32)) + 32) % 32; }
 constexpr int make_odd(int v) { return v | 1; }
 
@@ -105,7 +114,8 @@ __global__ void pack_conv1_kernel(const float* __restrict__ w, float* __restrict
 template <int CIN, int COUT, int HIN, int WIN, int WAVES, bool APPLY>
 __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
-                                                                const float* __restrict__ shift, float* __restrict__ y, int bands) {
+                                                                const float* __restrict__ shift, float* __restrict__ y,
+                                                                float* __restrict__ stats, int bands) {
     constexpr int HO = (HIN - 1) / 2 + 1, WO = WIN / 2;
     constexpr int NT = WAVES * 64, ROWS = 2 * WAVES, IN_ROWS = 2 * ROWS + 1;
     constexpr int NBT = (WO + 15) / 16, RT = COUT / 16;
@@ -118,6 +128,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
     __shared__ __attribute__((aligned(16))) float s_in[8 * PS + 64];
     __shared__ __attribute__((aligned(16))) float s_w[72 * QS];
     __shared__ float s_ss[2 * CIN];
+    __shared__ float s_red[WAVES][COUT][2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
     const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
@@ -239,6 +250,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
         if (t == 12345.f) y[0] = t;
         return;
     }
+    // epilogue: + bias, store; with `stats`, the workgroup's sums of relu(y) and relu(y)^2 per output channel over its valid pixels
+    // (what the following ReLU + BatchNorm needs as batch statistics, and - last layer - the global average pool as plane sums)
+    float ssum[RT][4], ssq[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ssum[rt][i] = ssq[rt][i] = 0.f;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int oy = oy0 + 2 * wave + r;
@@ -252,8 +270,31 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int co = 16 * rt + 4 * q + i;
-                    y[(((size_t)n * COUT + co) * HO + oy) * WO + ox] = acc[r][bt][rt][i] + bias[co];
+                    const float v = acc[r][bt][rt][i] + bias[co];
+                    y[(((size_t)n * COUT + co) * HO + oy) * WO + ox] = v;
+                    const float rl = fmaxf(v, 0.f);
+                    ssum[rt][i] += rl;
+                    ssq[rt][i] = fmaf(rl, rl, ssq[rt][i]);
                 }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = row_sum16(ssum[rt][i]), b = row_sum16(ssq[rt][i]);
+                if (m == 0) {
+                    s_red[wave][16 * rt + 4 * q + i][0] = a;
+                    s_red[wave][16 * rt + 4 * q + i][1] = b;
+                }
+            }
+        __syncthreads();
+        for (int u = tid; u < COUT * 2; u += NT) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += (&s_red[w][0][0])[u];
+            stats[(size_t)blockIdx.x * COUT * 2 + u] = t;
         }
     }
 }
@@ -584,70 +625,111 @@ __global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __re
 template <bool NORM>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nmean,
                                                        const float* __restrict__ nstd, const float* __restrict__ w1,
-                                                       const float* __restrict__ bias, float* __restrict__ y, int bands) {
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       float* __restrict__ stats) {
+    // One workgroup per image walks its 14 bands of 8 output rows (the next band's rows are loaded while this one is convolved);
+    // with `stats`, every lane keeps running sums of relu(y), relu(y)^2 per channel and the workgroup reduces them ONCE at the end:
+    // stats[n][16][2], the batch statistics of the following ReLU + BatchNorm without another pass over the 1.9 GB output.
     constexpr int HIN = 212, WIN = 120, HO = 106, WO = 60, ROWS = 8, IN_ROWS = 2 * ROWS + 3, EO = 66, RS = 132;
+    constexpr int BANDS = (HO + ROWS - 1) / ROWS;
     __shared__ __attribute__((aligned(16))) float s_in[IN_ROWS * RS + 8];
+    __shared__ float s_red[4][4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
-    const int oy0 = band * ROWS;
+    const int n = blockIdx.x;
     const float* xin = x + (size_t)n * HIN * WIN;
     constexpr int IN_UNITS = IN_ROWS * (WIN / 2), IN_IT = (IN_UNITS + 255) / 256;
     float2 vin[IN_IT], vm[NORM ? IN_IT : 1], vs[NORM ? IN_IT : 1];
-    const int t = tid;
     const __amdgpu_buffer_rsrc_t rx = buf_of(xin, HIN * WIN * 4);
     const __amdgpu_buffer_rsrc_t rm = buf_of(NORM ? nmean : x, HIN * WIN * 4), rs = buf_of(NORM ? nstd : x, HIN * WIN * 4);
+    auto fetch = [&](int band) {
 #pragma unroll
-    for (int it = 0; it < IN_IT; ++it) {
-        const int u = t + it * 256;
-        const int row = u / (WIN / 2), j = u - row * (WIN / 2);
-        const int iy = 2 * oy0 - 2 + row;
-        const unsigned off = (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob;
-        vin[it] = buf_f2(rx, off);
-        if (NORM) { vm[it] = buf_f2(rm, off); vs[it] = buf_f2(rs, off); }
-    }
-#pragma unroll
-    for (int it = 0; it < IN_IT; ++it) {
-        const int u = t + it * 256;
-        if (u >= IN_UNITS) continue;
-        const int row = u / (WIN / 2), j = u - row * (WIN / 2);
-        float* rowp = s_in + row * RS;
-        float2 v = vin[it];
-        if (NORM) {
-            const int iy = 2 * oy0 - 2 + row;
-            if (iy >= 0 && iy < HIN) {
-                v.x = fminf(fmaxf((v.x - vm[it].x) / vs[it].x, -5.f), 5.f);
-                v.y = fminf(fmaxf((v.y - vm[it].y) / vs[it].y, -5.f), 5.f);
-            }
+        for (int it = 0; it < IN_IT; ++it) {
+            const int u = tid + it * 256;
+            const int row = u / (WIN / 2), j = u - row * (WIN / 2);
+            const int iy = 2 * band * ROWS - 2 + row;
+            const unsigned off = (u < IN_UNITS && iy >= 0 && iy < HIN) ? (unsigned)((iy * WIN + 2 * j) * 4) : kOob;
+            vin[it] = buf_f2(rx, off);
+            if (NORM) { vm[it] = buf_f2(rm, off); vs[it] = buf_f2(rs, off); }
         }
-        rowp[j + 1] = v.x;            // c = ix + 2 = 2j + 2
-        rowp[EO + j + 1] = v.y;       // c = 2j + 3
-        if (j == 0) { rowp[0] = 0.f; rowp[EO] = 0.f; rowp[WIN / 2 + 1] = 0.f; rowp[EO + WIN / 2 + 1] = 0.f; }
-    }
-    __syncthreads();
-    float acc[2][16];
+    };
+    auto stash = [&](int band) {
 #pragma unroll
-    for (int co = 0; co < 16; ++co) { acc[0][co] = bias[co]; acc[1][co] = acc[0][co]; }
+        for (int it = 0; it < IN_IT; ++it) {
+            const int u = tid + it * 256;
+            if (u >= IN_UNITS) continue;
+            const int row = u / (WIN / 2), j = u - row * (WIN / 2);
+            float* rowp = s_in + row * RS;
+            float2 v = vin[it];
+            if (NORM) {
+                const int iy = 2 * band * ROWS - 2 + row;
+                if (iy >= 0 && iy < HIN) {
+                    v.x = fminf(fmaxf((v.x - vm[it].x) / vs[it].x, -5.f), 5.f);
+                    v.y = fminf(fmaxf((v.y - vm[it].y) / vs[it].y, -5.f), 5.f);
+                }
+            }
+            rowp[j + 1] = v.x;            // c = ix + 2 = 2j + 2
+            rowp[EO + j + 1] = v.y;       // c = 2j + 3
+            if (j == 0) { rowp[0] = 0.f; rowp[EO] = 0.f; rowp[WIN / 2 + 1] = 0.f; rowp[EO + WIN / 2 + 1] = 0.f; }
+        }
+    };
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) ssum[co] = ssq[co] = 0.f;
     const float* p0 = s_in + (4 * wave) * RS + lane;
+    fetch(0);
+    for (int band = 0; band < BANDS; ++band) {
+        __syncthreads();
+        stash(band);
+        __syncthreads();
+        if (band + 1 < BANDS) fetch(band + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float acc[2][16];
+#pragma unroll
+        for (int co = 0; co < 16; ++co) { acc[0][co] = bias[co]; acc[1][co] = acc[0][co]; }
 #pragma unroll 1
-    for (int ky = 0; ky < 5; ++ky)            // not unrolled: 80 weights (scalar registers) live per kernel row, not 400
+        for (int ky = 0; ky < 5; ++ky)            // not unrolled: 80 weights (scalar registers) live per kernel row, not 400
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) {
-            const int off = (kx & 1) ? EO + (kx >> 1) : (kx >> 1);
-            const float v0 = p0[ky * RS + off], v1 = p0[(2 + ky) * RS + off];
+            for (int kx = 0; kx < 5; ++kx) {
+                const int off = (kx & 1) ? EO + (kx >> 1) : (kx >> 1);
+                const float v0 = p0[ky * RS + off], v1 = p0[(2 + ky) * RS + off];
 #pragma unroll
-            for (int co = 0; co < 16; ++co) {
-                const float wv = w1[(ky * 5 + kx) * 16 + co];
-                acc[0][co] = fmaf(wv, v0, acc[0][co]);
-                acc[1][co] = fmaf(wv, v1, acc[1][co]);
+                for (int co = 0; co < 16; ++co) {
+                    const float wv = w1[(ky * 5 + kx) * 16 + co];
+                    acc[0][co] = fmaf(wv, v0, acc[0][co]);
+                    acc[1][co] = fmaf(wv, v1, acc[1][co]);
+                }
+            }
+        if (lane < WO) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int oy = band * ROWS + 2 * wave + r;
+                if (oy >= HO) continue;
+#pragma unroll
+                for (int co = 0; co < 16; ++co) {
+                    y[(((size_t)n * 16 + co) * HO + oy) * WO + lane] = acc[r][co];
+                    const float rl = fmaxf(acc[r][co], 0.f);
+                    ssum[co] += rl;
+                    ssq[co] = fmaf(rl, rl, ssq[co]);
+                }
             }
         }
-    if (lane >= WO) return;
+    }
+    if (stats) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int oy = oy0 + 2 * wave + r;
-        if (oy >= HO) continue;
+        for (int co = 0; co < 16; ++co) {
+            const float a = row_sum16(ssum[co]), b = row_sum16(ssq[co]);
+            if ((lane & 15) == 0) {
+                s_red[wave][lane >> 4][2 * co] = a;
+                s_red[wave][lane >> 4][2 * co + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
 #pragma unroll
-        for (int co = 0; co < 16; ++co) y[(((size_t)n * 16 + co) * HO + oy) * WO + lane] = acc[r][co];
+            for (int k = 0; k < 16; ++k) t += (&s_red[0][0][0])[k * 32 + tid];
+            stats[(size_t)n * 32 + tid] = t;
+        }
     }
 }
 
@@ -806,17 +888,15 @@ extern "C" int ag_cnn_conv_workspace_floats(int cin, int cout) {
 }
 
 extern "C" int ag_cnn_conv1_fwd(const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, const float* w_dev,
-                                const float* b_dev, float* y_dev, int n, float* workspace_dev, void* stream) {
+                                const float* b_dev, float* y_dev, float* stats_dev, int n, float* workspace_dev, void* stream) {
     if (!x_dev || !w_dev || !b_dev || !y_dev || !workspace_dev || n <= 0 || (!norm_mean_dev) != (!norm_std_dev)) return AG_ERR_INVALID_ARG;
-    const int bands = (106 + 7) / 8;
-    if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_conv1_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev);
     if (norm_mean_dev)
-        hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(n * bands), dim3(256), 0, (hipStream_t)stream, x_dev, norm_mean_dev, norm_std_dev,
-                           workspace_dev, b_dev, y_dev, bands);
+        hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(n), dim3(256), 0, (hipStream_t)stream, x_dev, norm_mean_dev, norm_std_dev,
+                           workspace_dev, b_dev, y_dev, stats_dev);
     else
-        hipLaunchKernelGGL(conv1_fwd_kernel<false>, dim3(n * bands), dim3(256), 0, (hipStream_t)stream, x_dev, norm_mean_dev,
-                           norm_std_dev, workspace_dev, b_dev, y_dev, bands);
+        hipLaunchKernelGGL(conv1_fwd_kernel<false>, dim3(n), dim3(256), 0, (hipStream_t)stream, x_dev, norm_mean_dev, norm_std_dev,
+                           workspace_dev, b_dev, y_dev, stats_dev);
     return AG_CONV_LAUNCH_OK();
 }
 
@@ -847,34 +927,35 @@ extern "C" int ag_cnn_conv1_wgrad(const float* dz_dev, const float* bn_x_dev, co
 
 extern "C" int ag_cnn_conv_supported(int cin, int cout, int hin, int win) { return layer_of(cin, cout, hin, win) != 0; }
 
+extern "C" int ag_cnn_conv_fwd_bands(int cin, int cout, int hin, int win) {
+    const int layer = layer_of(cin, cout, hin, win);
+    if (layer == 2) return (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
+    if (layer == 3) return (27 + 2 * kL3Waves - 1) / (2 * kL3Waves);
+    return AG_ERR_UNSUPPORTED;
+}
+
 extern "C" int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev,
-                               const float* b_dev, float* y_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev,
-                               void* stream) {
+                               const float* b_dev, float* y_dev, float* stats_dev, int n, int cin, int cout, int hin, int win,
+                               float* workspace_dev, void* stream) {
     if (!x_dev || !w_dev || !b_dev || !y_dev || !workspace_dev || n <= 0 || (!scale_dev) != (!shift_dev)) return AG_ERR_INVALID_ARG;
     const int layer = layer_of(cin, cout, hin, win);
     if (!layer) return AG_ERR_UNSUPPORTED;
     const int tot = 9 * cin * cout;
     hipLaunchKernelGGL(pack_fwd_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, cin, cout);
     const bool apply = scale_dev != nullptr;
+    const int bands = ag_cnn_conv_fwd_bands(cin, cout, hin, win);
+    if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+#define AG_CF(CIN_, COUT_, HIN_, WIN_, WAVES_, APPLY_)                                                                           \
+    hipLaunchKernelGGL((conv_s2_fwd_kernel<CIN_, COUT_, HIN_, WIN_, WAVES_, APPLY_>), dim3(n * bands), dim3(WAVES_ * 64), 0,      \
+                       (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, stats_dev, bands)
     if (layer == 2) {
-        const int bands = (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
-        if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
-        if (apply)
-            hipLaunchKernelGGL((conv_s2_fwd_kernel<16, 32, 106, 60, kL2Waves, true>), dim3(n * bands), dim3(kL2Waves * 64), 0,
-                               (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, bands);
-        else
-            hipLaunchKernelGGL((conv_s2_fwd_kernel<16, 32, 106, 60, kL2Waves, false>), dim3(n * bands), dim3(kL2Waves * 64), 0,
-                               (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, bands);
+        if (apply) AG_CF(16, 32, 106, 60, kL2Waves, true);
+        else AG_CF(16, 32, 106, 60, kL2Waves, false);
     } else {
-        const int bands = (27 + 2 * kL3Waves - 1) / (2 * kL3Waves);
-        if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
-        if (apply)
-            hipLaunchKernelGGL((conv_s2_fwd_kernel<32, 64, 53, 30, kL3Waves, true>), dim3(n * bands), dim3(kL3Waves * 64), 0,
-                               (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, bands);
-        else
-            hipLaunchKernelGGL((conv_s2_fwd_kernel<32, 64, 53, 30, kL3Waves, false>), dim3(n * bands), dim3(kL3Waves * 64), 0,
-                               (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, bands);
+        if (apply) AG_CF(32, 64, 53, 30, kL3Waves, true);
+        else AG_CF(32, 64, 53, 30, kL3Waves, false);
     }
+#undef AG_CF
     return AG_CONV_LAUNCH_OK();
 }
 

@@ -5,9 +5,11 @@ Same function of the parameters as the module sequence (float32; summation order
 sequence writes and reads never formed:
   * the ReLU + BatchNorm outputs of layers 1 and 2 - the next convolution applies `relu(x) * scale[c] + shift[c]` while it stages its
     input (forward and weight gradient both recompute it from the convolution output x);
-  * the ReLU + BatchNorm output of layer 3 and its gradient - the global average pool only needs per-plane sums of relu(x3)
-    (`ag_relu_plane_sums`), from which the batch statistics AND the pooled features follow; in the backward every pixel of a plane
-    receives the same upstream gradient (`ag_relu_bn_bwd_dx_plane`).
+  * the ReLU + BatchNorm output of layer 3 and its gradient - the global average pool only needs per-plane sums of relu(x3), from
+    which the batch statistics AND the pooled features follow; in the backward every pixel of a plane receives the same upstream
+    gradient (`ag_relu_bn_bwd_dx_plane`);
+  * the normalised image and the gradient of the first convolution's output (both folded into the first layer's kernels).
+The batch statistics of every ReLU + BatchNorm come out of the producing convolution's epilogue (no statistics pass).
 Per-image multiplicities (`weights`, frame de-duplication) enter exactly as in fused_relu_bn.py."""
 import ctypes
 
@@ -49,23 +51,30 @@ def _norm_ptrs(norm):
     return (norm[0].data_ptr(), norm[1].data_ptr()) if norm is not None else (None, None)
 
 
-def _conv1_fwd(lib, img, norm, w, b):
+def _conv1_fwd(lib, img, norm, w, b, want_stats):
+    """(y, stats): stats [n, 16, 2] = per image (sum relu(y), sum relu(y)^2) per channel, or None."""
     n = img.shape[0]
     y = torch.empty(n, 16, 106, 60, dtype=torch.float32, device=img.device)
+    stats = torch.empty(n, 16, 2, dtype=torch.float32, device=img.device) if want_stats else None
     ws = torch.empty(lib.ag_cnn_conv_workspace_floats(1, 16), dtype=torch.float32, device=img.device)
-    N.check(lib.ag_cnn_conv1_fwd(img.data_ptr(), *_norm_ptrs(norm), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, ws.data_ptr(),
-                                 _stream(img)), "ag_cnn_conv1_fwd")
-    return y
+    N.check(lib.ag_cnn_conv1_fwd(img.data_ptr(), *_norm_ptrs(norm), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                 stats.data_ptr() if want_stats else None, n, ws.data_ptr(), _stream(img)), "ag_cnn_conv1_fwd")
+    return y, stats
 
 
-def _conv_fwd(lib, x, scale, shift, w, b):
+def _conv_fwd(lib, x, scale, shift, w, b, want_stats):
+    """(y, stats): stats [n, cout, 2] = per image (sum relu(y), sum relu(y)^2) per output channel (the kernel's per-band sums
+    added up), or None."""
     n, cin, hin, win = x.shape
     cout = w.shape[0]
     y = torch.empty(n, cout, (hin - 1) // 2 + 1, win // 2, dtype=torch.float32, device=x.device)
+    bands = lib.ag_cnn_conv_fwd_bands(cin, cout, hin, win)
+    stats = torch.empty(n, bands, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
     ws = torch.empty(lib.ag_cnn_conv_workspace_floats(cin, cout), dtype=torch.float32, device=x.device)
-    N.check(lib.ag_cnn_conv_fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, cin,
-                                cout, hin, win, ws.data_ptr(), _stream(x)), "ag_cnn_conv_fwd")
-    return y
+    N.check(lib.ag_cnn_conv_fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                stats.data_ptr() if want_stats else None, n, cin, cout, hin, win, ws.data_ptr(), _stream(x)),
+            "ag_cnn_conv_fwd")
+    return y, (stats.sum(1) if want_stats else None)
 
 
 def _conv_dgrad(lib, dz, w, like):
@@ -109,13 +118,10 @@ def _wptr(weights):
     return weights.data_ptr() if weights is not None else None
 
 
-def _channel_sums(lib, x, weights):
-    """float64 [C, 2]: weighted sum and sum of squares of relu(x) over images and pixels."""
-    n, c, h, w = x.shape
-    partials = torch.empty(_blocks(lib, n, c), c, 2, dtype=torch.float32, device=x.device)
-    N.check(lib.ag_relu_bn_stats_weighted(x.data_ptr(), _wptr(weights), partials.data_ptr(), n, c, h * w, _stream(x)),
-            "ag_relu_bn_stats")
-    return partials.sum(0, dtype=torch.float64)
+def _channel_sums(stats, weights):
+    """float64 [C, 2]: weighted sum over images of the per-image sums [n, C, 2] a forward kernel produced."""
+    d = stats.double()
+    return (d if weights is None else d * weights.double().view(-1, 1, 1)).sum(0)
 
 
 def _coefficients(sums, m, bn, training):
@@ -173,16 +179,12 @@ class _Trunk(torch.autograd.Function):
         if norm is not None:
             norm = tuple(t.to(device=img.device, dtype=torch.float32).contiguous().view(-1) for t in norm)
             assert norm[0].numel() == 212 * 120 and norm[1].numel() == 212 * 120
-        x1 = _conv1_fwd(lib, img, norm, w1, b1)
-        mean1, invstd1, sc1, sh1 = _coefficients(_channel_sums(lib, x1, weights) if training else None, wsum * _HW[0], bns[0], training)
-        x2 = _conv_fwd(lib, x1, sc1, sh1, w2, b2)
-        mean2, invstd2, sc2, sh2 = _coefficients(_channel_sums(lib, x2, weights) if training else None, wsum * _HW[1], bns[1], training)
-        x3 = _conv_fwd(lib, x2, sc2, sh2, w3, b3)
-        ps = torch.empty(n, 64, 2, dtype=torch.float32, device=img.device)
-        N.check(lib.ag_relu_plane_sums(x3.data_ptr(), ps.data_ptr(), n, 64, _HW[2], _stream(img)), "ag_relu_plane_sums")
-        sums3 = None
-        if training:
-            sums3 = (ps.double() if weights is None else ps.double() * weights.double().view(-1, 1, 1)).sum(0)
+        x1, st1 = _conv1_fwd(lib, img, norm, w1, b1, training)
+        mean1, invstd1, sc1, sh1 = _coefficients(_channel_sums(st1, weights) if training else None, wsum * _HW[0], bns[0], training)
+        x2, st2 = _conv_fwd(lib, x1, sc1, sh1, w2, b2, training)
+        mean2, invstd2, sc2, sh2 = _coefficients(_channel_sums(st2, weights) if training else None, wsum * _HW[1], bns[1], training)
+        x3, ps = _conv_fwd(lib, x2, sc2, sh2, w3, b3, True)        # ps [n, 64, 2]: plane sums of relu(x3), relu(x3)^2
+        sums3 = _channel_sums(ps, weights) if training else None
         mean3, invstd3, sc3, sh3 = _coefficients(sums3, wsum * _HW[2], bns[2], training)
         pooled = ps[:, :, 0] * (sc3 / _HW[2]) + sh3
         ctx.wsum = wsum

@@ -43,7 +43,7 @@ class _Conv1(torch.autograd.Function):
         w = w.contiguous()
         y = torch.empty(n, 16, 106, 60, dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.ag_cnn_conv_workspace_floats(1, 16), dtype=torch.float32, device=x.device)
-        N.check(lib.ag_cnn_conv1_fwd(x.data_ptr(), None, None, w.data_ptr(), b.data_ptr(), y.data_ptr(), n, ws.data_ptr(),
+        N.check(lib.ag_cnn_conv1_fwd(x.data_ptr(), None, None, w.data_ptr(), b.data_ptr(), y.data_ptr(), None, n, ws.data_ptr(),
                                      _stream(x)), "ag_cnn_conv1_fwd")
         ctx.save_for_backward(x)
         return y
@@ -74,8 +74,8 @@ class _ConvS2(torch.autograd.Function):
         w = w.contiguous()
         y = torch.empty(n, cout, (hin - 1) // 2 + 1, win // 2, dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.ag_cnn_conv_workspace_floats(cin, cout), dtype=torch.float32, device=x.device)
-        N.check(lib.ag_cnn_conv_fwd(x.data_ptr(), None, None, w.data_ptr(), b.data_ptr(), y.data_ptr(), n, cin, cout, hin, win,
-                                    ws.data_ptr(), _stream(x)), "ag_cnn_conv_fwd")
+        N.check(lib.ag_cnn_conv_fwd(x.data_ptr(), None, None, w.data_ptr(), b.data_ptr(), y.data_ptr(), None, n, cin, cout, hin,
+                                    win, ws.data_ptr(), _stream(x)), "ag_cnn_conv_fwd")
         ctx.save_for_backward(x, w)
         return y
 

@@ -376,10 +376,8 @@ int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const fl
  *                          statistics of its DISTINCT images weighted by m_i; in the backward dy is the gradient summed over the
  *                          copies and the two mean terms are scaled by m_i (coef[c][3] = 1 / (sum_i m_i HW)).  Same result as
  *                          the reference's computation on the full minibatch, on 1/4 of the images. */
-/*   ag_relu_plane_sums   : out_dev [N * C, 2] = per-PLANE (sum relu(x), sum relu(x)^2).  The extractor's last BatchNorm is followed by
- *                          AdaptiveAvgPool2d((1, 1)) (cnn.py:14): batch statistics and pooled features both follow from these sums
- *                          (mean_hw(relu(x) scale + shift) = scale S1 / HW + shift); the normalised tensor is never formed.
- *   ag_relu_bn_bwd_dx_plane: ag_relu_bn_bwd_dx_weighted with dy constant over each plane, dyp_dev [N * C] (the pool's backward). */
+/*   ag_relu_bn_bwd_dx_plane: ag_relu_bn_bwd_dx_weighted with dy constant over each plane, dyp_dev [N * C]: the backward of the global
+ *                          average pool that follows the extractor's last BatchNorm (cnn.py:14). */
 int ag_relu_bn_planes_per_block(void);
 int ag_relu_bn_stats(const float* x_dev, float* partials_dev, int N, int C, int HW, void* stream);
 int ag_relu_bn_apply(const float* x_dev, const float* scale_dev, const float* shift_dev, float* y_dev, int N, int C, int HW,
@@ -392,7 +390,6 @@ int ag_relu_bn_stats_weighted(const float* x_dev, const float* weights_dev, floa
                               void* stream);
 int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                                const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream);
-int ag_relu_plane_sums(const float* x_dev, float* out_dev, int N, int C, int HW, void* stream);
 int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                             const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream);
 
@@ -403,6 +400,7 @@ int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const floa
  *   ag_cnn_conv1_fwd      : y [n,16,106,60] = conv(in, w [16,1,5,5]) + b with in = x [n,1,212,120], or, with norm_mean_dev /
  *                           norm_std_dev [212*120] given, in = clamp((x - mean) / std, -5, 5): the policy's image normaliser
  *                           (running_mean_std.py:78-79, per-pixel statistics) applied while the image is staged.
+ *                           stats_dev (NULL = off) [n][16][2]: per image the sums of relu(y) and relu(y)^2 of every channel.
  *   ag_cnn_conv1_wgrad    : partials_dev [ag_cnn_conv1_wgrad_partials(n)][16][32]: columns 0-24 = dw[co][tap], column 25 = db[co]
  *                           (26-31 zero); the caller sums over dim 0 (fixed order -> deterministic).  x / norm_* as in the forward.
  *                           With bn_x_dev (the layer's own output x1 [n,16,106,60]) and bn_tab_dev [16][4] = {A, B, C, 0} per channel,
@@ -413,20 +411,25 @@ int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const floa
  *   ag_cnn_conv_fwd       : y [n,cout,ho,wo] = conv(in, w) + b with in = x, or, with scale_dev / shift_dev [cin] given,
  *                           in = relu(x) * scale[c] + shift[c] - the previous layer's ReLU + BatchNorm applied while the input is
  *                           staged, so that activation is never written to memory.
+ *                           stats_dev (NULL = off) [n * ag_cnn_conv_fwd_bands(...)][cout][2]: per (image, band of output rows)
+ *                           the sums of relu(y) and relu(y)^2 of every output channel - the following ReLU + BatchNorm's batch
+ *                           statistics (sum over images and bands) and, for the last layer, the plane sums the global average pool
+ *                           needs (sum over bands), with no extra pass over y.
  *   ag_cnn_conv_dgrad     : dx [n,cin,hin,win] = gradient of the layer's input (w.r.t. `in` above) from dz [n,cout,ho,wo].
  *   ag_cnn_conv_wgrad     : partials_dev [ag_cnn_conv_wgrad_partials(...)][cout*cin*9 + cout]: dw [cout][cin][3][3] then db [cout];
  *                           x / scale / shift as in ag_cnn_conv_fwd.
  * workspace_dev: ag_cnn_conv_workspace_floats(cin, cout) floats (the weights re-laid out for the kernel, rebuilt every call). */
 int ag_cnn_conv_workspace_floats(int cin, int cout);
 int ag_cnn_conv1_fwd(const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, const float* w_dev,
-                     const float* b_dev, float* y_dev, int n, float* workspace_dev, void* stream);
+                     const float* b_dev, float* y_dev, float* stats_dev, int n, float* workspace_dev, void* stream);
 int ag_cnn_conv1_wgrad_partials(int n);
 int ag_cnn_conv1_wgrad(const float* dz_dev, const float* bn_x_dev, const float* bn_tab_dev, const float* weights_dev,
                        const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, float* partials_dev, int n,
                        void* stream);
 int ag_cnn_conv_supported(int cin, int cout, int hin, int win);
+int ag_cnn_conv_fwd_bands(int cin, int cout, int hin, int win);
 int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev, const float* b_dev,
-                    float* y_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev, void* stream);
+                    float* y_dev, float* stats_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev, void* stream);
 int ag_cnn_conv_dgrad(const float* dz_dev, const float* w_dev, float* dx_dev, int n, int cin, int cout, int hin, int win,
                       float* workspace_dev, void* stream);
 int ag_cnn_conv_wgrad_partials(int n, int cin, int cout, int hin, int win);

@@ -83,8 +83,8 @@ def test_previous_relu_batchnorm_applied_while_staging(name):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     y = torch.empty(yr.shape, dtype=torch.float32, device=dev)
     ws = torch.empty(lib.ag_cnn_conv_workspace_floats(c["cin"], c["cout"]), dtype=torch.float32, device=dev)
-    N.check(lib.ag_cnn_conv_fwd(xg.data_ptr(), sc.data_ptr(), sh.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), n, c["cin"],
-                                c["cout"], c["hin"], c["win"], ws.data_ptr(), stream), "fwd")
+    N.check(lib.ag_cnn_conv_fwd(xg.data_ptr(), sc.data_ptr(), sh.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, n,
+                                c["cin"], c["cout"], c["hin"], c["win"], ws.data_ptr(), stream), "fwd")
     _close(y, yr.detach(), 2e-5, name + " forward with the previous layer's ReLU + BatchNorm")
     gparts = lib.ag_cnn_conv_wgrad_partials(n, c["cin"], c["cout"], c["hin"], c["win"])
     plen = c["cout"] * c["cin"] * 9 + c["cout"]
@@ -107,7 +107,7 @@ def test_unsupported_shapes_are_refused():
     assert hip_conv.supported(torch.zeros(2, 16, 106, 60, device="cuda"), conv)
     assert not hip_conv.supported(torch.zeros(2, 16, 106, 60), conv.cpu())
     ws = torch.zeros(16, device="cuda")
-    assert lib.ag_cnn_conv_fwd(ws.data_ptr(), None, None, ws.data_ptr(), ws.data_ptr(), ws.data_ptr(), 1, 16, 32, 100, 60,
+    assert lib.ag_cnn_conv_fwd(ws.data_ptr(), None, None, ws.data_ptr(), ws.data_ptr(), ws.data_ptr(), None, 1, 16, 32, 100, 60,
                                ws.data_ptr(), None) == N.AG_ERR_UNSUPPORTED
 
 
