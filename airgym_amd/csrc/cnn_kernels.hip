@@ -231,6 +231,164 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The per-channel arithmetic between the big passes (each entry point replaces 10 - 30 launches of [C]-sized torch operations per
+// layer and step).  Column sums run in two stages - kColBlocks workgroups over row ranges, then one workgroup over their float64
+// partials - in a fixed order: deterministic.
+constexpr int kColBlocks = 128, kSmallThreads = 1024;
+
+// stage 1: part[block][W] (double) = sums over the block's rows of rows[r][col] * wts[r / G] (wts NULL = 1).  W <= 128.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ rows, const float* __restrict__ wts, long long R, int G, int W,
+                                                     double* __restrict__ part) {
+    __shared__ double s_part[256];
+    const int t = threadIdx.x, stripes = 256 / W, col = t % W, stripe = t / W;
+    const long long per = (R + gridDim.x - 1) / gridDim.x, r0 = (long long)blockIdx.x * per, r1 = (r0 + per < R) ? r0 + per : R;
+    double acc = 0.0;
+    if (stripe < stripes) {
+        long long r = r0 + stripe;
+        for (; r + 3LL * stripes < r1; r += 4LL * stripes) {        // four independent loads in flight
+            const float v0 = rows[r * W + col], v1 = rows[(r + stripes) * W + col], v2 = rows[(r + 2 * stripes) * W + col],
+                        v3 = rows[(r + 3 * stripes) * W + col];
+            const float w0 = wts ? wts[r / G] : 1.f, w1 = wts ? wts[(r + stripes) / G] : 1.f, w2 = wts ? wts[(r + 2 * stripes) / G] : 1.f,
+                        w3 = wts ? wts[(r + 3 * stripes) / G] : 1.f;
+            acc += (double)v0 * (double)w0;
+            acc += (double)v1 * (double)w1;
+            acc += (double)v2 * (double)w2;
+            acc += (double)v3 * (double)w3;
+        }
+        for (; r < r1; r += stripes) acc += (double)rows[r * W + col] * (double)(wts ? wts[r / G] : 1.f);
+    }
+    s_part[t] = acc;
+    __syncthreads();
+    if (t < W) {
+        double tot = 0.0;
+        for (int k = 0; k < stripes; ++k) tot += s_part[k * W + t];
+        part[(size_t)blockIdx.x * W + t] = tot;
+    }
+}
+
+// stage 1 of the pooled layer's backward: part[block][2c] = sum_n a[n][c], part[block][2c + 1] = sum_n a[n][c] b[n][c]; also
+// dyp = a * inv_hw.  C <= 64.
+__global__ __launch_bounds__(256) void colsum_pair_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, int C,
+                                                          float inv_hw, double* __restrict__ part, float* __restrict__ dyp) {
+    __shared__ double s_part[2][256];
+    const int t = threadIdx.x, stripes = 256 / C, c = t % C, stripe = t / C;
+    const long long per = (n + gridDim.x - 1) / gridDim.x, r0 = (long long)blockIdx.x * per, r1 = (r0 + per < n) ? r0 + per : n;
+    double a0 = 0.0, a1 = 0.0;
+    if (stripe < stripes) {
+        for (long long r = r0 + stripe; r < r1; r += stripes) {
+            const float av = a[r * C + c], bv = b[r * C + c];
+            dyp[r * C + c] = av * inv_hw;
+            a0 += (double)av;
+            a1 += (double)av * (double)bv;
+        }
+    }
+    s_part[0][t] = a0;
+    s_part[1][t] = a1;
+    __syncthreads();
+    if (t < 2 * C) {
+        const int cc = t >> 1, j = t & 1;
+        double tot = 0.0;
+        for (int k = 0; k < stripes; ++k) tot += s_part[j][k * C + cc];
+        part[(size_t)blockIdx.x * 2 * C + t] = tot;
+    }
+}
+
+// stage 2 helper: tot[W] (LDS, double) = sum over the kColBlocks partial rows
+__device__ void sum_partials(const double* __restrict__ part, int W, double* s_part, double* s_tot) {
+    const int t = threadIdx.x, stripes = kSmallThreads / W, col = t % W, stripe = t / W;
+    double acc = 0.0;
+    for (int r = stripe; r < kColBlocks; r += stripes) acc += part[(size_t)r * W + col];
+    s_part[t] = acc;
+    __syncthreads();
+    if (t < W) {
+        double tot = 0.0;
+        for (int k = 0; k < stripes; ++k) tot += s_part[k * W + t];
+        s_tot[t] = tot;
+    }
+    __syncthreads();
+}
+
+// forward: coef [4][C] = {mean, invstd, scale = gamma invstd, shift = beta - mean scale} from the batch sums (training; running
+// statistics updated as nn.BatchNorm2d does: momentum, unbiased variance) or from the running statistics (eval)
+__global__ __launch_bounds__(kSmallThreads) void bn_finalize_kernel(const double* __restrict__ part, int C, double m,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                   long long* __restrict__ num_batches, float momentum, double eps,
+                                                                   int training, float* __restrict__ coef) {
+    __shared__ double s_part[kSmallThreads], s_tot[128];
+    const int t = threadIdx.x;
+    if (training) sum_partials(part, 2 * C, s_part, s_tot);
+    if (t < C) {
+        double mean, var;
+        if (training) {
+            mean = s_tot[2 * t] / m;
+            var = s_tot[2 * t + 1] / m - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double unbiased = var * (m / (m - 1.0 > 1.0 ? m - 1.0 : 1.0));
+            running_mean[t] = (float)((1.0 - (double)momentum) * (double)running_mean[t] + (double)momentum * mean);
+            running_var[t] = (float)((1.0 - (double)momentum) * (double)running_var[t] + (double)momentum * unbiased);
+        } else {
+            mean = (double)running_mean[t];
+            var = (double)running_var[t];
+        }
+        const double invstd = 1.0 / sqrt(var + eps);
+        const double scale = (double)gamma[t] * invstd, shift = (double)beta[t] - mean * scale;
+        coef[t] = (float)mean;
+        coef[C + t] = (float)invstd;
+        coef[2 * C + t] = (float)scale;
+        coef[3 * C + t] = (float)shift;
+    }
+    if (t == 0 && training && num_batches) *num_batches += 1;
+}
+
+// last layer: plane1 [n][C] = per-image sum of relu(y) (over the G bands), pooled = scale plane1 / HW + shift
+__global__ __launch_bounds__(256) void bn_pool_kernel(const float* __restrict__ stats, long long total, int G, int C,
+                                                      const float* __restrict__ coef, float inv_hw, float* __restrict__ plane1,
+                                                      float* __restrict__ pooled) {
+    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= total) return;
+    const long long i = u / C;
+    const int c = (int)(u - i * C);
+    float s1 = 0.f;
+    for (int g = 0; g < G; ++g) s1 += stats[((i * G + g) * C + c) * 2];
+    plane1[u] = s1;
+    pooled[u] = coef[2 * C + c] * (s1 * inv_hw) + coef[3 * C + c];
+}
+
+// backward: sums [C][2] = {dbeta, dgamma} and the table the next kernel wants.  mode 0 / 1: part = column sums of
+// ag_relu_bn_bwd_reduce's partials; mode 0: tab {mean, invstd, gamma invstd, 1 / m} (ag_relu_bn_bwd_dx), mode 1: tab {A, B, C, 0}
+// (ag_cnn_conv1_wgrad: A = gamma invstd, B = -A invstd dgamma / m, C = A (invstd mean dgamma - dbeta) / m).  mode 2 (pooled layer):
+// part = {sum_n dpool, sum_n dpool plane1}: dbeta = the first, dgamma = invstd (inv_hw the second - mean the first); tab as mode 0.
+__global__ __launch_bounds__(kSmallThreads) void bn_bwd_prep_kernel(const double* __restrict__ part, int C, const float* __restrict__ coef_fwd,
+                                                                   const float* __restrict__ gamma, double m, int mode, double inv_hw,
+                                                                   float* __restrict__ sums, float* __restrict__ tab) {
+    __shared__ double s_part[kSmallThreads], s_tot[128];
+    const int t = threadIdx.x;
+    sum_partials(part, 2 * C, s_part, s_tot);
+    if (t < C) {
+        const double mean = (double)coef_fwd[t], invstd = (double)coef_fwd[C + t];
+        double db = s_tot[2 * t], dg = s_tot[2 * t + 1];
+        if (mode == 2) dg = invstd * (inv_hw * dg - mean * db);
+        sums[2 * t] = (float)db;
+        sums[2 * t + 1] = (float)dg;
+        const double a = (double)gamma[t] * invstd;
+        if (mode != 1) {
+            tab[4 * t + 0] = (float)mean;
+            tab[4 * t + 1] = (float)invstd;
+            tab[4 * t + 2] = (float)a;
+            tab[4 * t + 3] = (float)(1.0 / m);
+        } else {
+            // the float32 sums are what ag_relu_bn_bwd_dx would read: keep the two paths on the same inputs
+            const double dbf = (double)(float)db, dgf = (double)(float)dg;
+            tab[4 * t + 0] = (float)a;
+            tab[4 * t + 1] = (float)(-a * invstd * dgf / m);
+            tab[4 * t + 2] = (float)(a * (invstd * mean * dgf - dbf) / m);
+            tab[4 * t + 3] = 0.f;
+        }
+    }
+}
+
 int vec_width(const void* a, const void* b, const void* c, int HW) {
     const uintptr_t bits = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
     if ((HW & 3) == 0 && (bits & 15) == 0) return 4;
@@ -308,5 +466,53 @@ extern "C" int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev,
     AG_BN_CHECK(N, C, HW);
     const int w = vec_width(x_dev, dx_dev, nullptr, HW);
     AG_BN_DISPATCH(relu_bn_bwd_dx_plane_kernel, w, dyp_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, planes, C, HW);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" long long ag_bn_scratch_doubles(void) { return (long long)kColBlocks * 128; }
+
+extern "C" int ag_bn_finalize(const float* stats_dev, const float* weights_dev, long long n, int G, int C, double m,
+                              const float* gamma_dev, const float* beta_dev, float* running_mean_dev, float* running_var_dev,
+                              long long* num_batches_dev, float momentum, double eps, int training, float* coef_dev,
+                              float* plane1_dev, float* pooled_dev, int HW, double* scratch_dev, void* stream) {
+    if (!gamma_dev || !beta_dev || !running_mean_dev || !running_var_dev || !coef_dev || (training && (!stats_dev || !scratch_dev)) ||
+        n <= 0 || G <= 0 || (!plane1_dev) != (!pooled_dev) || (pooled_dev && !stats_dev) || HW <= 0)
+        return AG_ERR_INVALID_ARG;
+    if (C <= 0 || C > kMaxC || (256 % (2 * C)) != 0) return AG_ERR_UNSUPPORTED;
+    if (training)
+        hipLaunchKernelGGL(colsum_kernel, dim3(kColBlocks), dim3(256), 0, (hipStream_t)stream, stats_dev, weights_dev, n * G, G, 2 * C,
+                           scratch_dev);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, scratch_dev, C, m, gamma_dev, beta_dev,
+                       running_mean_dev, running_var_dev, num_batches_dev, momentum, eps, training, coef_dev);
+    if (pooled_dev) {
+        const long long total = n * C;
+        hipLaunchKernelGGL(bn_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats_dev, total, G, C,
+                           coef_dev, 1.0f / (float)HW, plane1_dev, pooled_dev);
+    }
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_bn_bwd_prep(const float* partials_dev, long long blocks, int C, const float* coef_fwd_dev, const float* gamma_dev,
+                              double m, int mode, float* sums_dev, float* tab_dev, double* scratch_dev, void* stream) {
+    if (!partials_dev || !coef_fwd_dev || !gamma_dev || !sums_dev || !tab_dev || !scratch_dev || blocks <= 0 || (mode != 0 && mode != 1))
+        return AG_ERR_INVALID_ARG;
+    if (C <= 0 || C > kMaxC || (256 % (2 * C)) != 0) return AG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(colsum_kernel, dim3(kColBlocks), dim3(256), 0, (hipStream_t)stream, partials_dev, (const float*)nullptr, blocks, 1,
+                       2 * C, scratch_dev);
+    hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, scratch_dev, C, coef_fwd_dev, gamma_dev, m,
+                       mode, 0.0, sums_dev, tab_dev);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_bn_pool_bwd_prep(const float* dpool_dev, const float* plane1_dev, long long n, int C, const float* coef_fwd_dev,
+                                   const float* gamma_dev, double m, int HW, float* sums_dev, float* tab_dev, float* dyp_dev,
+                                   double* scratch_dev, void* stream) {
+    if (!dpool_dev || !plane1_dev || !coef_fwd_dev || !gamma_dev || !sums_dev || !tab_dev || !dyp_dev || !scratch_dev || n <= 0 || HW <= 0)
+        return AG_ERR_INVALID_ARG;
+    if (C <= 0 || C > kMaxC || (256 % C) != 0) return AG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(colsum_pair_kernel, dim3(kColBlocks), dim3(256), 0, (hipStream_t)stream, dpool_dev, plane1_dev, n, C,
+                       1.0f / (float)HW, scratch_dev, dyp_dev);
+    hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, scratch_dev, C, coef_fwd_dev, gamma_dev, m,
+                       2, 1.0 / (double)HW, sums_dev, tab_dev);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }

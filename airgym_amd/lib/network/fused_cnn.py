@@ -52,29 +52,29 @@ def _norm_ptrs(norm):
 
 
 def _conv1_fwd(lib, img, norm, w, b, want_stats):
-    """(y, stats): stats [n, 16, 2] = per image (sum relu(y), sum relu(y)^2) per channel, or None."""
+    """(y, stats): stats [n, 1, 16, 2] = per image (sum relu(y), sum relu(y)^2) per channel, or None."""
     n = img.shape[0]
     y = torch.empty(n, 16, 106, 60, dtype=torch.float32, device=img.device)
-    stats = torch.empty(n, 16, 2, dtype=torch.float32, device=img.device) if want_stats else None
+    stats = torch.empty(n, 1, 16, 2, dtype=torch.float32, device=img.device) if want_stats else None
     ws = torch.empty(lib.ag_cnn_conv_workspace_floats(1, 16), dtype=torch.float32, device=img.device)
     N.check(lib.ag_cnn_conv1_fwd(img.data_ptr(), *_norm_ptrs(norm), w.data_ptr(), b.data_ptr(), y.data_ptr(),
                                  stats.data_ptr() if want_stats else None, n, ws.data_ptr(), _stream(img)), "ag_cnn_conv1_fwd")
     return y, stats
 
 
-def _conv_fwd(lib, x, scale, shift, w, b, want_stats):
-    """(y, stats): stats [n, cout, 2] = per image (sum relu(y), sum relu(y)^2) per output channel (the kernel's per-band sums
-    added up), or None."""
+def _conv_fwd(lib, x, coef, w, b, want_stats):
+    """(y, stats): the layer applied to relu(x) * coef[2] + coef[3]; stats [n, bands, cout, 2] = per (image, band of output rows)
+    the sums (relu(y), relu(y)^2) per output channel, or None."""
     n, cin, hin, win = x.shape
     cout = w.shape[0]
     y = torch.empty(n, cout, (hin - 1) // 2 + 1, win // 2, dtype=torch.float32, device=x.device)
     bands = lib.ag_cnn_conv_fwd_bands(cin, cout, hin, win)
     stats = torch.empty(n, bands, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
     ws = torch.empty(lib.ag_cnn_conv_workspace_floats(cin, cout), dtype=torch.float32, device=x.device)
-    N.check(lib.ag_cnn_conv_fwd(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+    N.check(lib.ag_cnn_conv_fwd(x.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
                                 stats.data_ptr() if want_stats else None, n, cin, cout, hin, win, ws.data_ptr(), _stream(x)),
             "ag_cnn_conv_fwd")
-    return y, (stats.sum(1) if want_stats else None)
+    return y, stats
 
 
 def _conv_dgrad(lib, dz, w, like):
@@ -87,12 +87,12 @@ def _conv_dgrad(lib, dz, w, like):
     return dx
 
 
-def _conv_wgrad(lib, dz, x, scale, shift, cout):
+def _conv_wgrad(lib, dz, x, coef, cout):
     n, cin, hin, win = x.shape
     g = lib.ag_cnn_conv_wgrad_partials(n, cin, cout, hin, win)
     partials = torch.empty(g, cout * cin * 9 + cout, dtype=torch.float32, device=x.device)
-    N.check(lib.ag_cnn_conv_wgrad(dz.data_ptr(), x.data_ptr(), scale.data_ptr(), shift.data_ptr(), partials.data_ptr(), n, cin, cout,
-                                  hin, win, _stream(x)), "ag_cnn_conv_wgrad")
+    N.check(lib.ag_cnn_conv_wgrad(dz.data_ptr(), x.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), partials.data_ptr(), n, cin,
+                                  cout, hin, win, _stream(x)), "ag_cnn_conv_wgrad")
     s = partials.sum(0)
     return s[:cout * cin * 9].reshape(cout, cin, 3, 3), s[cout * cin * 9:]
 
@@ -118,49 +118,39 @@ def _wptr(weights):
     return weights.data_ptr() if weights is not None else None
 
 
-def _channel_sums(stats, weights):
-    """float64 [C, 2]: weighted sum over images of the per-image sums [n, C, 2] a forward kernel produced."""
-    d = stats.double()
-    return (d if weights is None else d * weights.double().view(-1, 1, 1)).sum(0)
+def _finalize(lib, stats, weights, n, m, bn, training, hw, pool=False):
+    """ag_bn_finalize: coef [4, C] = (mean, invstd, scale, shift) of the ReLU + BatchNorm that follows a convolution, from the
+    convolution's `stats`; running statistics updated in training.  pool: also (plane1, pooled) [n, C] (last layer)."""
+    c = bn.num_features
+    dev = bn.weight.device
+    coef = torch.empty(4, c, dtype=torch.float32, device=dev)
+    plane1 = torch.empty(n, c, dtype=torch.float32, device=dev) if pool else None
+    pooled = torch.empty(n, c, dtype=torch.float32, device=dev) if pool else None
+    g = stats.shape[1] if stats is not None else 1
+    nb = bn.num_batches_tracked
+    scratch = torch.empty(lib.ag_bn_scratch_doubles(), dtype=torch.float64, device=dev)
+    N.check(lib.ag_bn_finalize(stats.data_ptr() if stats is not None else None, _wptr(weights), n, g, c, float(m), bn.weight.data_ptr(),
+                               bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                               nb.data_ptr() if nb is not None else None, float(bn.momentum), float(bn.eps), int(training),
+                               coef.data_ptr(), plane1.data_ptr() if pool else None, pooled.data_ptr() if pool else None, hw,
+                               scratch.data_ptr(), _stream(coef)), "ag_bn_finalize")
+    return coef, plane1, pooled
 
 
-def _coefficients(sums, m, bn, training):
-    """(mean, invstd, scale, shift) float32 [C] of ReLU + BatchNorm: batch statistics from `sums` (training; running statistics
-    updated as nn.BatchNorm2d does) or the running statistics (eval)."""
-    if training:
-        mean = sums[:, 0] / m
-        var = torch.clamp(sums[:, 1] / m - mean * mean, min=0.0)
-        with torch.no_grad():
-            mom = float(bn.momentum)
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
-            bn.running_mean.mul_(1.0 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
-            bn.running_var.mul_(1.0 - mom).add_((var * (m / max(m - 1.0, 1.0))).to(bn.running_var.dtype), alpha=mom)
-    else:
-        mean, var = bn.running_mean.double(), bn.running_var.double()
-    invstd = torch.rsqrt(var + bn.eps)
-    scale = bn.weight.detach().double() * invstd
-    shift = bn.bias.detach().double() - mean * scale
-    return mean.float(), invstd.float(), scale.float().contiguous(), shift.float().contiguous()
-
-
-def _bn_reduce(lib, dy, x, mean, invstd):
-    """float32 [C, 2] = (dbeta, dgamma) of ReLU + BatchNorm from the gradient dy of its output and the layer's own output x."""
+def _bn_reduce(lib, dy, x, coef, gamma, m, mode):
+    """ReLU + BatchNorm backward, first half: (sums [C, 2] = (dbeta, dgamma), tab [C, 4]) from the gradient dy of the layer's output
+    and the layer's own output x (ag_relu_bn_bwd_reduce + ag_bn_bwd_prep; mode: see ag_bn_bwd_prep)."""
     n, c, h, w = x.shape
-    partials = torch.empty(_blocks(lib, n, c), c, 2, dtype=torch.float32, device=x.device)
-    N.check(lib.ag_relu_bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), partials.data_ptr(), n, c,
+    blocks = _blocks(lib, n, c)
+    partials = torch.empty(blocks, c, 2, dtype=torch.float32, device=x.device)
+    N.check(lib.ag_relu_bn_bwd_reduce(dy.data_ptr(), x.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), partials.data_ptr(), n, c,
                                       h * w, _stream(x)), "ag_relu_bn_bwd_reduce")
-    return partials.sum(0, dtype=torch.float64).float().contiguous()
-
-
-def _bn_backward(lib, dy, x, mean, invstd, gamma, m, weights):
-    """ReLU + BatchNorm backward of a layer whose output gradient dy is a tensor: returns (dx written over dy, dgamma, dbeta)."""
-    n, c, h, w = x.shape
-    sums = _bn_reduce(lib, dy, x, mean, invstd)
-    coef = torch.stack((mean, invstd, gamma.detach() * invstd, torch.full_like(mean, 1.0 / m)), dim=1).contiguous()
-    N.check(lib.ag_relu_bn_bwd_dx_weighted(dy.data_ptr(), x.data_ptr(), coef.data_ptr(), sums.data_ptr(), _wptr(weights),
-                                           dy.data_ptr(), n, c, h * w, _stream(x)), "ag_relu_bn_bwd_dx")
-    return dy, sums[:, 1], sums[:, 0]
+    sums = torch.empty(c, 2, dtype=torch.float32, device=x.device)
+    tab = torch.empty(c, 4, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(lib.ag_bn_scratch_doubles(), dtype=torch.float64, device=x.device)
+    N.check(lib.ag_bn_bwd_prep(partials.data_ptr(), blocks, c, coef.data_ptr(), gamma.data_ptr(), float(m), mode, sums.data_ptr(),
+                               tab.data_ptr(), scratch.data_ptr(), _stream(x)), "ag_bn_bwd_prep")
+    return sums, tab
 
 
 class _Trunk(torch.autograd.Function):
@@ -180,54 +170,53 @@ class _Trunk(torch.autograd.Function):
             norm = tuple(t.to(device=img.device, dtype=torch.float32).contiguous().view(-1) for t in norm)
             assert norm[0].numel() == 212 * 120 and norm[1].numel() == 212 * 120
         x1, st1 = _conv1_fwd(lib, img, norm, w1, b1, training)
-        mean1, invstd1, sc1, sh1 = _coefficients(_channel_sums(st1, weights) if training else None, wsum * _HW[0], bns[0], training)
-        x2, st2 = _conv_fwd(lib, x1, sc1, sh1, w2, b2, training)
-        mean2, invstd2, sc2, sh2 = _coefficients(_channel_sums(st2, weights) if training else None, wsum * _HW[1], bns[1], training)
-        x3, ps = _conv_fwd(lib, x2, sc2, sh2, w3, b3, True)        # ps [n, 64, 2]: plane sums of relu(x3), relu(x3)^2
-        sums3 = _channel_sums(ps, weights) if training else None
-        mean3, invstd3, sc3, sh3 = _coefficients(sums3, wsum * _HW[2], bns[2], training)
-        pooled = ps[:, :, 0] * (sc3 / _HW[2]) + sh3
+        coef1, _, _ = _finalize(lib, st1, weights, n, wsum * _HW[0], bns[0], training, _HW[0])
+        x2, st2 = _conv_fwd(lib, x1, coef1, w2, b2, training)
+        coef2, _, _ = _finalize(lib, st2, weights, n, wsum * _HW[1], bns[1], training, _HW[1])
+        x3, st3 = _conv_fwd(lib, x2, coef2, w3, b3, True)
+        coef3, plane1, pooled = _finalize(lib, st3, weights, n, wsum * _HW[2], bns[2], training, _HW[2], pool=True)
         ctx.wsum = wsum
         ctx.has_weights = weights is not None
         ctx.norm = norm
-        ctx.save_for_backward(img, x1, x2, x3, ps, weights if weights is not None else img.new_empty(0), w2, w3, g1, g2, g3,
-                              mean1, invstd1, sc1, sh1, mean2, invstd2, sc2, sh2, mean3, invstd3)
+        ctx.save_for_backward(img, x1, x2, x3, plane1, weights if weights is not None else img.new_empty(0), w2, w3, g1, g2, g3,
+                              coef1, coef2, coef3)
         return pooled
 
     @staticmethod
     def backward(ctx, dpool):
-        (img, x1, x2, x3, ps, weights, w2, w3, g1, g2, g3, mean1, invstd1, sc1, sh1, mean2, invstd2, sc2, sh2, mean3,
-         invstd3) = ctx.saved_tensors
+        img, x1, x2, x3, plane1, weights, w2, w3, g1, g2, g3, coef1, coef2, coef3 = ctx.saved_tensors
         lib = N.load()
         weights = weights if ctx.has_weights else None
         n = img.shape[0]
         m1, m2, m3 = (ctx.wsum * hw for hw in _HW)
+        dev = img.device
         dpool = dpool.contiguous()
         # layer 3: the pool spreads dpool / HW over the plane; sum dy = sum_n dpool, sum dy xhat = sum_n dpool mean_hw(xhat)
-        dbeta3 = dpool.sum(0, dtype=torch.float64)
-        xhat_mean = (ps[:, :, 0].double() / _HW[2] - mean3.double()) * invstd3.double()
-        dgamma3 = (dpool.double() * xhat_mean).sum(0)
-        sums3 = torch.stack((dbeta3, dgamma3), dim=1).float().contiguous()
-        coef3 = torch.stack((mean3, invstd3, g3.detach() * invstd3, torch.full_like(mean3, 1.0 / m3)), dim=1).contiguous()
-        dyp = (dpool / _HW[2]).contiguous()
+        sums3 = torch.empty(64, 2, dtype=torch.float32, device=dev)
+        tab3 = torch.empty(64, 4, dtype=torch.float32, device=dev)
+        dyp = torch.empty(n, 64, dtype=torch.float32, device=dev)
+        scratch = torch.empty(lib.ag_bn_scratch_doubles(), dtype=torch.float64, device=dev)
+        N.check(lib.ag_bn_pool_bwd_prep(dpool.data_ptr(), plane1.data_ptr(), n, 64, coef3.data_ptr(), g3.data_ptr(), float(m3), _HW[2],
+                                        sums3.data_ptr(), tab3.data_ptr(), dyp.data_ptr(), scratch.data_ptr(), _stream(img)),
+                "ag_bn_pool_bwd_prep")
         dx3 = torch.empty_like(x3)
-        N.check(lib.ag_relu_bn_bwd_dx_plane(dyp.data_ptr(), x3.data_ptr(), coef3.data_ptr(), sums3.data_ptr(), _wptr(weights),
+        N.check(lib.ag_relu_bn_bwd_dx_plane(dyp.data_ptr(), x3.data_ptr(), tab3.data_ptr(), sums3.data_ptr(), _wptr(weights),
                                             dx3.data_ptr(), n, 64, _HW[2], _stream(img)), "ag_relu_bn_bwd_dx_plane")
-        dw3, db3 = _conv_wgrad(lib, dx3, x2, sc2, sh2, 64)
+        dw3, db3 = _conv_wgrad(lib, dx3, x2, coef2, 64)
         dy2 = _conv_dgrad(lib, dx3, w3, x2)
         del dx3
-        dx2, dgamma2, dbeta2 = _bn_backward(lib, dy2, x2, mean2, invstd2, g2, m2, weights)
-        dw2, db2 = _conv_wgrad(lib, dx2, x1, sc1, sh1, 32)
-        dy1 = _conv_dgrad(lib, dx2, w2, x1)
-        del dx2, dy2
+        # layer 2: dx2 written over dy2
+        sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0)
+        N.check(lib.ag_relu_bn_bwd_dx_weighted(dy2.data_ptr(), x2.data_ptr(), tab2.data_ptr(), sums2.data_ptr(), _wptr(weights),
+                                               dy2.data_ptr(), n, 32, _HW[1], _stream(img)), "ag_relu_bn_bwd_dx")
+        dw2, db2 = _conv_wgrad(lib, dy2, x1, coef1, 32)
+        dy1 = _conv_dgrad(lib, dy2, w2, x1)
+        del dy2
         # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)
-        sums1 = _bn_reduce(lib, dy1, x1, mean1, invstd1)
-        a = g1.detach() * invstd1
-        tab = torch.stack((a, -a * invstd1 * sums1[:, 1] / m1, a * (invstd1 * mean1 * sums1[:, 1] - sums1[:, 0]) / m1,
-                           torch.zeros_like(a)), dim=1).contiguous()
-        dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab, weights, img, ctx.norm)
-        return (None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, dgamma2, dbeta2, dw3, db3,
-                sums3[:, 1].clone(), sums3[:, 0].clone())
+        sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1)
+        dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.norm)
+        return (None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
+                sums3[:, 1], sums3[:, 0])
 
 
 def trunk(x, features, weights=None, norm=None):

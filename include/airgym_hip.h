@@ -393,6 +393,31 @@ int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const fl
 int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                             const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream);
 
+/* The per-channel arithmetic of ReLU + BatchNorm between the big passes (two-stage float64 column sums in a fixed order, then one
+ * workgroup; each call replaces 10 - 30 launches of [C]-sized tensor operations per layer and step) - airgym_amd/csrc/cnn_kernels.hip.
+ *   ag_bn_finalize     : forward.  stats_dev [n][G][C][2] = per (image, band) sums of relu(y), relu(y)^2 (ag_cnn_conv*_fwd's stats),
+ *                        weights_dev [n] image multiplicities (NULL = 1), m = (sum of multiplicities) * HW.  training != 0: batch
+ *                        statistics, running_mean / running_var / num_batches updated as nn.BatchNorm2d does (momentum, unbiased
+ *                        variance); training == 0: the running statistics.  coef_dev [4][C] = {mean, invstd, scale = gamma invstd,
+ *                        shift = beta - mean scale}.  With pooled_dev / plane1_dev [n][C] (the extractor's last layer, followed by
+ *                        AdaptiveAvgPool2d((1, 1)), cnn.py:14): plane1 = per-image sum of relu(y), pooled = scale plane1 / HW + shift.
+ *   ag_bn_bwd_prep     : backward.  partials_dev [blocks][C][2] of ag_relu_bn_bwd_reduce -> sums_dev [C][2] = {dbeta, dgamma} and
+ *                        tab_dev [C][4]: mode 0 {mean, invstd, gamma invstd, 1 / m} (coef of ag_relu_bn_bwd_dx), mode 1 {A, B, C, 0}
+ *                        (bn_tab of ag_cnn_conv1_wgrad).  coef_fwd_dev = ag_bn_finalize's coef.
+ *   ag_bn_pool_bwd_prep: backward of the last layer from dpool_dev [n][C] (gradient of the pooled features) and plane1_dev:
+ *                        sums {sum_n dpool, sum_n dpool (plane1 / HW - mean) invstd}, tab (mode 0), dyp_dev [n][C] = dpool / HW
+ *                        (input of ag_relu_bn_bwd_dx_plane). */
+long long ag_bn_scratch_doubles(void);      /* scratch_dev: this many doubles (stage-1 partial sums), reusable between calls on a stream */
+int ag_bn_finalize(const float* stats_dev, const float* weights_dev, long long n, int G, int C, double m, const float* gamma_dev,
+                   const float* beta_dev, float* running_mean_dev, float* running_var_dev, long long* num_batches_dev,
+                   float momentum, double eps, int training, float* coef_dev, float* plane1_dev, float* pooled_dev, int HW,
+                   double* scratch_dev, void* stream);
+int ag_bn_bwd_prep(const float* partials_dev, long long blocks, int C, const float* coef_fwd_dev, const float* gamma_dev, double m,
+                   int mode, float* sums_dev, float* tab_dev, double* scratch_dev, void* stream);
+int ag_bn_pool_bwd_prep(const float* dpool_dev, const float* plane1_dev, long long n, int C, const float* coef_fwd_dev,
+                        const float* gamma_dev, double m, int HW, float* sums_dev, float* tab_dev, float* dyp_dev, double* scratch_dev,
+                        void* stream);
+
 /* The three stride-2 convolutions of the same feature extractor (reference: lib/network/cnn.py:11-13 - nn.Conv2d(1, 16, 5, 2, 2),
  * nn.Conv2d(16, 32, 3, 2, 1), nn.Conv2d(32, 64, 3, 2, 1) on (1, 212, 120) images; they replace torch's conv2d / MIOpen for exactly
  * these shapes) - airgym_amd/csrc/conv_kernels.hip.  All tensors NCHW float32 as torch holds them, weights [COUT][CIN][k][k], exact
