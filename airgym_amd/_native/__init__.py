@@ -193,9 +193,11 @@ SYMBOLS = [
     ("ag_bn_bwd_prep", ctypes.c_int, [_P, ctypes.c_longlong, ctypes.c_int, _P, _P, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P]),
     ("ag_bn_pool_bwd_prep", ctypes.c_int, [_P, _P, ctypes.c_longlong, ctypes.c_int, _P, _P, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P, _P]),
     ("ag_cnn_conv_workspace_floats", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
-    ("ag_cnn_conv1_fwd", ctypes.c_int, [_P] * 7 + [ctypes.c_int, _P, _P]),
+    ("ag_weighted_moments_chunks", ctypes.c_int, []),
+    ("ag_weighted_moments", ctypes.c_int, [_P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P]),
+    ("ag_cnn_conv1_fwd", ctypes.c_int, [_P] * 8 + [ctypes.c_int, _P, _P]),
     ("ag_cnn_conv1_wgrad_partials", ctypes.c_int, [ctypes.c_int]),
-    ("ag_cnn_conv1_wgrad", ctypes.c_int, [_P] * 8 + [ctypes.c_int, _P]),
+    ("ag_cnn_conv1_wgrad", ctypes.c_int, [_P] * 9 + [ctypes.c_int, _P]),
     ("ag_cnn_conv_supported", ctypes.c_int, [ctypes.c_int] * 4),
     ("ag_cnn_conv_fwd_bands", ctypes.c_int, [ctypes.c_int] * 4),
     ("ag_cnn_conv_fwd", ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 5 + [_P, _P]),

@@ -626,7 +626,7 @@ template <bool NORM>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ nmean,
                                                        const float* __restrict__ nstd, const float* __restrict__ w1,
                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                       float* __restrict__ stats) {
+                                                       float* __restrict__ stats, const long long* __restrict__ index) {
     // One workgroup per image walks its 14 bands of 8 output rows (the next band's rows are loaded while this one is convolved);
     // with `stats`, every lane keeps running sums of relu(y), relu(y)^2 per channel and the workgroup reduces them ONCE at the end:
     // stats[n][16][2], the batch statistics of the following ReLU + BatchNorm without another pass over the 1.9 GB output.
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     __shared__ float s_red[4][4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x;
-    const float* xin = x + (size_t)n * HIN * WIN;
+    const float* xin = x + (size_t)(index ? index[n] : (long long)n) * HIN * WIN;      // index: image n lives at row index[n] of x
     constexpr int IN_UNITS = IN_ROWS * (WIN / 2), IN_IT = (IN_UNITS + 255) / 256;
     float2 vin[IN_IT], vm[NORM ? IN_IT : 1], vs[NORM ? IN_IT : 1];
     const __amdgpu_buffer_rsrc_t rx = buf_of(xin, HIN * WIN * 4);
@@ -743,8 +743,8 @@ template <bool NORM, bool BNBWD>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x1,
                                                          const float* __restrict__ tab, const float* __restrict__ wts,
                                                          const float* __restrict__ x, const float* __restrict__ nmean,
-                                                         const float* __restrict__ nstd, float* __restrict__ partials, int items,
-                                                         int bands) {
+                                                         const float* __restrict__ nstd, float* __restrict__ partials,
+                                                         const long long* __restrict__ index, int items, int bands) {
     constexpr int HIN = 212, WIN = 120, HO = 106, WO = 60, ROWS = 8, IN_ROWS = 2 * ROWS + 3;
     constexpr int EO = 68, RS = 136, PSZ = 482;     // RS = 8, EO = 4, PSZ = 2 (mod 32): conflict-free operand reads
     __shared__ __attribute__((aligned(16))) float s_in[IN_ROWS * RS + 8];
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
         const int oy0 = band * ROWS;
         const __amdgpu_buffer_rsrc_t rz = buf_of(dz + (size_t)n * 16 * HO * WO, 16 * HO * WO * 4);
         const __amdgpu_buffer_rsrc_t rz1 = buf_of((BNBWD ? x1 : dz) + (size_t)n * 16 * HO * WO, 16 * HO * WO * 4);
-        const __amdgpu_buffer_rsrc_t rx = buf_of(x + (size_t)n * HIN * WIN, HIN * WIN * 4);
+        const __amdgpu_buffer_rsrc_t rx = buf_of(x + (size_t)(index ? index[n] : (long long)n) * HIN * WIN, HIN * WIN * 4);
         const unsigned zoff = (z_act && oy0 + zlr < HO) ? (unsigned)(((oy0 + zlr) * WO + 2 * zj) * 4) : kOob;
 #pragma unroll
         for (int co = 0; co < 16; ++co) {
@@ -875,7 +875,16 @@ inline int layer_of(int cin, int cout, int hin, int win) {
     if (cin == kL3.cin && cout == kL3.cout && hin == kL3.hin && win == kL3.win) return 3;
     return 0;
 }
-constexpr int kL2Waves = 4, kL3Waves = 7;          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1)
+#if defined(AG_EXPERIMENTS) && defined(AG_L2_WAVES)
+constexpr int kL2Waves = AG_L2_WAVES;
+#else
+constexpr int kL2Waves = 4;
+#endif
+#if defined(AG_EXPERIMENTS) && defined(AG_L3_WAVES)
+constexpr int kL3Waves = AG_L3_WAVES;
+#else
+constexpr int kL3Waves = 7;
+#endif          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1)
 constexpr int kWgradWorkgroups = 512;              // persistent: two per CU
 
 }  // namespace
@@ -887,16 +896,17 @@ extern "C" int ag_cnn_conv_workspace_floats(int cin, int cout) {
     return 9 * cin * cout;
 }
 
-extern "C" int ag_cnn_conv1_fwd(const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, const float* w_dev,
-                                const float* b_dev, float* y_dev, float* stats_dev, int n, float* workspace_dev, void* stream) {
+extern "C" int ag_cnn_conv1_fwd(const float* x_dev, const long long* index_dev, const float* norm_mean_dev, const float* norm_std_dev,
+                                const float* w_dev, const float* b_dev, float* y_dev, float* stats_dev, int n, float* workspace_dev,
+                                void* stream) {
     if (!x_dev || !w_dev || !b_dev || !y_dev || !workspace_dev || n <= 0 || (!norm_mean_dev) != (!norm_std_dev)) return AG_ERR_INVALID_ARG;
     hipLaunchKernelGGL(pack_conv1_kernel, dim3(2), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev);
     if (norm_mean_dev)
         hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(n), dim3(256), 0, (hipStream_t)stream, x_dev, norm_mean_dev, norm_std_dev,
-                           workspace_dev, b_dev, y_dev, stats_dev);
+                           workspace_dev, b_dev, y_dev, stats_dev, index_dev);
     else
         hipLaunchKernelGGL(conv1_fwd_kernel<false>, dim3(n), dim3(256), 0, (hipStream_t)stream, x_dev, norm_mean_dev, norm_std_dev,
-                           workspace_dev, b_dev, y_dev, stats_dev);
+                           workspace_dev, b_dev, y_dev, stats_dev, index_dev);
     return AG_CONV_LAUNCH_OK();
 }
 
@@ -906,8 +916,8 @@ extern "C" int ag_cnn_conv1_wgrad_partials(int n) {
 }
 
 extern "C" int ag_cnn_conv1_wgrad(const float* dz_dev, const float* bn_x_dev, const float* bn_tab_dev, const float* weights_dev,
-                                  const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, float* partials_dev, int n,
-                                  void* stream) {
+                                  const float* x_dev, const long long* index_dev, const float* norm_mean_dev, const float* norm_std_dev,
+                                  float* partials_dev, int n, void* stream) {
     if (!dz_dev || !x_dev || !partials_dev || n <= 0 || (!norm_mean_dev) != (!norm_std_dev) || (!bn_x_dev) != (!bn_tab_dev))
         return AG_ERR_INVALID_ARG;
     const int bands = (106 + 7) / 8;
@@ -916,7 +926,7 @@ extern "C" int ag_cnn_conv1_wgrad(const float* dz_dev, const float* bn_x_dev, co
     const bool norm = norm_mean_dev != nullptr, bn = bn_x_dev != nullptr;
 #define AG_C1W(NORM_, BN_)                                                                                                        \
     hipLaunchKernelGGL((conv1_wgrad_kernel<NORM_, BN_>), grid, block, 0, (hipStream_t)stream, dz_dev, bn_x_dev, bn_tab_dev, weights_dev, \
-                       x_dev, norm_mean_dev, norm_std_dev, partials_dev, n * bands, bands)
+                       x_dev, norm_mean_dev, norm_std_dev, partials_dev, index_dev, n * bands, bands)
     if (norm && bn) AG_C1W(true, true);
     else if (norm) AG_C1W(true, false);
     else if (bn) AG_C1W(false, true);

@@ -72,8 +72,9 @@ class DedupFrames:
     every env: the camera runs on a global cadence).  Slicing [b0:b1] - what PPODataset does for a minibatch - yields the
     distinct images of those samples, the sample -> image map and the multiplicities."""
 
-    def __init__(self, frames, frame_of_step, horizon):
+    def __init__(self, frames, frame_of_step, horizon, in_place=False):
         self.frames = frames
+        self.in_place = in_place
         self.S, self.N = frames.shape[0], frames.shape[1]
         self.H = horizon
         self.frame_of_step = torch.tensor(frame_of_step, dtype=torch.long, device=frames.device)
@@ -88,8 +89,10 @@ class DedupFrames:
         uniq, inverse, counts = torch.unique_consecutive(keys, return_inverse=True, return_counts=True)
         u_env = torch.div(uniq, self.S, rounding_mode="floor")
         flat = self.frames.view((self.S * self.N,) + tuple(self.frames.shape[2:]))
-        return {"image": flat.index_select(0, (uniq - u_env * self.S) * self.N + u_env), "image_inverse": inverse,
-                "image_counts": counts.to(torch.float32)}
+        rows = (uniq - u_env * self.S) * self.N + u_env
+        if self.in_place:       # the model reads flat[rows] where it lies (cnn.forward(..., index)): no [U, 1, 212, 120] copy
+            return {"image": flat, "image_index": rows, "image_inverse": inverse, "image_counts": counts.to(torch.float32)}
+        return {"image": flat.index_select(0, rows), "image_inverse": inverse, "image_counts": counts.to(torch.float32)}
 
 
 class FlatAdam:
@@ -639,7 +642,7 @@ class A2CAgent:
             mb_returns = mb_advs + self.values_buf
         if getattr(self, "_dedup", False):
             obses = {"observation": swap_and_flatten01(self.obs_buf["observation"][:H]),
-                     "frames": DedupFrames(self._frames, self._frame_of_slot[:H], H)}
+                     "frames": DedupFrames(self._frames, self._frame_of_slot[:H], H, in_place=self._frames.is_cuda)}
         elif isinstance(self.obs_buf, dict):
             obses = {k: swap_and_flatten01(v[:H]) for k, v in self.obs_buf.items()}
         else:

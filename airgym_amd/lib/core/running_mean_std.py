@@ -22,16 +22,24 @@ class RunningMeanStd(nn.Module):
         self.register_buffer("count", torch.ones((), dtype=torch.float64))
 
     @torch.no_grad()
-    def update(self, x, group=None, weights=None):
+    def update(self, x, group=None, weights=None, index=None):
         """Merge the moments of batch x ([B, ...]).  With `group` (torch.distributed) the batch moments
         are first combined across ranks so that every replica keeps identical statistics (the reference
         lets them drift).  weights [B] (optional): row i stands for weights[i] identical rows
-        (frame de-duplication of the depth images): the moments are those of the expanded batch."""
-        if weights is not None:
-            wv = weights.to(device=x.device, dtype=torch.float64).view(-1, *([1] * (x.dim() - 1)))
-            n = wv.sum()
-            mean = (wv * x).sum(0) / n
-            var = (wv * (x - mean) ** 2).sum(0) / torch.clamp(n - 1.0, min=1.0)      # unbiased, like x.var(0) of the expansion
+        (frame de-duplication of the depth images): the moments are those of the expanded batch.
+        index [B] (optional, int64): the batch is x[index] (read in place)."""
+        if weights is not None or index is not None:
+            if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous():
+                n, mean, var = self._weighted_moments_hip(x, weights, index)
+            else:
+                if index is not None:
+                    x = x.index_select(0, index)
+                if weights is None:
+                    weights = torch.ones(x.shape[0], device=x.device)
+                wv = weights.to(device=x.device, dtype=torch.float64).view(-1, *([1] * (x.dim() - 1)))
+                n = wv.sum()
+                mean = (wv * x).sum(0) / n
+                var = (wv * (x - mean) ** 2).sum(0) / torch.clamp(n - 1.0, min=1.0)      # unbiased, like x.var(0) of the expansion
             if group is not None:
                 import torch.distributed as dist
                 if dist.get_world_size(group) > 1:
@@ -78,6 +86,30 @@ class RunningMeanStd(nn.Module):
         self.running_mean.copy_(new_mean)
         self.running_var.copy_(m2 / tot_count)
         self.count.copy_(tot_count)
+
+    def _weighted_moments_hip(self, x, weights, index):
+        """(n, mean, unbiased var) of the weighted / indexed batch in ONE pass over the rows (`ag_weighted_moments`: float64 sums of
+        w x and w x^2 per element; images are 25 440 elements wide, so the torch formulation above costs two passes over float64
+        temporaries of the whole batch)."""
+        import ctypes
+
+        from airgym_amd import _native as N
+        lib = N.load()
+        rows = x.shape[0] if index is None else index.shape[0]
+        D = x[0].numel()
+        if weights is not None:
+            weights = weights.to(device=x.device, dtype=torch.float32).contiguous()
+        if index is not None:
+            index = index.to(device=x.device, dtype=torch.long).contiguous()
+        partial = torch.empty(lib.ag_weighted_moments_chunks(), 2, D, dtype=torch.float64, device=x.device)
+        N.check(lib.ag_weighted_moments(x.data_ptr(), index.data_ptr() if index is not None else None,
+                                        weights.data_ptr() if weights is not None else None, rows, D, partial.data_ptr(),
+                                        ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)), "ag_weighted_moments")
+        s = partial.sum(0)
+        n = weights.double().sum() if weights is not None else torch.tensor(float(rows), dtype=torch.float64, device=x.device)
+        mean = s[0] / n
+        var = torch.clamp(s[1] - n * mean * mean, min=0.0) / torch.clamp(n - 1.0, min=1.0)
+        return n, mean.view(x.shape[1:]), var.view(x.shape[1:])
 
     def _update_hip(self, x):
         """Same merge in two HIP launches (`ag_rms_update`): float64 column moments, then the in-place merge."""

@@ -119,7 +119,7 @@ class ModelA2CContinuousLogStd(nn.Module):
     def norm_image(self, image, weights=None):
         return self._norm(self.running_mean_std.running_mean_std["image"], image, weights) if self.normalize_input else image
 
-    def image_norm(self, image, weights=None):
+    def image_norm(self, image, weights=None, index=None):
         """The image normaliser as (mean, std) per pixel instead of a normalised copy of `image` (None when inputs are not
         normalised): the CNN's first convolution applies clamp((x - mean) / std, -5, 5) while it reads the raw image
         (lib/network/cnn.py forward(..., norm)).  The statistics are updated exactly where norm_image would update them."""
@@ -128,7 +128,10 @@ class ModelA2CContinuousLogStd(nn.Module):
         rms = self.running_mean_std.running_mean_std["image"]
         with torch.no_grad():
             if self.update_stats:
-                rms.update(image.detach(), self.stats_group, weights) if weights is not None else rms.update(image.detach(), self.stats_group)
+                if weights is not None or index is not None:
+                    rms.update(image.detach(), self.stats_group, weights, index)
+                else:
+                    rms.update(image.detach(), self.stats_group)
             return rms.running_mean.float(), torch.sqrt(rms.running_var.float() + rms.epsilon)
 
     def norm_observation(self, observation):
@@ -179,9 +182,10 @@ class ModelA2CContinuousLogStd(nn.Module):
             if "cnn_features" in obs:       # rollout: features computed when the image was rendered (weights are fixed there)
                 a_feat = c_feat = obs["cnn_features"]
             else:
-                norm = self.image_norm(obs["image"], counts)
-                a_feat = self.actor_cnn(obs["image"], counts, norm)
-                c_feat = self.critic_cnn(obs["image"], counts, norm) if self.separate else None
+                index = obs.get("image_index")      # the distinct frames are obs["image"][index] (read in place, not gathered)
+                norm = self.image_norm(obs["image"], counts, index)
+                a_feat = self.actor_cnn(obs["image"], counts, norm, index)
+                c_feat = self.critic_cnn(obs["image"], counts, norm, index) if self.separate else None
                 if inverse is not None:
                     a_feat = a_feat.index_select(0, inverse)
                     c_feat = c_feat.index_select(0, inverse) if c_feat is not None else None

@@ -18,16 +18,20 @@ class CNNFeatureExtractor(nn.Module):
         self.hip_convs = True           # False: torch's conv2d (MIOpen: NHWC kernels between NCHW<->NHWC transposes)
         self.fused_trunk = True         # False: layer by layer (every ReLU + BatchNorm output written and read)
 
-    def forward(self, x, weights=None, norm=None):
+    def forward(self, x, weights=None, norm=None, index=None):
         """weights [N] (optional, training): image i stands for weights[i] identical images of the minibatch (frame
         de-duplication, see fused_relu_bn.relu_batchnorm): BatchNorm statistics are those of the full minibatch.
         norm = (mean, std) (optional, broadcastable to an image): x is the RAW image, normalised here as the policy's input
-        normaliser does (clamp((x - mean) / std, -5, 5), running_mean_std.py:78-79) - inside the first convolution on the GPU."""
+        normaliser does (clamp((x - mean) / std, -5, 5), running_mean_std.py:78-79) - inside the first convolution on the GPU.
+        index (optional, int64 [N]): the batch is x[index] (the distinct frames of a minibatch inside the rollout's frame store);
+        the GPU trunk reads them in place."""
         if x.is_cuda and self.fused_trunk and self.hip_convs and self.fused_relu_bn and not x.requires_grad:
             # the whole trunk as one autograd node (lib/network/fused_cnn.py): the ReLU + BatchNorm outputs are never written
             from airgym_amd.lib.network import fused_cnn
             if fused_cnn.usable(x, self.features) and (self.features[2].training or not torch.is_grad_enabled()):
-                return self.fc(fused_cnn.trunk(x, self.features, weights, norm))
+                return self.fc(fused_cnn.trunk(x, self.features, weights, norm, index))
+        if index is not None:
+            x = x.index_select(0, index)
         if norm is not None:
             x = torch.clamp((x - norm[0].view(1, *x.shape[1:])) / norm[1].view(1, *x.shape[1:]), min=-5.0, max=5.0)
         if (x.is_cuda and (self.fused_relu_bn or self.hip_convs)) or weights is not None:

@@ -51,13 +51,14 @@ def _norm_ptrs(norm):
     return (norm[0].data_ptr(), norm[1].data_ptr()) if norm is not None else (None, None)
 
 
-def _conv1_fwd(lib, img, norm, w, b, want_stats):
-    """(y, stats): stats [n, 1, 16, 2] = per image (sum relu(y), sum relu(y)^2) per channel, or None."""
-    n = img.shape[0]
+def _conv1_fwd(lib, img, index, norm, w, b, want_stats):
+    """(y, stats): stats [n, 1, 16, 2] = per image (sum relu(y), sum relu(y)^2) per channel, or None.  index (optional, int64
+    [n]): image i is img[index[i]]."""
+    n = img.shape[0] if index is None else index.shape[0]
     y = torch.empty(n, 16, 106, 60, dtype=torch.float32, device=img.device)
     stats = torch.empty(n, 1, 16, 2, dtype=torch.float32, device=img.device) if want_stats else None
     ws = torch.empty(lib.ag_cnn_conv_workspace_floats(1, 16), dtype=torch.float32, device=img.device)
-    N.check(lib.ag_cnn_conv1_fwd(img.data_ptr(), *_norm_ptrs(norm), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+    N.check(lib.ag_cnn_conv1_fwd(img.data_ptr(), _wptr(index), *_norm_ptrs(norm), w.data_ptr(), b.data_ptr(), y.data_ptr(),
                                  stats.data_ptr() if want_stats else None, n, ws.data_ptr(), _stream(img)), "ag_cnn_conv1_fwd")
     return y, stats
 
@@ -97,14 +98,14 @@ def _conv_wgrad(lib, dz, x, coef, cout):
     return s[:cout * cin * 9].reshape(cout, cin, 3, 3), s[cout * cin * 9:]
 
 
-def _conv1_wgrad(lib, dy, x1, tab, weights, img, norm):
+def _conv1_wgrad(lib, dy, x1, tab, weights, img, index, norm):
     """Weight / bias gradient of the first convolution from the gradient dy of its ReLU + BatchNorm output (the BatchNorm backward
     is folded into the kernel's staging: tab [16, 4], see ag_cnn_conv1_wgrad)."""
-    n = img.shape[0]
+    n = x1.shape[0]
     g = lib.ag_cnn_conv1_wgrad_partials(n)
     partials = torch.empty(g, 16, 32, dtype=torch.float32, device=img.device)
-    N.check(lib.ag_cnn_conv1_wgrad(dy.data_ptr(), x1.data_ptr(), tab.data_ptr(), _wptr(weights), img.data_ptr(), *_norm_ptrs(norm),
-                                   partials.data_ptr(), n, _stream(img)), "ag_cnn_conv1_wgrad")
+    N.check(lib.ag_cnn_conv1_wgrad(dy.data_ptr(), x1.data_ptr(), tab.data_ptr(), _wptr(weights), img.data_ptr(), _wptr(index),
+                                   *_norm_ptrs(norm), partials.data_ptr(), n, _stream(img)), "ag_cnn_conv1_wgrad")
     s = partials.sum(0)
     return s[:, :25].reshape(16, 1, 5, 5), s[:, 25]
 
@@ -155,10 +156,12 @@ def _bn_reduce(lib, dy, x, coef, gamma, m, mode):
 
 class _Trunk(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, weights, bns, training, norm, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
+    def forward(ctx, img, weights, bns, training, norm, index, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
         lib = N.load()
         img = img.contiguous()
-        n = img.shape[0]
+        if index is not None:
+            index = index.to(device=img.device, dtype=torch.long).contiguous()
+        n = img.shape[0] if index is None else index.shape[0]
         if weights is not None:
             weights = weights.to(device=img.device, dtype=torch.float32).contiguous()
             assert weights.shape == (n,)
@@ -169,7 +172,7 @@ class _Trunk(torch.autograd.Function):
         if norm is not None:
             norm = tuple(t.to(device=img.device, dtype=torch.float32).contiguous().view(-1) for t in norm)
             assert norm[0].numel() == 212 * 120 and norm[1].numel() == 212 * 120
-        x1, st1 = _conv1_fwd(lib, img, norm, w1, b1, training)
+        x1, st1 = _conv1_fwd(lib, img, index, norm, w1, b1, training)
         coef1, _, _ = _finalize(lib, st1, weights, n, wsum * _HW[0], bns[0], training, _HW[0])
         x2, st2 = _conv_fwd(lib, x1, coef1, w2, b2, training)
         coef2, _, _ = _finalize(lib, st2, weights, n, wsum * _HW[1], bns[1], training, _HW[1])
@@ -178,6 +181,7 @@ class _Trunk(torch.autograd.Function):
         ctx.wsum = wsum
         ctx.has_weights = weights is not None
         ctx.norm = norm
+        ctx.index = index
         ctx.save_for_backward(img, x1, x2, x3, plane1, weights if weights is not None else img.new_empty(0), w2, w3, g1, g2, g3,
                               coef1, coef2, coef3)
         return pooled
@@ -187,7 +191,7 @@ class _Trunk(torch.autograd.Function):
         img, x1, x2, x3, plane1, weights, w2, w3, g1, g2, g3, coef1, coef2, coef3 = ctx.saved_tensors
         lib = N.load()
         weights = weights if ctx.has_weights else None
-        n = img.shape[0]
+        n = x1.shape[0]
         m1, m2, m3 = (ctx.wsum * hw for hw in _HW)
         dev = img.device
         dpool = dpool.contiguous()
@@ -214,15 +218,16 @@ class _Trunk(torch.autograd.Function):
         del dy2
         # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)
         sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1)
-        dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.norm)
-        return (None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
+        dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.index, ctx.norm)
+        return (None, None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
                 sums3[:, 1], sums3[:, 0])
 
 
-def trunk(x, features, weights=None, norm=None):
+def trunk(x, features, weights=None, norm=None, index=None):
     """`features(x)` flattened to [N, 64] (the caller has checked `usable(x, features)`): batch statistics when the BatchNorm
     layers are in training mode (all three must agree), running statistics otherwise.  norm = (mean, std) (optional, per-pixel
-    [212 * 120]): x is the RAW image and the first convolution normalises it, clamp((x - mean) / std, -5, 5), while staging."""
+    [212 * 120]): x is the RAW image and the first convolution normalises it, clamp((x - mean) / std, -5, 5), while staging.
+    index (optional, int64 [N]): the batch is x[index] - read in place, e.g. out of the rollout's frame store."""
     layers = list(features)
     convs, bns = (layers[0], layers[3], layers[6]), (layers[2], layers[5], layers[8])
     training = bns[0].training
@@ -232,4 +237,4 @@ def trunk(x, features, weights=None, norm=None):
     args = []
     for conv, bn in zip(convs, bns):
         args += [conv.weight, conv.bias, bn.weight, bn.bias]
-    return _Trunk.apply(x, weights if training else None, bns, training, norm, *args)
+    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, *args)

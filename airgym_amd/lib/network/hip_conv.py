@@ -43,7 +43,7 @@ class _Conv1(torch.autograd.Function):
         w = w.contiguous()
         y = torch.empty(n, 16, 106, 60, dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.ag_cnn_conv_workspace_floats(1, 16), dtype=torch.float32, device=x.device)
-        N.check(lib.ag_cnn_conv1_fwd(x.data_ptr(), None, None, w.data_ptr(), b.data_ptr(), y.data_ptr(), None, n, ws.data_ptr(),
+        N.check(lib.ag_cnn_conv1_fwd(x.data_ptr(), None, None, None, w.data_ptr(), b.data_ptr(), y.data_ptr(), None, n, ws.data_ptr(),
                                      _stream(x)), "ag_cnn_conv1_fwd")
         ctx.save_for_backward(x)
         return y
@@ -58,7 +58,8 @@ class _Conv1(torch.autograd.Function):
         dy = dy.contiguous()
         g = lib.ag_cnn_conv1_wgrad_partials(n)
         partials = torch.empty(g, 16, 32, dtype=torch.float32, device=x.device)
-        N.check(lib.ag_cnn_conv1_wgrad(dy.data_ptr(), None, None, None, x.data_ptr(), None, None, partials.data_ptr(), n, _stream(x)),
+        N.check(lib.ag_cnn_conv1_wgrad(dy.data_ptr(), None, None, None, x.data_ptr(), None, None, None, partials.data_ptr(), n,
+                                       _stream(x)),
                 "ag_cnn_conv1_wgrad")
         s = partials.sum(0)
         return None, s[:, :25].reshape(16, 1, 5, 5), s[:, 25].clone()

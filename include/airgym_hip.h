@@ -418,6 +418,14 @@ int ag_bn_pool_bwd_prep(const float* dpool_dev, const float* plane1_dev, long lo
                         const float* gamma_dev, double m, int HW, float* sums_dev, float* tab_dev, float* dyp_dev, double* scratch_dev,
                         void* stream);
 
+/* Weighted per-element moments of a batch of wide rows (depth images) for the input normaliser (reference: RunningMeanStd.update,
+ * running_mean_std.py:34-60, on the 'image' observation) - airgym_amd/csrc/cnn_kernels.hip.  partial_dev
+ * [ag_weighted_moments_chunks()][2][D] (double) = (sum w x, sum w x^2) over each chunk's rows; the caller adds the chunks.  Row r is
+ * x_dev[index_dev[r]] (NULL = r), w = weights_dev[r] (NULL = 1).  One pass over the rows. */
+int ag_weighted_moments_chunks(void);
+int ag_weighted_moments(const float* x_dev, const long long* index_dev, const float* weights_dev, long long rows, long long D,
+                        double* partial_dev, void* stream);
+
 /* The three stride-2 convolutions of the same feature extractor (reference: lib/network/cnn.py:11-13 - nn.Conv2d(1, 16, 5, 2, 2),
  * nn.Conv2d(16, 32, 3, 2, 1), nn.Conv2d(32, 64, 3, 2, 1) on (1, 212, 120) images; they replace torch's conv2d / MIOpen for exactly
  * these shapes) - airgym_amd/csrc/conv_kernels.hip.  All tensors NCHW float32 as torch holds them, weights [COUT][CIN][k][k], exact
@@ -426,6 +434,8 @@ int ag_bn_pool_bwd_prep(const float* dpool_dev, const float* plane1_dev, long lo
  *                           norm_std_dev [212*120] given, in = clamp((x - mean) / std, -5, 5): the policy's image normaliser
  *                           (running_mean_std.py:78-79, per-pixel statistics) applied while the image is staged.
  *                           stats_dev (NULL = off) [n][16][2]: per image the sums of relu(y) and relu(y)^2 of every channel.
+ *                           index_dev (NULL = identity) [n] int64: image i is row index[i] of x_dev - the minibatch's distinct frames
+ *                           are read straight out of the rollout's frame store, not gathered into a tensor of their own first.
  *   ag_cnn_conv1_wgrad    : partials_dev [ag_cnn_conv1_wgrad_partials(n)][16][32]: columns 0-24 = dw[co][tap], column 25 = db[co]
  *                           (26-31 zero); the caller sums over dim 0 (fixed order -> deterministic).  x / norm_* as in the forward.
  *                           With bn_x_dev (the layer's own output x1 [n,16,106,60]) and bn_tab_dev [16][4] = {A, B, C, 0} per channel,
@@ -445,12 +455,13 @@ int ag_bn_pool_bwd_prep(const float* dpool_dev, const float* plane1_dev, long lo
  *                           x / scale / shift as in ag_cnn_conv_fwd.
  * workspace_dev: ag_cnn_conv_workspace_floats(cin, cout) floats (the weights re-laid out for the kernel, rebuilt every call). */
 int ag_cnn_conv_workspace_floats(int cin, int cout);
-int ag_cnn_conv1_fwd(const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, const float* w_dev,
-                     const float* b_dev, float* y_dev, float* stats_dev, int n, float* workspace_dev, void* stream);
+int ag_cnn_conv1_fwd(const float* x_dev, const long long* index_dev, const float* norm_mean_dev, const float* norm_std_dev,
+                     const float* w_dev, const float* b_dev, float* y_dev, float* stats_dev, int n, float* workspace_dev,
+                     void* stream);
 int ag_cnn_conv1_wgrad_partials(int n);
 int ag_cnn_conv1_wgrad(const float* dz_dev, const float* bn_x_dev, const float* bn_tab_dev, const float* weights_dev,
-                       const float* x_dev, const float* norm_mean_dev, const float* norm_std_dev, float* partials_dev, int n,
-                       void* stream);
+                       const float* x_dev, const long long* index_dev, const float* norm_mean_dev, const float* norm_std_dev,
+                       float* partials_dev, int n, void* stream);
 int ag_cnn_conv_supported(int cin, int cout, int hin, int win);
 int ag_cnn_conv_fwd_bands(int cin, int cout, int hin, int win);
 int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev, const float* b_dev,

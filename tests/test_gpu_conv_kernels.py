@@ -170,3 +170,21 @@ def test_fused_trunk_is_the_layer_sequence(weighted):
     with torch.no_grad():
         ea, eb = a(x, None, norm), b(x, None, norm)
     assert (ea - eb).abs().max().item() <= 2e-4 * eb.abs().max().item()
+
+
+def test_weighted_indexed_moments_match_the_expanded_batch():
+    """RunningMeanStd.update(x, weights=, index=) on the GPU (ag_weighted_moments, one pass) against the plain update on the
+    batch written out: x[index] with row i repeated weights[i] times (what the reference's normaliser would see)."""
+    from airgym_amd.lib.core.running_mean_std import RunningMeanStd
+    torch.manual_seed(4)
+    store = torch.rand(40, 1, 212, 120, device="cuda") * 3.0 + 0.5
+    index = torch.tensor([3, 7, 8, 20, 21, 39, 0], device="cuda")
+    weights = torch.tensor([4., 1., 3., 4., 2., 1., 4.], device="cuda")
+    a = RunningMeanStd((1, 212, 120)).cuda()
+    b = RunningMeanStd((1, 212, 120)).cuda()
+    for _ in range(2):
+        a.update(store, None, weights, index)
+        b.update(torch.repeat_interleave(store[index].double(), weights.long(), dim=0))
+    assert float(a.count) == float(b.count)
+    assert torch.allclose(a.running_mean, b.running_mean, rtol=0, atol=1e-9)
+    assert torch.allclose(a.running_var, b.running_var, rtol=1e-9, atol=1e-12)

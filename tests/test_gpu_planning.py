@@ -483,7 +483,8 @@ def test_frame_dedup_is_the_same_update_on_a_quarter_of_the_images():
         calls = []
         cnn = agent.model.actor_cnn
         orig = cnn.forward
-        cnn.forward = lambda x, weights=None, norm=None: (calls.append(x.shape[0]), orig(x, weights, norm))[1]
+        cnn.forward = lambda x, weights=None, norm=None, index=None: (
+            calls.append(x.shape[0] if index is None else index.shape[0]), orig(x, weights, norm, index))[1]
         torch.manual_seed(11)
         batch = agent.play_steps()
         rollout_calls = list(calls)
