@@ -875,17 +875,8 @@ inline int layer_of(int cin, int cout, int hin, int win) {
     if (cin == kL3.cin && cout == kL3.cout && hin == kL3.hin && win == kL3.win) return 3;
     return 0;
 }
-#if defined(AG_EXPERIMENTS) && defined(AG_L2_WAVES)
-constexpr int kL2Waves = AG_L2_WAVES;
-#else
-constexpr int kL2Waves = 4;
-#endif
-#if defined(AG_EXPERIMENTS) && defined(AG_L3_WAVES)
-constexpr int kL3Waves = AG_L3_WAVES;
-#else
-constexpr int kL3Waves = 7;
-#endif          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1)
-constexpr int kWgradWorkgroups = 512;              // persistent: two per CU
+constexpr int kL2Waves = 4, kL3Waves = 7;          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1); 2 / 7 and 4 / 5 waves measured slower          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1)
+constexpr int kWgradWorkgroups = 512;              // persistent: two per CU (conv3's 149 registers leave room for one; 256 is no slower)
 
 }  // namespace
 

@@ -5,8 +5,8 @@ OUT=gpurun_out; mkdir -p $OUT
 for T in "$@"; do
   echo "== $T"
   if [ "$T" = "shipped" ]; then
-    timeout 300 python tools/conv_probe.py --layers conv2,conv3 2> $OUT/conv_exp_$T.err | python -c "import sys,json; [print(' ', d['layer'], d['pass'][:14].ljust(14), d['hip_us']) for d in map(json.loads, sys.stdin)]"
+    timeout 300 python tools/conv_probe.py --reps 10 --layers conv2,conv3 2> $OUT/conv_exp_$T.err | python -c "import sys,json; [print(' ', d['layer'], d['pass'][:14].ljust(14), d['hip_us']) for d in map(json.loads, sys.stdin)]"
   else
-    AIRGYM_EXPERIMENTS=1 AIRGYM_EXP_LIB=airgym_amd/_native/libairgym_hip_exp_$T.so timeout 300 python tools/conv_probe.py --layers conv2,conv3 2> $OUT/conv_exp_$T.err | python -c "import sys,json; [print(' ', d['layer'], d['pass'][:14].ljust(14), d['hip_us']) for d in map(json.loads, sys.stdin)]"
+    AIRGYM_EXPERIMENTS=1 AIRGYM_EXP_LIB=airgym_amd/_native/libairgym_hip_exp_$T.so timeout 300 python tools/conv_probe.py --reps 10 --layers conv2,conv3 2> $OUT/conv_exp_$T.err | python -c "import sys,json; [print(' ', d['layer'], d['pass'][:14].ljust(14), d['hip_us']) for d in map(json.loads, sys.stdin)]"
   fi
 done
