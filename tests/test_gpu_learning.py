@@ -23,3 +23,17 @@ def test_headline_configuration_learns_on_4_of_5_seeds():
         best.append(max((c["reward"] or 0.0) for c in out["curve"]))
         assert all(c["kl"] == c["kl"] and c["c_loss"] == c["c_loss"] for c in out["curve"]), "NaN in the losses"
     assert sum(b >= 2000.0 for b in best) >= 4, best
+
+
+def test_planning_cnn_policy_learns_on_the_hand_written_trunk():
+    """Planning with the shipped YAML's trainable CNN (frame de-duplication, csrc/conv_kernels.hip, lib/network/fused_cnn.py) at
+    2 048 envs: the mean episode reward must grow tenfold within 40 epochs (epoch 1: ~25, a 12-step episode; the three arms of
+    profiles/r03_planning_learning_ab.md - this one, torch's conv2d, the reference's shape - all reach 500-730 by epoch 40)."""
+    assert torch.cuda.is_available()
+    sys.path.insert(0, REPO)
+    from tools.planning_learning_ab import run
+    out = run("hip_trunk", 2048, 40, 10, 0)
+    assert out["dedup"]
+    rewards = [c["reward"] for c in out["curve"] if c["reward"] is not None]
+    assert all(c["kl"] == c["kl"] and c["c_loss"] == c["c_loss"] for c in out["curve"]), "NaN in the losses"
+    assert max(rewards) >= 10.0 * rewards[0] and max(rewards) >= 250.0, rewards
