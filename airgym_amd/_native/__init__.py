@@ -186,8 +186,8 @@ SYMBOLS = [
     ("ag_relu_bn_bwd_reduce", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_dx", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_stats_weighted", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    ("ag_relu_bn_bwd_dx_plane", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_bwd_dx_plane", ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_bn_scratch_doubles", ctypes.c_longlong, []),
     ("ag_bn_finalize", ctypes.c_int, [_P, _P, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_double, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_double, ctypes.c_int, _P, _P, _P, ctypes.c_int, _P, _P]),
     ("ag_bn_bwd_prep", ctypes.c_int, [_P, ctypes.c_longlong, ctypes.c_int, _P, _P, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P]),
@@ -203,7 +203,7 @@ SYMBOLS = [
     ("ag_cnn_conv_fwd", ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 5 + [_P, _P]),
     ("ag_cnn_conv_dgrad", ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
     ("ag_cnn_conv_wgrad_partials", ctypes.c_int, [ctypes.c_int] * 5),
-    ("ag_cnn_conv_wgrad", ctypes.c_int, [_P] * 5 + [ctypes.c_int] * 5 + [_P]),
+    ("ag_cnn_conv_wgrad", ctypes.c_int, [_P] * 5 + [ctypes.c_int] * 6 + [_P]),
     ("ag_wgrad_rows_per_block", ctypes.c_int, [ctypes.c_int]),
     ("ag_input_wgrad_rows", ctypes.c_int, [ctypes.c_int]),
     ("ag_sum_rows_groups", ctypes.c_int, []),

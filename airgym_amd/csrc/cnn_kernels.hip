@@ -161,7 +161,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ coef, const float* __restrict__ sums,
                                                              const float* __restrict__ wts, float* __restrict__ dx,
-                                                             long long planes, int C, int HW) {
+                                                             float* __restrict__ psum, long long planes, int C, int HW) {
     typedef typename VecT<VEC>::type vec_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long p0 = (long long)blockIdx.x * kPlanesPerBlock;
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __rest
         const float mu = coef[c * 4 + 0], is = coef[c * 4 + 1], gi = coef[c * 4 + 2];
         const float rm = coef[c * 4 + 3] * (wts ? wts[p / C] : 1.0f);
         const float db = sums[c * 2 + 0] * rm, dg = sums[c * 2 + 1] * rm;
+        float ps = 0.0f;                                    // sum of dx over the plane: the bias gradient of the convolution behind x
         const vec_t* gx = reinterpret_cast<const vec_t*>(x + p * HW);
         const vec_t* gd = reinterpret_cast<const vec_t*>(dy + p * HW);
         vec_t* out = reinterpret_cast<vec_t*>(dx + p * HW);
@@ -187,8 +188,13 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __rest
                 const float xhat = (fmaxf(f[e], 0.0f) - mu) * is;
                 const float dr = gi * (g[e] - db - xhat * dg);
                 g[e] = f[e] > 0.0f ? dr : 0.0f;              // ReLU' at 0 is 0, as torch's threshold_backward
+                ps += g[e];
             }
             out[i] = d;
+        }
+        if (psum) {
+            ps = wave_sum(ps);
+            if (lane == 0) psum[p] = ps;
         }
     }
 }
@@ -202,7 +208,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* __restrict__ dyp, const float* __restrict__ x,
                                                                    const float* __restrict__ coef, const float* __restrict__ sums,
                                                                    const float* __restrict__ wts, float* __restrict__ dx,
-                                                                   long long planes, int C, int HW) {
+                                                                   float* __restrict__ psum, long long planes, int C, int HW) {
     typedef typename VecT<VEC>::type vec_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long p0 = (long long)blockIdx.x * kPlanesPerBlock;
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* 
         const float d0 = dyp[p] - sums[c * 2 + 0] * rm;
         const vec_t* gx = reinterpret_cast<const vec_t*>(x + p * HW);
         vec_t* out = reinterpret_cast<vec_t*>(dx + p * HW);
+        float ps = 0.0f;
 #pragma unroll 2
         for (int i = lane; i < nvec; i += 64) {
             vec_t v = gx[i];
@@ -225,8 +232,13 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* 
             for (int e = 0; e < VEC; ++e) {
                 const float xhat = (fmaxf(f[e], 0.0f) - mu) * is;
                 f[e] = f[e] > 0.0f ? gi * (d0 - xhat * dg) : 0.0f;
+                ps += f[e];
             }
             out[i] = v;
+        }
+        if (psum) {
+            ps = wave_sum(ps);
+            if (lane == 0) psum[p] = ps;
         }
     }
 }
@@ -484,25 +496,28 @@ extern "C" int ag_relu_bn_bwd_reduce(const float* dy_dev, const float* x_dev, co
 }
 
 extern "C" int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
-                                          const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream) {
+                                          const float* weights_dev, float* dx_dev, float* plane_sums_dev, int N, int C, int HW,
+                                          void* stream) {
     if (!dy_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev) return AG_ERR_INVALID_ARG;
     AG_BN_CHECK(N, C, HW);
     const int w = vec_width(x_dev, dy_dev, dx_dev, HW);
-    AG_BN_DISPATCH(relu_bn_bwd_dx_kernel, w, dy_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, planes, C, HW);
+    AG_BN_DISPATCH(relu_bn_bwd_dx_kernel, w, dy_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, plane_sums_dev, planes, C, HW);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
 extern "C" int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                                  float* dx_dev, int N, int C, int HW, void* stream) {
-    return ag_relu_bn_bwd_dx_weighted(dy_dev, x_dev, coef_dev, sums_dev, nullptr, dx_dev, N, C, HW, stream);
+    return ag_relu_bn_bwd_dx_weighted(dy_dev, x_dev, coef_dev, sums_dev, nullptr, dx_dev, nullptr, N, C, HW, stream);
 }
 
 extern "C" int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
-                                       const float* weights_dev, float* dx_dev, int N, int C, int HW, void* stream) {
+                                       const float* weights_dev, float* dx_dev, float* plane_sums_dev, int N, int C, int HW,
+                                       void* stream) {
     if (!dyp_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev) return AG_ERR_INVALID_ARG;
     AG_BN_CHECK(N, C, HW);
     const int w = vec_width(x_dev, dx_dev, nullptr, HW);
-    AG_BN_DISPATCH(relu_bn_bwd_dx_plane_kernel, w, dyp_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, planes, C, HW);
+    AG_BN_DISPATCH(relu_bn_bwd_dx_plane_kernel, w, dyp_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, plane_sums_dev, planes, C,
+                   HW);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 

@@ -89,13 +89,14 @@ def _conv_dgrad(lib, dz, w, like):
 
 
 def _conv_wgrad(lib, dz, x, coef, cout):
+    """Weight gradient of a 3x3 layer whose input is relu(x) * coef[2] + coef[3] (the bias gradient comes from the plane sums of dz
+    that the kernel producing dz emits: with_bias = 0)."""
     n, cin, hin, win = x.shape
     g = lib.ag_cnn_conv_wgrad_partials(n, cin, cout, hin, win)
     partials = torch.empty(g, cout * cin * 9 + cout, dtype=torch.float32, device=x.device)
-    N.check(lib.ag_cnn_conv_wgrad(dz.data_ptr(), x.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), partials.data_ptr(), n, cin,
+    N.check(lib.ag_cnn_conv_wgrad(dz.data_ptr(), x.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), partials.data_ptr(), 0, n, cin,
                                   cout, hin, win, _stream(x)), "ag_cnn_conv_wgrad")
-    s = partials.sum(0)
-    return s[:cout * cin * 9].reshape(cout, cin, 3, 3), s[cout * cin * 9:]
+    return partials[:, :cout * cin * 9].sum(0).reshape(cout, cin, 3, 3)
 
 
 def _conv1_wgrad(lib, dy, x1, tab, weights, img, index, norm):
@@ -204,16 +205,18 @@ class _Trunk(torch.autograd.Function):
                                         sums3.data_ptr(), tab3.data_ptr(), dyp.data_ptr(), scratch.data_ptr(), _stream(img)),
                 "ag_bn_pool_bwd_prep")
         dx3 = torch.empty_like(x3)
+        ps3 = torch.empty(n, 64, dtype=torch.float32, device=dev)          # per-plane sums of dx3: db3 = their sum over images
         N.check(lib.ag_relu_bn_bwd_dx_plane(dyp.data_ptr(), x3.data_ptr(), tab3.data_ptr(), sums3.data_ptr(), _wptr(weights),
-                                            dx3.data_ptr(), n, 64, _HW[2], _stream(img)), "ag_relu_bn_bwd_dx_plane")
-        dw3, db3 = _conv_wgrad(lib, dx3, x2, coef2, 64)
+                                            dx3.data_ptr(), ps3.data_ptr(), n, 64, _HW[2], _stream(img)), "ag_relu_bn_bwd_dx_plane")
+        dw3, db3 = _conv_wgrad(lib, dx3, x2, coef2, 64), ps3.sum(0)
         dy2 = _conv_dgrad(lib, dx3, w3, x2)
         del dx3
         # layer 2: dx2 written over dy2
         sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0)
+        ps2 = torch.empty(n, 32, dtype=torch.float32, device=dev)
         N.check(lib.ag_relu_bn_bwd_dx_weighted(dy2.data_ptr(), x2.data_ptr(), tab2.data_ptr(), sums2.data_ptr(), _wptr(weights),
-                                               dy2.data_ptr(), n, 32, _HW[1], _stream(img)), "ag_relu_bn_bwd_dx")
-        dw2, db2 = _conv_wgrad(lib, dy2, x1, coef1, 32)
+                                               dy2.data_ptr(), ps2.data_ptr(), n, 32, _HW[1], _stream(img)), "ag_relu_bn_bwd_dx")
+        dw2, db2 = _conv_wgrad(lib, dy2, x1, coef1, 32), ps2.sum(0)
         dy1 = _conv_dgrad(lib, dy2, w2, x1)
         del dy2
         # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)

@@ -95,7 +95,7 @@ class _ConvS2(torch.autograd.Function):
                                           _stream(x)), "ag_cnn_conv_dgrad")
         g = lib.ag_cnn_conv_wgrad_partials(n, cin, cout, hin, win)
         partials = torch.empty(g, cout * cin * 9 + cout, dtype=torch.float32, device=x.device)
-        N.check(lib.ag_cnn_conv_wgrad(dy.data_ptr(), x.data_ptr(), None, None, partials.data_ptr(), n, cin, cout, hin, win,
+        N.check(lib.ag_cnn_conv_wgrad(dy.data_ptr(), x.data_ptr(), None, None, partials.data_ptr(), 1, n, cin, cout, hin, win,
                                       _stream(x)), "ag_cnn_conv_wgrad")
         s = partials.sum(0)
         return dx, s[:cout * cin * 9].reshape(cout, cin, 3, 3), s[cout * cin * 9:].clone()

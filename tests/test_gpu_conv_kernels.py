@@ -90,7 +90,7 @@ def test_previous_relu_batchnorm_applied_while_staging(name):
     plen = c["cout"] * c["cin"] * 9 + c["cout"]
     partials = torch.empty(gparts, plen, dtype=torch.float32, device=dev)
     dyg = dy.float().to(dev)
-    N.check(lib.ag_cnn_conv_wgrad(dyg.data_ptr(), xg.data_ptr(), sc.data_ptr(), sh.data_ptr(), partials.data_ptr(), n, c["cin"],
+    N.check(lib.ag_cnn_conv_wgrad(dyg.data_ptr(), xg.data_ptr(), sc.data_ptr(), sh.data_ptr(), partials.data_ptr(), 1, n, c["cin"],
                                   c["cout"], c["hin"], c["win"], stream), "wgrad")
     s = partials.sum(0)
     _close(s[:plen - c["cout"]].reshape(w.shape), w64.grad, 1e-4, name + " weight gradient with ReLU + BatchNorm")
