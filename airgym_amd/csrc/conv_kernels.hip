@@ -27,13 +27,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AG_MFMA4(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
 
-// experiments build only (tools/): -DAG_CONV_EXP=1 weight gradient without its MFMA loop, =2 without staging after the first item
-#if defined(AG_EXPERIMENTS) && defined(AG_CONV_EXP)
-constexpr int kConvExp = AG_CONV_EXP;
-#else
-constexpr int kConvExp = 0;
-#endif
-
 // Staging loads go through buffer descriptors: a 32-bit byte offset per lane and hardware bounds checking - an out-of-range
 // offset (kOob) returns 0, which is how padding rows, band tails and tail units are produced without a branch per load.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -212,11 +205,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
     fetch(0);
     for (int ch = 0; ch < CIN / 8; ++ch) {
         __syncthreads();
-        if (!(kConvExp & 8) || ch == 0) stash(ch);
+        stash(ch);
         __syncthreads();
-        if (!(kConvExp & 8) && ch + 1 < CIN / 8) fetch(ch + 1);
+        if (ch + 1 < CIN / 8) fetch(ch + 1);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
-        if (kConvExp & 4) { acc[0][0][0][0] += s_in[tid] + s_w[tid]; continue; }
         const float* bb = s_in + q * PS + (4 * wave) * RS + m;
         const float* ab = s_w + q * QS + m;
 #pragma unroll
@@ -238,17 +230,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
                     }
             }
         }
-    }
-    if (kConvExp & 16) {
-        float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int bt = 0; bt < NBT; ++bt)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) t += acc[r][bt][rt][0] + acc[r][bt][rt][1] + acc[r][bt][rt][2] + acc[r][bt][rt][3];
-        if (t == 12345.f) y[0] = t;
-        return;
     }
     // epilogue: + bias, store; with `stats`, the workgroup's sums of relu(y) and relu(y)^2 per output channel over its valid pixels
     // (what the following ReLU + BatchNorm needs as batch statistics, and - last layer - the global average pool as plane sums)
@@ -388,11 +369,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
     fetch(0);
     for (int ch = 0; ch < COUT / 16; ++ch) {
         __syncthreads();
-        if (!(kConvExp & 8) || ch == 0) stash();
+        stash();
         __syncthreads();
-        if (!(kConvExp & 8) && ch + 1 < COUT / 16) fetch(ch + 1);
+        if (ch + 1 < COUT / 16) fetch(ch + 1);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
-        if (kConvExp & 4) { acc[0][0][0][0][0][0] += s_z[tid] + s_w[tid]; continue; }
         const float* zb = s_z + q * PSZ + (2 * wave) * RSZ + m;
         const float* ab = s_w + q * CINP + m;
 #pragma unroll
@@ -574,11 +554,10 @@ __global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __re
     fetch(blockIdx.x);
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         __syncthreads();
-        if (!(kConvExp & 2) || item == (int)blockIdx.x) stash(item);
+        stash(item);
         __syncthreads();
-        if (!(kConvExp & 2) && item + (int)gridDim.x < items) fetch(item + gridDim.x);
+        if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
-        if (kConvExp & 1) { acc[0][0][0][0] += s_in[tid] + s_z[tid]; continue; }      // keeps the staging alive
 #pragma unroll
         for (int rp = 0; rp < (WIDE ? 2 : 1); ++rp) {
 #pragma unroll 4
