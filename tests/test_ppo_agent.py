@@ -457,3 +457,29 @@ def test_vae_model_accepts_cached_features():
     params["network"]["vae"]["return_sampled_latent"] = True
     m2 = ModelA2CContinuousLogStd(params, {"actions_num": 4, "input_shape": {"image": (1, 212, 120), "observation": (16,)}})
     assert not m2.frozen_features_cacheable
+
+
+def test_cnn_forward_index_norm_and_weights_on_cpu():
+    """CNNFeatureExtractor.forward(x, weights, norm, index) without a GPU (the torch formulation every GPU path is checked
+    against): index = read the batch out of a frame store, norm = the input normaliser applied to the raw image, weights = image
+    multiplicities.  Equals the plain modules on the batch written out (gathered, normalised, every image repeated)."""
+    from airgym_amd.lib.network.cnn import CNNFeatureExtractor
+    import copy
+    torch.manual_seed(0)
+    cnn = CNNFeatureExtractor(8).double().train()
+    ref = copy.deepcopy(cnn)
+    store = torch.rand(9, 1, 212, 120, dtype=torch.float64) * 4.0
+    index = torch.tensor([7, 2, 5])
+    weights = torch.tensor([3.0, 1.0, 2.0], dtype=torch.float64)
+    mean, std = torch.rand(212 * 120, dtype=torch.float64), torch.rand(212 * 120, dtype=torch.float64) * 0.2 + 0.05
+    out = cnn(store, weights, (mean, std), index)
+    xb = torch.clamp((store[index] - mean.view(1, 1, 212, 120)) / std.view(1, 1, 212, 120), -5.0, 5.0)
+    full = ref(torch.repeat_interleave(xb, weights.long(), dim=0))
+    assert torch.allclose(out, full[[0, 3, 4]], atol=1e-10)
+    for (name, a), (_, b) in zip(cnn.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(a.double(), b.double(), atol=1e-10), name
+    g = torch.randn(3, 8, dtype=torch.float64)
+    out.backward(g)
+    full.backward(g[[0, 0, 0, 1, 2, 2]] / weights[[0, 0, 0, 1, 2, 2]].view(-1, 1))
+    for (name, a), (_, b) in zip(cnn.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(a.grad, b.grad, atol=1e-9), name
