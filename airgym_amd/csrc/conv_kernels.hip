@@ -429,22 +429,23 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
 
 // ------------------------------------------------------------------------------------------------------------------------
 // weight gradient of a 3x3 / stride 2 / pad 1 layer: dw[co][ci][ky][kx] = sum_{n,oy,ox} dz[co][oy][ox] in[ci][2oy+ky-1][2ox+kx-1],
-// db[co] = sum dz.  D[co][ci] tiles of 16 x 16 per tap, K = output pixels (4 per instruction, one per lane quarter).  Six waves:
-// wave w owns kernel row ky = w >> 1 (its three kx taps) and half of the co tiles (w & 1); all waves walk the same pixels of
-// a band of 4 output rows.  Workgroups are persistent: each accumulates its (image, band) items in registers and writes ONE
+// db[co] = sum dz.  D[co][ci] tiles of 16 x 16 per tap, K = output pixels (4 per instruction, one per lane quarter).  Twelve waves:
+// wave w owns kernel row ky = w >> 2 (its three kx taps), half of the co tiles and one ci tile (conv3) or half of the pixel
+// steps (conv2); a band is 4 output rows.  Workgroups are persistent: each accumulates its (image, band) items in registers and writes ONE
 // partial [COUT*CIN*9 + COUT]; the caller sums the partials (fixed order -> deterministic).
 // Pixel <-> quarter map (chosen for the bank rule): WO > 16 (30 wide): quarter = (row & 1, half) - rows 2r'+(q>>1), ox = j + 16 (q&1);
 // WO <= 16 (15 wide): quarter = row, ox = j.  Pixels ox >= WO have dz = 0 in LDS (and finite input values).
 // BIAS = false: db is not computed (the fused trunk takes it from the per-plane sums of dz that the ReLU + BatchNorm backward kernel
 // producing dz emits for free; the constant-1 MFMA column costs the kernel-row-0 waves a third more matrix work: 1.30 -> 1.09 ms).
 template <int CIN, int COUT, int HIN, int WIN, bool APPLY, bool BIAS>
-__global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+__global__ __launch_bounds__(768) void conv_s2_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            float* __restrict__ partials, int items, int bands) {
     constexpr int HO = (HIN - 1) / 2 + 1, WO = WIN / 2;
-    constexpr int NT = 384, R = 4, IN_ROWS = 2 * R + 1;
+    constexpr int NT = 768, R = 4, IN_ROWS = 2 * R + 1;
     constexpr bool WIDE = (WO > 16);
     constexpr int RT = COUT / 16, CT = CIN / 16, RTW = RT / 2;
+    static_assert(CT == 1 || CT == 2, "the fourth wave-id bit is the ci tile (CT = 2) or the K half (CT = 1)");
     constexpr int RSZ = WIDE ? 32 : 16, PSZ = R * RSZ + 1;
     constexpr int EO = WIDE ? 33 : 17, RS = WIDE ? 65 : 40;
     constexpr int PS = make_odd(IN_ROWS * RS);
@@ -455,31 +456,36 @@ __global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __re
     __shared__ __attribute__((aligned(16))) float s_z[COUT * PSZ + 32];
     __shared__ float s_ss[2 * CIN];
 
+    // twelve waves, three per SIMD: kernel row ky (3) x half of the co tiles rg (2) x { ci tile (CT = 2) | half of the pixel steps
+    // (CT = 1: the two halves write separate partials) } - every wave has the same number of MFMAs and a workgroup fills the CU evenly
+    // (six waves were 2,2,1,1 per SIMD: the barrier waited for the doubly loaded ones)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
-    const int ky = wave >> 1, rg = wave & 1;
+    const int ky = wave >> 2, rg = (wave >> 1) & 1, sel = wave & 1;
+    const int cg = (CT == 2) ? sel : 0;             // this wave's ci tile
+    const int kh = (CT == 1) ? sel : 0;             // this wave's K half (WIDE layers: the row pair rp = kh)
+    static_assert((CT == 1) == WIDE, "K halves are the two row pairs of a wide band; a narrow band is one row group");
 
     for (int u = tid; u < CIN * PS + 32; u += NT) s_in[u] = 0.f;
     for (int u = tid; u < COUT * PSZ + 32; u += NT) s_z[u] = 0.f;
 
-    f32x4 acc[RTW][3][CT], accb[RTW];
+    f32x4 acc[RTW][3], accb[RTW];
 #pragma unroll
     for (int rt = 0; rt < RTW; ++rt) {
         accb[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[rt][kx][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kx = 0; kx < 3; ++kx) acc[rt][kx] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int aq = WIDE ? (q >> 1) * RSZ + 16 * (q & 1) : q * RSZ;
     const int bq = WIDE ? (q >> 1) * 2 * RS + 16 * (q & 1) : q * 2 * RS;
-    const float* ab = s_z + (16 * rg * RTW + m) * PSZ + aq;
-    const float* bb = s_in + m * PS + bq + ky * RS;
+    const float* ab = s_z + (16 * rg * RTW + m) * PSZ + aq + (CT == 1 ? kh * 2 * RSZ : 0);
+    const float* bb = s_in + (16 * cg + m) * PS + bq + ky * RS + (CT == 1 ? kh * 4 * RS : 0);
 
     // Staging, slot-major: a thread owns ONE position of a plane (input: (row, column pair) of the band; dz: (row, column) of the
     // band) and walks the planes - every address is (per-thread base, computed once per item) + (plane step: a constant scalar
     // offset of the load / an immediate offset of the LDS store), so staging costs no address arithmetic per element.
     constexpr int SLOTS_IN = IN_ROWS * W2;               // 270 / 135 float2 per input plane
-    constexpr int PG = NT / SLOTS_IN;                    // plane groups walking in parallel: 1 / 2
+    constexpr int PG = WIDE ? 2 : 4;                     // plane groups walking in parallel (540 of the 768 threads)
+    static_assert(PG * SLOTS_IN <= NT, "plane groups fit the workgroup");
     constexpr int IN_IT = CIN / PG;
     static_assert(CIN % PG == 0, "planes split evenly over the plane groups");
     const int ipg = tid / SLOTS_IN, islot = tid - ipg * SLOTS_IN;
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __re
     float* const in_dst = s_in + ipg * PS + irow * RS + ij;
     constexpr int ZV = WIDE ? 2 : 1;                     // dz row width 30: float2 units; 15: single floats (rows are 4-byte aligned)
     constexpr int SLOTS_Z = R * WO / ZV;                 // 60 per dz plane
-    constexpr int ZG = NT / 64;                          // 6 plane groups of 64 threads (60 active)
+    constexpr int ZG = NT / 64;                          // 12 plane groups of 64 threads (60 active)
     constexpr int Z_IT = (COUT + ZG - 1) / ZG;
     static_assert(SLOTS_Z <= 64, "one dz slot per lane");
     const int zg = tid >> 6, zslot = tid & 63;
@@ -558,41 +564,33 @@ __global__ __launch_bounds__(384, 3) void conv_s2_wgrad_kernel(const float* __re
         __syncthreads();
         if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
-#pragma unroll
-        for (int rp = 0; rp < (WIDE ? 2 : 1); ++rp) {
+        // the wave's pixel steps: the whole band (CT = 2, narrow: one row group) or its row pair (CT = 1; folded into ab / bb)
 #pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                float a[RTW];
+        for (int j = 0; j < 16; ++j) {
+            float a[RTW];
 #pragma unroll
-                for (int rt = 0; rt < RTW; ++rt) a[rt] = ab[(16 * rt) * PSZ + rp * 2 * RSZ + j];
-                float b[3][CT];
+            for (int rt = 0; rt < RTW; ++rt) a[rt] = ab[(16 * rt) * PSZ + j];
+            float b[3];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+            for (int kx = 0; kx < 3; ++kx) b[kx] = bb[(kx == 1 ? EO : 0) + (kx == 2 ? 1 : 0) + j];
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        b[kx][ct] = bb[(16 * ct) * PS + rp * 4 * RS + (kx == 1 ? EO : 0) + (kx == 2 ? 1 : 0) + j];
+            for (int rt = 0; rt < RTW; ++rt) {
 #pragma unroll
-                for (int rt = 0; rt < RTW; ++rt) {
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) acc[rt][kx][ct] = AG_MFMA4(a[rt], b[kx][ct], acc[rt][kx][ct]);
-                    if (BIAS && ky == 0) accb[rt] = AG_MFMA4(a[rt], 1.0f, accb[rt]);
-                }
+                for (int kx = 0; kx < 3; ++kx) acc[rt][kx] = AG_MFMA4(a[rt], b[kx], acc[rt][kx]);
+                if (BIAS && ky == 0 && cg == 0) accb[rt] = AG_MFMA4(a[rt], 1.0f, accb[rt]);
             }
         }
     }
-    float* part = partials + (size_t)blockIdx.x * PLEN;
+    // one partial per workgroup - two (the K halves) where CT = 1
+    float* part = partials + ((size_t)blockIdx.x * (CT == 1 ? 2 : 1) + kh) * PLEN;
 #pragma unroll
     for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = 16 * (rg * RTW + rt) + 4 * q + i;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) part[((size_t)(co * CIN + 16 * ct + m) * 3 + ky) * 3 + kx] = acc[rt][kx][ct][i];
-            if (BIAS && ky == 0 && m == 0) part[COUT * CIN * 9 + co] = accb[rt][i];
+            for (int kx = 0; kx < 3; ++kx) part[((size_t)(co * CIN + 16 * cg + m) * 3 + ky) * 3 + kx] = acc[rt][kx][i];
+            if (BIAS && ky == 0 && cg == 0 && m == 0) part[COUT * CIN * 9 + co] = accb[rt][i];
         }
 }
 
@@ -857,7 +855,7 @@ inline int layer_of(int cin, int cout, int hin, int win) {
     return 0;
 }
 constexpr int kL2Waves = 4, kL3Waves = 7;          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1); 2 / 7 and 4 / 5 waves measured slower          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1)
-constexpr int kWgradWorkgroups = 512;              // persistent: two per CU (conv3's 149 registers leave room for one; 256 is no slower)
+constexpr int kWgradWorkgroups = 512;              // persistent 12-wave workgroups: two per CU where registers allow (conv2), else they queue
 
 }  // namespace
 
@@ -962,12 +960,16 @@ extern "C" int ag_cnn_conv_dgrad(const float* dz_dev, const float* w_dev, float*
     return AG_CONV_LAUNCH_OK();
 }
 
-extern "C" int ag_cnn_conv_wgrad_partials(int n, int cin, int cout, int hin, int win) {
-    const int layer = layer_of(cin, cout, hin, win);
-    if (!layer) return AG_ERR_UNSUPPORTED;
+static int wgrad_grid(int n, int hin) {
     const int ho = (hin - 1) / 2 + 1;
     const long long items = (long long)n * ((ho + 3) / 4);
     return (int)(items < kWgradWorkgroups ? items : kWgradWorkgroups);
+}
+
+extern "C" int ag_cnn_conv_wgrad_partials(int n, int cin, int cout, int hin, int win) {
+    const int layer = layer_of(cin, cout, hin, win);
+    if (!layer) return AG_ERR_UNSUPPORTED;
+    return wgrad_grid(n, hin) * (cin == 16 ? 2 : 1);        // one partial per workgroup; two where the waves split the pixel steps
 }
 
 extern "C" int ag_cnn_conv_wgrad(const float* dz_dev, const float* x_dev, const float* scale_dev, const float* shift_dev,
@@ -977,9 +979,9 @@ extern "C" int ag_cnn_conv_wgrad(const float* dz_dev, const float* x_dev, const 
     if (!layer) return AG_ERR_UNSUPPORTED;
     const int ho = (hin - 1) / 2 + 1, bands = (ho + 3) / 4;
     if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
-    const int g = ag_cnn_conv_wgrad_partials(n, cin, cout, hin, win);
+    const int g = wgrad_grid(n, hin);
     const bool apply = scale_dev != nullptr;
-    const dim3 grid(g), block(384);
+    const dim3 grid(g), block(768);
 #define AG_CW(CIN_, COUT_, HIN_, WIN_, APPLY_, BIAS_)                                                                          \
     hipLaunchKernelGGL((conv_s2_wgrad_kernel<CIN_, COUT_, HIN_, WIN_, APPLY_, BIAS_>), grid, block, 0, (hipStream_t)stream, dz_dev, \
                        x_dev, scale_dev, shift_dev, partials_dev, n * bands, bands)
