@@ -190,8 +190,8 @@ SYMBOLS = [
     ("ag_relu_bn_bwd_dx_plane", ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_bn_scratch_doubles", ctypes.c_longlong, []),
     ("ag_bn_finalize", ctypes.c_int, [_P, _P, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_double, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_double, ctypes.c_int, _P, _P, _P, ctypes.c_int, _P, _P]),
-    ("ag_bn_bwd_prep", ctypes.c_int, [_P, ctypes.c_longlong, ctypes.c_int, _P, _P, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P]),
-    ("ag_bn_pool_bwd_prep", ctypes.c_int, [_P, _P, ctypes.c_longlong, ctypes.c_int, _P, _P, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P, _P]),
+    ("ag_bn_bwd_prep", ctypes.c_int, [_P, ctypes.c_longlong, ctypes.c_int, _P, _P, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
+    ("ag_bn_pool_bwd_prep", ctypes.c_int, [_P, _P, ctypes.c_longlong, ctypes.c_int, _P, _P, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P, _P, _P, _P]),
     ("ag_cnn_conv_workspace_floats", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     ("ag_weighted_moments_chunks", ctypes.c_int, []),
     ("ag_weighted_moments", ctypes.c_int, [_P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, _P, _P]),

@@ -380,7 +380,8 @@ __global__ __launch_bounds__(256) void bn_pool_kernel(const float* __restrict__ 
 // part = {sum_n dpool, sum_n dpool plane1}: dbeta = the first, dgamma = invstd (inv_hw the second - mean the first); tab as mode 0.
 __global__ __launch_bounds__(kSmallThreads) void bn_bwd_prep_kernel(const double* __restrict__ part, int C, const float* __restrict__ coef_fwd,
                                                                    const float* __restrict__ gamma, double m, int mode, double inv_hw,
-                                                                   float* __restrict__ sums, float* __restrict__ tab) {
+                                                                   float* __restrict__ sums, float* __restrict__ tab,
+                                                                   float* __restrict__ dgamma_out, float* __restrict__ dbeta_out) {
     __shared__ double s_part[kSmallThreads], s_tot[128];
     const int t = threadIdx.x;
     sum_partials(part, 2 * C, s_part, s_tot);
@@ -390,6 +391,10 @@ __global__ __launch_bounds__(kSmallThreads) void bn_bwd_prep_kernel(const double
         if (mode == 2) dg = invstd * (inv_hw * dg - mean * db);
         sums[2 * t] = (float)db;
         sums[2 * t + 1] = (float)dg;
+        if (dgamma_out) {           // the parameter gradients written where the optimizer reads them (no accumulation launch)
+            dgamma_out[t] = (float)dg;
+            dbeta_out[t] = (float)db;
+        }
         const double a = (double)gamma[t] * invstd;
         if (mode != 1) {
             tab[4 * t + 0] = (float)mean;
@@ -551,27 +556,30 @@ extern "C" int ag_bn_finalize(const float* stats_dev, const float* weights_dev, 
 }
 
 extern "C" int ag_bn_bwd_prep(const float* partials_dev, long long blocks, int C, const float* coef_fwd_dev, const float* gamma_dev,
-                              double m, int mode, float* sums_dev, float* tab_dev, double* scratch_dev, void* stream) {
-    if (!partials_dev || !coef_fwd_dev || !gamma_dev || !sums_dev || !tab_dev || !scratch_dev || blocks <= 0 || (mode != 0 && mode != 1))
+                              double m, int mode, float* sums_dev, float* tab_dev, float* dgamma_out_dev, float* dbeta_out_dev,
+                              double* scratch_dev, void* stream) {
+    if (!partials_dev || !coef_fwd_dev || !gamma_dev || !sums_dev || !tab_dev || !scratch_dev || blocks <= 0 || (mode != 0 && mode != 1) ||
+        (!dgamma_out_dev) != (!dbeta_out_dev))
         return AG_ERR_INVALID_ARG;
     if (C <= 0 || C > kMaxC || (256 % (2 * C)) != 0) return AG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(colsum_kernel, dim3(kColBlocks), dim3(256), 0, (hipStream_t)stream, partials_dev, (const float*)nullptr, blocks, 1,
                        2 * C, scratch_dev);
     hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, scratch_dev, C, coef_fwd_dev, gamma_dev, m,
-                       mode, 0.0, sums_dev, tab_dev);
+                       mode, 0.0, sums_dev, tab_dev, dgamma_out_dev, dbeta_out_dev);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
 extern "C" int ag_bn_pool_bwd_prep(const float* dpool_dev, const float* plane1_dev, long long n, int C, const float* coef_fwd_dev,
                                    const float* gamma_dev, double m, int HW, float* sums_dev, float* tab_dev, float* dyp_dev,
-                                   double* scratch_dev, void* stream) {
-    if (!dpool_dev || !plane1_dev || !coef_fwd_dev || !gamma_dev || !sums_dev || !tab_dev || !dyp_dev || !scratch_dev || n <= 0 || HW <= 0)
+                                   float* dgamma_out_dev, float* dbeta_out_dev, double* scratch_dev, void* stream) {
+    if (!dpool_dev || !plane1_dev || !coef_fwd_dev || !gamma_dev || !sums_dev || !tab_dev || !dyp_dev || !scratch_dev || n <= 0 || HW <= 0 ||
+        (!dgamma_out_dev) != (!dbeta_out_dev))
         return AG_ERR_INVALID_ARG;
     if (C <= 0 || C > kMaxC || (256 % C) != 0) return AG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(colsum_pair_kernel, dim3(kColBlocks), dim3(256), 0, (hipStream_t)stream, dpool_dev, plane1_dev, n, C,
                        1.0f / (float)HW, scratch_dev, dyp_dev);
     hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, scratch_dev, C, coef_fwd_dev, gamma_dev, m,
-                       2, 1.0 / (double)HW, sums_dev, tab_dev);
+                       2, 1.0 / (double)HW, sums_dev, tab_dev, dgamma_out_dev, dbeta_out_dev);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 

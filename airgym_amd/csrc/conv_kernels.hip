@@ -209,6 +209,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
         __syncthreads();
         if (ch + 1 < CIN / 8) fetch(ch + 1);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
+        if (oy0 + 2 * wave >= HO) continue;      // both rows of this wave lie below the image (last band): staging only
         const float* bb = s_in + q * PS + (4 * wave) * RS + m;
         const float* ab = s_w + q * QS + m;
 #pragma unroll
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
         __syncthreads();
         if (ch + 1 < COUT / 16) fetch(ch + 1);
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
+        if (a0 + 2 * wave >= HO) continue;       // both rows of this wave lie below the tensor (last band): staging only
         const float* zb = s_z + q * PSZ + (2 * wave) * RSZ + m;
         const float* ab = s_w + q * CINP + m;
 #pragma unroll

@@ -78,11 +78,19 @@ class DedupFrames:
         self.S, self.N = frames.shape[0], frames.shape[1]
         self.H = horizon
         self.frame_of_step = torch.tensor(frame_of_step, dtype=torch.long, device=frames.device)
+        self._slices = {}           # (start, stop) -> index tensors: the mini-epochs of an update ask for the same slices again
 
     def __len__(self):
         return self.N * self.H
 
     def __getitem__(self, sl):
+        hit = self._slices.get((sl.start, sl.stop))
+        if hit is not None:
+            rows, inverse, counts = hit
+            flat = self.frames.view((self.S * self.N,) + tuple(self.frames.shape[2:]))
+            if self.in_place:
+                return {"image": flat, "image_index": rows, "image_inverse": inverse, "image_counts": counts}
+            return {"image": flat.index_select(0, rows), "image_inverse": inverse, "image_counts": counts}
         b = torch.arange(sl.start, sl.stop, device=self.frames.device)
         env = torch.div(b, self.H, rounding_mode="floor")
         keys = env * self.S + self.frame_of_step[b - env * self.H]          # non-decreasing within an env, envs ascending
@@ -90,9 +98,11 @@ class DedupFrames:
         u_env = torch.div(uniq, self.S, rounding_mode="floor")
         flat = self.frames.view((self.S * self.N,) + tuple(self.frames.shape[2:]))
         rows = (uniq - u_env * self.S) * self.N + u_env
+        counts = counts.to(torch.float32)
+        self._slices[(sl.start, sl.stop)] = (rows, inverse, counts)
         if self.in_place:       # the model reads flat[rows] where it lies (cnn.forward(..., index)): no [U, 1, 212, 120] copy
-            return {"image": flat, "image_index": rows, "image_inverse": inverse, "image_counts": counts.to(torch.float32)}
-        return {"image": flat.index_select(0, rows), "image_inverse": inverse, "image_counts": counts.to(torch.float32)}
+            return {"image": flat, "image_index": rows, "image_inverse": inverse, "image_counts": counts}
+        return {"image": flat.index_select(0, rows), "image_inverse": inverse, "image_counts": counts}
 
 
 class FlatAdam:
@@ -353,6 +363,11 @@ class A2CAgent:
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
             off += n
         self._params = ps
+        # every backward of this agent starts from a zeroed gradient buffer (calc_gradients), so a module whose parameters have no
+        # other consumer may write its gradients into these views itself (lib/network/fused_cnn.py: no AccumulateGrad launches)
+        for mod in self.model.modules():
+            if hasattr(mod, "direct_grads"):
+                mod.direct_grads = True
         self.heads_w = self.heads_b = self.heads_w_grad = self.heads_b_grad = None
         if fused_heads:
             A1, Hd = m.mu.weight.shape[0] + 1, m.mu.weight.shape[1]

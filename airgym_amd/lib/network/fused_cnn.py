@@ -88,18 +88,22 @@ def _conv_dgrad(lib, dz, w, like):
     return dx
 
 
-def _conv_wgrad(lib, dz, x, coef, cout):
+def _conv_wgrad(lib, dz, x, coef, cout, out=None):
     """Weight gradient of a 3x3 layer whose input is relu(x) * coef[2] + coef[3] (the bias gradient comes from the plane sums of dz
-    that the kernel producing dz emits: with_bias = 0)."""
+    that the kernel producing dz emits: with_bias = 0).  out: a contiguous [cout, cin, 3, 3] tensor the result is summed into
+    directly (returns None then)."""
     n, cin, hin, win = x.shape
     g = lib.ag_cnn_conv_wgrad_partials(n, cin, cout, hin, win)
     partials = torch.empty(g, cout * cin * 9 + cout, dtype=torch.float32, device=x.device)
     N.check(lib.ag_cnn_conv_wgrad(dz.data_ptr(), x.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), partials.data_ptr(), 0, n, cin,
                                   cout, hin, win, _stream(x)), "ag_cnn_conv_wgrad")
+    if out is not None:
+        torch.sum(partials[:, :cout * cin * 9], 0, out=out.view(-1))
+        return None
     return partials[:, :cout * cin * 9].sum(0).reshape(cout, cin, 3, 3)
 
 
-def _conv1_wgrad(lib, dy, x1, tab, weights, img, index, norm):
+def _conv1_wgrad(lib, dy, x1, tab, weights, img, index, norm, out=None):
     """Weight / bias gradient of the first convolution from the gradient dy of its ReLU + BatchNorm output (the BatchNorm backward
     is folded into the kernel's staging: tab [16, 4], see ag_cnn_conv1_wgrad)."""
     n = x1.shape[0]
@@ -107,6 +111,10 @@ def _conv1_wgrad(lib, dy, x1, tab, weights, img, index, norm):
     partials = torch.empty(g, 16, 32, dtype=torch.float32, device=img.device)
     N.check(lib.ag_cnn_conv1_wgrad(dy.data_ptr(), x1.data_ptr(), tab.data_ptr(), _wptr(weights), img.data_ptr(), _wptr(index),
                                    *_norm_ptrs(norm), partials.data_ptr(), n, _stream(img)), "ag_cnn_conv1_wgrad")
+    if out is not None:
+        torch.sum(partials[:, :, :25], 0, out=out[0].view(16, 25))
+        torch.sum(partials[:, :, 25], 0, out=out[1])
+        return None, None
     s = partials.sum(0)
     return s[:, :25].reshape(16, 1, 5, 5), s[:, 25]
 
@@ -139,9 +147,14 @@ def _finalize(lib, stats, weights, n, m, bn, training, hw, pool=False):
     return coef, plane1, pooled
 
 
-def _bn_reduce(lib, dy, x, coef, gamma, m, mode):
+def _gptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _bn_reduce(lib, dy, x, coef, gamma, m, mode, gout=(None, None)):
     """ReLU + BatchNorm backward, first half: (sums [C, 2] = (dbeta, dgamma), tab [C, 4]) from the gradient dy of the layer's output
-    and the layer's own output x (ag_relu_bn_bwd_reduce + ag_bn_bwd_prep; mode: see ag_bn_bwd_prep)."""
+    and the layer's own output x (ag_relu_bn_bwd_reduce + ag_bn_bwd_prep; mode: see ag_bn_bwd_prep).  gout = (dgamma, dbeta) tensors
+    the two parameter gradients are also written into."""
     n, c, h, w = x.shape
     blocks = _blocks(lib, n, c)
     partials = torch.empty(blocks, c, 2, dtype=torch.float32, device=x.device)
@@ -151,13 +164,13 @@ def _bn_reduce(lib, dy, x, coef, gamma, m, mode):
     tab = torch.empty(c, 4, dtype=torch.float32, device=x.device)
     scratch = torch.empty(lib.ag_bn_scratch_doubles(), dtype=torch.float64, device=x.device)
     N.check(lib.ag_bn_bwd_prep(partials.data_ptr(), blocks, c, coef.data_ptr(), gamma.data_ptr(), float(m), mode, sums.data_ptr(),
-                               tab.data_ptr(), scratch.data_ptr(), _stream(x)), "ag_bn_bwd_prep")
+                               tab.data_ptr(), _gptr(gout[0]), _gptr(gout[1]), scratch.data_ptr(), _stream(x)), "ag_bn_bwd_prep")
     return sums, tab
 
 
 class _Trunk(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, weights, bns, training, norm, index, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
+    def forward(ctx, img, weights, bns, training, norm, index, gout, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
         lib = N.load()
         img = img.contiguous()
         if index is not None:
@@ -183,6 +196,7 @@ class _Trunk(torch.autograd.Function):
         ctx.has_weights = weights is not None
         ctx.norm = norm
         ctx.index = index
+        ctx.gout = gout
         ctx.save_for_backward(img, x1, x2, x3, plane1, weights if weights is not None else img.new_empty(0), w2, w3, g1, g2, g3,
                               coef1, coef2, coef3)
         return pooled
@@ -197,40 +211,50 @@ class _Trunk(torch.autograd.Function):
         dev = img.device
         dpool = dpool.contiguous()
         # layer 3: the pool spreads dpool / HW over the plane; sum dy = sum_n dpool, sum dy xhat = sum_n dpool mean_hw(xhat)
+        # gout: the twelve parameters' .grad tensors (views of the optimizer's flat gradient buffer): results are written there
+        # directly and autograd is handed None (no accumulation launches); otherwise the gradients are returned
+        go = ctx.gout
+        G = (lambda i: go[i]) if go is not None else (lambda i: None)
         sums3 = torch.empty(64, 2, dtype=torch.float32, device=dev)
         tab3 = torch.empty(64, 4, dtype=torch.float32, device=dev)
         dyp = torch.empty(n, 64, dtype=torch.float32, device=dev)
         scratch = torch.empty(lib.ag_bn_scratch_doubles(), dtype=torch.float64, device=dev)
         N.check(lib.ag_bn_pool_bwd_prep(dpool.data_ptr(), plane1.data_ptr(), n, 64, coef3.data_ptr(), g3.data_ptr(), float(m3), _HW[2],
-                                        sums3.data_ptr(), tab3.data_ptr(), dyp.data_ptr(), scratch.data_ptr(), _stream(img)),
-                "ag_bn_pool_bwd_prep")
+                                        sums3.data_ptr(), tab3.data_ptr(), dyp.data_ptr(), _gptr(G(10)), _gptr(G(11)),
+                                        scratch.data_ptr(), _stream(img)), "ag_bn_pool_bwd_prep")
         dx3 = torch.empty_like(x3)
         ps3 = torch.empty(n, 64, dtype=torch.float32, device=dev)          # per-plane sums of dx3: db3 = their sum over images
         N.check(lib.ag_relu_bn_bwd_dx_plane(dyp.data_ptr(), x3.data_ptr(), tab3.data_ptr(), sums3.data_ptr(), _wptr(weights),
                                             dx3.data_ptr(), ps3.data_ptr(), n, 64, _HW[2], _stream(img)), "ag_relu_bn_bwd_dx_plane")
-        dw3, db3 = _conv_wgrad(lib, dx3, x2, coef2, 64), ps3.sum(0)
+        dw3 = _conv_wgrad(lib, dx3, x2, coef2, 64, G(8))
+        db3 = torch.sum(ps3, 0, out=G(9)) if go is not None else ps3.sum(0)
         dy2 = _conv_dgrad(lib, dx3, w3, x2)
         del dx3
         # layer 2: dx2 written over dy2
-        sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0)
+        sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0, (G(6), G(7)))
         ps2 = torch.empty(n, 32, dtype=torch.float32, device=dev)
         N.check(lib.ag_relu_bn_bwd_dx_weighted(dy2.data_ptr(), x2.data_ptr(), tab2.data_ptr(), sums2.data_ptr(), _wptr(weights),
                                                dy2.data_ptr(), ps2.data_ptr(), n, 32, _HW[1], _stream(img)), "ag_relu_bn_bwd_dx")
-        dw2, db2 = _conv_wgrad(lib, dy2, x1, coef1, 32), ps2.sum(0)
+        dw2 = _conv_wgrad(lib, dy2, x1, coef1, 32, G(4))
+        db2 = torch.sum(ps2, 0, out=G(5)) if go is not None else ps2.sum(0)
         dy1 = _conv_dgrad(lib, dy2, w2, x1)
         del dy2
         # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)
-        sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1)
-        dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.index, ctx.norm)
-        return (None, None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
+        sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1, (G(2), G(3)))
+        dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.index, ctx.norm, (G(0), G(1)) if go is not None else None)
+        if go is not None:
+            return (None,) * 19
+        return (None, None, None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
                 sums3[:, 1], sums3[:, 0])
 
 
-def trunk(x, features, weights=None, norm=None, index=None):
+def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False):
     """`features(x)` flattened to [N, 64] (the caller has checked `usable(x, features)`): batch statistics when the BatchNorm
     layers are in training mode (all three must agree), running statistics otherwise.  norm = (mean, std) (optional, per-pixel
     [212 * 120]): x is the RAW image and the first convolution normalises it, clamp((x - mean) / std, -5, 5), while staging.
-    index (optional, int64 [N]): the batch is x[index] - read in place, e.g. out of the rollout's frame store."""
+    index (optional, int64 [N]): the batch is x[index] - read in place, e.g. out of the rollout's frame store.
+    direct_grads: the backward OVERWRITES the parameters' existing .grad tensors instead of handing gradients to autograd for
+    accumulation (the caller zeroes its gradient buffer before every backward and the trunk is applied once per backward)."""
     layers = list(features)
     convs, bns = (layers[0], layers[3], layers[6]), (layers[2], layers[5], layers[8])
     training = bns[0].training
@@ -240,4 +264,11 @@ def trunk(x, features, weights=None, norm=None, index=None):
     args = []
     for conv, bn in zip(convs, bns):
         args += [conv.weight, conv.bias, bn.weight, bn.bias]
-    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, *args)
+    # parameters with pre-allocated contiguous float32 .grad (the agent keeps them as views of one flat buffer it has just zeroed):
+    # the backward writes the gradients there itself.  Valid because the trunk is the parameters' only consumer in the graph.
+    gout = None
+    if direct_grads and training and torch.is_grad_enabled():
+        grads = [p.grad for p in args]
+        if all(g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == p.device for g, p in zip(grads, args)):
+            gout = grads
+    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, gout, *args)

@@ -405,7 +405,8 @@ int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const floa
  *                        AdaptiveAvgPool2d((1, 1)), cnn.py:14): plane1 = per-image sum of relu(y), pooled = scale plane1 / HW + shift.
  *   ag_bn_bwd_prep     : backward.  partials_dev [blocks][C][2] of ag_relu_bn_bwd_reduce -> sums_dev [C][2] = {dbeta, dgamma} and
  *                        tab_dev [C][4]: mode 0 {mean, invstd, gamma invstd, 1 / m} (coef of ag_relu_bn_bwd_dx), mode 1 {A, B, C, 0}
- *                        (bn_tab of ag_cnn_conv1_wgrad).  coef_fwd_dev = ag_bn_finalize's coef.
+ *                        (bn_tab of ag_cnn_conv1_wgrad).  coef_fwd_dev = ag_bn_finalize's coef.  dgamma_out_dev / dbeta_out_dev (NULL =
+ *                        off) [C]: the two parameter gradients also written there (e.g. straight into the optimizer's gradient buffer).
  *   ag_bn_pool_bwd_prep: backward of the last layer from dpool_dev [n][C] (gradient of the pooled features) and plane1_dev:
  *                        sums {sum_n dpool, sum_n dpool (plane1 / HW - mean) invstd}, tab (mode 0), dyp_dev [n][C] = dpool / HW
  *                        (input of ag_relu_bn_bwd_dx_plane). */
@@ -415,10 +416,11 @@ int ag_bn_finalize(const float* stats_dev, const float* weights_dev, long long n
                    float momentum, double eps, int training, float* coef_dev, float* plane1_dev, float* pooled_dev, int HW,
                    double* scratch_dev, void* stream);
 int ag_bn_bwd_prep(const float* partials_dev, long long blocks, int C, const float* coef_fwd_dev, const float* gamma_dev, double m,
-                   int mode, float* sums_dev, float* tab_dev, double* scratch_dev, void* stream);
+                   int mode, float* sums_dev, float* tab_dev, float* dgamma_out_dev, float* dbeta_out_dev, double* scratch_dev,
+                   void* stream);
 int ag_bn_pool_bwd_prep(const float* dpool_dev, const float* plane1_dev, long long n, int C, const float* coef_fwd_dev,
-                        const float* gamma_dev, double m, int HW, float* sums_dev, float* tab_dev, float* dyp_dev, double* scratch_dev,
-                        void* stream);
+                        const float* gamma_dev, double m, int HW, float* sums_dev, float* tab_dev, float* dyp_dev,
+                        float* dgamma_out_dev, float* dbeta_out_dev, double* scratch_dev, void* stream);
 
 /* Weighted per-element moments of a batch of wide rows (depth images) for the input normaliser (reference: RunningMeanStd.update,
  * running_mean_std.py:34-60, on the 'image' observation) - airgym_amd/csrc/cnn_kernels.hip.  partial_dev

@@ -150,6 +150,7 @@ def test_fused_trunk_is_the_layer_sequence(weighted):
     b = copy.deepcopy(a)
     b.fused_trunk = False
     b.hip_convs = False
+    before = copy.deepcopy(a.state_dict())
     x = torch.rand(7, 1, 212, 120, device="cuda")
     w = torch.tensor([1., 4., 2., 1., 3., 4., 1.], device="cuda") if weighted else None
     g = torch.randn(7, 12, device="cuda")
@@ -165,6 +166,18 @@ def test_fused_trunk_is_the_layer_sequence(weighted):
         assert (pa.grad - pb.grad).abs().max().item() <= 1e-3 * s + 1e-6, (name, (pa.grad - pb.grad).abs().max().item(), s)
     for (name, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-4, atol=1e-6), name
+    # direct_grads: the backward writes into pre-allocated .grad tensors instead of handing gradients to autograd
+    c = copy.deepcopy(b)
+    c.fused_trunk = c.hip_convs = True
+    c.direct_grads = True
+    c.load_state_dict(before)
+    trunk_params = [p for n_, p in c.named_parameters() if n_.startswith("features.")]
+    for p in c.parameters():
+        p.grad = torch.full_like(p, 7.0) if any(p is q for q in trunk_params) else torch.zeros_like(p)   # overwritten, not accumulated
+    c(x, w, norm).backward(g)
+    for (name, pa), (_, pc) in zip(a.named_parameters(), c.named_parameters()):
+        # (same kernels; the partial sums are added up by differently shaped torch reductions: float32 rounding only)
+        assert (pa.grad - pc.grad).abs().max().item() <= 1e-4 * pa.grad.abs().max().item() + 1e-9, name
     # eval mode (running statistics), no gradient: the rollout's path
     a.eval(), b.eval()
     with torch.no_grad():
