@@ -600,7 +600,8 @@ __global__ __launch_bounds__(768) void conv_s2_wgrad_kernel(const float* __restr
 // first layer, forward: Conv2d(1, 16, 5, stride 2, pad 2) on (212, 120) -> (16, 106, 60).  One lane per output pixel of a row
 // (60 of 64 lanes), 16 accumulators per row, two rows per wave; the 400 weights are wave-uniform (scalar loads, [tap][co]).
 // Bound: the 1.93 GB of output per 4 750 images.
-// NORM: the image normaliser of the policy (clamp((x - mean) / std, -5, 5) with per-pixel statistics, model
+// NORM: the image normaliser of the policy (clamp((x - mean) / std, -5, 5) with per-pixel statistics - the division as v_rcp_f32
+// (1 ulp) and a multiply: the IEEE division sequence was a tenth of this kernel's vector-ALU work -, model
 // a2c_continuous_logstd_model.py:106-114 / running_mean_std.py:78-79) applied while the band is staged: the kernels take the RAW
 // image and the normalised copy is never written (mean / std are 100 KB each and stay in L2).
 template <bool NORM>
@@ -644,8 +645,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             if (NORM) {
                 const int iy = 2 * band * ROWS - 2 + row;
                 if (iy >= 0 && iy < HIN) {
-                    v.x = fminf(fmaxf((v.x - vm[it].x) / vs[it].x, -5.f), 5.f);
-                    v.y = fminf(fmaxf((v.y - vm[it].y) / vs[it].y, -5.f), 5.f);
+                    v.x = fminf(fmaxf((v.x - vm[it].x) * __builtin_amdgcn_rcpf(vs[it].x), -5.f), 5.f);
+                    v.y = fminf(fmaxf((v.y - vm[it].y) * __builtin_amdgcn_rcpf(vs[it].y), -5.f), 5.f);
                 }
             }
             rowp[j + 1] = v.x;            // c = ix + 2 = 2j + 2
@@ -804,8 +805,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
             if (NORM) {
                 const int iy = 2 * oy0 - 2 + row;
                 if (iy >= 0 && iy < HIN) {
-                    v.x = fminf(fmaxf((v.x - vm[it].x) / vs[it].x, -5.f), 5.f);
-                    v.y = fminf(fmaxf((v.y - vm[it].y) / vs[it].y, -5.f), 5.f);
+                    v.x = fminf(fmaxf((v.x - vm[it].x) * __builtin_amdgcn_rcpf(vs[it].x), -5.f), 5.f);
+                    v.y = fminf(fmaxf((v.y - vm[it].y) * __builtin_amdgcn_rcpf(vs[it].y), -5.f), 5.f);
                 }
             }
             s_in[row * RS + j + 1] = v.x;
