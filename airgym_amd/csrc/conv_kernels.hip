@@ -623,6 +623,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     float2 vin[IN_IT], vm[NORM ? IN_IT : 1], vs[NORM ? IN_IT : 1];
     const __amdgpu_buffer_rsrc_t rx = buf_of(xin, HIN * WIN * 4);
     const __amdgpu_buffer_rsrc_t rm = buf_of(NORM ? nmean : x, HIN * WIN * 4), rs = buf_of(NORM ? nstd : x, HIN * WIN * 4);
+    const __amdgpu_buffer_rsrc_t ry = buf_of(y + (size_t)n * 16 * HO * WO, 16 * HO * WO * 4);
     auto fetch = [&](int band) {
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
@@ -686,9 +687,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int r = 0; r < 2; ++r) {
                 const int oy = band * ROWS + 2 * wave + r;
                 if (oy >= HO) continue;
+                const unsigned yoff = (unsigned)((oy * WO + lane) * 4);
 #pragma unroll
                 for (int co = 0; co < 16; ++co) {
-                    y[(((size_t)n * 16 + co) * HO + oy) * WO + lane] = acc[r][co];
+                    // buffer store: one per-lane offset for the row, the channel plane as a scalar offset - no address arithmetic
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r][co]), ry, yoff, co * (HO * WO * 4), 0);
                     const float rl = fmaxf(acc[r][co], 0.f);
                     ssum[co] += rl;
                     ssq[co] = fmaf(rl, rl, ssq[co]);
