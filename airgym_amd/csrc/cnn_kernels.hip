@@ -449,6 +449,40 @@ __global__ __launch_bounds__(256) void wide_moments_kernel(const float* __restri
     partial[((size_t)chunk * 2 + 1) * D + col] = q;
 }
 
+// Border sums of a gradient tensor dz [planes][H][W]: out[plane] = {sum of row 0, sum of row H-1, sum of column 0, dz[0][0], dz[H-1][0]}.
+// Why: the two reductions of a ReLU + BatchNorm backward (sum dy, sum dy * xhat over all pixels) need no pass over dy when the layer
+// feeds a convolution: with y = the BatchNorm output (the convolution's zero-padded input), dy = conv^T(dz) and dw = the weight gradient,
+//     sum_p dy[ci,p] y[ci,p] = sum_{co,tap} w[co,ci,tap] dw[co,ci,tap]        (both sides are the same bilinear form)
+//     sum_p dy[ci,p]         = sum_{co,tap} w[co,ci,tap] S[co,tap],   S[co,tap] = sum of dz[co] over the output pixels whose tap lies
+//                                                                       inside the image = total minus these border sums
+// and xhat = (y - beta) / gamma.  One wave per plane; reads 2 rows + 1 column.
+__global__ __launch_bounds__(256) void plane_border_sums_kernel(const float* __restrict__ dz, float* __restrict__ out, long long planes,
+                                                                int H, int W) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long p0 = (long long)blockIdx.x * kPlanesPerBlock;
+    for (int k = wave; k < kPlanesPerBlock; k += 4) {
+        const long long p = p0 + k;
+        if (p >= planes) break;
+        const float* z = dz + p * H * W;
+        float r0 = 0.f, rl = 0.f, c0 = 0.f;
+        for (int ox = lane; ox < W; ox += 64) {
+            r0 += z[ox];
+            rl += z[(size_t)(H - 1) * W + ox];
+        }
+        for (int oy = lane; oy < H; oy += 64) c0 += z[(size_t)oy * W];
+        r0 = wave_sum(r0);
+        rl = wave_sum(rl);
+        c0 = wave_sum(c0);
+        if (lane == 0) {
+            out[p * 5 + 0] = r0;
+            out[p * 5 + 1] = rl;
+            out[p * 5 + 2] = c0;
+            out[p * 5 + 3] = z[0];
+            out[p * 5 + 4] = z[(size_t)(H - 1) * W];
+        }
+    }
+}
+
 int vec_width(const void* a, const void* b, const void* c, int HW) {
     const uintptr_t bits = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
     if ((HW & 3) == 0 && (bits & 15) == 0) return 4;
@@ -591,5 +625,12 @@ extern "C" int ag_weighted_moments(const float* x_dev, const long long* index_de
     if ((D + 255) / 256 > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(wide_moments_kernel, dim3((unsigned)((D + 255) / 256), kMomentChunks), dim3(256), 0, (hipStream_t)stream, x_dev,
                        index_dev, weights_dev, rows, D, partial_dev);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_plane_border_sums(const float* dz_dev, float* out_dev, int N, int C, int H, int W, void* stream) {
+    if (!dz_dev || !out_dev || H <= 0 || W <= 0) return AG_ERR_INVALID_ARG;
+    AG_BN_CHECK(N, C, H * W);
+    hipLaunchKernelGGL(plane_border_sums_kernel, grid, block, 0, (hipStream_t)stream, dz_dev, out_dev, planes, H, W);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }

@@ -168,9 +168,56 @@ def _bn_reduce(lib, dy, x, coef, gamma, m, mode, gout=(None, None)):
     return sums, tab
 
 
+def bn_sums_from_conv(w, dw, total, border, gamma, beta, hin):
+    """The two reductions of a ReLU + BatchNorm backward - (dbeta, dgamma) = (sum dy, sum dy xhat) over images and pixels, [C, 2] -
+    WITHOUT a pass over dy, for a layer whose output y feeds a 3x3 / stride-2 / pad-1 convolution with weights w [co, C, 3, 3]:
+    with dz the convolution's output gradient, dy = conv^T(dz) and dw its weight gradient,
+        sum_p dy[c,p] y[c,p] = sum_{co,tap} w[co,c,tap] dw[co,c,tap]                (both are the same bilinear form in (dz, y))
+        sum_p dy[c,p]        = sum_{co,tap} w[co,c,tap] S[co,tap]
+    where S[co,tap] sums dz[co] over the output pixels whose tap lies inside the (unpadded) input: the plane total minus border rows /
+    columns - total [co] = sum dz, border [co, 5] = (row 0, last row, column 0, dz[0][0], dz[last][0]) sums (ag_plane_border_sums).
+    xhat = (y - beta) / gamma, so dgamma = (sum dy y - beta sum dy) / gamma; gamma = 0 (y constant: xhat is not recoverable) is
+    clamped away from zero - callers that can meet it use the reduction kernel instead (`CNNFeatureExtractor.bn_sums_from_weights`)."""
+    w64, dw64 = w.detach().double(), dw.detach().double()
+    t, b = total.double(), border.double()
+    last_row_out = (hin % 2 == 1)           # tap ky = 2 of the last output row reads row hin (padding) iff hin is odd
+    S = t.view(-1, 1, 1).repeat(1, 3, 3)
+    S[:, 0, :] -= b[:, 0:1]                  # ky = 0: output row 0 reads input row -1
+    S[:, :, 0] -= b[:, 2:3]                  # kx = 0: output column 0 reads input column -1
+    S[:, 0, 0] += b[:, 3]
+    if last_row_out:
+        S[:, 2, :] -= b[:, 1:2]
+        S[:, 2, 0] += b[:, 4]
+    sum_dy_y = (w64 * dw64).sum((0, 2, 3))
+    sum_dy = torch.einsum("ockl,okl->c", w64, S)
+    g = gamma.detach().double()
+    g = torch.where(g.abs() < 1e-30, torch.full_like(g, 1e-30), g)
+    return torch.stack((sum_dy, (sum_dy_y - beta.detach().double() * sum_dy) / g), dim=1)
+
+
+def _bn_prep_from_sums(lib, sums64, coef, gamma, m, mode, gout=(None, None)):
+    """(sums [C, 2] float32, tab [C, 4]) from already reduced (dbeta, dgamma) (ag_bn_bwd_prep on a single partial row)."""
+    c = sums64.shape[0]
+    part = sums64.float().contiguous()
+    sums = torch.empty(c, 2, dtype=torch.float32, device=part.device)
+    tab = torch.empty(c, 4, dtype=torch.float32, device=part.device)
+    scratch = torch.empty(lib.ag_bn_scratch_doubles(), dtype=torch.float64, device=part.device)
+    N.check(lib.ag_bn_bwd_prep(part.data_ptr(), 1, c, coef.data_ptr(), gamma.data_ptr(), float(m), mode, sums.data_ptr(), tab.data_ptr(),
+                               _gptr(gout[0]), _gptr(gout[1]), scratch.data_ptr(), _stream(part)), "ag_bn_bwd_prep")
+    return sums, tab
+
+
+def _border_sums(lib, dz):
+    """[C, 5]: over all images, the sums of row 0, the last row, column 0 and the two left corners of dz [n, C, H, W]."""
+    n, c, h, w = dz.shape
+    out = torch.empty(n, c, 5, dtype=torch.float32, device=dz.device)
+    N.check(lib.ag_plane_border_sums(dz.data_ptr(), out.data_ptr(), n, c, h, w, _stream(dz)), "ag_plane_border_sums")
+    return out.sum(0, dtype=torch.float64)
+
+
 class _Trunk(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, weights, bns, training, norm, index, gout, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
+    def forward(ctx, img, weights, bns, training, norm, index, gout, from_weights, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
         lib = N.load()
         img = img.contiguous()
         if index is not None:
@@ -197,13 +244,14 @@ class _Trunk(torch.autograd.Function):
         ctx.norm = norm
         ctx.index = index
         ctx.gout = gout
+        ctx.from_weights = from_weights
         ctx.save_for_backward(img, x1, x2, x3, plane1, weights if weights is not None else img.new_empty(0), w2, w3, g1, g2, g3,
-                              coef1, coef2, coef3)
+                              coef1, coef2, coef3, be1, be2)
         return pooled
 
     @staticmethod
     def backward(ctx, dpool):
-        img, x1, x2, x3, plane1, weights, w2, w3, g1, g2, g3, coef1, coef2, coef3 = ctx.saved_tensors
+        img, x1, x2, x3, plane1, weights, w2, w3, g1, g2, g3, coef1, coef2, coef3, be1, be2 = ctx.saved_tensors
         lib = N.load()
         weights = weights if ctx.has_weights else None
         n = x1.shape[0]
@@ -226,35 +274,48 @@ class _Trunk(torch.autograd.Function):
         ps3 = torch.empty(n, 64, dtype=torch.float32, device=dev)          # per-plane sums of dx3: db3 = their sum over images
         N.check(lib.ag_relu_bn_bwd_dx_plane(dyp.data_ptr(), x3.data_ptr(), tab3.data_ptr(), sums3.data_ptr(), _wptr(weights),
                                             dx3.data_ptr(), ps3.data_ptr(), n, 64, _HW[2], _stream(img)), "ag_relu_bn_bwd_dx_plane")
+        fw = ctx.from_weights       # the ReLU + BatchNorm reductions from the next convolution's (w, dw) instead of a pass over dy
+        border3 = _border_sums(lib, dx3) if fw else None
         dw3 = _conv_wgrad(lib, dx3, x2, coef2, 64, G(8))
         db3 = torch.sum(ps3, 0, out=G(9)) if go is not None else ps3.sum(0)
+        if fw:
+            s2 = bn_sums_from_conv(w3, G(8) if go is not None else dw3, db3, border3, g2, be2, 53)
+            sums2, tab2 = _bn_prep_from_sums(lib, s2, coef2, g2, m2, 0, (G(6), G(7)))
         dy2 = _conv_dgrad(lib, dx3, w3, x2)
         del dx3
         # layer 2: dx2 written over dy2
-        sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0, (G(6), G(7)))
+        if not fw:
+            sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0, (G(6), G(7)))
         ps2 = torch.empty(n, 32, dtype=torch.float32, device=dev)
         N.check(lib.ag_relu_bn_bwd_dx_weighted(dy2.data_ptr(), x2.data_ptr(), tab2.data_ptr(), sums2.data_ptr(), _wptr(weights),
                                                dy2.data_ptr(), ps2.data_ptr(), n, 32, _HW[1], _stream(img)), "ag_relu_bn_bwd_dx")
+        border2 = _border_sums(lib, dy2) if fw else None
         dw2 = _conv_wgrad(lib, dy2, x1, coef1, 32, G(4))
         db2 = torch.sum(ps2, 0, out=G(5)) if go is not None else ps2.sum(0)
+        if fw:
+            s1 = bn_sums_from_conv(w2, G(4) if go is not None else dw2, db2, border2, g1, be1, 106)
+            sums1, tab1 = _bn_prep_from_sums(lib, s1, coef1, g1, m1, 1, (G(2), G(3)))
         dy1 = _conv_dgrad(lib, dy2, w2, x1)
         del dy2
         # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)
-        sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1, (G(2), G(3)))
+        if not fw:
+            sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1, (G(2), G(3)))
         dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.index, ctx.norm, (G(0), G(1)) if go is not None else None)
         if go is not None:
-            return (None,) * 19
-        return (None, None, None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
+            return (None,) * 20
+        return (None, None, None, None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
                 sums3[:, 1], sums3[:, 0])
 
 
-def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False):
+def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, sums_from_weights=True):
     """`features(x)` flattened to [N, 64] (the caller has checked `usable(x, features)`): batch statistics when the BatchNorm
     layers are in training mode (all three must agree), running statistics otherwise.  norm = (mean, std) (optional, per-pixel
     [212 * 120]): x is the RAW image and the first convolution normalises it, clamp((x - mean) / std, -5, 5), while staging.
     index (optional, int64 [N]): the batch is x[index] - read in place, e.g. out of the rollout's frame store.
     direct_grads: the backward OVERWRITES the parameters' existing .grad tensors instead of handing gradients to autograd for
-    accumulation (the caller zeroes its gradient buffer before every backward and the trunk is applied once per backward)."""
+    accumulation (the caller zeroes its gradient buffer before every backward and the trunk is applied once per backward).
+    sums_from_weights: the backward takes the reductions of the first two ReLU + BatchNorm layers from the following convolution's
+    weights and weight gradient (`bn_sums_from_conv`: no pass over the 1.9 GB / 1.0 GB gradients); False = the reduction kernel."""
     layers = list(features)
     convs, bns = (layers[0], layers[3], layers[6]), (layers[2], layers[5], layers[8])
     training = bns[0].training
@@ -271,4 +332,4 @@ def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False):
         grads = [p.grad for p in args]
         if all(g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == p.device for g, p in zip(grads, args)):
             gout = grads
-    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, gout, *args)
+    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, gout, bool(sums_from_weights), *args)

@@ -410,6 +410,11 @@ int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const floa
  *   ag_bn_pool_bwd_prep: backward of the last layer from dpool_dev [n][C] (gradient of the pooled features) and plane1_dev:
  *                        sums {sum_n dpool, sum_n dpool (plane1 / HW - mean) invstd}, tab (mode 0), dyp_dev [n][C] = dpool / HW
  *                        (input of ag_relu_bn_bwd_dx_plane). */
+/*   ag_plane_border_sums: out_dev [N * C][5] = per plane of dz_dev [N,C,H,W] {sum of row 0, sum of row H-1, sum of column 0, dz[0][0],
+ *                        dz[H-1][0]}.  With them (and the plane totals of ag_relu_bn_bwd_dx*) the two reductions of the ReLU + BatchNorm
+ *                        backward of the layer in FRONT of a convolution follow from that convolution's weights and weight gradient
+ *                        (sum dy y = sum w dw, sum dy = sum w S; airgym_amd/lib/network/fused_cnn.py) - no pass over dy. */
+int ag_plane_border_sums(const float* dz_dev, float* out_dev, int N, int C, int H, int W, void* stream);
 long long ag_bn_scratch_doubles(void);      /* scratch_dev: this many doubles (stage-1 partial sums), reusable between calls on a stream */
 int ag_bn_finalize(const float* stats_dev, const float* weights_dev, long long n, int G, int C, double m, const float* gamma_dev,
                    const float* beta_dev, float* running_mean_dev, float* running_var_dev, long long* num_batches_dev,
