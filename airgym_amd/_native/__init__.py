@@ -189,6 +189,7 @@ SYMBOLS = [
     ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_dx_plane", ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_plane_border_sums", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_bn_sums_from_conv", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     ("ag_bn_scratch_doubles", ctypes.c_longlong, []),
     ("ag_bn_finalize", ctypes.c_int, [_P, _P, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_double, _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_double, ctypes.c_int, _P, _P, _P, ctypes.c_int, _P, _P]),
     ("ag_bn_bwd_prep", ctypes.c_int, [_P, ctypes.c_longlong, ctypes.c_int, _P, _P, ctypes.c_double, ctypes.c_int, _P, _P, _P, _P, _P, _P]),

@@ -483,6 +483,68 @@ __global__ __launch_bounds__(256) void plane_border_sums_kernel(const float* __r
     }
 }
 
+// The identities above in one workgroup: from total [CO] (sum of dz per output channel = the convolution's bias gradient) and border
+// [CO][5] (plane_border_sums_kernel's rows summed over the images) S[co][tap] is formed, and for every input channel c
+//     part[c] = { sum_dy = sum_{co,tap} w S,   (sum_{co,tap} w dw - beta[c] sum_dy) / gamma[c] }     (float64 accumulation)
+// which is what ag_relu_bn_bwd_reduce + the column sums would have produced for the ReLU + BatchNorm in front of the convolution.
+__global__ __launch_bounds__(kSmallThreads) void bn_sums_from_conv_kernel(const float* __restrict__ w, const float* __restrict__ dw,
+                                                                         const float* __restrict__ total,
+                                                                         const float* __restrict__ border, int CO, int C,
+                                                                         int last_row_out, const float* __restrict__ gamma,
+                                                                         const float* __restrict__ beta, float* __restrict__ part) {
+    __shared__ double s_b[64][6];            // per output channel: total, row 0, last row, column 0, corner (0,0), corner (last,0)
+    __shared__ double s_S[64][9];
+    __shared__ double s_acc[kSmallThreads][2];
+    const int t = threadIdx.x;
+    if (t < CO * 6) {
+        const int co = t / 6, k = t - co * 6;
+        s_b[co][k] = (double)(k == 0 ? total[co] : border[co * 5 + (k - 1)]);
+    }
+    __syncthreads();
+    if (t < CO * 9) {
+        const int co = t / 9, tap = t - co * 9, ky = tap / 3, kx = tap - ky * 3;
+        double v = s_b[co][0];
+        if (ky == 0) v -= s_b[co][1];
+        if (kx == 0) v -= s_b[co][3];
+        if (ky == 0 && kx == 0) v += s_b[co][4];
+        if (last_row_out && ky == 2) {
+            v -= s_b[co][2];
+            if (kx == 0) v += s_b[co][5];
+        }
+        s_S[co][tap] = v;
+    }
+    __syncthreads();
+    // stage 2: thread = (c, stripe over co)
+    const int stripes = kSmallThreads / C, c = t % C, stripe = t / C;
+    double a0 = 0.0, a1 = 0.0;
+    if (stripe < stripes) {
+        for (int co = stripe; co < CO; co += stripes) {
+            const float* wp = w + ((size_t)co * C + c) * 9;
+            const float* dp = dw + ((size_t)co * C + c) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const double wv = (double)wp[tap];
+                a0 += wv * s_S[co][tap];
+                a1 += wv * (double)dp[tap];
+            }
+        }
+    }
+    s_acc[t][0] = a0;
+    s_acc[t][1] = a1;
+    __syncthreads();
+    if (t < C) {
+        double sd = 0.0, sy = 0.0;
+        for (int k = 0; k < stripes; ++k) {
+            sd += s_acc[k * C + t][0];
+            sy += s_acc[k * C + t][1];
+        }
+        double g = (double)gamma[t];
+        if (g > -1e-30 && g < 1e-30) g = 1e-30;
+        part[2 * t] = (float)sd;
+        part[2 * t + 1] = (float)((sy - (double)beta[t] * sd) / g);
+    }
+}
+
 int vec_width(const void* a, const void* b, const void* c, int HW) {
     const uintptr_t bits = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
     if ((HW & 3) == 0 && (bits & 15) == 0) return 4;
@@ -632,5 +694,14 @@ extern "C" int ag_plane_border_sums(const float* dz_dev, float* out_dev, int N, 
     if (!dz_dev || !out_dev || H <= 0 || W <= 0) return AG_ERR_INVALID_ARG;
     AG_BN_CHECK(N, C, H * W);
     hipLaunchKernelGGL(plane_border_sums_kernel, grid, block, 0, (hipStream_t)stream, dz_dev, out_dev, planes, H, W);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_bn_sums_from_conv(const float* w_dev, const float* dw_dev, const float* total_dev, const float* border_dev, int cout,
+                                    int cin, int hin, const float* gamma_dev, const float* beta_dev, float* part_dev, void* stream) {
+    if (!w_dev || !dw_dev || !total_dev || !border_dev || !gamma_dev || !beta_dev || !part_dev || hin <= 0) return AG_ERR_INVALID_ARG;
+    if (cout <= 0 || cout > 64 || cin <= 0 || cin > 64) return AG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_sums_from_conv_kernel, dim3(1), dim3(kSmallThreads), 0, (hipStream_t)stream, w_dev, dw_dev, total_dev, border_dev,
+                       cout, cin, hin & 1, gamma_dev, beta_dev, part_dev);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }

@@ -195,24 +195,28 @@ def bn_sums_from_conv(w, dw, total, border, gamma, beta, hin):
     return torch.stack((sum_dy, (sum_dy_y - beta.detach().double() * sum_dy) / g), dim=1)
 
 
-def _bn_prep_from_sums(lib, sums64, coef, gamma, m, mode, gout=(None, None)):
-    """(sums [C, 2] float32, tab [C, 4]) from already reduced (dbeta, dgamma) (ag_bn_bwd_prep on a single partial row)."""
-    c = sums64.shape[0]
-    part = sums64.float().contiguous()
-    sums = torch.empty(c, 2, dtype=torch.float32, device=part.device)
-    tab = torch.empty(c, 4, dtype=torch.float32, device=part.device)
-    scratch = torch.empty(lib.ag_bn_scratch_doubles(), dtype=torch.float64, device=part.device)
-    N.check(lib.ag_bn_bwd_prep(part.data_ptr(), 1, c, coef.data_ptr(), gamma.data_ptr(), float(m), mode, sums.data_ptr(), tab.data_ptr(),
-                               _gptr(gout[0]), _gptr(gout[1]), scratch.data_ptr(), _stream(part)), "ag_bn_bwd_prep")
-    return sums, tab
-
-
 def _border_sums(lib, dz):
     """[C, 5]: over all images, the sums of row 0, the last row, column 0 and the two left corners of dz [n, C, H, W]."""
     n, c, h, w = dz.shape
     out = torch.empty(n, c, 5, dtype=torch.float32, device=dz.device)
     N.check(lib.ag_plane_border_sums(dz.data_ptr(), out.data_ptr(), n, c, h, w, _stream(dz)), "ag_plane_border_sums")
-    return out.sum(0, dtype=torch.float64)
+    return out.sum(0)
+
+
+def _bn_prep_from_conv(lib, w, dw, total, border, coef, gamma, beta, hin, m, mode, gout=(None, None)):
+    """(sums [C, 2], tab [C, 4]) of the ReLU + BatchNorm in front of a convolution from that convolution's weights w, weight
+    gradient dw, the total [cout] (= its bias gradient) and border sums [cout, 5] of its output gradient: `bn_sums_from_conv` as one
+    launch (ag_bn_sums_from_conv), then ag_bn_bwd_prep on the single row."""
+    cout, c = w.shape[0], w.shape[1]
+    part = torch.empty(1, c, 2, dtype=torch.float32, device=w.device)
+    N.check(lib.ag_bn_sums_from_conv(w.data_ptr(), dw.data_ptr(), total.data_ptr(), border.data_ptr(), cout, c, hin, gamma.data_ptr(),
+                                     beta.data_ptr(), part.data_ptr(), _stream(w)), "ag_bn_sums_from_conv")
+    sums = torch.empty(c, 2, dtype=torch.float32, device=w.device)
+    tab = torch.empty(c, 4, dtype=torch.float32, device=w.device)
+    scratch = torch.empty(lib.ag_bn_scratch_doubles(), dtype=torch.float64, device=w.device)
+    N.check(lib.ag_bn_bwd_prep(part.data_ptr(), 1, c, coef.data_ptr(), gamma.data_ptr(), float(m), mode, sums.data_ptr(), tab.data_ptr(),
+                               _gptr(gout[0]), _gptr(gout[1]), scratch.data_ptr(), _stream(w)), "ag_bn_bwd_prep")
+    return sums, tab
 
 
 class _Trunk(torch.autograd.Function):
@@ -279,8 +283,8 @@ class _Trunk(torch.autograd.Function):
         dw3 = _conv_wgrad(lib, dx3, x2, coef2, 64, G(8))
         db3 = torch.sum(ps3, 0, out=G(9)) if go is not None else ps3.sum(0)
         if fw:
-            s2 = bn_sums_from_conv(w3, G(8) if go is not None else dw3, db3, border3, g2, be2, 53)
-            sums2, tab2 = _bn_prep_from_sums(lib, s2, coef2, g2, m2, 0, (G(6), G(7)))
+            sums2, tab2 = _bn_prep_from_conv(lib, w3, (G(8) if go is not None else dw3).contiguous(), db3.contiguous(), border3, coef2, g2, be2, 53, m2,
+                                             0, (G(6), G(7)))
         dy2 = _conv_dgrad(lib, dx3, w3, x2)
         del dx3
         # layer 2: dx2 written over dy2
@@ -293,8 +297,8 @@ class _Trunk(torch.autograd.Function):
         dw2 = _conv_wgrad(lib, dy2, x1, coef1, 32, G(4))
         db2 = torch.sum(ps2, 0, out=G(5)) if go is not None else ps2.sum(0)
         if fw:
-            s1 = bn_sums_from_conv(w2, G(4) if go is not None else dw2, db2, border2, g1, be1, 106)
-            sums1, tab1 = _bn_prep_from_sums(lib, s1, coef1, g1, m1, 1, (G(2), G(3)))
+            sums1, tab1 = _bn_prep_from_conv(lib, w2, (G(4) if go is not None else dw2).contiguous(), db2.contiguous(), border2, coef1, g1, be1, 106, m1,
+                                             1, (G(2), G(3)))
         dy1 = _conv_dgrad(lib, dy2, w2, x1)
         del dy2
         # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)

@@ -415,6 +415,13 @@ int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const floa
  *                        backward of the layer in FRONT of a convolution follow from that convolution's weights and weight gradient
  *                        (sum dy y = sum w dw, sum dy = sum w S; airgym_amd/lib/network/fused_cnn.py) - no pass over dy. */
 int ag_plane_border_sums(const float* dz_dev, float* out_dev, int N, int C, int H, int W, void* stream);
+/*   ag_bn_sums_from_conv: those identities in one launch.  w_dev / dw_dev [cout][cin][3][3] of the 3x3 / stride-2 / pad-1 convolution
+ *                        BEHIND the ReLU + BatchNorm (input height hin), total_dev [cout] = sum of its output gradient per channel (its
+ *                        bias gradient), border_dev [cout][5] = ag_plane_border_sums' rows summed over the images, gamma / beta [cin]
+ *                        of the BatchNorm: part_dev [cin][2] = {sum dy, sum dy xhat} - one "partial" row for ag_bn_bwd_prep (blocks = 1).
+ *                        gamma = 0 is clamped to 1e-30 (xhat is not recoverable from a constant y: use ag_relu_bn_bwd_reduce there). */
+int ag_bn_sums_from_conv(const float* w_dev, const float* dw_dev, const float* total_dev, const float* border_dev, int cout, int cin,
+                         int hin, const float* gamma_dev, const float* beta_dev, float* part_dev, void* stream);
 long long ag_bn_scratch_doubles(void);      /* scratch_dev: this many doubles (stage-1 partial sums), reusable between calls on a stream */
 int ag_bn_finalize(const float* stats_dev, const float* weights_dev, long long n, int G, int C, double m, const float* gamma_dev,
                    const float* beta_dev, float* running_mean_dev, float* running_var_dev, long long* num_batches_dev,

@@ -201,3 +201,27 @@ def test_weighted_indexed_moments_match_the_expanded_batch():
     assert float(a.count) == float(b.count)
     assert torch.allclose(a.running_mean, b.running_mean, rtol=0, atol=1e-9)
     assert torch.allclose(a.running_var, b.running_var, rtol=1e-9, atol=1e-12)
+
+
+def test_reductions_from_weights_equal_the_reduction_kernel():
+    """The trunk's backward with the ReLU + BatchNorm reductions taken from the next convolution's (w, dw) (ag_bn_sums_from_conv,
+    default) against the same trunk with ag_relu_bn_bwd_reduce passes over the gradients: every parameter gradient."""
+    import copy
+    from airgym_amd.lib.network.cnn import CNNFeatureExtractor
+    torch.manual_seed(3)
+    a = CNNFeatureExtractor(12).cuda().train()
+    with torch.no_grad():
+        for mod in a.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_()
+    b = copy.deepcopy(a)
+    b.bn_sums_from_weights = False
+    x = torch.rand(9, 1, 212, 120, device="cuda") * 3.0
+    w = torch.tensor([1., 4., 2., 1., 3., 4., 1., 2., 2.], device="cuda")
+    g = torch.randn(9, 12, device="cuda")
+    a(x, w).backward(g)
+    b(x, w).backward(g)
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        s = pb.grad.abs().max().item()
+        assert (pa.grad - pb.grad).abs().max().item() <= 2e-4 * s + 1e-8, (name, (pa.grad - pb.grad).abs().max().item(), s)

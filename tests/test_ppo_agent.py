@@ -483,3 +483,29 @@ def test_cnn_forward_index_norm_and_weights_on_cpu():
     full.backward(g[[0, 0, 0, 1, 2, 2]] / weights[[0, 0, 0, 1, 2, 2]].view(-1, 1))
     for (name, a), (_, b) in zip(cnn.named_parameters(), ref.named_parameters()):
         assert torch.allclose(a.grad, b.grad, atol=1e-9), name
+
+
+def test_batchnorm_backward_reductions_from_the_next_convolution():
+    """fused_cnn.bn_sums_from_conv: (sum dy, sum dy xhat) of a ReLU + BatchNorm whose output feeds a 3x3 / stride-2 / pad-1 convolution,
+    from that convolution's weights, weight gradient and border sums of its output gradient - against the sums over dy itself
+    (float64: an identity, not an approximation), for an odd and an even input height."""
+    import torch.nn.functional as F
+    from airgym_amd.lib.network.fused_cnn import bn_sums_from_conv
+    torch.manual_seed(0)
+    for hin, win in ((13, 8), (10, 6)):
+        n, c, co = 3, 4, 5
+        x = torch.randn(n, c, hin, win, dtype=torch.float64)
+        gamma, beta = torch.rand(c, dtype=torch.float64) + 0.5, torch.randn(c, dtype=torch.float64)
+        r = torch.relu(x)
+        mean, var = r.mean((0, 2, 3)), r.var((0, 2, 3), unbiased=False)
+        xhat = (r - mean.view(1, -1, 1, 1)) * (var + 1e-5).rsqrt().view(1, -1, 1, 1)
+        y = (xhat * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)).requires_grad_(True)
+        w = torch.randn(co, c, 3, 3, dtype=torch.float64, requires_grad=True)
+        z = F.conv2d(y, w, None, stride=2, padding=1)
+        dz = torch.randn_like(z)
+        z.backward(dz)
+        ref = torch.stack((y.grad.sum((0, 2, 3)), (y.grad * xhat).sum((0, 2, 3))), 1)
+        border = torch.stack((dz[:, :, 0, :].sum((0, 2)), dz[:, :, -1, :].sum((0, 2)), dz[:, :, :, 0].sum((0, 2)),
+                              dz[:, :, 0, 0].sum(0), dz[:, :, -1, 0].sum(0)), 1)
+        got = bn_sums_from_conv(w, w.grad, dz.sum((0, 2, 3)), border, gamma, beta, hin)
+        assert torch.allclose(got, ref, rtol=1e-11, atol=1e-11), (hin, (got - ref).abs().max())
