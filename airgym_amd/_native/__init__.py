@@ -186,8 +186,8 @@ SYMBOLS = [
     ("ag_relu_bn_bwd_reduce", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_bwd_dx", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_stats_weighted", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
-    ("ag_relu_bn_bwd_dx_plane", ctypes.c_int, [_P] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_relu_bn_bwd_dx_weighted", ctypes.c_int, [_P] * 8 + [ctypes.c_int] * 4 + [_P]),
+    ("ag_relu_bn_bwd_dx_plane", ctypes.c_int, [_P] * 8 + [ctypes.c_int] * 4 + [_P]),
     ("ag_plane_border_sums", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_bn_sums_from_conv", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P, _P, _P]),
     ("ag_bn_scratch_doubles", ctypes.c_longlong, []),

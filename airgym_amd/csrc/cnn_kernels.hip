@@ -163,15 +163,29 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_reduce_kernel(const float* __
 // coef [C][4] = {mean, invstd, gamma * invstd, 1 / m} ; sums [C][2] = {dbeta, dgamma}
 // With multiplicities (`wts`, see relu_bn_stats_kernel) dy is the gradient SUMMED over the copies of an image and the two mean
 // terms, which every copy receives, are scaled by the image's multiplicity: dx_i = [x > 0] g (dy_i - m_i db / m - m_i xhat dg / m).
+// border bookkeeping of a value at element index idx of an [H][W] plane (see plane_border_sums_kernel): b = {row 0, last row, column 0,
+// (0,0), (H-1,0)}.  (idx + 0.5) / W in float is exact for the plane sizes here (idx < 2^16, W >= 2).
+__device__ __forceinline__ void border_add(float (&b)[5], float v, int idx, int H, int W, float inv_w) {
+    const int oy = (int)(((float)idx + 0.5f) * inv_w), ox = idx - oy * W;
+    b[0] += oy == 0 ? v : 0.f;
+    b[1] += oy == H - 1 ? v : 0.f;
+    b[2] += ox == 0 ? v : 0.f;
+    b[3] += idx == 0 ? v : 0.f;
+    b[4] += idx == (H - 1) * W ? v : 0.f;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ coef, const float* __restrict__ sums,
                                                              const float* __restrict__ wts, float* __restrict__ dx,
-                                                             float* __restrict__ psum, long long planes, int C, int HW) {
+                                                             float* __restrict__ psum, float* __restrict__ bsum, int W,
+                                                             long long planes, int C, int HW) {
     typedef typename VecT<VEC>::type vec_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long p0 = (long long)blockIdx.x * kPlanesPerBlock;
     const int nvec = HW / VEC;
+    const int H = bsum ? HW / W : 0;
+    const float inv_w = bsum ? 1.0f / (float)W : 0.f;
     for (int k = wave; k < kPlanesPerBlock; k += 4) {
         const long long p = p0 + k;
         if (p >= planes) break;
@@ -180,6 +194,7 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __rest
         const float rm = coef[c * 4 + 3] * (wts ? wts[p / C] : 1.0f);
         const float db = sums[c * 2 + 0] * rm, dg = sums[c * 2 + 1] * rm;
         float ps = 0.0f;                                    // sum of dx over the plane: the bias gradient of the convolution behind x
+        float bs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};            // and its border sums (bsum)
         const vec_t* gx = reinterpret_cast<const vec_t*>(x + p * HW);
         const vec_t* gd = reinterpret_cast<const vec_t*>(dy + p * HW);
         vec_t* out = reinterpret_cast<vec_t*>(dx + p * HW);
@@ -195,12 +210,20 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __rest
                 const float dr = gi * (g[e] - db - xhat * dg);
                 g[e] = f[e] > 0.0f ? dr : 0.0f;              // ReLU' at 0 is 0, as torch's threshold_backward
                 ps += g[e];
+                if (bsum) border_add(bs, g[e], i * VEC + e, H, W, inv_w);
             }
             out[i] = d;
         }
         if (psum) {
             ps = wave_sum(ps);
             if (lane == 0) psum[p] = ps;
+        }
+        if (bsum) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float t = wave_sum(bs[j]);
+                if (lane == 0) bsum[p * 5 + j] = t;
+            }
         }
     }
 }
@@ -214,11 +237,14 @@ template <int VEC>
 __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* __restrict__ dyp, const float* __restrict__ x,
                                                                    const float* __restrict__ coef, const float* __restrict__ sums,
                                                                    const float* __restrict__ wts, float* __restrict__ dx,
-                                                                   float* __restrict__ psum, long long planes, int C, int HW) {
+                                                                   float* __restrict__ psum, float* __restrict__ bsum, int W,
+                                                                   long long planes, int C, int HW) {
     typedef typename VecT<VEC>::type vec_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long p0 = (long long)blockIdx.x * kPlanesPerBlock;
     const int nvec = HW / VEC;
+    const int H = bsum ? HW / W : 0;
+    const float inv_w = bsum ? 1.0f / (float)W : 0.f;
     for (int k = wave; k < kPlanesPerBlock; k += 4) {
         const long long p = p0 + k;
         if (p >= planes) break;
@@ -230,6 +256,7 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* 
         const vec_t* gx = reinterpret_cast<const vec_t*>(x + p * HW);
         vec_t* out = reinterpret_cast<vec_t*>(dx + p * HW);
         float ps = 0.0f;
+        float bs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
         for (int i = lane; i < nvec; i += 64) {
             vec_t v = gx[i];
@@ -239,12 +266,20 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* 
                 const float xhat = (fmaxf(f[e], 0.0f) - mu) * is;
                 f[e] = f[e] > 0.0f ? gi * (d0 - xhat * dg) : 0.0f;
                 ps += f[e];
+                if (bsum) border_add(bs, f[e], i * VEC + e, H, W, inv_w);
             }
             out[i] = v;
         }
         if (psum) {
             ps = wave_sum(ps);
             if (lane == 0) psum[p] = ps;
+        }
+        if (bsum) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float t = wave_sum(bs[j]);
+                if (lane == 0) bsum[p * 5 + j] = t;
+            }
         }
     }
 }
@@ -603,28 +638,31 @@ extern "C" int ag_relu_bn_bwd_reduce(const float* dy_dev, const float* x_dev, co
 }
 
 extern "C" int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
-                                          const float* weights_dev, float* dx_dev, float* plane_sums_dev, int N, int C, int HW,
-                                          void* stream) {
-    if (!dy_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev) return AG_ERR_INVALID_ARG;
+                                          const float* weights_dev, float* dx_dev, float* plane_sums_dev, float* border_sums_dev,
+                                          int W, int N, int C, int HW, void* stream) {
+    if (!dy_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev || (border_sums_dev && (W <= 1 || HW % W != 0 || HW >= 65536)))
+        return AG_ERR_INVALID_ARG;
     AG_BN_CHECK(N, C, HW);
     const int w = vec_width(x_dev, dy_dev, dx_dev, HW);
-    AG_BN_DISPATCH(relu_bn_bwd_dx_kernel, w, dy_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, plane_sums_dev, planes, C, HW);
+    AG_BN_DISPATCH(relu_bn_bwd_dx_kernel, w, dy_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, plane_sums_dev, border_sums_dev, W,
+                   planes, C, HW);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
 extern "C" int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                                  float* dx_dev, int N, int C, int HW, void* stream) {
-    return ag_relu_bn_bwd_dx_weighted(dy_dev, x_dev, coef_dev, sums_dev, nullptr, dx_dev, nullptr, N, C, HW, stream);
+    return ag_relu_bn_bwd_dx_weighted(dy_dev, x_dev, coef_dev, sums_dev, nullptr, dx_dev, nullptr, nullptr, 0, N, C, HW, stream);
 }
 
 extern "C" int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
-                                       const float* weights_dev, float* dx_dev, float* plane_sums_dev, int N, int C, int HW,
-                                       void* stream) {
-    if (!dyp_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev) return AG_ERR_INVALID_ARG;
+                                       const float* weights_dev, float* dx_dev, float* plane_sums_dev, float* border_sums_dev, int W,
+                                       int N, int C, int HW, void* stream) {
+    if (!dyp_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev || (border_sums_dev && (W <= 1 || HW % W != 0 || HW >= 65536)))
+        return AG_ERR_INVALID_ARG;
     AG_BN_CHECK(N, C, HW);
     const int w = vec_width(x_dev, dx_dev, nullptr, HW);
-    AG_BN_DISPATCH(relu_bn_bwd_dx_plane_kernel, w, dyp_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, plane_sums_dev, planes, C,
-                   HW);
+    AG_BN_DISPATCH(relu_bn_bwd_dx_plane_kernel, w, dyp_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, plane_sums_dev,
+                   border_sums_dev, W, planes, C, HW);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 

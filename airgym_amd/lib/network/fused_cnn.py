@@ -195,14 +195,6 @@ def bn_sums_from_conv(w, dw, total, border, gamma, beta, hin):
     return torch.stack((sum_dy, (sum_dy_y - beta.detach().double() * sum_dy) / g), dim=1)
 
 
-def _border_sums(lib, dz):
-    """[C, 5]: over all images, the sums of row 0, the last row, column 0 and the two left corners of dz [n, C, H, W]."""
-    n, c, h, w = dz.shape
-    out = torch.empty(n, c, 5, dtype=torch.float32, device=dz.device)
-    N.check(lib.ag_plane_border_sums(dz.data_ptr(), out.data_ptr(), n, c, h, w, _stream(dz)), "ag_plane_border_sums")
-    return out.sum(0)
-
-
 def _bn_prep_from_conv(lib, w, dw, total, border, coef, gamma, beta, hin, m, mode, gout=(None, None)):
     """(sums [C, 2], tab [C, 4]) of the ReLU + BatchNorm in front of a convolution from that convolution's weights w, weight
     gradient dw, the total [cout] (= its bias gradient) and border sums [cout, 5] of its output gradient: `bn_sums_from_conv` as one
@@ -275,11 +267,13 @@ class _Trunk(torch.autograd.Function):
                                         sums3.data_ptr(), tab3.data_ptr(), dyp.data_ptr(), _gptr(G(10)), _gptr(G(11)),
                                         scratch.data_ptr(), _stream(img)), "ag_bn_pool_bwd_prep")
         dx3 = torch.empty_like(x3)
-        ps3 = torch.empty(n, 64, dtype=torch.float32, device=dev)          # per-plane sums of dx3: db3 = their sum over images
-        N.check(lib.ag_relu_bn_bwd_dx_plane(dyp.data_ptr(), x3.data_ptr(), tab3.data_ptr(), sums3.data_ptr(), _wptr(weights),
-                                            dx3.data_ptr(), ps3.data_ptr(), n, 64, _HW[2], _stream(img)), "ag_relu_bn_bwd_dx_plane")
         fw = ctx.from_weights       # the ReLU + BatchNorm reductions from the next convolution's (w, dw) instead of a pass over dy
-        border3 = _border_sums(lib, dx3) if fw else None
+        ps3 = torch.empty(n, 64, dtype=torch.float32, device=dev)          # per-plane sums of dx3: db3 = their sum over images
+        bs3 = torch.empty(n, 64, 5, dtype=torch.float32, device=dev) if fw else None      # and its border sums
+        N.check(lib.ag_relu_bn_bwd_dx_plane(dyp.data_ptr(), x3.data_ptr(), tab3.data_ptr(), sums3.data_ptr(), _wptr(weights),
+                                            dx3.data_ptr(), ps3.data_ptr(), _gptr(bs3), 15, n, 64, _HW[2], _stream(img)),
+                "ag_relu_bn_bwd_dx_plane")
+        border3 = bs3.sum(0) if fw else None
         dw3 = _conv_wgrad(lib, dx3, x2, coef2, 64, G(8))
         db3 = torch.sum(ps3, 0, out=G(9)) if go is not None else ps3.sum(0)
         if fw:
@@ -291,9 +285,11 @@ class _Trunk(torch.autograd.Function):
         if not fw:
             sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0, (G(6), G(7)))
         ps2 = torch.empty(n, 32, dtype=torch.float32, device=dev)
+        bs2 = torch.empty(n, 32, 5, dtype=torch.float32, device=dev) if fw else None
         N.check(lib.ag_relu_bn_bwd_dx_weighted(dy2.data_ptr(), x2.data_ptr(), tab2.data_ptr(), sums2.data_ptr(), _wptr(weights),
-                                               dy2.data_ptr(), ps2.data_ptr(), n, 32, _HW[1], _stream(img)), "ag_relu_bn_bwd_dx")
-        border2 = _border_sums(lib, dy2) if fw else None
+                                               dy2.data_ptr(), ps2.data_ptr(), _gptr(bs2), 30, n, 32, _HW[1], _stream(img)),
+                "ag_relu_bn_bwd_dx")
+        border2 = bs2.sum(0) if fw else None
         dw2 = _conv_wgrad(lib, dy2, x1, coef1, 32, G(4))
         db2 = torch.sum(ps2, 0, out=G(5)) if go is not None else ps2.sum(0)
         if fw:

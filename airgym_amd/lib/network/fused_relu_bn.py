@@ -70,7 +70,7 @@ class _ReluBatchNormTrain(torch.autograd.Function):
         coef = torch.stack((mean, invstd, gamma.detach() * invstd, torch.full_like(mean, 1.0 / m)), dim=1).contiguous()
         dx = torch.empty_like(x)
         N.check(lib.ag_relu_bn_bwd_dx_weighted(dy.data_ptr(), x.data_ptr(), coef.data_ptr(), sums.data_ptr(),
-                                               weights.data_ptr() if weights.numel() else None, dx.data_ptr(), None, n, c, hw,
+                                               weights.data_ptr() if weights.numel() else None, dx.data_ptr(), None, None, 0, n, c, hw,
                                                _stream(x)), "ag_relu_bn_bwd_dx")
         return dx, sums[:, 1].clone(), sums[:, 0].clone(), None, None, None, None, None
 

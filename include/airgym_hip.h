@@ -377,7 +377,9 @@ int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const fl
  *                          copies and the two mean terms are scaled by m_i (coef[c][3] = 1 / (sum_i m_i HW)).  Same result as
  *                          the reference's computation on the full minibatch, on 1/4 of the images.
  *                          plane_sums_dev (NULL = off) [N * C]: the sum of dx over each plane - summed over images this is the bias
- *                          gradient of the convolution that produced x, which ag_cnn_conv_wgrad(with_bias = 0) then need not form. */
+ *                          gradient of the convolution that produced x, which ag_cnn_conv_wgrad(with_bias = 0) then need not form.
+ *                          border_sums_dev (NULL = off; W = plane width) [N * C][5]: what ag_plane_border_sums(dx) would return, formed
+ *                          in passing. */
 /*   ag_relu_bn_bwd_dx_plane: ag_relu_bn_bwd_dx_weighted with dy constant over each plane, dyp_dev [N * C]: the backward of the global
  *                          average pool that follows the extractor's last BatchNorm (cnn.py:14). */
 int ag_relu_bn_planes_per_block(void);
@@ -391,9 +393,11 @@ int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const float* coef
 int ag_relu_bn_stats_weighted(const float* x_dev, const float* weights_dev, float* partials_dev, int N, int C, int HW,
                               void* stream);
 int ag_relu_bn_bwd_dx_weighted(const float* dy_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
-                               const float* weights_dev, float* dx_dev, float* plane_sums_dev, int N, int C, int HW, void* stream);
+                               const float* weights_dev, float* dx_dev, float* plane_sums_dev, float* border_sums_dev, int W, int N,
+                               int C, int HW, void* stream);
 int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
-                            const float* weights_dev, float* dx_dev, float* plane_sums_dev, int N, int C, int HW, void* stream);
+                            const float* weights_dev, float* dx_dev, float* plane_sums_dev, float* border_sums_dev, int W, int N, int C,
+                            int HW, void* stream);
 
 /* The per-channel arithmetic of ReLU + BatchNorm between the big passes (two-stage float64 column sums in a fixed order, then one
  * workgroup; each call replaces 10 - 30 launches of [C]-sized tensor operations per layer and step) - airgym_amd/csrc/cnn_kernels.hip.

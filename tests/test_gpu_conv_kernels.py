@@ -225,3 +225,30 @@ def test_reductions_from_weights_equal_the_reduction_kernel():
     for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         s = pb.grad.abs().max().item()
         assert (pa.grad - pb.grad).abs().max().item() <= 2e-4 * s + 1e-8, (name, (pa.grad - pb.grad).abs().max().item(), s)
+
+
+@pytest.mark.parametrize("shape", [(5, 32, 53, 30), (4, 64, 27, 15)])
+def test_border_sums_in_passing_equal_the_standalone_kernel_and_torch(shape):
+    """ag_relu_bn_bwd_dx_weighted's plane / border sums (formed while dx is written) against ag_plane_border_sums on the result and
+    against torch slicing."""
+    import ctypes
+    from airgym_amd import _native as N
+    lib = N.load()
+    n, c, h, w = shape
+    torch.manual_seed(6)
+    dev = torch.device("cuda")
+    x, dy = torch.randn(shape, device=dev), torch.randn(shape, device=dev)
+    coef = torch.stack((torch.rand(c, device=dev), torch.rand(c, device=dev) + 0.5, torch.rand(c, device=dev) + 0.5,
+                        torch.full((c,), 1.0 / (n * h * w), device=dev)), 1).contiguous()
+    sums = torch.randn(c, 2, device=dev)
+    dx = torch.empty_like(x)
+    ps, bs = torch.empty(n, c, device=dev), torch.empty(n, c, 5, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N.check(lib.ag_relu_bn_bwd_dx_weighted(dy.data_ptr(), x.data_ptr(), coef.data_ptr(), sums.data_ptr(), None, dx.data_ptr(),
+                                           ps.data_ptr(), bs.data_ptr(), w, n, c, h * w, stream), "dx")
+    ref = torch.stack((dx[:, :, 0, :].sum(2), dx[:, :, -1, :].sum(2), dx[:, :, :, 0].sum(2), dx[:, :, 0, 0], dx[:, :, -1, 0]), 2)
+    alone = torch.empty(n, c, 5, device=dev)
+    N.check(lib.ag_plane_border_sums(dx.data_ptr(), alone.data_ptr(), n, c, h, w, stream), "border")
+    scale = ref.abs().max().item()
+    assert (bs - ref).abs().max().item() <= 1e-5 * scale and (alone - ref).abs().max().item() <= 1e-5 * scale
+    assert (ps - dx.sum((2, 3))).abs().max().item() <= 1e-5 * dx.sum((2, 3)).abs().max().item()
