@@ -288,9 +288,17 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
 // so every tap reads dz at (a + dy, b + dx), dy, dx in {0, 1}: UNIT-stride reads, no de-interleaving; a lane holds the px = 0
 // and px = 1 results of its b and stores them as one float2 (rows of din are written contiguously).
 // D[ci][b] tiles of 16 x 16, K = 16 output channels per LDS chunk x the taps of the class.  Wave w owns a-rows 2w, 2w + 1.
-template <int CIN, int COUT, int HIN, int WIN, int WAVES>
+// EPI (the layer's input is the output of a ReLU + BatchNorm whose backward coefficients are known before this kernel runs - see
+// bn_sums_from_conv in cnn_kernels.hip): 1 = the epilogue turns the gradient of the BatchNorm output into the gradient of the
+// convolution output x in front of it, din <- [x > 0] (A din + m_i (B x + C)), tab[ci] = {A, B, C, 0}, m_i = wts[n] (the arithmetic of
+// conv1_wgrad_kernel's BNBWD): ag_relu_bn_bwd_dx's pass over the tensor (read 2, write 1) becomes one extra read here.
+// 2 = also emits, per workgroup, sums[ci][6] = {total, row 0, last row, column 0, (0,0), (last row, 0)} of what it stored: the bias
+// gradient and the border sums the layer below needs for ITS reductions.
+template <int CIN, int COUT, int HIN, int WIN, int WAVES, int EPI>
 __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wd,
-                                                                  float* __restrict__ dx, int bands) {
+                                                                  float* __restrict__ dx, int bands, const float* __restrict__ bnx,
+                                                                  const float* __restrict__ tab, const float* __restrict__ wts,
+                                                                  float* __restrict__ sums) {
     constexpr int HO = (HIN - 1) / 2 + 1, WO = WIN / 2;
     constexpr int NT = WAVES * 64, AROWS = 2 * WAVES, ZR = AROWS + 1;
     constexpr int NBT = (WO + 15) / 16, RT = CIN / 16;
@@ -404,6 +412,22 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
         }
     }
     float* dout = dx + (size_t)n * CIN * HIN * WIN;
+    const float* xin = EPI ? bnx + (size_t)n * CIN * HIN * WIN : nullptr;
+    float tA[RT][4], tB[RT][4], tC[RT][4];
+    float tot[RT][4], r0[RT][4], rl[RT][4], c0[RT][4], k00[RT][4], kl0[RT][4];
+    if (EPI) {
+        const float wi = wts ? wts[n] : 1.0f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 t4 = *reinterpret_cast<const float4*>(tab + 4 * (16 * rt + 4 * q + i));
+                tA[rt][i] = t4.x;
+                tB[rt][i] = wi * t4.y;
+                tC[rt][i] = wi * t4.z;
+                tot[rt][i] = r0[rt][i] = rl[rt][i] = c0[rt][i] = k00[rt][i] = kl0[rt][i] = 0.f;
+            }
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int a = a0 + 2 * wave + r;
@@ -421,10 +445,55 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int ci = 16 * rt + 4 * q + i;
-                        *reinterpret_cast<float2*>(dout + ((size_t)ci * HIN + iy) * WIN + 2 * b) =
-                            make_float2(acc[r][py][0][rt][bt][i], acc[r][py][1][rt][bt][i]);
+                        const size_t at = ((size_t)ci * HIN + iy) * WIN + 2 * b;
+                        float2 v = make_float2(acc[r][py][0][rt][bt][i], acc[r][py][1][rt][bt][i]);
+                        if (EPI) {
+                            const float2 xv = *reinterpret_cast<const float2*>(xin + at);
+                            v.x = xv.x > 0.f ? fmaf(v.x, tA[rt][i], fmaf(xv.x, tB[rt][i], tC[rt][i])) : 0.f;
+                            v.y = xv.y > 0.f ? fmaf(v.y, tA[rt][i], fmaf(xv.y, tB[rt][i], tC[rt][i])) : 0.f;
+                        }
+                        if (EPI == 2) {
+                            const float both = v.x + v.y;
+                            tot[rt][i] += both;
+                            if (iy == 0) r0[rt][i] += both;                 // wave-uniform conditions
+                            if (iy == HIN - 1) rl[rt][i] += both;
+                            if (b == 0) {
+                                c0[rt][i] += v.x;
+                                if (iy == 0) k00[rt][i] += v.x;
+                                if (iy == HIN - 1) kl0[rt][i] += v.x;
+                            }
+                        }
+                        *reinterpret_cast<float2*>(dout + at) = v;
                     }
             }
+        }
+    }
+    if (EPI == 2) {
+        // per-wave sums over the 16 columns of a row group, then over the waves through LDS (s_z is free after this barrier)
+        __syncthreads();
+        float* red = s_z;       // [WAVES][CIN][6]
+        static_assert(WAVES * CIN * 6 <= 16 * PSZ, "reduction scratch fits the staging buffer");
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t = row_sum16(tot[rt][i]), u0 = row_sum16(r0[rt][i]), ul = row_sum16(rl[rt][i]);
+                if (m == 0) {
+                    float* o = red + (wave * CIN + 16 * rt + 4 * q + i) * 6;
+                    o[0] = t;
+                    o[1] = u0;
+                    o[2] = ul;
+                    o[3] = c0[rt][i];
+                    o[4] = k00[rt][i];
+                    o[5] = kl0[rt][i];
+                }
+            }
+        __syncthreads();
+        for (int u = tid; u < CIN * 6; u += NT) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += red[w * CIN * 6 + u];
+            sums[(size_t)blockIdx.x * (CIN * 6) + u] = t;
         }
     }
 }
@@ -860,7 +929,7 @@ inline int layer_of(int cin, int cout, int hin, int win) {
     if (cin == kL3.cin && cout == kL3.cout && hin == kL3.hin && win == kL3.win) return 3;
     return 0;
 }
-constexpr int kL2Waves = 4, kL3Waves = 7;          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1); 2 / 7 and 4 / 5 waves measured slower          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1)
+constexpr int kL2Waves = 4, kL3Waves = 7;          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1); 2 / 7 and 4 / 5 waves measured slower
 constexpr int kWgradWorkgroups = 512;              // persistent 12-wave workgroups: two per CU where registers allow (conv2), else they queue
 
 }  // namespace
@@ -952,17 +1021,48 @@ extern "C" int ag_cnn_conv_dgrad(const float* dz_dev, const float* w_dev, float*
     if (!layer) return AG_ERR_UNSUPPORTED;
     const int tot = 9 * cin * cout;
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, cin, cout);
+    const float* none = nullptr;
     if (layer == 2) {
         const int bands = (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
         if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((conv_s2_dgrad_kernel<16, 32, 106, 60, kL2Waves>), dim3(n * bands), dim3(kL2Waves * 64), 0,
-                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands);
+        hipLaunchKernelGGL((conv_s2_dgrad_kernel<16, 32, 106, 60, kL2Waves, 0>), dim3(n * bands), dim3(kL2Waves * 64), 0,
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, none, none, none, (float*)nullptr);
     } else {
         const int bands = (27 + 2 * kL3Waves - 1) / (2 * kL3Waves);
         if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((conv_s2_dgrad_kernel<32, 64, 53, 30, kL3Waves>), dim3(n * bands), dim3(kL3Waves * 64), 0,
-                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands);
+        hipLaunchKernelGGL((conv_s2_dgrad_kernel<32, 64, 53, 30, kL3Waves, 0>), dim3(n * bands), dim3(kL3Waves * 64), 0,
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, none, none, none, (float*)nullptr);
     }
+    return AG_CONV_LAUNCH_OK();
+}
+
+// Workgroups (= rows of `sums`) of ag_cnn_conv_dgrad_bn for n images.
+extern "C" int ag_cnn_conv_dgrad_bn_rows(int n, int cin, int cout, int hin, int win) {
+    if (layer_of(cin, cout, hin, win) != 3) return AG_ERR_UNSUPPORTED;
+    const long long rows = (long long)n * ((27 + 2 * kL3Waves - 1) / (2 * kL3Waves));
+    return rows > 0x7fffffffLL ? AG_ERR_UNSUPPORTED : (int)rows;
+}
+
+// ag_cnn_conv_dgrad followed by the backward of the ReLU + BatchNorm in front of the layer, in the kernel's epilogue (the third
+// layer only: the second layer's input gradient is consumed by ag_cnn_conv1_wgrad, which folds the same arithmetic into its staging).
+// dx <- [bn_x > 0] (A g + m_i (B bn_x + C)) with g the convolution's input gradient, bn_tab [cin][4] = {A, B, C, 0} as
+// ag_bn_bwd_prep(mode 1) writes it, weights [n] the image multiplicities or NULL.  sums (NULL = not wanted):
+// [ag_cnn_conv_dgrad_bn_rows][cin][6] = per workgroup {total, row 0, last row, column 0, (0,0), (last row, 0)} of dx.
+extern "C" int ag_cnn_conv_dgrad_bn(const float* dz_dev, const float* w_dev, const float* bn_x_dev, const float* bn_tab_dev,
+                                    const float* weights_dev, float* dx_dev, float* sums_dev, int n, int cin, int cout, int hin, int win,
+                                    float* workspace_dev, void* stream) {
+    if (!dz_dev || !w_dev || !bn_x_dev || !bn_tab_dev || !dx_dev || !workspace_dev || n <= 0) return AG_ERR_INVALID_ARG;
+    if (layer_of(cin, cout, hin, win) != 3) return AG_ERR_UNSUPPORTED;
+    const int bands = (27 + 2 * kL3Waves - 1) / (2 * kL3Waves);
+    if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+    const int tot = 9 * cin * cout;
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, cin, cout);
+    if (sums_dev)
+        hipLaunchKernelGGL((conv_s2_dgrad_kernel<32, 64, 53, 30, kL3Waves, 2>), dim3(n * bands), dim3(kL3Waves * 64), 0,
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, bn_x_dev, bn_tab_dev, weights_dev, sums_dev);
+    else
+        hipLaunchKernelGGL((conv_s2_dgrad_kernel<32, 64, 53, 30, kL3Waves, 1>), dim3(n * bands), dim3(kL3Waves * 64), 0,
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, bn_x_dev, bn_tab_dev, weights_dev, sums_dev);
     return AG_CONV_LAUNCH_OK();
 }
 

@@ -88,6 +88,20 @@ def _conv_dgrad(lib, dz, w, like):
     return dx
 
 
+def _conv_dgrad_bn(lib, dz, w, x, tab, weights):
+    """Input gradient of the third convolution with the backward of the ReLU + BatchNorm in front of it applied in the kernel's
+    epilogue: (gradient of the second convolution's output x, [32, 6] sums of it: total, row 0, last row, column 0, two corners)."""
+    n, cin, hin, win = x.shape
+    cout = w.shape[0]
+    dx = torch.empty_like(x)
+    ws = torch.empty(lib.ag_cnn_conv_workspace_floats(cin, cout), dtype=torch.float32, device=dz.device)
+    rows = lib.ag_cnn_conv_dgrad_bn_rows(n, cin, cout, hin, win)
+    sums = torch.empty(rows, cin, 6, dtype=torch.float32, device=dz.device)
+    N.check(lib.ag_cnn_conv_dgrad_bn(dz.data_ptr(), w.data_ptr(), x.data_ptr(), tab.data_ptr(), _wptr(weights), dx.data_ptr(),
+                                     sums.data_ptr(), n, cin, cout, hin, win, ws.data_ptr(), _stream(dz)), "ag_cnn_conv_dgrad_bn")
+    return dx, sums.sum(0)
+
+
 def _conv_wgrad(lib, dz, x, coef, cout, out=None):
     """Weight gradient of a 3x3 layer whose input is relu(x) * coef[2] + coef[3] (the bias gradient comes from the plane sums of dz
     that the kernel producing dz emits: with_bias = 0).  out: a contiguous [cout, cin, 3, 3] tensor the result is summed into
@@ -213,7 +227,8 @@ def _bn_prep_from_conv(lib, w, dw, total, border, coef, gamma, beta, hin, m, mod
 
 class _Trunk(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, weights, bns, training, norm, index, gout, from_weights, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, g3, be3):
+    def forward(ctx, img, weights, bns, training, norm, index, gout, from_weights, dgrad_epilogue, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3,
+                g3, be3):
         lib = N.load()
         img = img.contiguous()
         if index is not None:
@@ -241,6 +256,7 @@ class _Trunk(torch.autograd.Function):
         ctx.index = index
         ctx.gout = gout
         ctx.from_weights = from_weights
+        ctx.dgrad_epilogue = bool(from_weights and dgrad_epilogue)
         ctx.save_for_backward(img, x1, x2, x3, plane1, weights if weights is not None else img.new_empty(0), w2, w3, g1, g2, g3,
                               coef1, coef2, coef3, be1, be2)
         return pooled
@@ -276,22 +292,31 @@ class _Trunk(torch.autograd.Function):
         border3 = bs3.sum(0) if fw else None
         dw3 = _conv_wgrad(lib, dx3, x2, coef2, 64, G(8))
         db3 = torch.sum(ps3, 0, out=G(9)) if go is not None else ps3.sum(0)
+        epi = ctx.dgrad_epilogue    # layer 2's ReLU + BatchNorm backward in the epilogue of conv3's input gradient
         if fw:
             sums2, tab2 = _bn_prep_from_conv(lib, w3, (G(8) if go is not None else dw3).contiguous(), db3.contiguous(), border3, coef2, g2, be2, 53, m2,
-                                             0, (G(6), G(7)))
-        dy2 = _conv_dgrad(lib, dx3, w3, x2)
-        del dx3
-        # layer 2: dx2 written over dy2
-        if not fw:
-            sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0, (G(6), G(7)))
-        ps2 = torch.empty(n, 32, dtype=torch.float32, device=dev)
-        bs2 = torch.empty(n, 32, 5, dtype=torch.float32, device=dev) if fw else None
-        N.check(lib.ag_relu_bn_bwd_dx_weighted(dy2.data_ptr(), x2.data_ptr(), tab2.data_ptr(), sums2.data_ptr(), _wptr(weights),
-                                               dy2.data_ptr(), ps2.data_ptr(), _gptr(bs2), 30, n, 32, _HW[1], _stream(img)),
-                "ag_relu_bn_bwd_dx")
-        border2 = bs2.sum(0) if fw else None
+                                             1 if epi else 0, (G(6), G(7)))
+        if epi:
+            dy2, tot2 = _conv_dgrad_bn(lib, dx3, w3, x2, tab2, weights)       # dy2 is the gradient of x2 already
+            del dx3
+            border2 = tot2[:, 1:].contiguous()
+        else:
+            dy2 = _conv_dgrad(lib, dx3, w3, x2)
+            del dx3
+            # layer 2: dx2 written over dy2
+            if not fw:
+                sums2, tab2 = _bn_reduce(lib, dy2, x2, coef2, g2, m2, 0, (G(6), G(7)))
+            ps2 = torch.empty(n, 32, dtype=torch.float32, device=dev)
+            bs2 = torch.empty(n, 32, 5, dtype=torch.float32, device=dev) if fw else None
+            N.check(lib.ag_relu_bn_bwd_dx_weighted(dy2.data_ptr(), x2.data_ptr(), tab2.data_ptr(), sums2.data_ptr(), _wptr(weights),
+                                                   dy2.data_ptr(), ps2.data_ptr(), _gptr(bs2), 30, n, 32, _HW[1], _stream(img)),
+                    "ag_relu_bn_bwd_dx")
+            border2 = bs2.sum(0) if fw else None
         dw2 = _conv_wgrad(lib, dy2, x1, coef1, 32, G(4))
-        db2 = torch.sum(ps2, 0, out=G(5)) if go is not None else ps2.sum(0)
+        if epi:
+            db2 = G(5).copy_(tot2[:, 0]) if go is not None else tot2[:, 0].contiguous()
+        else:
+            db2 = torch.sum(ps2, 0, out=G(5)) if go is not None else ps2.sum(0)
         if fw:
             sums1, tab1 = _bn_prep_from_conv(lib, w2, (G(4) if go is not None else dw2).contiguous(), db2.contiguous(), border2, coef1, g1, be1, 106, m1,
                                              1, (G(2), G(3)))
@@ -302,12 +327,12 @@ class _Trunk(torch.autograd.Function):
             sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1, (G(2), G(3)))
         dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.index, ctx.norm, (G(0), G(1)) if go is not None else None)
         if go is not None:
-            return (None,) * 20
-        return (None, None, None, None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
+            return (None,) * 21
+        return (None, None, None, None, None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
                 sums3[:, 1], sums3[:, 0])
 
 
-def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, sums_from_weights=True):
+def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, sums_from_weights=True, dgrad_epilogue=True):
     """`features(x)` flattened to [N, 64] (the caller has checked `usable(x, features)`): batch statistics when the BatchNorm
     layers are in training mode (all three must agree), running statistics otherwise.  norm = (mean, std) (optional, per-pixel
     [212 * 120]): x is the RAW image and the first convolution normalises it, clamp((x - mean) / std, -5, 5), while staging.
@@ -315,7 +340,9 @@ def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, 
     direct_grads: the backward OVERWRITES the parameters' existing .grad tensors instead of handing gradients to autograd for
     accumulation (the caller zeroes its gradient buffer before every backward and the trunk is applied once per backward).
     sums_from_weights: the backward takes the reductions of the first two ReLU + BatchNorm layers from the following convolution's
-    weights and weight gradient (`bn_sums_from_conv`: no pass over the 1.9 GB / 1.0 GB gradients); False = the reduction kernel."""
+    weights and weight gradient (`bn_sums_from_conv`: no pass over the 1.9 GB / 1.0 GB gradients); False = the reduction kernel.
+    dgrad_epilogue (needs sums_from_weights, which makes the coefficients known in time): the second layer's ReLU + BatchNorm
+    backward runs in the epilogue of the third convolution's input gradient instead of as a pass of its own."""
     layers = list(features)
     convs, bns = (layers[0], layers[3], layers[6]), (layers[2], layers[5], layers[8])
     training = bns[0].training
@@ -332,4 +359,4 @@ def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, 
         grads = [p.grad for p in args]
         if all(g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == p.device for g, p in zip(grads, args)):
             gout = grads
-    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, gout, bool(sums_from_weights), *args)
+    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, gout, bool(sums_from_weights), bool(dgrad_epilogue), *args)

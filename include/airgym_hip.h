@@ -471,6 +471,14 @@ int ag_weighted_moments(const float* x_dev, const long long* index_dev, const fl
  *                           statistics (sum over images and bands) and, for the last layer, the plane sums the global average pool
  *                           needs (sum over bands), with no extra pass over y.
  *   ag_cnn_conv_dgrad     : dx [n,cin,hin,win] = gradient of the layer's input (w.r.t. `in` above) from dz [n,cout,ho,wo].
+ *   ag_cnn_conv_dgrad_bn  : (32, 64, 53, 30) only.  ag_cnn_conv_dgrad followed, in the kernel's epilogue, by the backward of the
+ *                           nn.ReLU() + nn.BatchNorm2d in front of the layer (cnn.py:12): dx <- [bn_x > 0] (A g + m_i (B bn_x + C)),
+ *                           g = the input gradient, bn_x = the previous convolution's output, bn_tab [cin][4] = {A, B, C, 0} as
+ *                           ag_bn_bwd_prep (mode 1) writes it, weights [n] = image multiplicities m_i (NULL = 1).  The coefficients
+ *                           are known before this kernel runs when they come from ag_bn_sums_from_conv.  sums_dev (NULL = off)
+ *                           [ag_cnn_conv_dgrad_bn_rows(...)][cin][6]: per workgroup {total, row 0, last row, column 0, (0,0),
+ *                           (last row, 0)} of dx - summed over the rows: the previous convolution's bias gradient and the border
+ *                           sums ag_bn_sums_from_conv needs for the layer below.
  *   ag_cnn_conv_wgrad     : partials_dev [ag_cnn_conv_wgrad_partials(...)][cout*cin*9 + cout]: dw [cout][cin][3][3] then db [cout];
  *                           x / scale / shift as in ag_cnn_conv_fwd.  with_bias = 0: the db part is left unwritten (taken from
  *                           ag_relu_bn_bwd_dx*'s plane sums instead; the weight gradient alone is 10 - 16 % faster).
@@ -489,6 +497,10 @@ int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const float* shi
                     float* y_dev, float* stats_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev, void* stream);
 int ag_cnn_conv_dgrad(const float* dz_dev, const float* w_dev, float* dx_dev, int n, int cin, int cout, int hin, int win,
                       float* workspace_dev, void* stream);
+int ag_cnn_conv_dgrad_bn_rows(int n, int cin, int cout, int hin, int win);
+int ag_cnn_conv_dgrad_bn(const float* dz_dev, const float* w_dev, const float* bn_x_dev, const float* bn_tab_dev,
+                         const float* weights_dev, float* dx_dev, float* sums_dev, int n, int cin, int cout, int hin, int win,
+                         float* workspace_dev, void* stream);
 int ag_cnn_conv_wgrad_partials(int n, int cin, int cout, int hin, int win);
 int ag_cnn_conv_wgrad(const float* dz_dev, const float* x_dev, const float* scale_dev, const float* shift_dev,
                       float* partials_dev, int with_bias, int n, int cin, int cout, int hin, int win, void* stream);

@@ -220,11 +220,15 @@ def test_reductions_from_weights_equal_the_reduction_kernel():
     x = torch.rand(9, 1, 212, 120, device="cuda") * 3.0
     w = torch.tensor([1., 4., 2., 1., 3., 4., 1., 2., 2.], device="cuda")
     g = torch.randn(9, 12, device="cuda")
+    c = copy.deepcopy(a)
+    c.dgrad_epilogue = False        # the second layer's ReLU + BatchNorm backward as a pass of its own
     a(x, w).backward(g)
     b(x, w).backward(g)
-    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+    c(x, w).backward(g)
+    for (name, pa), (_, pb), (_, pc) in zip(a.named_parameters(), b.named_parameters(), c.named_parameters()):
         s = pb.grad.abs().max().item()
         assert (pa.grad - pb.grad).abs().max().item() <= 2e-4 * s + 1e-8, (name, (pa.grad - pb.grad).abs().max().item(), s)
+        assert (pa.grad - pc.grad).abs().max().item() <= 2e-4 * s + 1e-8, (name, (pa.grad - pc.grad).abs().max().item(), s)
 
 
 @pytest.mark.parametrize("shape", [(5, 32, 53, 30), (4, 64, 27, 15)])
@@ -252,3 +256,45 @@ def test_border_sums_in_passing_equal_the_standalone_kernel_and_torch(shape):
     scale = ref.abs().max().item()
     assert (bs - ref).abs().max().item() <= 1e-5 * scale and (alone - ref).abs().max().item() <= 1e-5 * scale
     assert (ps - dx.sum((2, 3))).abs().max().item() <= 1e-5 * dx.sum((2, 3)).abs().max().item()
+
+
+@pytest.mark.parametrize("weighted,with_sums", [(False, True), (True, True), (True, False)])
+def test_input_gradient_with_the_batchnorm_backward_in_its_epilogue(weighted, with_sums):
+    """ag_cnn_conv_dgrad_bn (third layer): [x > 0] (A g + m_i (B x + C)) with g the convolution's input gradient, against float64
+    (aten's convolution_backward for g), and the per-workgroup sums of the result against torch slicing."""
+    import ctypes
+    from airgym_amd import _native as N
+    lib = N.load()
+    torch.manual_seed(8)
+    dev = torch.device("cuda")
+    n = 5
+    dz = torch.randn(n, 64, 27, 15, device=dev)
+    w = torch.randn(64, 32, 3, 3, device=dev) * 0.1
+    x = torch.randn(n, 32, 53, 30, device=dev)
+    tab = torch.cat((torch.randn(32, 3, device=dev), torch.zeros(32, 1, device=dev)), 1).contiguous()
+    wts = torch.tensor([1., 3., 2., 4., 1.], device=dev) if weighted else None
+    g = torch.ops.aten.convolution_backward(dz.double(), x.double(), w.double(), [64], [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                            [True, False, False])[0]
+    t = tab.double()
+    mi = (wts.double() if weighted else torch.ones(n, device=dev, dtype=torch.float64)).view(n, 1, 1, 1)
+    ref = (x.double() > 0) * (t[:, 0].view(1, 32, 1, 1) * g + mi * (t[:, 1].view(1, 32, 1, 1) * x.double() + t[:, 2].view(1, 32, 1, 1)))
+    dx = torch.empty_like(x)
+    ws = torch.empty(lib.ag_cnn_conv_workspace_floats(32, 64), device=dev)
+    rows = lib.ag_cnn_conv_dgrad_bn_rows(n, 32, 64, 53, 30)
+    assert rows > 0
+    sums = torch.full((rows, 32, 6), float("nan"), device=dev) if with_sums else None
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N.check(lib.ag_cnn_conv_dgrad_bn(dz.data_ptr(), w.data_ptr(), x.data_ptr(), tab.data_ptr(), wts.data_ptr() if weighted else None,
+                                     dx.data_ptr(), sums.data_ptr() if with_sums else None, n, 32, 64, 53, 30, ws.data_ptr(), stream),
+            "ag_cnn_conv_dgrad_bn")
+    scale = ref.abs().max().item()
+    assert (dx.double() - ref).abs().max().item() <= 2e-6 * scale
+    if with_sums:
+        d = dx.double()
+        want = torch.stack((d.sum((0, 2, 3)), d[:, :, 0, :].sum((0, 2)), d[:, :, -1, :].sum((0, 2)), d[:, :, :, 0].sum((0, 2)),
+                            d[:, :, 0, 0].sum(0), d[:, :, -1, 0].sum(0)), 1)
+        got = sums.double().sum(0)
+        assert torch.isfinite(sums).all()
+        assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    # other layers are refused
+    assert lib.ag_cnn_conv_dgrad_bn_rows(n, 16, 32, 106, 60) == N.AG_ERR_UNSUPPORTED
