@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_kernel(const float* __rest
 // (conv_kernels.hip, `stats`): mean_hw(relu(x) scale + shift) = scale S1 / HW + shift.  The backward of that pool:
 // the gradient of the pooled output reaches every pixel of a plane as the same number dyp[plane] (already
 // divided by HW by the caller), so relu_bn_bwd_dx needs no dy tensor: dx = [x > 0] g (dyp - m_i db / m - m_i xhat dg / m).
+// The result is affine in x on each plane: dx = [x > 0] (Bp x + Kp), Bp = -g invstd dg m_i / m, Kp = g (dyp - m_i db / m + invstd mean
+// dg m_i / m).  The border sums re-read the two border rows and the first column of x (cache hits) instead of classifying every element
+// on the way (0.40 -> 0.30 ms per 4 750 images at 64 x 27 x 15).
 template <int VEC>
 __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* __restrict__ dyp, const float* __restrict__ x,
                                                                    const float* __restrict__ coef, const float* __restrict__ sums,
@@ -244,7 +247,6 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* 
     const long long p0 = (long long)blockIdx.x * kPlanesPerBlock;
     const int nvec = HW / VEC;
     const int H = bsum ? HW / W : 0;
-    const float inv_w = bsum ? 1.0f / (float)W : 0.f;
     for (int k = wave; k < kPlanesPerBlock; k += 4) {
         const long long p = p0 + k;
         if (p >= planes) break;
@@ -253,32 +255,80 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_dx_plane_kernel(const float* 
         const float rm = coef[c * 4 + 3] * (wts ? wts[p / C] : 1.0f);
         const float dg = sums[c * 2 + 1] * rm;
         const float d0 = dyp[p] - sums[c * 2 + 0] * rm;
+        const float bp = -gi * is * dg, kp = gi * fmaf(is * mu, dg, d0);
         const vec_t* gx = reinterpret_cast<const vec_t*>(x + p * HW);
         vec_t* out = reinterpret_cast<vec_t*>(dx + p * HW);
+        const float* xp = x + p * HW;
+        auto val = [&](float t) { return t > 0.0f ? fmaf(t, bp, kp) : 0.0f; };
         float ps = 0.0f;
-        float bs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int i = lane; i < nvec; i += 64) {
-            vec_t v = gx[i];
-            float* f = reinterpret_cast<float*>(&v);
+        // border values first (independent of everything else: all of a plane's loads are in flight together); lanes cover a row /
+        // a column when W, H <= 64, else the loops below
+        const bool small_border = bsum && W <= 64 && H <= 64;
+        float t0 = 0.f, tl = 0.f, tc = 0.f;
+        if (small_border) {
+            if (lane < W) { t0 = xp[lane]; tl = xp[(H - 1) * W + lane]; }
+            if (lane < H) tc = xp[lane * W];
+        }
+        if (nvec <= 8 * 64) {
+            vec_t v[8];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float xhat = (fmaxf(f[e], 0.0f) - mu) * is;
-                f[e] = f[e] > 0.0f ? gi * (d0 - xhat * dg) : 0.0f;
-                ps += f[e];
-                if (bsum) border_add(bs, f[e], i * VEC + e, H, W, inv_w);
+            for (int j = 0; j < 8; ++j)
+                if (lane + 64 * j < nvec) v[j] = gx[lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (lane + 64 * j < nvec) {
+                    float* f = reinterpret_cast<float*>(&v[j]);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        f[e] = val(f[e]);
+                        ps += f[e];
+                    }
+                    out[lane + 64 * j] = v[j];
+                }
             }
-            out[i] = v;
+        } else {
+#pragma unroll 4
+            for (int i = lane; i < nvec; i += 64) {
+                vec_t v = gx[i];
+                float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    f[e] = val(f[e]);
+                    ps += f[e];
+                }
+                out[i] = v;
+            }
         }
         if (psum) {
             ps = wave_sum(ps);
             if (lane == 0) psum[p] = ps;
         }
         if (bsum) {
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const float t = wave_sum(bs[j]);
-                if (lane == 0) bsum[p * 5 + j] = t;
+            float r0 = 0.f, rl = 0.f, c0 = 0.f, k0, kl;
+            if (small_border) {
+                r0 = lane < W ? val(t0) : 0.f;
+                rl = lane < W ? val(tl) : 0.f;
+                c0 = lane < H ? val(tc) : 0.f;
+                k0 = r0;            // lane 0: element (0, 0) / (H - 1, 0)
+                kl = rl;
+            } else {
+                for (int ox = lane; ox < W; ox += 64) {
+                    r0 += val(xp[ox]);
+                    rl += val(xp[(H - 1) * W + ox]);
+                }
+                for (int oy = lane; oy < H; oy += 64) c0 += val(xp[oy * W]);
+                k0 = val(xp[0]);
+                kl = val(xp[(H - 1) * W]);
+            }
+            r0 = wave_sum(r0);
+            rl = wave_sum(rl);
+            c0 = wave_sum(c0);
+            if (lane == 0) {
+                bsum[p * 5 + 0] = r0;
+                bsum[p * 5 + 1] = rl;
+                bsum[p * 5 + 2] = c0;
+                bsum[p * 5 + 3] = k0;
+                bsum[p * 5 + 4] = kl;
             }
         }
     }
@@ -657,8 +707,9 @@ extern "C" int ag_relu_bn_bwd_dx(const float* dy_dev, const float* x_dev, const 
 extern "C" int ag_relu_bn_bwd_dx_plane(const float* dyp_dev, const float* x_dev, const float* coef_dev, const float* sums_dev,
                                        const float* weights_dev, float* dx_dev, float* plane_sums_dev, float* border_sums_dev, int W,
                                        int N, int C, int HW, void* stream) {
-    if (!dyp_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev || (border_sums_dev && (W <= 1 || HW % W != 0 || HW >= 65536)))
-        return AG_ERR_INVALID_ARG;
+    if (!dyp_dev || !x_dev || !coef_dev || !sums_dev || !dx_dev || dx_dev == x_dev ||
+        (border_sums_dev && (W <= 1 || HW % W != 0 || HW >= 65536)))
+        return AG_ERR_INVALID_ARG;          // (not in place: the border sums read x again)
     AG_BN_CHECK(N, C, HW);
     const int w = vec_width(x_dev, dx_dev, nullptr, HW);
     AG_BN_DISPATCH(relu_bn_bwd_dx_plane_kernel, w, dyp_dev, x_dev, coef_dev, sums_dev, weights_dev, dx_dev, plane_sums_dev,
