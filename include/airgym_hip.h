@@ -381,7 +381,8 @@ int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const fl
  *                          border_sums_dev (NULL = off; W = plane width) [N * C][5]: what ag_plane_border_sums(dx) would return, formed
  *                          in passing. */
 /*   ag_relu_bn_bwd_dx_plane: ag_relu_bn_bwd_dx_weighted with dy constant over each plane, dyp_dev [N * C]: the backward of the global
- *                          average pool that follows the extractor's last BatchNorm (cnn.py:14). */
+ *                          average pool that follows the extractor's last BatchNorm (cnn.py:14).  Not in place (dx_dev != x_dev: the
+ *                          border sums read x again). */
 int ag_relu_bn_planes_per_block(void);
 int ag_relu_bn_stats(const float* x_dev, float* partials_dev, int N, int C, int HW, void* stream);
 int ag_relu_bn_apply(const float* x_dev, const float* scale_dev, const float* shift_dev, float* y_dev, int N, int C, int HW,
