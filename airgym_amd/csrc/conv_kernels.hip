@@ -375,12 +375,35 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
         for (int it = 0; it < W_IT; ++it)
             if (tid + it * NT < W_UNITS) *reinterpret_cast<float4*>(w_dst[it]) = vw[it];
     };
+    // EPI: the values of the layer's output the epilogue needs (one float2 per float2 it stores), loaded behind the LAST chunk's
+    // staging so that they land under its MFMA loop - all waves of the workgroup reach the epilogue together and nothing else would
+    // hide the latency there (one workgroup per CU)
+    float2 xpre[EPI ? 2 : 1][EPI ? 2 : 1][EPI ? NBT : 1][EPI ? RT : 1][EPI ? 4 : 1];
+    auto prefetch_x = [&]() {
+        const __amdgpu_buffer_rsrc_t rx = buf_of(bnx + (size_t)n * CIN * HIN * WIN, CIN * HIN * WIN * 4);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int iy = 2 * (a0 + 2 * wave + r) + py;
+#pragma unroll
+                for (int bt = 0; bt < NBT; ++bt) {
+                    const int b = 16 * bt + m;
+                    const unsigned off = (iy < HIN && b < WO) ? (unsigned)(((4 * q * HIN + iy) * WIN + 2 * b) * 4) : kOob;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xpre[r][py][bt][rt][i] = buf_f2(rx, off, (16 * rt + i) * (HIN * WIN * 4));
+                }
+            }
+    };
     fetch(0);
     for (int ch = 0; ch < COUT / 16; ++ch) {
         __syncthreads();
         stash();
         __syncthreads();
         if (ch + 1 < COUT / 16) fetch(ch + 1);
+        else if (EPI) prefetch_x();
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
         if (a0 + 2 * wave >= HO) continue;       // both rows of this wave lie below the tensor (last band): staging only
         const float* zb = s_z + q * PSZ + (2 * wave) * RSZ + m;
@@ -412,7 +435,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
         }
     }
     float* dout = dx + (size_t)n * CIN * HIN * WIN;
-    const float* xin = EPI ? bnx + (size_t)n * CIN * HIN * WIN : nullptr;
     float tA[RT][4], tB[RT][4], tC[RT][4];
     float tot[RT][4], r0[RT][4], rl[RT][4], c0[RT][4], k00[RT][4], kl0[RT][4];
     if (EPI) {
@@ -448,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
                         const size_t at = ((size_t)ci * HIN + iy) * WIN + 2 * b;
                         float2 v = make_float2(acc[r][py][0][rt][bt][i], acc[r][py][1][rt][bt][i]);
                         if (EPI) {
-                            const float2 xv = *reinterpret_cast<const float2*>(xin + at);
+                            const float2 xv = xpre[r][py][bt][rt][i];
                             v.x = xv.x > 0.f ? fmaf(v.x, tA[rt][i], fmaf(xv.x, tB[rt][i], tC[rt][i])) : 0.f;
                             v.y = xv.y > 0.f ? fmaf(v.y, tA[rt][i], fmaf(xv.y, tB[rt][i], tC[rt][i])) : 0.f;
                         }
