@@ -951,7 +951,8 @@ inline int layer_of(int cin, int cout, int hin, int win) {
     if (cin == kL3.cin && cout == kL3.cout && hin == kL3.hin && win == kL3.win) return 3;
     return 0;
 }
-constexpr int kL2Waves = 4, kL3Waves = 7;          // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1); 2 / 7 and 4 / 5 waves measured slower
+// output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1); 2 / 7 and 4 / 5 waves measured slower
+constexpr int kL2Waves = 4, kL3Waves = 7;
 constexpr int kWgradWorkgroups = 512;              // persistent 12-wave workgroups: two per CU where registers allow (conv2), else they queue
 
 }  // namespace

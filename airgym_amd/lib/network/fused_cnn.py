@@ -294,8 +294,8 @@ class _Trunk(torch.autograd.Function):
         db3 = torch.sum(ps3, 0, out=G(9)) if go is not None else ps3.sum(0)
         epi = ctx.dgrad_epilogue    # layer 2's ReLU + BatchNorm backward in the epilogue of conv3's input gradient
         if fw:
-            sums2, tab2 = _bn_prep_from_conv(lib, w3, (G(8) if go is not None else dw3).contiguous(), db3.contiguous(), border3, coef2, g2, be2, 53, m2,
-                                             1 if epi else 0, (G(6), G(7)))
+            sums2, tab2 = _bn_prep_from_conv(lib, w3, (G(8) if go is not None else dw3).contiguous(), db3.contiguous(), border3, coef2,
+                                             g2, be2, 53, m2, 1 if epi else 0, (G(6), G(7)))
         if epi:
             dy2, tot2 = _conv_dgrad_bn(lib, dx3, w3, x2, tab2, weights)       # dy2 is the gradient of x2 already
             del dx3
@@ -318,8 +318,8 @@ class _Trunk(torch.autograd.Function):
         else:
             db2 = torch.sum(ps2, 0, out=G(5)) if go is not None else ps2.sum(0)
         if fw:
-            sums1, tab1 = _bn_prep_from_conv(lib, w2, (G(4) if go is not None else dw2).contiguous(), db2.contiguous(), border2, coef1, g1, be1, 106, m1,
-                                             1, (G(2), G(3)))
+            sums1, tab1 = _bn_prep_from_conv(lib, w2, (G(4) if go is not None else dw2).contiguous(), db2.contiguous(), border2, coef1,
+                                             g1, be1, 106, m1, 1, (G(2), G(3)))
         dy1 = _conv_dgrad(lib, dy2, w2, x1)
         del dy2
         # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)
@@ -328,8 +328,8 @@ class _Trunk(torch.autograd.Function):
         dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.index, ctx.norm, (G(0), G(1)) if go is not None else None)
         if go is not None:
             return (None,) * 21
-        return (None, None, None, None, None, None, None, None, None, dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3,
-                sums3[:, 1], sums3[:, 0])
+        return ((None,) * 9 + (dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3, sums3[:, 1],
+                               sums3[:, 0]))
 
 
 def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, sums_from_weights=True, dgrad_epilogue=True):
