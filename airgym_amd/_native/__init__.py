@@ -206,6 +206,8 @@ SYMBOLS = [
     ("ag_cnn_conv_dgrad", ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
     ("ag_cnn_conv_dgrad_bn_rows", ctypes.c_int, [ctypes.c_int] * 5),
     ("ag_cnn_conv_dgrad_bn", ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 5 + [_P, _P]),
+    ("ag_cnn_conv_dgrad_conv1_wgrad_partials", ctypes.c_int, [ctypes.c_int]),
+    ("ag_cnn_conv_dgrad_conv1_wgrad", ctypes.c_int, [_P] * 10 + [ctypes.c_int, _P, _P]),
     ("ag_cnn_conv_wgrad_partials", ctypes.c_int, [ctypes.c_int] * 5),
     ("ag_cnn_conv_wgrad", ctypes.c_int, [_P] * 5 + [ctypes.c_int] * 6 + [_P]),
     ("ag_wgrad_rows_per_block", ctypes.c_int, [ctypes.c_int]),

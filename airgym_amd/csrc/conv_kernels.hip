@@ -294,11 +294,22 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
 // conv1_wgrad_kernel's BNBWD): ag_relu_bn_bwd_dx's pass over the tensor (read 2, write 1) becomes one extra read here.
 // 2 = also emits, per workgroup, sums[ci][6] = {total, row 0, last row, column 0, (0,0), (last row, 0)} of what it stored: the bias
 // gradient and the border sums the layer below needs for ITS reductions.
+// 3 (second layer only) = the input gradient is not stored at all: the epilogue applies the FIRST layer's ReLU + BatchNorm backward
+// (as 1) and feeds the result, through LDS, straight into the first convolution's weight gradient (conv1_wgrad_kernel's MFMA loop on
+// the band's 16 rows, the image band staged with the normaliser as there): `c1_part` [grid][16][32] = per workgroup dw1 [16][25], db1
+// in column 25.  The 1.9 GB gradient of the first layer's output is neither written nor read.
+struct Conv1Side {             // EPI == 3: the first convolution's input side
+    const float* img;          // frames [*, 212, 120]
+    const long long* index;    // image i of the batch = frame index[i] (NULL: i)
+    const float* nmean;        // per-pixel normaliser statistics (NULL: the image is used as it is)
+    const float* nstd;
+    float* c1_part;
+};
 template <int CIN, int COUT, int HIN, int WIN, int WAVES, int EPI>
 __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wd,
                                                                   float* __restrict__ dx, int bands, const float* __restrict__ bnx,
                                                                   const float* __restrict__ tab, const float* __restrict__ wts,
-                                                                  float* __restrict__ sums) {
+                                                                  float* __restrict__ sums, const Conv1Side c1) {
     constexpr int HO = (HIN - 1) / 2 + 1, WO = WIN / 2;
     constexpr int NT = WAVES * 64, AROWS = 2 * WAVES, ZR = AROWS + 1;
     constexpr int NBT = (WO + 15) / 16, RT = CIN / 16;
@@ -306,8 +317,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
     constexpr int PSZ = pad16mod32(ZR * RSZ);
     constexpr int CINP = (CIN == 16) ? 16 : CIN + 16;
     static_assert(CIN % 16 == 0 && COUT % 16 == 0, "shape");
-    __shared__ __attribute__((aligned(16))) float s_z[16 * PSZ + 32];
-    __shared__ __attribute__((aligned(16))) float s_w[9 * 16 * CINP];
+    static_assert(EPI != 3 || (CIN == 16 && HIN == 106 && WIN == 60 && WAVES == 4), "EPI 3: the second layer");
+    // EPI 3 reuses the staging buffers after the main loop: image band [35][136] + 8, gradient tile [16][482], table [64]
+    constexpr int C1_RS = 136, C1_EO = 68, C1_ROWS = 2 * (2 * AROWS) + 3, C1_PSZ = 482;
+    constexpr int MAIN_FLOATS = 16 * PSZ + 32 + 9 * 16 * CINP, C1_FLOATS = C1_ROWS * C1_RS + 8 + 16 * C1_PSZ + 64;
+    __shared__ __attribute__((aligned(16))) float s_all[(EPI == 3 && C1_FLOATS > MAIN_FLOATS) ? C1_FLOATS : MAIN_FLOATS];
+    float* const s_z = s_all;
+    float* const s_w = s_all + 16 * PSZ + 32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, q = lane >> 4;
     const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
@@ -378,7 +394,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
     // EPI: the values of the layer's output the epilogue needs (one float2 per float2 it stores), loaded behind the LAST chunk's
     // staging so that they land under its MFMA loop - all waves of the workgroup reach the epilogue together and nothing else would
     // hide the latency there (one workgroup per CU)
-    float2 xpre[EPI ? 2 : 1][EPI ? 2 : 1][EPI ? NBT : 1][EPI ? RT : 1][EPI ? 4 : 1];
+    constexpr bool PRE = EPI == 1 || EPI == 2;
+    float2 xpre[PRE ? 2 : 1][PRE ? 2 : 1][PRE ? NBT : 1][PRE ? RT : 1][PRE ? 4 : 1];
     auto prefetch_x = [&]() {
         const __amdgpu_buffer_rsrc_t rx = buf_of(bnx + (size_t)n * CIN * HIN * WIN, CIN * HIN * WIN * 4);
 #pragma unroll
@@ -397,13 +414,36 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
                 }
             }
     };
+    // EPI 3: the image band of the first convolution's weight gradient (and the normaliser's statistics at the same pixels), loaded
+    // in the same place
+    constexpr int IM_IT = EPI == 3 ? (C1_ROWS * 60 + NT - 1) / NT : 1;
+    float2 im[IM_IT], imu[IM_IT], isd[IM_IT];
+    auto prefetch_img = [&]() {
+        const float* xim = c1.img + (size_t)(c1.index ? c1.index[n] : (long long)n) * (212 * 120);
+        const __amdgpu_buffer_rsrc_t ri = buf_of(xim, 212 * 120 * 4);
+        const __amdgpu_buffer_rsrc_t rm = buf_of(c1.nmean ? c1.nmean : xim, 212 * 120 * 4);
+        const __amdgpu_buffer_rsrc_t rs = buf_of(c1.nstd ? c1.nstd : xim, 212 * 120 * 4);
+#pragma unroll
+        for (int it = 0; it < IM_IT; ++it) {
+            const int u = tid + it * NT;
+            const int row = u / 60, jj = u - row * 60;
+            const int iy = 4 * a0 - 2 + row;
+            const unsigned off = (u < C1_ROWS * 60 && iy >= 0 && iy < 212) ? (unsigned)((iy * 120 + 2 * jj) * 4) : kOob;
+            im[it] = buf_f2(ri, off);
+            if (c1.nmean) {
+                imu[it] = buf_f2(rm, off);
+                isd[it] = buf_f2(rs, off);
+            }
+        }
+    };
     fetch(0);
     for (int ch = 0; ch < COUT / 16; ++ch) {
         __syncthreads();
         stash();
         __syncthreads();
         if (ch + 1 < COUT / 16) fetch(ch + 1);
-        else if (EPI) prefetch_x();
+        else if (PRE) prefetch_x();
+        else if (EPI == 3) prefetch_img();
         __builtin_amdgcn_sched_barrier(0);      // the loads stay ahead of the MFMA loop
         if (a0 + 2 * wave >= HO) continue;       // both rows of this wave lie below the tensor (last band): staging only
         const float* zb = s_z + q * PSZ + (2 * wave) * RSZ + m;
@@ -433,6 +473,118 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_dgrad_kernel(const float* 
                             acc[r][py][px][rt][bt] = AG_MFMA4(a[rt], B[r + dy][dxx][bt], acc[r][py][px][rt][bt]);
             }
         }
+    }
+    if constexpr (EPI == 3) {
+        float* const s_in = s_all;
+        float* const s_dz = s_all + C1_ROWS * C1_RS + 8;
+        float* const s_tab = s_dz + 16 * C1_PSZ;
+        // the layer's own output at this lane's positions, one half (r) at a time: loaded ahead of use
+        const __amdgpu_buffer_rsrc_t rx1 = buf_of(bnx + (size_t)n * CIN * HIN * WIN, CIN * HIN * WIN * 4);
+        float2 xq[2][2][NBT][4];
+        auto load_x = [&](int r) {
+            const int a = a0 + 2 * wave + r;
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int bt = 0; bt < NBT; ++bt) {
+                    const int b = 16 * bt + m;
+                    const unsigned off = (a < HO && b < WO) ? (unsigned)(((4 * q * HIN + 2 * a + py) * WIN + 2 * b) * 4) : kOob;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xq[r][py][bt][i] = buf_f2(rx1, off, i * (HIN * WIN * 4));
+                }
+        };
+        load_x(0);
+        __syncthreads();                    // every wave is done with the main loop's buffers
+        if (tid < 64) s_tab[tid] = tab[tid];
+        // the image band of the 16 gradient rows (rows 4 a0 - 2 .. + 34), columns de-interleaved by parity as in conv1_wgrad_kernel:
+        // E[k] = column 2k - 2 at [k], O[k] = column 2k - 1 at [EO + k]; the pad positions (columns -2, -1, 120 ...) are zero
+        for (int u = tid; u < C1_ROWS * 16; u += NT) {
+            const int row = u >> 4, k = u & 15;
+            s_in[row * C1_RS + (k == 0 ? 0 : (k < 9 ? 60 + k : 120 + k))] = 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < IM_IT; ++it) {
+            const int u = tid + it * NT;
+            if (u >= C1_ROWS * 60) continue;
+            const int row = u / 60, jj = u - row * 60;
+            const int iy = 4 * a0 - 2 + row;
+            float2 v = im[it];
+            if (c1.nmean && iy >= 0 && iy < 212) {
+                v.x = fminf(fmaxf((v.x - imu[it].x) * __builtin_amdgcn_rcpf(isd[it].x), -5.f), 5.f);
+                v.y = fminf(fmaxf((v.y - imu[it].y) * __builtin_amdgcn_rcpf(isd[it].y), -5.f), 5.f);
+            }
+            s_in[row * C1_RS + jj + 1] = v.x;
+            s_in[row * C1_RS + C1_EO + jj + 1] = v.y;
+        }
+        const float wi = wts ? wts[n] : 1.0f;
+        int boff[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tap = m + 16 * t, kyy = tap / 5, kxx = tap - 5 * kyy;
+            boff[t] = (tap < 25) ? kyy * C1_RS + (kxx & 1) * C1_EO + (kxx >> 1) + q : 0;
+        }
+        const bool t1_data = (m + 16) < 25;
+        const float t1_const = (m + 16 == 25) ? 1.f : 0.f;
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+        float tA[4], tB[4], tC[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 t4 = *reinterpret_cast<const float4*>(tab + 4 * (4 * q + i));
+            tA[i] = t4.x;
+            tB[i] = wi * t4.y;
+            tC[i] = wi * t4.z;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int a = a0 + 2 * wave + r;
+            const bool live = a < HO;           // wave-uniform: a-rows past the tensor (last band) contribute nothing
+            if (live) {
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int bt = 0; bt < NBT; ++bt) {
+                        const int b = 16 * bt + m;
+                        if (b >= WO) continue;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float2 xv = xq[r][py][bt][i];
+                            float2 v = make_float2(acc[r][py][0][0][bt][i], acc[r][py][1][0][bt][i]);
+                            v.x = xv.x > 0.f ? fmaf(v.x, tA[i], fmaf(xv.x, tB[i], tC[i])) : 0.f;
+                            v.y = xv.y > 0.f ? fmaf(v.y, tA[i], fmaf(xv.y, tB[i], tC[i])) : 0.f;
+                            *reinterpret_cast<float2*>(s_dz + (4 * q + i) * C1_PSZ + (2 * wave + py) * 60 + 2 * b) = v;
+                        }
+                    }
+            }
+            if (r == 0) load_x(1);
+            __syncthreads();        // the gradient rows of this half (and, the first time, the image band) are in LDS
+            if (live) {
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const int lr = 2 * (2 * wave + r) + py;         // gradient row within the band's 16
+                    const float* ap = s_dz + m * C1_PSZ + (2 * wave + py) * 60 + q;
+                    const float* bp = s_in + (2 * lr) * C1_RS;
+#pragma unroll 5
+                    for (int j = 0; j < 15; ++j) {
+                        const float av = ap[4 * j];
+                        const float b0 = bp[boff[0] + 4 * j];
+                        float b1 = bp[boff[1] + 4 * j];
+                        b1 = t1_data ? b1 : t1_const;
+                        w0 = AG_MFMA4(av, b0, w0);
+                        w1 = AG_MFMA4(av, b1, w1);
+                    }
+                }
+            }
+            __syncthreads();        // before the next half overwrites the tile / the reduction reuses it
+        }
+        float* red = s_dz;          // [4 waves][16 co][32 taps]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[(wave * 16 + 4 * q + i) * 32 + m] = w0[i];
+            red[(wave * 16 + 4 * q + i) * 32 + 16 + m] = w1[i];
+        }
+        __syncthreads();
+        for (int u = tid; u < 512; u += NT) c1.c1_part[(size_t)blockIdx.x * 512 + u] = red[u] + red[512 + u] + red[1024 + u] + red[1536 + u];
+        return;
     }
     float* dout = dx + (size_t)n * CIN * HIN * WIN;
     float tA[RT][4], tB[RT][4], tC[RT][4];
@@ -1049,12 +1201,12 @@ extern "C" int ag_cnn_conv_dgrad(const float* dz_dev, const float* w_dev, float*
         const int bands = (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
         if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((conv_s2_dgrad_kernel<16, 32, 106, 60, kL2Waves, 0>), dim3(n * bands), dim3(kL2Waves * 64), 0,
-                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, none, none, none, (float*)nullptr);
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, none, none, none, (float*)nullptr, Conv1Side{});
     } else {
         const int bands = (27 + 2 * kL3Waves - 1) / (2 * kL3Waves);
         if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((conv_s2_dgrad_kernel<32, 64, 53, 30, kL3Waves, 0>), dim3(n * bands), dim3(kL3Waves * 64), 0,
-                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, none, none, none, (float*)nullptr);
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, none, none, none, (float*)nullptr, Conv1Side{});
     }
     return AG_CONV_LAUNCH_OK();
 }
@@ -1082,10 +1234,35 @@ extern "C" int ag_cnn_conv_dgrad_bn(const float* dz_dev, const float* w_dev, con
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, cin, cout);
     if (sums_dev)
         hipLaunchKernelGGL((conv_s2_dgrad_kernel<32, 64, 53, 30, kL3Waves, 2>), dim3(n * bands), dim3(kL3Waves * 64), 0,
-                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, bn_x_dev, bn_tab_dev, weights_dev, sums_dev);
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, bn_x_dev, bn_tab_dev, weights_dev, sums_dev, Conv1Side{});
     else
         hipLaunchKernelGGL((conv_s2_dgrad_kernel<32, 64, 53, 30, kL3Waves, 1>), dim3(n * bands), dim3(kL3Waves * 64), 0,
-                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, bn_x_dev, bn_tab_dev, weights_dev, sums_dev);
+                           (hipStream_t)stream, dz_dev, workspace_dev, dx_dev, bands, bn_x_dev, bn_tab_dev, weights_dev, sums_dev, Conv1Side{});
+    return AG_CONV_LAUNCH_OK();
+}
+
+// Rows of `partials` ag_cnn_conv_dgrad_conv1_wgrad writes for n images (one [16][32] block per workgroup).
+extern "C" int ag_cnn_conv_dgrad_conv1_wgrad_partials(int n) {
+    const long long rows = (long long)n * ((53 + 2 * kL2Waves - 1) / (2 * kL2Waves));
+    return (n <= 0 || rows > 0x7fffffffLL) ? AG_ERR_UNSUPPORTED : (int)rows;
+}
+
+// The second convolution's input gradient, the first layer's ReLU + BatchNorm backward and the first convolution's weight gradient in
+// one kernel (ag_cnn_conv_dgrad(16, 32, 106, 60) + ag_cnn_conv1_wgrad with bn_x / bn_tab, without the 1.9 GB tensor between them):
+// partials [ag_cnn_conv_dgrad_conv1_wgrad_partials(n)][16][32], columns 0-24 = dw1 [16][5][5], column 25 = db1; the caller sums the rows.
+extern "C" int ag_cnn_conv_dgrad_conv1_wgrad(const float* dz_dev, const float* w_dev, const float* bn_x_dev, const float* bn_tab_dev,
+                                             const float* weights_dev, const float* x_dev, const long long* index_dev,
+                                             const float* norm_mean_dev, const float* norm_std_dev, float* partials_dev, int n,
+                                             float* workspace_dev, void* stream) {
+    if (!dz_dev || !w_dev || !bn_x_dev || !bn_tab_dev || !x_dev || !partials_dev || !workspace_dev || n <= 0 ||
+        (!norm_mean_dev) != (!norm_std_dev))
+        return AG_ERR_INVALID_ARG;
+    const int bands = (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
+    if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3((9 * 16 * 32 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, 16, 32);
+    const Conv1Side c1{x_dev, index_dev, norm_mean_dev, norm_std_dev, partials_dev};
+    hipLaunchKernelGGL((conv_s2_dgrad_kernel<16, 32, 106, 60, kL2Waves, 3>), dim3(n * bands), dim3(kL2Waves * 64), 0, (hipStream_t)stream,
+                       dz_dev, workspace_dev, (float*)nullptr, bands, bn_x_dev, bn_tab_dev, weights_dev, (float*)nullptr, c1);
     return AG_CONV_LAUNCH_OK();
 }
 

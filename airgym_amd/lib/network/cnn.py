@@ -21,6 +21,8 @@ class CNNFeatureExtractor(nn.Module):
                                            # identity, fused_cnn.bn_sums_from_conv; needs BatchNorm weights != 0); False: reduction kernel
         self.dgrad_epilogue = True      # (with bn_sums_from_weights) the second layer's ReLU + BatchNorm backward in the epilogue of the
                                         # third convolution's input gradient; False: as a pass of its own (ag_relu_bn_bwd_dx)
+        self.conv1_wgrad_fused = True   # (with bn_sums_from_weights) conv2's input gradient + layer 1's backward + conv1's weight gradient
+                                        # as one kernel; False: two kernels with the 1.9 GB gradient between them
         self.direct_grads = False       # True (set by an owner that zeroes .grad before every backward): the trunk's backward writes
                                         # the parameter gradients into the existing .grad tensors itself (no accumulation launches)
 
@@ -36,7 +38,7 @@ class CNNFeatureExtractor(nn.Module):
             from airgym_amd.lib.network import fused_cnn
             if fused_cnn.usable(x, self.features) and (self.features[2].training or not torch.is_grad_enabled()):
                 return self.fc(fused_cnn.trunk(x, self.features, weights, norm, index, self.direct_grads, self.bn_sums_from_weights,
-                                                 self.dgrad_epilogue))
+                                                 self.dgrad_epilogue, self.conv1_wgrad_fused))
         if index is not None:
             x = x.index_select(0, index)
         if norm is not None:

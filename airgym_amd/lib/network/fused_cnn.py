@@ -133,6 +133,24 @@ def _conv1_wgrad(lib, dy, x1, tab, weights, img, index, norm, out=None):
     return s[:, :25].reshape(16, 1, 5, 5), s[:, 25]
 
 
+def _conv_dgrad_conv1_wgrad(lib, dz, w, x1, tab, weights, img, index, norm, out=None):
+    """conv2's input gradient, the first layer's ReLU + BatchNorm backward and the first convolution's weight / bias gradient as one
+    kernel (ag_cnn_conv_dgrad_conv1_wgrad): the gradient of the first convolution's output is never written."""
+    n = x1.shape[0]
+    rows = lib.ag_cnn_conv_dgrad_conv1_wgrad_partials(n)
+    partials = torch.empty(rows, 16, 32, dtype=torch.float32, device=img.device)
+    ws = torch.empty(lib.ag_cnn_conv_workspace_floats(16, 32), dtype=torch.float32, device=img.device)
+    N.check(lib.ag_cnn_conv_dgrad_conv1_wgrad(dz.data_ptr(), w.data_ptr(), x1.data_ptr(), tab.data_ptr(), _wptr(weights), img.data_ptr(),
+                                              _wptr(index), *_norm_ptrs(norm), partials.data_ptr(), n, ws.data_ptr(), _stream(img)),
+            "ag_cnn_conv_dgrad_conv1_wgrad")
+    if out is not None:
+        torch.sum(partials[:, :, :25], 0, out=out[0].view(16, 25))
+        torch.sum(partials[:, :, 25], 0, out=out[1])
+        return None, None
+    s = partials.sum(0)
+    return s[:, :25].reshape(16, 1, 5, 5), s[:, 25]
+
+
 def _blocks(lib, n, c):
     ppb = lib.ag_relu_bn_planes_per_block()
     return (n * c + ppb - 1) // ppb
@@ -227,8 +245,8 @@ def _bn_prep_from_conv(lib, w, dw, total, border, coef, gamma, beta, hin, m, mod
 
 class _Trunk(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, weights, bns, training, norm, index, gout, from_weights, dgrad_epilogue, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3,
-                g3, be3):
+    def forward(ctx, img, weights, bns, training, norm, index, gout, from_weights, dgrad_epilogue, conv1_fused, w1, b1, g1, be1, w2, b2, g2,
+                be2, w3, b3, g3, be3):
         lib = N.load()
         img = img.contiguous()
         if index is not None:
@@ -257,6 +275,7 @@ class _Trunk(torch.autograd.Function):
         ctx.gout = gout
         ctx.from_weights = from_weights
         ctx.dgrad_epilogue = bool(from_weights and dgrad_epilogue)
+        ctx.conv1_fused = bool(from_weights and conv1_fused)
         ctx.save_for_backward(img, x1, x2, x3, plane1, weights if weights is not None else img.new_empty(0), w2, w3, g1, g2, g3,
                               coef1, coef2, coef3, be1, be2)
         return pooled
@@ -320,19 +339,26 @@ class _Trunk(torch.autograd.Function):
         if fw:
             sums1, tab1 = _bn_prep_from_conv(lib, w2, (G(4) if go is not None else dw2).contiguous(), db2.contiguous(), border2, coef1,
                                              g1, be1, 106, m1, 1, (G(2), G(3)))
-        dy1 = _conv_dgrad(lib, dy2, w2, x1)
-        del dy2
-        # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)
-        if not fw:
-            sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1, (G(2), G(3)))
-        dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.index, ctx.norm, (G(0), G(1)) if go is not None else None)
+        if ctx.conv1_fused:
+            # layer 1 in the same kernel as conv2's input gradient: neither that gradient nor dx1 is ever written
+            dw1, db1 = _conv_dgrad_conv1_wgrad(lib, dy2, w2, x1, tab1, weights, img, ctx.index, ctx.norm,
+                                               (G(0), G(1)) if go is not None else None)
+            del dy2
+        else:
+            dy1 = _conv_dgrad(lib, dy2, w2, x1)
+            del dy2
+            # layer 1: the ReLU + BatchNorm backward is folded into the weight-gradient kernel (dx1 is never written)
+            if not fw:
+                sums1, tab1 = _bn_reduce(lib, dy1, x1, coef1, g1, m1, 1, (G(2), G(3)))
+            dw1, db1 = _conv1_wgrad(lib, dy1, x1, tab1, weights, img, ctx.index, ctx.norm, (G(0), G(1)) if go is not None else None)
         if go is not None:
-            return (None,) * 21
-        return ((None,) * 9 + (dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3, sums3[:, 1],
+            return (None,) * 22
+        return ((None,) * 10 + (dw1, db1, sums1[:, 1], sums1[:, 0], dw2, db2, sums2[:, 1], sums2[:, 0], dw3, db3, sums3[:, 1],
                                sums3[:, 0]))
 
 
-def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, sums_from_weights=True, dgrad_epilogue=True):
+def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, sums_from_weights=True, dgrad_epilogue=True,
+          conv1_fused=True):
     """`features(x)` flattened to [N, 64] (the caller has checked `usable(x, features)`): batch statistics when the BatchNorm
     layers are in training mode (all three must agree), running statistics otherwise.  norm = (mean, std) (optional, per-pixel
     [212 * 120]): x is the RAW image and the first convolution normalises it, clamp((x - mean) / std, -5, 5), while staging.
@@ -342,7 +368,9 @@ def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, 
     sums_from_weights: the backward takes the reductions of the first two ReLU + BatchNorm layers from the following convolution's
     weights and weight gradient (`bn_sums_from_conv`: no pass over the 1.9 GB / 1.0 GB gradients); False = the reduction kernel.
     dgrad_epilogue (needs sums_from_weights, which makes the coefficients known in time): the second layer's ReLU + BatchNorm
-    backward runs in the epilogue of the third convolution's input gradient instead of as a pass of its own."""
+    backward runs in the epilogue of the third convolution's input gradient instead of as a pass of its own.
+    conv1_fused (needs sums_from_weights too): the second convolution's input gradient, the first layer's ReLU + BatchNorm backward
+    and the first convolution's weight gradient run as one kernel."""
     layers = list(features)
     convs, bns = (layers[0], layers[3], layers[6]), (layers[2], layers[5], layers[8])
     training = bns[0].training
@@ -359,4 +387,4 @@ def trunk(x, features, weights=None, norm=None, index=None, direct_grads=False, 
         grads = [p.grad for p in args]
         if all(g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == p.device for g, p in zip(grads, args)):
             gout = grads
-    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, gout, bool(sums_from_weights), bool(dgrad_epilogue), *args)
+    return _Trunk.apply(x, weights if training else None, bns, training, norm, index, gout, bool(sums_from_weights), bool(dgrad_epilogue), bool(conv1_fused), *args)

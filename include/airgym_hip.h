@@ -502,6 +502,15 @@ int ag_cnn_conv_dgrad_bn_rows(int n, int cin, int cout, int hin, int win);
 int ag_cnn_conv_dgrad_bn(const float* dz_dev, const float* w_dev, const float* bn_x_dev, const float* bn_tab_dev,
                          const float* weights_dev, float* dx_dev, float* sums_dev, int n, int cin, int cout, int hin, int win,
                          float* workspace_dev, void* stream);
+/*   ag_cnn_conv_dgrad_conv1_wgrad: ag_cnn_conv_dgrad(16, 32, 106, 60) + ag_cnn_conv1_wgrad(bn_x, bn_tab, ...) as ONE kernel: the second
+ *                           convolution's input gradient is turned into the gradient of the first convolution's output in the
+ *                           epilogue (as ag_cnn_conv_dgrad_bn) and consumed from LDS by the first convolution's weight gradient; the
+ *                           1.9 GB tensor between the two never exists.  partials_dev [ag_cnn_conv_dgrad_conv1_wgrad_partials(n)][16][32]
+ *                           (columns 0-24 dw [16][5][5], column 25 db; the caller sums the rows in order). */
+int ag_cnn_conv_dgrad_conv1_wgrad_partials(int n);
+int ag_cnn_conv_dgrad_conv1_wgrad(const float* dz_dev, const float* w_dev, const float* bn_x_dev, const float* bn_tab_dev,
+                                  const float* weights_dev, const float* x_dev, const long long* index_dev, const float* norm_mean_dev,
+                                  const float* norm_std_dev, float* partials_dev, int n, float* workspace_dev, void* stream);
 int ag_cnn_conv_wgrad_partials(int n, int cin, int cout, int hin, int win);
 int ag_cnn_conv_wgrad(const float* dz_dev, const float* x_dev, const float* scale_dev, const float* shift_dev,
                       float* partials_dev, int with_bias, int n, int cin, int cout, int hin, int win, void* stream);

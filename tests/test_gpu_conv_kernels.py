@@ -222,6 +222,7 @@ def test_reductions_from_weights_equal_the_reduction_kernel():
     g = torch.randn(9, 12, device="cuda")
     c = copy.deepcopy(a)
     c.dgrad_epilogue = False        # the second layer's ReLU + BatchNorm backward as a pass of its own
+    c.conv1_wgrad_fused = False     # and conv2's input gradient / conv1's weight gradient as two kernels
     a(x, w).backward(g)
     b(x, w).backward(g)
     c(x, w).backward(g)
@@ -298,3 +299,43 @@ def test_input_gradient_with_the_batchnorm_backward_in_its_epilogue(weighted, wi
         assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
     # other layers are refused
     assert lib.ag_cnn_conv_dgrad_bn_rows(n, 16, 32, 106, 60) == N.AG_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("weighted,normalised,indexed", [(False, False, False), (True, True, True)])
+def test_input_gradient_feeding_the_first_weight_gradient_in_one_kernel(weighted, normalised, indexed):
+    """ag_cnn_conv_dgrad_conv1_wgrad against the two kernels it replaces (ag_cnn_conv_dgrad, then ag_cnn_conv1_wgrad with the
+    first layer's ReLU + BatchNorm backward in its staging): the same float32 gradient values, summed in a different order."""
+    import ctypes
+    from airgym_amd import _native as N
+    lib = N.load()
+    torch.manual_seed(10)
+    dev = torch.device("cuda")
+    n = 5
+    dz = torch.randn(n, 32, 53, 30, device=dev)
+    w = torch.randn(32, 16, 3, 3, device=dev) * 0.1
+    x1 = torch.randn(n, 16, 106, 60, device=dev)
+    tab = torch.cat((torch.randn(16, 3, device=dev), torch.zeros(16, 1, device=dev)), 1).contiguous()
+    wts = torch.tensor([1., 3., 2., 4., 1.], device=dev) if weighted else None
+    store = torch.rand(12, 1, 212, 120, device=dev) * 3.0
+    index = torch.tensor([7, 0, 3, 11, 4], device=dev) if indexed else None
+    img = store if indexed else store[:n].contiguous()
+    mean = torch.rand(212 * 120, device=dev) if normalised else None
+    std = (torch.rand(212 * 120, device=dev) * 0.3 + 0.02) if normalised else None
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: t.data_ptr() if t is not None else None
+    ws = torch.empty(lib.ag_cnn_conv_workspace_floats(16, 32), device=dev)
+    # the two kernels
+    dy1 = torch.empty_like(x1)
+    N.check(lib.ag_cnn_conv_dgrad(dz.data_ptr(), w.data_ptr(), dy1.data_ptr(), n, 16, 32, 106, 60, ws.data_ptr(), stream), "dgrad")
+    pa = torch.empty(lib.ag_cnn_conv1_wgrad_partials(n), 16, 32, device=dev)
+    N.check(lib.ag_cnn_conv1_wgrad(dy1.data_ptr(), x1.data_ptr(), tab.data_ptr(), P(wts), img.data_ptr(), P(index), P(mean), P(std),
+                                   pa.data_ptr(), n, stream), "conv1_wgrad")
+    # the one kernel
+    rows = lib.ag_cnn_conv_dgrad_conv1_wgrad_partials(n)
+    assert rows > 0
+    pb = torch.full((rows, 16, 32), float("nan"), device=dev)
+    N.check(lib.ag_cnn_conv_dgrad_conv1_wgrad(dz.data_ptr(), w.data_ptr(), x1.data_ptr(), tab.data_ptr(), P(wts), img.data_ptr(), P(index),
+                                              P(mean), P(std), pb.data_ptr(), n, ws.data_ptr(), stream), "dgrad_conv1_wgrad")
+    a, b = pa.double().sum(0)[:, :26], pb.double().sum(0)[:, :26]
+    assert torch.isfinite(pb[:, :, :26]).all()
+    assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item(), ((a - b).abs().max().item(), a.abs().max().item())
