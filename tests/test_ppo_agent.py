@@ -509,3 +509,49 @@ def test_batchnorm_backward_reductions_from_the_next_convolution():
                               dz[:, :, 0, 0].sum(0), dz[:, :, -1, 0].sum(0)), 1)
         got = bn_sums_from_conv(w, w.grad, dz.sum((0, 2, 3)), border, gamma, beta, hin)
         assert torch.allclose(got, ref, rtol=1e-11, atol=1e-11), (hin, (got - ref).abs().max())
+
+
+def _weighted_rms_worker(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from airgym_amd.lib.core.running_mean_std import RunningMeanStd
+    g = torch.Generator().manual_seed(11)
+    store = torch.rand(10, 1, 6, 5, generator=g, dtype=torch.float64) * 3.0          # the ranks' frame stores (here: the same tensor)
+    index = [torch.tensor([3, 7, 8, 0]), torch.tensor([9, 1, 2])][rank]            # different, differently sized de-duplicated batches
+    weights = [torch.tensor([4., 1., 3., 2.]), torch.tensor([2., 5., 1.])][rank]
+    rms = RunningMeanStd((1, 6, 5))
+    for _ in range(2):
+        rms.update(store, dist.group.WORLD, weights, index)
+    q.put((rank, {"mean": rms.running_mean.numpy().copy(), "var": rms.running_var.numpy().copy(), "count": float(rms.count)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weighted_indexed_normaliser_moments_across_two_ranks():
+    """RunningMeanStd.update(x, group, weights, index) at world size 2 (gloo): the de-duplicated image batches of the ranks differ in
+    size and multiplicities; both replicas must end with the statistics of ONE update on the concatenation of the expanded batches
+    (row i of x[index] repeated weights[i] times) - the multi-GPU form of the Planning image normaliser."""
+    import socket
+    from airgym_amd.lib.core.running_mean_std import RunningMeanStd
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_weighted_rms_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(11)
+    store = torch.rand(10, 1, 6, 5, generator=g, dtype=torch.float64) * 3.0
+    expanded = torch.cat((torch.repeat_interleave(store[torch.tensor([3, 7, 8, 0])], torch.tensor([4, 1, 3, 2]), dim=0),
+                          torch.repeat_interleave(store[torch.tensor([9, 1, 2])], torch.tensor([2, 5, 1]), dim=0)))
+    ref = RunningMeanStd((1, 6, 5))
+    for _ in range(2):
+        ref.update(expanded)
+    for r in (0, 1):
+        assert res[r]["count"] == float(ref.count) == 1.0 + 2 * 18
+        assert np.allclose(res[r]["mean"], ref.running_mean.numpy(), rtol=0, atol=1e-12)
+        assert np.allclose(res[r]["var"], ref.running_var.numpy(), rtol=1e-12, atol=1e-13)
+    assert np.array_equal(res[0]["mean"], res[1]["mean"]) and np.array_equal(res[0]["var"], res[1]["var"])
