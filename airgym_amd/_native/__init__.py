@@ -24,6 +24,7 @@ AG_CTL_MODES = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
 AG_FLAG_REWARD_TERMS = 1 << 0
 AG_FLAG_OBS_NOISE_OFF = 1 << 1
 AG_FLAG_FIX_TIME_OUTS = 1 << 2
+AG_FLAG_STAGGER_PHASE = 1 << 3
 AG_NUM_REWARD_TERMS = 11
 
 AG_ERR_UNKNOWN_TASK = -2

@@ -96,6 +96,7 @@ __global__ void reset_all_kernel(ag::KArgs k, int n_pad, int num_actions, int nu
     P.tick = *k.tick_in;
     if (i == 0) *k.tick_out = P.tick + 1u;
     ag::env_reset(s, c, pre_a, num_actions, P, P.env_id_offset + (uint32_t)i);
+    if (P.stagger_phase) s.progress = ag::stagger_progress(P, P.env_id_offset + (uint32_t)i);   // AG_FLAG_STAGGER_PHASE
     ag::store_env(k, i, s);
     ag::store_ctl<ag::CTL_POS>(k, i, c);  // writes all four controller arrays
     k.PA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -257,7 +258,7 @@ __global__ void planning_set_state_kernel(ag::KArgs k, ag::PlanArgs pa, ag_plann
 void fill_params(ag_env* h) {
     h->k.P = ag::make_step_params(h->cfg.task, h->cfg.dt, h->cfg.max_episode_length, h->cfg.target_state, h->cfg.seed,
                                   h->cfg.env_id_offset, (h->cfg.flags & AG_FLAG_OBS_NOISE_OFF) != 0,
-                                  (h->cfg.flags & AG_FLAG_FIX_TIME_OUTS) != 0);
+                                  (h->cfg.flags & AG_FLAG_FIX_TIME_OUTS) != 0, (h->cfg.flags & AG_FLAG_STAGGER_PHASE) != 0);
 }
 
 int validate(const ag_config* cfg) {
@@ -269,6 +270,9 @@ int validate(const ag_config* cfg) {
         return fail(AG_ERR_UNKNOWN_TASK, "Task with id " + std::to_string(cfg->task) + " was not registered");
     if (cfg->ctl_mode < AG_CTL_POS || cfg->ctl_mode > AG_CTL_PROP)
         return fail(AG_ERR_UNKNOWN_CTL, "unknown ctl_mode " + std::to_string(cfg->ctl_mode) + " (expected pos|vel|atti|rate|prop)");
+    if ((cfg->flags & AG_FLAG_STAGGER_PHASE) && cfg->task != AG_TASK_HOVERING)
+        return fail(AG_ERR_UNSUPPORTED, "AG_FLAG_STAGGER_PHASE: Hovering only (Tracking's reference point is a function of the "
+                                        "progress counter: an env started mid-trajectory is out of bounds at once)");
     if ((cfg->task == AG_TASK_PLANNING || cfg->task == AG_TASK_AVOID) && cfg->ctl_mode == AG_CTL_ATTI)
         return fail(AG_ERR_UNSUPPORTED, "planning / avoid observations hold 4 action values (planning.py:214, avoid.py:232: the "
                                         "reference's `obs_buf[..., 12:16] = actions_local` raises on atti's [N,5] actions): "

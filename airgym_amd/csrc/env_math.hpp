@@ -94,6 +94,7 @@ struct StepParams {
     uint32_t env_id_offset;
     uint32_t noise_off;
     uint32_t fix_time_outs; // AG_FLAG_FIX_TIME_OUTS (opt-in): see step_timeout()
+    uint32_t stagger_phase; // AG_FLAG_STAGGER_PHASE (opt-in): see stagger_progress()
     // reset distribution (hovering.py:316-329 / tracking.py:166-179)
     float reset_pos_scale[3], reset_pos_offset[3], reset_euler_scale[3];
     float reset_linvel_scale, reset_angvel_scale;
@@ -103,7 +104,8 @@ struct StepParams {
 // hovering.py:316-329 / tracking.py:166-179).  The oracle multiplies f32 tensors by python
 // doubles, i.e. the scalar is rounded to f32 once: dt, dt/2 and dt/6 are formed in double first.
 inline StepParams make_step_params(int task, double dt, int max_episode_length, const float* target18, uint64_t seed,
-                                   uint32_t env_id_offset, bool noise_off, bool fix_time_outs = false) {
+                                   uint32_t env_id_offset, bool noise_off, bool fix_time_outs = false,
+                                   bool stagger_phase = false) {
     StepParams P;
     P.dt = (float)dt;
     P.half_dt = (float)(0.5 * dt);
@@ -117,6 +119,7 @@ inline StepParams make_step_params(int task, double dt, int max_episode_length, 
     P.env_id_offset = env_id_offset;
     P.noise_off = noise_off ? 1u : 0u;
     P.fix_time_outs = fix_time_outs ? 1u : 0u;
+    P.stagger_phase = stagger_phase ? 1u : 0u;
     if (task == 1) {
         P.reset_pos_scale[0] = P.reset_pos_scale[1] = P.reset_pos_scale[2] = 0.1f;
         P.reset_pos_offset[0] = P.reset_pos_offset[1] = 0.0f;
@@ -229,7 +232,15 @@ AG_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
 AG_HD float u32_to_unit(uint32_t x) { return (float)(x >> 8) * kInv2p24; }
 AG_HD float u32_to_open_unit(uint32_t x) { return ((float)(x >> 8) + 1.0f) * kInv2p24; }
 
-enum : uint32_t { STREAM_RESET = 0, STREAM_OBS_NOISE = 1 };
+enum : uint32_t { STREAM_RESET = 0, STREAM_OBS_NOISE = 1, STREAM_PHASE = 2 };
+
+// AG_FLAG_STAGGER_PHASE: the progress a FULL reset gives env `env_global`, uniform on {0 .. max_episode_length - 2}
+// (oracle/hovering_ref.py HoveringRef._reset_all)
+AG_HD int stagger_progress(const StepParams& P, uint32_t env_global) {
+    const U4 r = philox4x32_10(env_global, P.tick, STREAM_PHASE, 0u, P.key0, P.key1);
+    const uint32_t span = (uint32_t)(P.max_episode_length > 1 ? P.max_episode_length - 1 : 1);
+    return (int)(r.x % span);
+}
 
 // 12 U[0,1): pos3 euler3 linvel3 angvel3
 AG_HD void reset_uniforms(const StepParams& P, uint32_t env_global, float* u) {

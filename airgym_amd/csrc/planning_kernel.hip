@@ -372,28 +372,32 @@ hipError_t launch_planning_step(const KArgs& k, const PlanArgs& pa, int ctl, int
     }
 }
 
-hipError_t launch_planning_render(const KArgs& k, const PlanArgs& pa, hipStream_t st) {
-    static bool attr_set = false;
-    const size_t lds = planning_render_lds_bytes();
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planning_render_kernel<SCENE_PLANNING>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+// The dynamic-LDS limit is an attribute of (function, device): remembered per device ordinal, as in split_gemm.hip
+template <int SCENE>
+static hipError_t render_lds_attr(size_t lds) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(planning_render_kernel<SCENE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
+    return hipSuccess;
+}
+
+hipError_t launch_planning_render(const KArgs& k, const PlanArgs& pa, hipStream_t st) {
+    const size_t lds = planning_render_lds_bytes();
+    if (hipError_t e = render_lds_attr<SCENE_PLANNING>(lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(planning_render_kernel<SCENE_PLANNING>, dim3(k.n), dim3(kRenderThreads), lds, st, k, pa);
     return hipGetLastError();
 }
 
 hipError_t launch_avoid_render(const KArgs& k, const PlanArgs& pa, hipStream_t st) {
-    static bool attr_set = false;
     const size_t lds = planning_render_lds_bytes();
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(planning_render_kernel<SCENE_AVOID>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = render_lds_attr<SCENE_AVOID>(lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(planning_render_kernel<SCENE_AVOID>, dim3(k.n), dim3(kRenderThreads), lds, st, k, pa);
     return hipGetLastError();
 }

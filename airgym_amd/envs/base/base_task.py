@@ -68,7 +68,10 @@ class BaseTask:
             target_state=self.cfg.env.target_state,
             reward_terms=getattr(self.cfg.env, "emit_reward_terms", True),
             # opt-in: extras["time_outs"] flags the envs that hit the time limit (the reference's is never true, quirk Q3)
-            fix_time_outs=bool(getattr(self.cfg.env, "fix_time_outs", False)))
+            fix_time_outs=bool(getattr(self.cfg.env, "fix_time_outs", False)),
+            # opt-in (Hovering): a full reset starts every env at its own progress, so the 2 400-step time limit does not
+            # end all episodes in the same rollout (the reference starts all at 0, hovering.py:310-335)
+            stagger_episode_phase=bool(getattr(self.cfg.env, "stagger_episode_phase", False)))
 
     def get_observations(self):
         return self.obs_buf

@@ -16,7 +16,8 @@ from . import _native as N
 
 class HipEnvHandle:
     def __init__(self, task, ctl_mode, num_envs, device="cuda:0", seed=0, env_id_offset=0, dt=0.01,
-                 max_episode_length=0, target_state=None, reward_terms=True, obs_noise=True, fix_time_outs=False):
+                 max_episode_length=0, target_state=None, reward_terms=True, obs_noise=True, fix_time_outs=False,
+                 stagger_episode_phase=False):
         if task not in N.AG_TASKS:
             raise ValueError(f"Task with name: {task} was not registered")
         if ctl_mode not in N.AG_CTL_MODES:
@@ -37,7 +38,11 @@ class HipEnvHandle:
         cfg.num_envs = self.num_envs
         cfg.device = self.device.index or 0
         cfg.flags = ((N.AG_FLAG_REWARD_TERMS if reward_terms else 0) | (0 if obs_noise else N.AG_FLAG_OBS_NOISE_OFF)
-                     | (N.AG_FLAG_FIX_TIME_OUTS if fix_time_outs else 0))
+                     | (N.AG_FLAG_FIX_TIME_OUTS if fix_time_outs else 0)
+                     | (N.AG_FLAG_STAGGER_PHASE if stagger_episode_phase else 0))
+        if stagger_episode_phase and task != "hovering":
+            raise ValueError("stagger_episode_phase: Hovering only")
+        self.stagger_episode_phase = bool(stagger_episode_phase)
         if fix_time_outs and task not in ("hovering", "tracking"):
             raise ValueError("fix_time_outs: Hovering / Tracking only")
         self.fix_time_outs = bool(fix_time_outs)

@@ -213,6 +213,13 @@ class A2CAgent:
                 config["device"] = "cuda:" + str(self.local_rank)
             if self.global_rank != 0:
                 config["print_stats"] = False
+        # `mixed_precision` (reference: torch.cuda.amp autocast + GradScaler, lib/agent/a2c_base.py:236-237,566,582) is not
+        # implemented: this build's update is float32 throughout (the 256-wide products run float32-ACCURATE on the bf16
+        # matrix cores).  A YAML that asks for it must not silently train in another precision.
+        if bool(config.get("mixed_precision", False)):
+            raise NotImplementedError(
+                "config.mixed_precision: true is not supported by airgym_amd (the PPO update is float32; see DESIGN.md 4.3) "
+                "- set it to false")
         self.ppo_device = config.get("device", "cuda:0")
         if str(self.ppo_device).startswith("cuda"):
             torch.cuda.set_device(self.ppo_device)

@@ -120,7 +120,8 @@ def relu_batchnorm_torch(x, bn, weights):
     with torch.no_grad():
         if bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        mom = float(bn.momentum)
+        # momentum = None is nn.BatchNorm2d's cumulative moving average: factor 1 / num_batches_tracked
+        mom = float(bn.momentum) if bn.momentum is not None else 1.0 / max(float(bn.num_batches_tracked), 1.0)
         bn.running_mean.mul_(1.0 - mom).add_(mean.detach(), alpha=mom)
         bn.running_var.mul_(1.0 - mom).add_(var.detach() * (m / torch.clamp(m - 1, min=1.0)), alpha=mom)
     return y

@@ -48,8 +48,13 @@ def update_cfg_from_args(env_cfg, args):
             env_cfg.seed = args.seed
         if getattr(args, "env_id_offset", None) is not None:
             env_cfg.env.env_id_offset = args.env_id_offset
-        # this build's opt-in (AG_FLAG_FIX_TIME_OUTS); always assigned: the registered cfg object is shared between calls
-        env_cfg.env.fix_time_outs = bool(getattr(args, "fix_time_outs", False))
+        # this build's opt-ins.  The registered cfg object is shared between make_env calls, so each call starts from the
+        # value the config CLASS declares (a task config may turn an opt-in on) and the command line only overrides it
+        # when the flag was actually given.
+        for key in ("fix_time_outs", "stagger_episode_phase"):
+            default = bool(getattr(type(env_cfg.env), key, False))
+            given = getattr(args, key, None)
+            setattr(env_cfg.env, key, default if given is None else bool(given))
     return env_cfg
 
 
@@ -82,6 +87,11 @@ def get_args(argv=None):
     p.add_argument("--num_threads", type=int, default=0)
     p.add_argument("--subscenes", type=int, default=0)
     p.add_argument("--slices", type=int, default=None)
+    # this build's opt-ins (default None = "not given": the task config's value stands, update_cfg_from_args)
+    p.add_argument("--fix_time_outs", action="store_true", default=None,
+                   help="extras['time_outs'] flags the envs that reached the time limit (the reference's never fires)")
+    p.add_argument("--stagger_episode_phase", action="store_true", default=None,
+                   help="Hovering: a full reset starts every env at its own progress (desynchronised time limits)")
     args = p.parse_args(argv)
     args.physics_engine = SIM_PHYSX
     args.use_gpu = True

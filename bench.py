@@ -31,6 +31,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# Planning side line: MIOpen's default find mode benchmarks every solver the first time a shape is seen (~100 s); FAST = immediate
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import yaml  # noqa: E402
@@ -163,6 +165,79 @@ def shipped_ratio_line(args, world, epochs=3, warmup=2):
     return out
 
 
+def _time_epochs(agent, epochs, warmup):
+    dev = agent.ppo_device
+    agent.init_tensors()
+    agent.obs = agent.env_reset()
+    agent.broadcast_parameters()
+    for _ in range(warmup):
+        agent.epoch_num += 1
+        agent.train_epoch()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    play = upd = 0.0
+    for _ in range(epochs):
+        agent.epoch_num += 1
+        st = agent.train_epoch()
+        play += st["play_time"]
+        upd += st["update_time"]
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0, st, play, upd
+
+
+def side_config_tracking(args, epochs=3, warmup=2):
+    """BASELINE config 2: Tracking (figure-8 reference), 65 536 envs, LV control, one GPU, the same MLP(256,256) PPO epoch
+    as the headline (reference: airgym/envs/task/tracking.py:202-296).  Timed after the headline's timed region, N = 1."""
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+
+    class A:
+        pass
+    a = A()
+    a.__dict__.update(vars(args))
+    a.task, a.ctl = "tracking", "vel"
+    params = build_params(a, 1)
+    agent = A2CAgent("bench_tracking", params)
+    el, st, play, upd = _time_epochs(agent, epochs, warmup)
+    out = {"value": args.envs * agent.horizon_length * epochs / el, "unit": "env-steps/s", "ms_per_step": el / epochs * 1e3,
+           "steps": epochs, "warmup": warmup, "dtype": "f32",
+           "config": {"workload": "tracking_lv_ppo_epoch", "task": "tracking", "ctl_mode": "vel", "envs_per_gpu": args.envs,
+                      "num_obs": 48, "horizon_length": agent.horizon_length, "mini_epochs": agent.mini_epochs_num,
+                      "minibatch_size": agent.minibatch_size, "policy": "MLP(256,256) actor-critic, fixed sigma"},
+           "last_kl": st["kl"], "finite": bool(st["kl"] == st["kl"] and st["a_loss"] == st["a_loss"])}
+    agent.vec_env.env.hip.close()
+    return out
+
+
+def side_config_planning(envs=16384, epochs=3, warmup=1, minibatches=24):
+    """BASELINE config 4 on one GPU: Planning, 16 384 envs, CTBR, 212 x 120 depth image every 4th step, the trainable CNN
+    policy of the shipped YAML (reference: airgym/envs/task/planning.py:138-184, scripts/config/ppo_planning.yaml:31,
+    lib/network/cnn.py:3-33).  The frozen-VAE encoder of BASELINE's wording has no shipped weights (.MISSING_LARGE_BLOBS);
+    the CNN is the configuration the reference ships and trains."""
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    with open(os.path.join(REPO, "scripts", "config", "ppo_planning.yaml")) as f:
+        params = yaml.safe_load(f)["params"]
+    c = params["config"]
+    H = c["horizon_length"]
+    c.update(num_actors=envs, minibatch_size=envs * H // minibatches, device="cuda:0", max_epochs=-1,
+             write_summaries=False, print_stats=False, save_frequency=0, save_best_after=10 ** 9, multi_gpu=False)
+    c["env_config"] = {"use_image": True, "num_envs": envs, "ctl_mode": "rate", "seed": 0, "sim_device": "cuda:0", "headless": True}
+    params["seed"] = 0
+    agent = A2CAgent("bench_planning", params)
+    el, st, play, upd = _time_epochs(agent, epochs, warmup)
+    out = {"value": envs * agent.horizon_length * epochs / el, "unit": "env-steps/s", "ms_per_step": el / epochs * 1e3,
+           "steps": epochs, "warmup": warmup, "dtype": "f32",
+           "config": {"workload": "planning_cnn_ctbr_ppo_epoch", "task": "planning", "ctl_mode": "rate", "envs_per_gpu": envs,
+                      "image": [1, 212, 120], "camera_every": 4, "horizon_length": agent.horizon_length,
+                      "mini_epochs": agent.mini_epochs_num, "minibatch_size": agent.minibatch_size,
+                      "policy": "CNNFeatureExtractor(30) + MLP(64,128,64), ppo_planning.yaml",
+                      "frame_dedup": bool(getattr(agent, "_dedup", False))},
+           "rollout_ms": play / epochs * 1e3, "update_ms": upd / epochs * 1e3,
+           "mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+           "last_kl": st["kl"], "finite": bool(st["kl"] == st["kl"] and st["a_loss"] == st["a_loss"])}
+    agent.vec_env.env.hip.close()
+    return out
+
+
 def _load_agent_class(spec):
     """'pkg.module:Class' -> the class.  The default is the product agent; tests pass a stub (tests/_stub_bench_agent.py)
     to exercise the launcher, the barriers and the collective without a GPU."""
@@ -246,6 +321,8 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-shipped-ratio", action="store_true", help="skip the second line at 48 minibatches per mini-epoch")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the side lines for BASELINE configs 2 (Tracking / LV) and 4 (Planning / CNN, 16 384 envs)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = launcher / collective test only (gloo)")
     ap.add_argument("--dist-backend", default=None, help="default: nccl (= RCCL) on cuda, gloo on cpu")
     ap.add_argument("--agent", default="airgym_amd.lib.agent.a2c_continuous:A2CAgent",
@@ -365,6 +442,19 @@ def main(argv=None):
                     if e["bound"] == "hbm":
                         e["frac_of_copy_ceiling"] = e["achieved"] / out["roofline"]["copy_ceiling_gbps"]
                 out["update_kernels"] = uk
+        if (world == 1 and on_gpu and not args.no_side_configs and (args.task, args.ctl) == ("hovering", "rate")
+                and hip is not None and args.envs == ENVS_PER_GPU):
+            # BASELINE configs 2 and 4 at their single-GPU size, timed by this process AFTER the headline's timed region
+            # (3 epochs each; not part of `value`)
+            side = {}
+            for name, fn in (("tracking_lv", lambda: side_config_tracking(args)),
+                             ("planning_cnn_16384", lambda: side_config_planning())):
+                try:
+                    side[name] = fn()
+                except Exception as e:      # a side line must never take the headline down with it
+                    side[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.empty_cache()
+            out["side_configs"] = side
         if world == 1 and on_gpu and not args.no_cpu_baseline and (args.task, args.ctl) == ("hovering", "rate"):
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -93,6 +93,12 @@ typedef enum ag_ctl_mode {
 enum {
     AG_FLAG_REWARD_TERMS = 1u << 0, /* emit the 9 item_reward_info arrays + cmd_thrusts each step */
     AG_FLAG_OBS_NOISE_OFF = 1u << 1, /* testing aid: skip add_noise (reference: always on, hovering.py:343) */
+    AG_FLAG_STAGGER_PHASE = 1u << 3, /* opt-in (Hovering): a FULL reset (ag_create, ag_reset_all) starts env i at
+                                        progress ~ U{0 .. max_episode_length - 2}, drawn from the counter RNG (stream 2) keyed
+                                        by the GLOBAL env id, instead of 0 - so that the 2 400-step time limit does not end every
+                                        episode of the shard in the same rollout.  Only the first episode of an env is
+                                        shorter; in-step resets (hovering.py:300-302) still start at progress 0 = the reference
+                                        (hovering.py:310-335 sets progress_buf[env_ids] = 0 for all envs at once) */
     AG_FLAG_FIX_TIME_OUTS = 1u << 2  /* opt-in (Hovering / Tracking): time_out_buf flags the envs whose episode reached the time
                                         limit this step (progress >= max_episode_length - 1 before the reset).  Default off =
                                         the reference: hovering.py:304 evaluates `progress_buf > max_episode_length` AFTER

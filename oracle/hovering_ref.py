@@ -91,11 +91,14 @@ class HoveringRef:
     action_limits = ACTION_LIMITS
 
     def __init__(self, num_envs, ctl_mode="rate", seed=0, env_id_offset=0, dt=0.01,
-                 target_state=None, integrator="rk4", fix_time_outs=False):
+                 target_state=None, integrator="rk4", fix_time_outs=False, stagger_episode_phase=False):
         assert ctl_mode in ACTION_LIMITS, f"unknown ctl_mode {ctl_mode!r}"
         # opt-in of the BUILD, not of the reference (AG_FLAG_FIX_TIME_OUTS): time_out_buf = "reached the time limit this step"
         # instead of the reference's never-true expression (hovering.py:304 after the reset of :300-302 zeroed the progress)
         self.fix_time_outs = bool(fix_time_outs)
+        # opt-in of the BUILD (AG_FLAG_STAGGER_PHASE): a full reset starts env i at progress ~ U{0 .. max_len - 2} (counter
+        # RNG stream 2, global env id) instead of 0 (hovering.py:333 progress_buf[env_ids] = 0)
+        self.stagger_episode_phase = bool(stagger_episode_phase)
         self.num_envs = num_envs
         self.ctl_mode = ctl_mode
         self.num_actions = 5 if ctl_mode == "atti" else 4          # hovering.py:47
@@ -129,7 +132,7 @@ class HoveringRef:
         self.ctl_state = CascadeState(num_envs)
         self.item_reward_info = {}
         # like ag_create: the state is valid (randomised, flagged reset) from the start
-        self.reset_idx(torch.arange(num_envs))
+        self._reset_all()
         self.tick += 1
 
     # views, hovering.py:73-77
@@ -183,9 +186,18 @@ class HoveringRef:
     def _reset_extra(self, env_ids):
         pass
 
+    def _reset_all(self):
+        """reset_idx(all envs) (hovering.py:310-335); with the build's stagger opt-in the progress counters then start at
+        philox(env, tick, stream 2, block 0).x mod (max_len - 1) instead of 0."""
+        self.reset_idx(torch.arange(self.num_envs))
+        if self.stagger_episode_phase:
+            raw = philox.raw_blocks(self.seed, self.env_ids_global, self.tick, philox.STREAM_PHASE, 1)[:, 0]
+            span = np.uint32(max(self.max_episode_length - 1, 1))
+            self.progress_buf[:] = torch.from_numpy((raw % span).astype(np.int64))
+
     def reset(self):
         """base_task.py:107-111"""
-        self.reset_idx(torch.arange(self.num_envs))
+        self._reset_all()
         self.tick += 1
         obs, priv, _, _, _ = self.step(torch.zeros(self.num_envs, self.num_actions))
         return obs, priv

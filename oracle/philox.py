@@ -23,6 +23,7 @@ PHILOX_W1 = np.uint32(0xBB67AE85)
 
 STREAM_RESET = 0
 STREAM_OBS_NOISE = 1
+STREAM_PHASE = 2      # the build's AG_FLAG_STAGGER_PHASE opt-in: initial progress of a full reset
 
 TWO_PI_F32 = np.float32(6.283185307179586)
 INV_2_24 = np.float32(1.0 / 16777216.0)

@@ -118,6 +118,15 @@ int agh_reset_all(int task, int num_actions, int n, double dt, int max_len, cons
     return 0;
 }
 
+// AG_FLAG_STAGGER_PHASE: the initial progress reset_all_kernel gives env i (env_math.hpp stagger_progress)
+int agh_stagger_progress(int n, int max_len, uint64_t seed, uint32_t tick, uint32_t env_id_offset, int32_t* progress) {
+    float target18[18] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    StepParams P = make_step_params(0, 0.01, max_len, target18, seed, env_id_offset, false, false, true);
+    P.tick = tick;
+    for (int i = 0; i < n; ++i) progress[i] = stagger_progress(P, env_id_offset + (uint32_t)i);
+    return 0;
+}
+
 // ---- Planning: the same per-env functions the gfx950 kernels inline (planning_math.hpp)
 int agh_plan_render(const float* pos3, const float* quat4, const float* obst /*[40,4]*/, const float* table,
                     const float* goal3, float* out_hw /*[H][W] raw z-depth, inf = no hit*/) {

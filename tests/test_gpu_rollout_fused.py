@@ -187,3 +187,40 @@ def test_fused_rollout_entry_point_validates(Handle):
     with pytest.raises(RuntimeError):
         pl.step_rollout_fused(t, torch.zeros(64 * 18, device="cuda"), buf[:64].contiguous(), d)
     pl.close()
+
+
+def test_stagger_episode_phase_matches_oracle(Handle):
+    """AG_FLAG_STAGGER_PHASE (opt-in): a full reset gives every env its own progress, U{0 .. max_len - 2} from the counter RNG
+    keyed by the GLOBAL env id; the episodes then end spread over max_len steps instead of all in the same one; in-step resets
+    still start at 0 (hovering.py:333).  Oracle: HoveringRef(stagger_episode_phase=True)."""
+    n, max_len, off = 700, 40, 4096
+    ora = HoveringRef(n, "rate", seed=11, env_id_offset=off, stagger_episode_phase=True)
+    # the oracle reads max_episode_length at reset time: rebuild its initial state with the short limit
+    ora.max_episode_length = max_len
+    ora.tick = 0
+    ora._reset_all()
+    ora.tick = 1
+    env = Handle("hovering", "rate", n, seed=11, env_id_offset=off, max_episode_length=max_len, stagger_episode_phase=True)
+    p0 = env.get_state()["progress"].cpu().numpy().astype(np.int64)
+    assert np.array_equal(p0, ora.progress_buf.numpy())
+    assert p0.min() >= 0 and p0.max() <= max_len - 2 and len(np.unique(p0)) > max_len // 2
+    # sharding-invariant: the same global ids on a handle with another offset give the same phases
+    half = Handle("hovering", "rate", n // 2, seed=11, env_id_offset=off + n // 2, max_episode_length=max_len,
+                  stagger_episode_phase=True)
+    assert np.array_equal(half.get_state()["progress"].cpu().numpy().astype(np.int64), p0[n // 2:])
+    half.close()
+    rng = np.random.default_rng(5)
+    per_step = []
+    for t in range(max_len + 5):
+        act = rng.uniform(-0.2, 0.2, size=(n, 4)).astype(np.float32)
+        act[:, 3] = rng.uniform(-0.75, -0.65, size=n)
+        obs, _, rew, reset, _ = ora.step(torch.from_numpy(act))
+        env.step(torch.from_numpy(act).cuda())
+        assert np.array_equal(env.reset_buf.cpu().numpy(), reset.numpy()), t
+        assert np.array_equal(env.get_state()["progress"].cpu().numpy().astype(np.int64), ora.progress_buf.numpy()), t
+        per_step.append(int(reset.sum()))
+    # the time limit fires on many different steps, never for (nearly) all envs at once
+    assert sum(1 for c in per_step if c > 0) > max_len // 2 and max(per_step) < n // 4
+    env.close()
+    with pytest.raises(ValueError):
+        Handle("tracking", "vel", 64, stagger_episode_phase=True)

@@ -345,3 +345,18 @@ def test_ray_aabb_matches_oracle(lib):
         ref = _ray_aabb(torch.from_numpy(o), torch.from_numpy(d)[None], torch.from_numpy(c), 0.15)[0].item()
         got = lib.agh_ray_aabb(fp(o), fp(d), fp(c), ctypes.c_float(0.15))
         assert (np.isinf(ref) and np.isinf(got)) or abs(ref - got) < 1e-5
+
+
+def test_stagger_progress_matches_oracle(lib):
+    """AG_FLAG_STAGGER_PHASE: the kernel's stagger_progress() (g++ build of env_math.hpp) == HoveringRef._reset_all's phases."""
+    n, max_len, seed, off = 513, 2400, 77, 1 << 20
+    out = np.zeros(n, np.int32)
+    assert lib.agh_stagger_progress(n, max_len, ctypes.c_uint64(seed), ctypes.c_uint32(0), ctypes.c_uint32(off), fp(out)) == 0
+    ora = HoveringRef(n, "rate", seed=seed, env_id_offset=off, stagger_episode_phase=True)
+    # the constructor's full reset ran at tick 0
+    raw = philox.raw_blocks(seed, np.arange(off, off + n, dtype=np.uint32), 0, philox.STREAM_PHASE, 1)[:, 0]
+    assert np.array_equal(out, (raw % np.uint32(max_len - 1)).astype(np.int32))
+    assert np.array_equal(out.astype(np.int64), ora.progress_buf.numpy())
+    assert out.min() >= 0 and out.max() <= max_len - 2 and len(np.unique(out)) > n // 2
+    # default (flag off): all zero, the reference's hovering.py:333
+    assert HoveringRef(8, "rate", seed=seed).progress_buf.sum() == 0

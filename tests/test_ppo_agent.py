@@ -555,3 +555,13 @@ def test_weighted_indexed_normaliser_moments_across_two_ranks():
         assert np.allclose(res[r]["mean"], ref.running_mean.numpy(), rtol=0, atol=1e-12)
         assert np.allclose(res[r]["var"], ref.running_var.numpy(), rtol=1e-12, atol=1e-13)
     assert np.array_equal(res[0]["mean"], res[1]["mean"]) and np.array_equal(res[0]["var"], res[1]["var"])
+
+
+def test_mixed_precision_is_refused_not_ignored():
+    """a2c_base.py:236-237 reads `mixed_precision`; this build has no autocast path, so the key must raise, not be dropped."""
+    params = _stub_env.ppo_params(num_actors=16, horizon=4, mini_epochs=1, max_epochs=1)
+    params["config"]["mixed_precision"] = True
+    with pytest.raises(NotImplementedError, match="mixed_precision"):
+        A2CAgent("mp", params)
+    params["config"]["mixed_precision"] = False
+    A2CAgent("mp", params)
