@@ -137,6 +137,7 @@ SYMBOLS = [
     ("ag_step_with_inputs", ctypes.c_int, [_P, _P, _P, _P, _P]),
     ("ag_term_sum_tiles", ctypes.c_int, [ctypes.c_int]),
     ("ag_step_rollout", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ("ag_step_multi", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P, _P, _P, _P]),
     ("ag_step_rollout_fused", ctypes.c_int, [_P, ctypes.POINTER(AgRolloutTail), _P, _P, _P, _P, _P]),
     ("ag_eval_obs_reward", ctypes.c_int, [_P, _P, _P, _P, _P]),
     ("ag_get_buffers", ctypes.c_int, [_P, ctypes.POINTER(AgBuffers)]),

@@ -299,7 +299,8 @@ void bind_tick(ag_env* h, ag::KArgs& k) {
 
 int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int64_t* reset_out,
             const float* noise, const float* uniforms, void* stream, uint8_t* done_u8 = nullptr,
-            float* term_sums = nullptr, bool rollout_form = false, const ag::TailArgs* tail = nullptr) {
+            float* term_sums = nullptr, bool rollout_form = false, const ag::TailArgs* tail = nullptr, int num_steps = 1,
+            uint8_t* timeout_steps = nullptr) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
     if (!actions && !tail) return fail(AG_ERR_INVALID_ARG, "actions_dev is NULL");
     if (actions && h->num_actions == 4 && ((uintptr_t)actions & 15)) return fail(AG_ERR_INVALID_ARG, "actions_dev must be 16-byte aligned");
@@ -355,7 +356,10 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
         k.term_sums = term_sums;
         k.cmd = nullptr;
     }
+    k.num_steps = num_steps;
+    k.timeout_steps = timeout_steps;
     bind_tick(h, k);
+    h->tick += (uint64_t)(num_steps - 1);      // the launch advances the device tick by num_steps
     hipError_t e = kLaunchers[h->cfg.task][h->cfg.ctl_mode](k, tail, (hipStream_t)stream);
     if (e != hipSuccess) return fail(AG_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
     return AG_OK;
@@ -462,6 +466,7 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
         if (terms) for (int t = 0; t < 11; ++t) pa.terms[t] = h->L.terms[t] ? (float*)(h->arena + h->L.terms[t]) : nullptr;
     }
     k.n = cfg->num_envs;
+    k.num_steps = 1;
     fill_params(h);
     h->tick = 0;
     h->parity = 0;
@@ -550,6 +555,22 @@ int ag_step_rollout(ag_handle h, const float* actions_dev, float* obs_out_dev, f
     if (!done_out_dev) return fail(AG_ERR_INVALID_ARG, "done_out_dev is NULL");
     if (term_sums_dev && ((uintptr_t)term_sums_dev & 3)) return fail(AG_ERR_INVALID_ARG, "term_sums_dev must be 4-byte aligned");
     return do_step(h, actions_dev, obs_out_dev, rew_out_dev, nullptr, nullptr, nullptr, stream, done_out_dev, term_sums_dev, true);
+}
+
+int ag_step_multi(ag_handle h, const float* actions_dev, int num_steps, float* obs_out_dev, float* rew_out_dev,
+                  uint8_t* done_out_dev, uint8_t* timeout_out_dev, float* term_sums_dev, void* stream) {
+    if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
+    if (h->cfg.task >= AG_TASK_PLANNING) return fail(AG_ERR_UNSUPPORTED, "ag_step_multi: hovering / tracking handles only");
+    if (num_steps < 1 || num_steps > 65536) return fail(AG_ERR_INVALID_ARG, "num_steps must be in [1, 65536]");
+    if (!obs_out_dev || !rew_out_dev || !done_out_dev)
+        return fail(AG_ERR_INVALID_ARG, "obs_out_dev / rew_out_dev / done_out_dev is NULL (each holds num_steps slices)");
+    if (term_sums_dev && ((uintptr_t)term_sums_dev & 3)) return fail(AG_ERR_INVALID_ARG, "term_sums_dev must be 4-byte aligned");
+    // slice kk of actions / observations starts at kk * num_envs * width floats: 16-byte alignment of every slice
+    if (num_steps > 1 && (((size_t)h->cfg.num_envs * h->num_obs) & 3))
+        return fail(AG_ERR_UNSUPPORTED, "ag_step_multi with num_steps > 1 needs num_envs * num_obs to be a multiple of 4 "
+                                        "(16-byte aligned observation slices)");
+    return do_step(h, actions_dev, obs_out_dev, rew_out_dev, nullptr, nullptr, nullptr, stream, done_out_dev, term_sums_dev, true,
+                   nullptr, num_steps, timeout_out_dev);
 }
 
 int ag_step_rollout_fused(ag_handle h, const ag_rollout_tail* t, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,

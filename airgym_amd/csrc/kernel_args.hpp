@@ -35,6 +35,10 @@ struct KArgs {
     // rollout form (ag_step_rollout): done flags as u8 (the width the rollout buffer stores, experience.py:329) and
     // per-64-env-tile sums of the reward terms instead of nine per-env arrays (Episode/<term> logging only needs means)
     uint8_t* reset_u8;           // [n] or null; when set, `reset` (int64) is not written
+    // K env steps per launch (ag_step_multi): actions / obs / rew / reset_u8 / term_sums / timeout_steps are [K, ...] arrays,
+    // step kk at offset kk * n * width; the state is loaded before step 0 and stored after step K - 1
+    int num_steps;               // >= 1
+    uint8_t* timeout_steps;      // [K, n] or null: per-step time-out flags (`timeout` [n] keeps the LAST step's)
     float* term_sums;            // [ceil(n/64), 12] or null: sums over the tile's envs of terms[0..8]
     // parity / inspection mode (ag_eval_obs_reward): processed actions + controller output supplied by the caller
     const float* eval_actions;   // [n, A]

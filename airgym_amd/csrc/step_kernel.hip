@@ -165,213 +165,253 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
     const int i = blockIdx.x * 64 + lane;
     const bool active = i < k.n;
     StepParams P = k.P;
-    P.tick = *k.tick_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *k.tick_out = P.tick + 1u;
+    // K env steps in this launch (ag_step_multi; every other entry point: 1).  Step kk runs at tick0 + kk, reads
+    // actions[kk] and writes obs / reward / done [kk]: exactly what K launches of this kernel would do, with the state,
+    // the controller memory and the previous action held in the physics wave's registers in between.
+    const int K = FUSED ? 1 : k.num_steps;
+    const uint32_t tick0 = *k.tick_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *k.tick_out = tick0 + (uint32_t)K;
     const uint32_t env_global = P.env_id_offset + (uint32_t)i;
     const bool want_terms = (k.term_sums != nullptr);
+    const size_t nsz = (size_t)k.n;
+    const int ntiles = (k.n + 63) >> 6;
 
+    // physics wave: the env's state lives here across the K steps
+    EnvState s;
+    CtlState c;
+    float pre_a[A], raw_next[A];
     if (wave == 0) {
-        EnvState s;
-        CtlState c;
         load_env(k, i, s);
         load_ctl<CTL>(k, i, c);
-        float pre_a[A], raw_a[A], a[A];
-        {
-            const float4 pa = k.PA[i];
-            pre_a[0] = pa.x; pre_a[1] = pa.y; pre_a[2] = pa.z; pre_a[3] = pa.w;
-            if (A == 5) pre_a[A - 1] = k.PA4[i];
-        }
-        if (FUSED) {
-            __syncthreads();   // barrier 0: this step's clamped actions are in tileA (zeros for padding lanes)
-            if (A == 4) {
-                const float4 av = reinterpret_cast<const float4*>(tileA)[lane];
-                raw_a[0] = av.x; raw_a[1] = av.y; raw_a[2] = av.z; raw_a[3] = av.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < A; ++j) raw_a[j] = tileA[lane * SA + j];
-            }
-        } else if (active) {
-            if (A == 4) {
-                const float4 av = reinterpret_cast<const float4*>(k.actions)[i];
-                raw_a[0] = av.x; raw_a[1] = av.y; raw_a[2] = av.z; raw_a[3] = av.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < A; ++j) raw_a[j] = k.actions[(size_t)i * A + j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < A; ++j) raw_a[j] = 0.0f;
-        }
-        StepOut o;
-        env_step_physics<TASK, CTL>(s, c, raw_a, P, a, o.cmd);
-        float obs[NOBS];
-        env_observe_reward<TASK, CTL, false, true>(s, a, pre_a, o.cmd, P, env_global, nullptr, obs, o);
-#pragma unroll
-        for (int j = 0; j < A; ++j) pre_a[j] = a[j];
-        const int progress_end = s.progress;      // progress_buf after the increment, before reset_idx zeroes it
-        s.was_reset = o.done;
-        if (o.done) env_reset_done<CTL, false>(s, c, pre_a, P, env_global, nullptr);
-        o.timeout = step_timeout(progress_end, s.progress, P);
-        store_env(k, i, s);
-        store_ctl<CTL>(k, i, c);
-        k.PA[i] = make_float4(pre_a[0], pre_a[1], pre_a[2], pre_a[3]);
-        if (A == 5) k.PA4[i] = pre_a[A - 1];
-        const unsigned long long ballot = __ballot(active && o.done);
-        if (active) {
-            k.rew[i] = o.rew;
-            if (k.reset_u8 != nullptr) k.reset_u8[i] = (uint8_t)o.done;
-            else k.reset[i] = (long long)o.done;
-            k.timeout[i] = (uint8_t)o.timeout;
-            if (lane == 0) k.mask[i >> 6] = ballot;
-            if (k.cmd != nullptr) {
-                k.cmd[i] = make_float4(o.cmd[0], o.cmd[1], o.cmd[2], o.cmd[3]);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) k.terms[t][i] = o.terms[t];
-            }
-        }
-        if (want_terms) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) tileT[lane * ST + t] = active ? o.terms[t] : 0.0f;
-        }
-        if (FUSED) {
-            tileR[lane] = o.rew;
-            tileD[lane] = (o.done ? 1 : 0) | (o.timeout ? 2 : 0);
-        }
-        __syncthreads();   // barrier 1: sigma*z rows are in tileB; reward / done / terms of this tile are in LDS
-        // obs = (clean + sigma*z) - target for the 18 noisy columns (hovering.py:343-345), clean elsewhere
-#pragma unroll
-        for (int j = 0; j < 18; ++j) {
-            float v = obs[j] + tileB[lane * SB + j];
-            if (TASK == TASK_HOVERING) v -= P.target[j];
-            obs[j] = v;
-        }
-        if (NOBS % 4 == 0) {
-#pragma unroll
-            for (int j = 0; j < NOBS / 4; ++j)
-                reinterpret_cast<float4*>(tileO)[lane * (NOBS / 4) + j] = make_float4(obs[4 * j], obs[4 * j + 1], obs[4 * j + 2], obs[4 * j + 3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NOBS / 2; ++j)
-                reinterpret_cast<float2*>(tileO)[lane * (NOBS / 2) + j] = make_float2(obs[2 * j], obs[2 * j + 1]);
-        }
-    } else {
-        // ---- rollout head: sample this step's action from the policy heads (FUSED only)
-        float value = 0.0f, cur_r = 0.0f, cur_s = 0.0f, cur_l = 0.0f;
-        if (FUSED) {
-            float ea[A];
-#pragma unroll
-            for (int j = 0; j < A; ++j) ea[j] = 0.0f;
+        const float4 pa = k.PA[i];
+        pre_a[0] = pa.x; pre_a[1] = pa.y; pre_a[2] = pa.z; pre_a[3] = pa.w;
+        if (A == 5) pre_a[A - 1] = k.PA4[i];
+        if (!FUSED) {      // step 0's action (steps kk + 1 are requested one step ahead, under step kk's arithmetic)
             if (active) {
-                cur_r = ta.cur_rew[i]; cur_s = ta.cur_shaped[i]; cur_l = ta.cur_len[i];   // consumed after barrier 1
-                float h[A + 1], ls[A], z[6], act[A], mu[A], sigma[A], nlp;
-#pragma unroll
-                for (int j = 0; j <= A; ++j) h[j] = ta.heads[(size_t)i * (A + 1) + j];
-#pragma unroll
-                for (int j = 0; j < A; ++j) ls[j] = ta.logstd[j];
-                const uint32_t ptick = (uint32_t)(*ta.counter) * (uint32_t)ta.horizon + (uint32_t)ta.slot;
-                policy_normals<A>((uint32_t)(ta.id_offset + i), ptick, ta.key0, ta.key1, z);
-                const bool denorm = ta.vmean != nullptr;
-                policy_sample_row<A>(h, ls, z, denorm, denorm ? (float)ta.vmean[0] : 0.f, denorm ? (float)ta.vvar[0] : 1.f,
-                                     ta.veps, act, mu, sigma, ea, nlp, value);
                 if (A == 4) {
-                    reinterpret_cast<float4*>(ta.actions)[i] = make_float4(act[0], act[1], act[2], act[3]);
-                    reinterpret_cast<float4*>(ta.mus)[i] = make_float4(mu[0], mu[1], mu[2], mu[3]);
-                    reinterpret_cast<float4*>(ta.sigmas)[i] = make_float4(sigma[0], sigma[1], sigma[2], sigma[3]);
+                    const float4 av = reinterpret_cast<const float4*>(k.actions)[i];
+                    raw_next[0] = av.x; raw_next[1] = av.y; raw_next[2] = av.z; raw_next[3] = av.w;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < A; ++j) {
-                        ta.actions[(size_t)i * A + j] = act[j];
-                        ta.mus[(size_t)i * A + j] = mu[j];
-                        ta.sigmas[(size_t)i * A + j] = sigma[j];
-                    }
+                    for (int j = 0; j < A; ++j) raw_next[j] = k.actions[(size_t)i * A + j];
                 }
-                ta.neglogp[i] = nlp;
-                ta.values[i] = value;
-            }
-            if (A == 4) {
-                reinterpret_cast<float4*>(tileA)[lane] = make_float4(ea[0], ea[1], ea[2], ea[3]);
             } else {
 #pragma unroll
-                for (int j = 0; j < A; ++j) tileA[lane * SA + j] = ea[j];
-            }
-            __syncthreads();   // barrier 0
-        }
-        // ---- observation noise
-        float z[18];
-        if (!P.noise_off) {
-            obs_noise_normals(P, env_global, z);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 18; ++j) z[j] = 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < 18; ++j) tileB[lane * SB + j] = noise_sigma(j) * z[j];
-        __syncthreads();   // barrier 1
-        // ---- between the barriers (the physics wave is adding the noise): reductions over the tile
-        if (want_terms) {  // per-tile sums of the reward terms, fixed order: 7 row groups x 9 terms, then 7 -> 1
-            const int term = lane % 9, part = lane / 9;          // lanes 0..62
-            const int r0 = (part == 0) ? 0 : 9 * part + 1, r1 = 9 * part + 10;   // row groups of 10,9,9,9,9,9,9
-            float acc = 0.0f;
-            if (lane < 63) {
-                for (int r = r0; r < r1; ++r) acc += tileT[r * ST + term];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 63) tileS[lane] = acc;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 9) {
-                float tot = 0.0f;
-#pragma unroll
-                for (int p = 0; p < 7; ++p) tot += tileS[p * 9 + lane];
-                k.term_sums[(size_t)blockIdx.x * 12 + lane] = tot;
-            }
-        }
-        if (FUSED) {       // rollout tail: reward shaping + episode accounting (a2c_base.py:668-695)
-            double sums[4] = {0.0, 0.0, 0.0, 0.0};
-            if (active) {
-                const float r = tileR[lane];
-                const int flags = tileD[lane];
-                const ShapeParams sp{ta.scale, ta.shift, ta.min_val, ta.max_val, ta.log_val, ta.gamma};
-                float sh = shape_reward(r, sp);
-                if (ta.bootstrap && (flags & 2)) sh += ta.gamma * value;
-                ta.shaped[i] = sh;
-                float cr = cur_r + r, cs = cur_s + sh, cl = cur_l + 1.0f;
-                if (flags & 1) {
-                    sums[0] = 1.0; sums[1] = cr; sums[2] = cs; sums[3] = cl;
-                    cr = cs = cl = 0.0f;
-                }
-                ta.cur_rew[i] = cr; ta.cur_shaped[i] = cs; ta.cur_len[i] = cl;
-            }
-            // episodes that ended in this tile: skip the 24 double shuffles when no lane has one (the usual case)
-            if (__ballot(sums[0] != 0.0) != 0ull) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    for (int off = 32; off > 0; off >>= 1) sums[j] += __shfl_down(sums[j], off, 64);
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ta.partials[(size_t)blockIdx.x * 4 + j] = sums[j];
+                for (int j = 0; j < A; ++j) raw_next[j] = 0.0f;
             }
         }
     }
-    __syncthreads();       // barrier 2: final rows are in tileO
 
-    const int block_env0 = blockIdx.x * 64;
-    const int valid = min(64, k.n - block_env0) * NOBS;    // floats of this tile that exist
-    float* out = k.obs + (size_t)block_env0 * NOBS;
-    constexpr int NV4 = 64 * NOBS / 4;
-    constexpr int ITERS = (NV4 + 127) / 128;
-    const int t2 = wave * 64 + lane;
+#pragma unroll 1
+    for (int kk = 0; kk < K; ++kk) {
+        P.tick = tick0 + (uint32_t)kk;
+        const bool last = (kk == K - 1);
+        float* obs_out = k.obs + (size_t)kk * nsz * NOBS;
+        float* term_out = want_terms ? k.term_sums + (size_t)kk * ntiles * 12 : nullptr;
+
+        if (wave == 0) {
+            float raw_a[A], a[A];
+            if (FUSED) {
+                __syncthreads();   // barrier 0: this step's clamped actions are in tileA (zeros for padding lanes)
+                if (A == 4) {
+                    const float4 av = reinterpret_cast<const float4*>(tileA)[lane];
+                    raw_a[0] = av.x; raw_a[1] = av.y; raw_a[2] = av.z; raw_a[3] = av.w;
+                } else {
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int m = t2 + it * 128;
-        if (m < NV4) {
-            const int e = 4 * m;
-            if (e + 3 < valid) {
-                reinterpret_cast<float4*>(out)[m] = reinterpret_cast<const float4*>(tileO)[m];
+                    for (int j = 0; j < A; ++j) raw_a[j] = tileA[lane * SA + j];
+                }
             } else {
-                for (int q = e; q < e + 4 && q < valid; ++q) out[q] = tileO[q];
+#pragma unroll
+                for (int j = 0; j < A; ++j) raw_a[j] = raw_next[j];
+                if (!last && active) {
+                    const float* an = k.actions + (size_t)(kk + 1) * nsz * A;
+                    if (A == 4) {
+                        const float4 av = reinterpret_cast<const float4*>(an)[i];
+                        raw_next[0] = av.x; raw_next[1] = av.y; raw_next[2] = av.z; raw_next[3] = av.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < A; ++j) raw_next[j] = an[(size_t)i * A + j];
+                    }
+                }
+            }
+            StepOut o;
+            env_step_physics<TASK, CTL>(s, c, raw_a, P, a, o.cmd);
+            float obs[NOBS];
+            env_observe_reward<TASK, CTL, false, true>(s, a, pre_a, o.cmd, P, env_global, nullptr, obs, o);
+#pragma unroll
+            for (int j = 0; j < A; ++j) pre_a[j] = a[j];
+            const int progress_end = s.progress;      // progress_buf after the increment, before reset_idx zeroes it
+            s.was_reset = o.done;
+            if (o.done) env_reset_done<CTL, false>(s, c, pre_a, P, env_global, nullptr);
+            o.timeout = step_timeout(progress_end, s.progress, P);
+            if (last) {            // the state goes back to HBM once per launch
+                store_env(k, i, s);
+                store_ctl<CTL>(k, i, c);
+                k.PA[i] = make_float4(pre_a[0], pre_a[1], pre_a[2], pre_a[3]);
+                if (A == 5) k.PA4[i] = pre_a[A - 1];
+            }
+            const unsigned long long ballot = __ballot(active && o.done);
+            if (active) {
+                k.rew[(size_t)kk * nsz + i] = o.rew;
+                if (k.reset_u8 != nullptr) k.reset_u8[(size_t)kk * nsz + i] = (uint8_t)o.done;
+                else k.reset[i] = (long long)o.done;
+                if (k.timeout_steps != nullptr) k.timeout_steps[(size_t)kk * nsz + i] = (uint8_t)o.timeout;
+                if (last) {
+                    k.timeout[i] = (uint8_t)o.timeout;
+                    if (lane == 0) k.mask[i >> 6] = ballot;
+                }
+                if (k.cmd != nullptr) {
+                    k.cmd[i] = make_float4(o.cmd[0], o.cmd[1], o.cmd[2], o.cmd[3]);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) k.terms[t][i] = o.terms[t];
+                }
+            }
+            if (want_terms) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) tileT[lane * ST + t] = active ? o.terms[t] : 0.0f;
+            }
+            if (FUSED) {
+                tileR[lane] = o.rew;
+                tileD[lane] = (o.done ? 1 : 0) | (o.timeout ? 2 : 0);
+            }
+            __syncthreads();   // barrier 1: sigma*z rows are in tileB; reward / done / terms of this tile are in LDS
+            // obs = (clean + sigma*z) - target for the 18 noisy columns (hovering.py:343-345), clean elsewhere
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                float v = obs[j] + tileB[lane * SB + j];
+                if (TASK == TASK_HOVERING) v -= P.target[j];
+                obs[j] = v;
+            }
+            if (NOBS % 4 == 0) {
+#pragma unroll
+                for (int j = 0; j < NOBS / 4; ++j)
+                    reinterpret_cast<float4*>(tileO)[lane * (NOBS / 4) + j] = make_float4(obs[4 * j], obs[4 * j + 1], obs[4 * j + 2], obs[4 * j + 3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NOBS / 2; ++j)
+                    reinterpret_cast<float2*>(tileO)[lane * (NOBS / 2) + j] = make_float2(obs[2 * j], obs[2 * j + 1]);
+            }
+        } else {
+            // ---- rollout head: sample this step's action from the policy heads (FUSED only)
+            float value = 0.0f, cur_r = 0.0f, cur_s = 0.0f, cur_l = 0.0f;
+            if (FUSED) {
+                float ea[A];
+#pragma unroll
+                for (int j = 0; j < A; ++j) ea[j] = 0.0f;
+                if (active) {
+                    cur_r = ta.cur_rew[i]; cur_s = ta.cur_shaped[i]; cur_l = ta.cur_len[i];   // consumed after barrier 1
+                    float h[A + 1], ls[A], z[6], act[A], mu[A], sigma[A], nlp;
+#pragma unroll
+                    for (int j = 0; j <= A; ++j) h[j] = ta.heads[(size_t)i * (A + 1) + j];
+#pragma unroll
+                    for (int j = 0; j < A; ++j) ls[j] = ta.logstd[j];
+                    const uint32_t ptick = (uint32_t)(*ta.counter) * (uint32_t)ta.horizon + (uint32_t)ta.slot;
+                    policy_normals<A>((uint32_t)(ta.id_offset + i), ptick, ta.key0, ta.key1, z);
+                    const bool denorm = ta.vmean != nullptr;
+                    policy_sample_row<A>(h, ls, z, denorm, denorm ? (float)ta.vmean[0] : 0.f, denorm ? (float)ta.vvar[0] : 1.f,
+                                         ta.veps, act, mu, sigma, ea, nlp, value);
+                    if (A == 4) {
+                        reinterpret_cast<float4*>(ta.actions)[i] = make_float4(act[0], act[1], act[2], act[3]);
+                        reinterpret_cast<float4*>(ta.mus)[i] = make_float4(mu[0], mu[1], mu[2], mu[3]);
+                        reinterpret_cast<float4*>(ta.sigmas)[i] = make_float4(sigma[0], sigma[1], sigma[2], sigma[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < A; ++j) {
+                            ta.actions[(size_t)i * A + j] = act[j];
+                            ta.mus[(size_t)i * A + j] = mu[j];
+                            ta.sigmas[(size_t)i * A + j] = sigma[j];
+                        }
+                    }
+                    ta.neglogp[i] = nlp;
+                    ta.values[i] = value;
+                }
+                if (A == 4) {
+                    reinterpret_cast<float4*>(tileA)[lane] = make_float4(ea[0], ea[1], ea[2], ea[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < A; ++j) tileA[lane * SA + j] = ea[j];
+                }
+                __syncthreads();   // barrier 0
+            }
+            // ---- observation noise
+            float z[18];
+            if (!P.noise_off) {
+                obs_noise_normals(P, env_global, z);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 18; ++j) z[j] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 18; ++j) tileB[lane * SB + j] = noise_sigma(j) * z[j];
+            __syncthreads();   // barrier 1
+            // ---- between the barriers (the physics wave is adding the noise): reductions over the tile
+            if (want_terms) {  // per-tile sums of the reward terms, fixed order: 7 row groups x 9 terms, then 7 -> 1
+                const int term = lane % 9, part = lane / 9;          // lanes 0..62
+                const int r0 = (part == 0) ? 0 : 9 * part + 1, r1 = 9 * part + 10;   // row groups of 10,9,9,9,9,9,9
+                float acc = 0.0f;
+                if (lane < 63) {
+                    for (int r = r0; r < r1; ++r) acc += tileT[r * ST + term];
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 63) tileS[lane] = acc;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 9) {
+                    float tot = 0.0f;
+#pragma unroll
+                    for (int p = 0; p < 7; ++p) tot += tileS[p * 9 + lane];
+                    term_out[(size_t)blockIdx.x * 12 + lane] = tot;
+                }
+            }
+            if (FUSED) {       // rollout tail: reward shaping + episode accounting (a2c_base.py:668-695)
+                double sums[4] = {0.0, 0.0, 0.0, 0.0};
+                if (active) {
+                    const float r = tileR[lane];
+                    const int flags = tileD[lane];
+                    const ShapeParams sp{ta.scale, ta.shift, ta.min_val, ta.max_val, ta.log_val, ta.gamma};
+                    float sh = shape_reward(r, sp);
+                    if (ta.bootstrap && (flags & 2)) sh += ta.gamma * value;
+                    ta.shaped[i] = sh;
+                    float cr = cur_r + r, cs = cur_s + sh, cl = cur_l + 1.0f;
+                    if (flags & 1) {
+                        sums[0] = 1.0; sums[1] = cr; sums[2] = cs; sums[3] = cl;
+                        cr = cs = cl = 0.0f;
+                    }
+                    ta.cur_rew[i] = cr; ta.cur_shaped[i] = cs; ta.cur_len[i] = cl;
+                }
+                // episodes that ended in this tile: skip the 24 double shuffles when no lane has one (the usual case)
+                if (__ballot(sums[0] != 0.0) != 0ull) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        for (int off = 32; off > 0; off >>= 1) sums[j] += __shfl_down(sums[j], off, 64);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ta.partials[(size_t)blockIdx.x * 4 + j] = sums[j];
+                }
             }
         }
+        __syncthreads();       // barrier 2: final rows are in tileO
+
+        const int block_env0 = blockIdx.x * 64;
+        const int valid = min(64, k.n - block_env0) * NOBS;    // floats of this tile that exist
+        float* out = obs_out + (size_t)block_env0 * NOBS;
+        constexpr int NV4 = 64 * NOBS / 4;
+        constexpr int ITERS = (NV4 + 127) / 128;
+        const int t2 = wave * 64 + lane;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int m = t2 + it * 128;
+            if (m < NV4) {
+                const int e = 4 * m;
+                if (e + 3 < valid) {
+                    reinterpret_cast<float4*>(out)[m] = reinterpret_cast<const float4*>(tileO)[m];
+                } else {
+                    for (int q = e; q < e + 4 && q < valid; ++q) out[q] = tileO[q];
+                }
+            }
+        }
+        // (next step: the physics wave writes tileO / tileT again only after barrier 1, which the noise wave reaches after
+        //  the copy-out reads above; the noise wave rewrites tileB only after barrier 2, behind the physics wave's reads)
     }
 }
 

@@ -176,6 +176,27 @@ class HipEnvHandle:
         N.check(self.lib.ag_step_rollout(self.h, actions.data_ptr(), obs_out.data_ptr(), rew_out.data_ptr(),
                                          done_out.data_ptr(), tp, self._stream()), "ag_step_rollout")
 
+    def step_multi(self, actions, obs_out, rew_out, done_out, timeout_out=None, term_sums=None):
+        """K = actions.shape[0] consecutive env steps in ONE launch (ag_step_multi): identical, bit for bit, to K calls of
+        step_rollout(actions[t], obs_out[t], rew_out[t], done_out[t], term_sums[t]); the state stays in registers between
+        the steps.  actions [K, n, A]; obs_out [K, n, num_obs]; rew_out [K, n]; done_out [K, n] u8; timeout_out [K, n] u8 or
+        None; term_sums [K, ceil(n/64), 12] or None."""
+        n, A = self.num_envs, self.num_actions
+        assert actions.dim() == 3 and tuple(actions.shape[1:]) == (n, A), f"actions must be [K, {n}, {A}]"
+        K = actions.shape[0]
+        assert actions.is_contiguous() and actions.dtype == torch.float32 and actions.device == self.device
+
+        def chk(t, dtype, numel):
+            assert t.is_contiguous() and t.dtype == dtype and t.device == self.device and t.numel() == numel, \
+                (tuple(t.shape), t.dtype, numel)
+            return t.data_ptr()
+        tiles = self.lib.ag_term_sum_tiles(n)
+        N.check(self.lib.ag_step_multi(self.h, actions.data_ptr(), K, chk(obs_out, torch.float32, K * n * self.num_obs),
+                                       chk(rew_out, torch.float32, K * n), chk(done_out, torch.uint8, K * n),
+                                       chk(timeout_out, torch.uint8, K * n) if timeout_out is not None else None,
+                                       chk(term_sums, torch.float32, K * tiles * 12) if term_sums is not None else None,
+                                       self._stream()), "ag_step_multi")
+
     def step_rollout_fused(self, tail, obs_out, rew_out, done_out, term_sums=None):
         """One rollout step in ONE launch: policy sampling + env step + reward shaping / episode accounting
         (ag_step_rollout_fused).  `tail` is a filled N.AgRolloutTail; the other arguments as step_rollout."""

@@ -473,12 +473,27 @@ class A2CAgent:
         return {k: v[n] for k, v in self.obs_buf.items()} if isinstance(self.obs_buf, dict) else self.obs_buf[n]
 
     @torch.no_grad()
-    def _new_frame(self, slot, first=False):
+    def _new_frame(self, slot, first=False, encode=True):
         """The env's camera buffer holds a new image: keep it as the next distinct frame of this rollout and refresh the
-        cached CNN features (policy weights and normalisers are fixed during a rollout)."""
+        cached CNN features (policy weights and normalisers are fixed during a rollout).  encode=False only stores the
+        frame: slot 0 of the NEXT rollout is stored before the update and encoded after it (_refresh_frame_features)."""
         self._frame_top = 0 if first else self._frame_top + 1
+        if self._frame_top >= self._frames.shape[0]:
+            raise RuntimeError(
+                f"frame store overflow: {self._frame_top + 1} rendered frames in one rollout, the store holds "
+                f"{self._frames.shape[0]} (sized for one render every 4 env steps, planning.py:153-156; a forced render or a "
+                f"different camera cadence needs a larger store)")
         self._frames[self._frame_top].copy_(self._hip_env.image)
         self._frame_of_slot[slot] = self._frame_top
+        if encode:
+            self._refresh_frame_features()
+
+    @torch.no_grad()
+    def _refresh_frame_features(self):
+        """CNN features of the newest stored frame with the CURRENT weights, BatchNorm statistics and image normaliser.
+        Called for every rendered frame and at the start of every rollout: slot 0 carries the image the env held when the
+        previous rollout ended, and the PPO update in between moved the CNN (the reference runs the current CNN on every
+        step, lib/agent/a2c_base.py:357-369)."""
         self.model.eval()
         self._frame_feat.copy_(self.model.cnn_features(self._frames[self._frame_top]))
 
@@ -629,6 +644,10 @@ class A2CAgent:
             if self._cache_latents:
                 # slot 0 carries the previous rollout's last features: re-encode with the normaliser as it is after the update
                 self._encode_current_image(0, count_moments=False)
+            if getattr(self, "_dedup", False):
+                # likewise for the trainable CNN: the features of slot 0's frame were not computed yet (or, after a restore,
+                # come from other weights) - encode it with the weights this rollout runs under
+                self._refresh_frame_features()
             for n in range(H):
                 self._rollout_step(n)
             if fr is not None:
@@ -685,7 +704,7 @@ class A2CAgent:
             # the update reads this rollout's frames: the next rollout (and its slot 0, the image the env holds now) uses the other store
             self._frames = self._frame_stores[1] if self._frames is self._frame_stores[0] else self._frame_stores[0]
             self.obs_buf["observation"][0].copy_(self.obs_buf["observation"][H])
-            self._new_frame(0, first=True)
+            self._new_frame(0, first=True, encode=False)      # encoded at the start of the next rollout, after the update
         else:
             self._obs_store(0, self._obs_at(H))
         self.dones_buf[0].copy_(self.dones_buf[H])

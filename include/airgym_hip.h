@@ -190,6 +190,20 @@ int ag_step_into(ag_handle h, const float* actions_dev, float* obs_out_dev, floa
 int ag_term_sum_tiles(int num_envs);
 int ag_step_rollout(ag_handle h, const float* actions_dev, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,
                     float* term_sums_dev, void* stream);
+/* num_steps consecutive env steps in ONE launch: the loop `for t in range(K): env.step(actions[t])` of a caller that
+ * already holds the K actions (replay of recorded actions, open-loop / scripted evaluation, the env-only throughput line of
+ * SURVEY.md 8(d) whose actions are pre-generated on the device; reference loop: Hovering.step, hovering.py:286-308, under
+ * A2CBase.play_steps, lib/agent/a2c_base.py:651-711).  Results are IDENTICAL, bit for bit, to num_steps calls of
+ * ag_step_rollout(actions_dev + t * num_envs * A, obs_out_dev + t * num_envs * num_obs, rew_out_dev + t * num_envs,
+ * done_out_dev + t * num_envs, term_sums_dev + t * tiles * 12) - same kernel, same arithmetic, Philox ticks tick0 + t, in-step
+ * resets included - but the env state, the controller memory and the previous action stay in registers between the steps:
+ * per env-step only the action (read) and observation / reward / done (written) move through HBM; the state is read once and
+ * written once per launch.  timeout_out_dev: [num_steps, num_envs] u8 or NULL (the handle's time_out buffer keeps the last
+ * step's flags).  actions_dev [num_steps, num_envs, A]; obs_out_dev [num_steps, num_envs, num_obs]; rew_out_dev
+ * [num_steps, num_envs]; done_out_dev [num_steps, num_envs] u8; term_sums_dev [num_steps, ag_term_sum_tiles(n), 12] or NULL.
+ * num_steps > 1 needs num_envs * num_obs % 4 == 0 (16-byte aligned slices).  Hovering / Tracking handles. */
+int ag_step_multi(ag_handle h, const float* actions_dev, int num_steps, float* obs_out_dev, float* rew_out_dev,
+                  uint8_t* done_out_dev, uint8_t* timeout_out_dev, float* term_sums_dev, void* stream);
 /* One whole step of A2CBase.play_steps behind the policy GEMMs (lib/agent/a2c_base.py:651-695) as ONE launch: what
  * ag_policy_sample does in front of ag_step_rollout (get_action_values' sampling, a2c_continuous_logstd_model.py:159-167;
  * preprocess_actions, a2c_base.py:229-236) and what ag_rollout_account does behind it (rewards_shaper + time-out bootstrap,

@@ -519,3 +519,30 @@ def test_frame_dedup_is_the_same_update_on_a_quarter_of_the_images():
         assert torch.allclose(x, y, rtol=1e-4, atol=1e-6)
     # image memory: two stores of ceil((H + 1) / 4) + 2 frames instead of H + 1 images per env (H = 24: 18 vs 25; this H = 8 test: 10 vs 9)
     assert d["mem"] == 2 * ((8 + 1 + 3) // 4 + 2) * 48 * 212 * 120 and f["mem"] == 9 * 48 * 212 * 120
+
+
+def test_frame_dedup_rollout_after_an_update_runs_the_updated_cnn():
+    """Across epochs: slot 0 of rollout k + 1 shows the image the env held when rollout k ended, and the PPO update in between
+    moved the CNN weights, the BatchNorm running statistics and the image normaliser.  The reference runs the CURRENT CNN on
+    every step (lib/agent/a2c_base.py:357-369), so the cached features of that frame must be recomputed before the first step:
+    with dedup on and off the SECOND rollout must be the same rollout too (stale features differ at the 1e-1 level - six
+    optimizer steps move the eval-mode BatchNorm statistics almost half way from their initial values)."""
+    out = []
+    for dedup in (True, False):
+        agent = _cnn_agent(32, dedup, horizon=8, seed=7, minibatches=2)
+        for ep in range(2):
+            torch.manual_seed(100 + ep)
+            agent.epoch_num += 1
+            agent.train_epoch()
+        torch.manual_seed(200)
+        batch = agent.play_steps()                     # third rollout, behind two updates
+        out.append({k: batch[k].clone() for k in ("values", "mus", "neglogpacs")})
+        agent.vec_env.env.hip.close()
+    d, f = out
+    H = 8
+    v_d, v_f = d["values"].view(32, H), f["values"].view(32, H)            # env-major: [env, step]
+    m_d, m_f = d["mus"].view(32, H, -1), f["mus"].view(32, H, -1)
+    # the steps that show slot 0's frame (before the first render of the rollout) are the ones stale features would hit
+    assert (v_d[:, :2] - v_f[:, :2]).abs().max().item() < 5e-3, (v_d[:, :2] - v_f[:, :2]).abs().max().item()
+    assert (m_d[:, :2] - m_f[:, :2]).abs().max().item() < 5e-3
+    assert (v_d - v_f).abs().max().item() < 2e-2 and (m_d - m_f).abs().max().item() < 2e-2
