@@ -27,7 +27,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from airgym_amd.lib.core import common_losses, schedulers, torch_ext
+from airgym_amd.lib.core import collectives, common_losses, schedulers, torch_ext
 from airgym_amd.lib.core.datasets import PPODataset
 from airgym_amd.lib.model.a2c_continuous_logstd_model import ModelA2CContinuousLogStd
 from airgym_amd.lib.utils import vecenv
@@ -339,8 +339,11 @@ class A2CAgent:
         from airgym_amd.lib.agent.fused_update import FusedMLPStep
         self._fused_step = FusedMLPStep(self) if FusedMLPStep.supported(self) else None
         self._graphs = {}
-        # minibatch graphs: only where launches dominate (small minibatches), single GPU (no collective inside a capture)
-        self._graph_update = bool(self._fused_step is not None and self.use_hip_graph and not self.multi_gpu
+        # minibatch graphs: only where launches dominate (small minibatches).  No collective is ever captured: with
+        # multi_gpu the capture is split at the gradient all-reduce (graph A: forward / backward / reductions; the
+        # all-reduce eager; graph B: average + clip + Adam + LR rule), and a minibatch whose forward all-reduces the
+        # normaliser moments (first mini-epoch, sync_normalizers) runs eagerly
+        self._graph_update = bool(self._fused_step is not None and self.use_hip_graph
                                   and config.get("use_hip_graph_update", self.minibatch_size <= 32768))
         self._upd_graphs = {}
         self._ds_bufs = None
@@ -388,9 +391,9 @@ class A2CAgent:
         pickled state dict, a2c_continuous.py:188-192) - one flat tensor broadcast instead."""
         if not self.multi_gpu:
             return
-        dist.broadcast(self.flat_param, 0)
+        collectives.broadcast(self.flat_param, 0, "initial_parameters")
         for b in self.model.buffers():
-            dist.broadcast(b, 0)
+            collectives.broadcast(b, 0, "initial_buffers")
 
     # ------------------------------------------------------------------ rollout
     def init_tensors(self):
@@ -795,11 +798,13 @@ class A2CAgent:
         return a_loss.detach(), c_loss.detach(), entropy.detach(), b_loss.detach(), mu.detach(), sigma.detach()
 
     @torch.no_grad()
-    def _reduce_clip_step(self, need_kl=True):
+    def _reduce_clip_step(self, need_kl=True, reduced=False):
         """trancate_gradients_and_step (a2c_base.py:293-316) + the legacy per-minibatch KL schedule
-        (a2c_continuous.py:111-118): one all-reduce, clip-by-norm, Adam, LR update - all on device."""
+        (a2c_continuous.py:111-118): one all-reduce, clip-by-norm, Adam, LR update - all on device.
+        reduced=True: the caller already all-reduced flat_grad (the captured tail of a multi-GPU minibatch graph)."""
         if self.multi_gpu:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            if not reduced:
+                collectives.all_reduce(self.flat_grad, "gradient", group=self.group)
             self.flat_grad /= self.world_size
         adaptive = self.is_adaptive_lr and self.schedule_type == "legacy"
         fused_adam = self.flat_grad.is_cuda and self.config.get("use_fused_adam", True)
@@ -827,24 +832,37 @@ class A2CAgent:
         """One optimizer step on minibatch idx; returns device scalars (no sync)."""
         mb = self.dataset[idx]
         if self._fused_step is not None and mb["obs"].shape[0] == self.minibatch_size:
-            if self._graph_update and self.epoch_num >= 2:
+            stats_on = bool(self.model.update_stats)
+            collective_in_forward = (self.multi_gpu and stats_on and getattr(self.model, "stats_group", None) is not None)
+            if self._graph_update and self.epoch_num >= 2 and not collective_in_forward:
                 # launch-bound regime (small minibatches): forward + backward + reductions + Adam of this minibatch as ONE
-                # hipGraph, one graph per (minibatch index, statistics-on/off); captured on first use, then replayed
-                key = (idx, bool(self.model.update_stats))
+                # hipGraph, one graph per (minibatch index, statistics-on/off); captured on first use, then replayed.
+                # multi_gpu: the graph ends in front of the gradient all-reduce; that runs eagerly, and the rank average +
+                # clip + Adam + LR rule behind it are a second graph shared by every minibatch (same buffers).
+                key = (idx, stats_on)
                 entry = self._upd_graphs.get(key)
                 if entry is None:
                     row = torch.zeros(8, dtype=torch.float32, device=self.ppo_device)
 
                     def body():
                         self._fused_step.step(mb, stats_out=row)
-                        self._reduce_clip_step(need_kl=False)
+                        if not self.multi_gpu:
+                            self._reduce_clip_step(need_kl=False)
                     entry = (self._capture(body, warmup=False), row, mb)      # mb kept alive: the graph reads its views
                     self._upd_graphs[key] = entry
                 entry[0].replay()
                 st = self._fused_step.next_stats_row()
                 st.copy_(entry[1])
                 self._last_clip = st[6]
-                return st[0], st[1], st[2], st[3], st[4]
+                if not self.multi_gpu:
+                    return st[0], st[1], st[2], st[3], st[4]
+                collectives.all_reduce(self.flat_grad, "gradient", group=self.group)
+                tail = self._upd_graphs.get("tail")
+                if tail is None:
+                    tail = self._capture(lambda: self._reduce_clip_step(need_kl=False, reduced=True), warmup=False)
+                    self._upd_graphs["tail"] = tail
+                tail.replay()
+                return st[0], st[1], st[2], st[3], self.flat_grad[-1].double()      # the rank-averaged KL
             st = self._fused_step.step(mb)
             self._last_clip = st[6]
             kl = self._reduce_clip_step(need_kl=self.multi_gpu)      # multi-GPU: the rank-averaged KL
@@ -893,7 +911,7 @@ class A2CAgent:
                 if self.multi_gpu and self.sync_normalizers:
                     # the same statistics on every rank (like RunningMeanStd.update with a group): merge the ranks' moments
                     packed = torch.cat(((mean * cnt).reshape(-1), ((var + mean * mean) * cnt).reshape(-1), cnt.reshape(1)))
-                    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+                    collectives.all_reduce(packed, "normaliser_moments", group=self.group)
                     npx = mean.numel()
                     tot = packed[-1].clamp_min(1.0)
                     gmean = (packed[:npx] / tot).view_as(mean)
@@ -923,7 +941,7 @@ class A2CAgent:
             av_kls = torch_ext.mean_list(ep_kls)
             if self.is_adaptive_lr and self.schedule_type == "standard":
                 if self.multi_gpu:
-                    dist.all_reduce(av_kls, op=dist.ReduceOp.SUM, group=self.group)
+                    collectives.all_reduce(av_kls, "epoch_kl", group=self.group)
                     av_kls /= self.world_size
                 self.last_lr, self.entropy_coef = self.scheduler.update(self.optimizer.lr.item(), self.entropy_coef,
                                                                         self.epoch_num, 0, av_kls.item())
@@ -1016,7 +1034,7 @@ class A2CAgent:
                     should_exit = True
             if self.multi_gpu:
                 t = torch.tensor(float(should_exit), device=self.ppo_device)
-                dist.broadcast(t, 0)
+                collectives.broadcast(t, 0, "should_exit")
                 should_exit = bool(t.item())
             if should_exit:
                 return self.last_mean_rewards, epoch_num

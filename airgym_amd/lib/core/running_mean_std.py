@@ -7,6 +7,8 @@ same device addresses."""
 import torch
 import torch.nn as nn
 
+from airgym_amd.lib.core import collectives
+
 
 class RunningMeanStd(nn.Module):
     def __init__(self, insize, epsilon=1e-05, per_channel=False, norm_only=False):
@@ -44,7 +46,7 @@ class RunningMeanStd(nn.Module):
                 import torch.distributed as dist
                 if dist.get_world_size(group) > 1:
                     packed = torch.cat(((mean * n).reshape(-1), ((var * (n - 1.0)) + n * mean * mean).reshape(-1), n.reshape(1)))
-                    dist.all_reduce(packed, group=group)
+                    collectives.all_reduce(packed, "normaliser_moments", group=group)
                     k = mean.numel()
                     n = packed[-1]
                     mean = (packed[:k] / n).view_as(mean)
@@ -62,7 +64,7 @@ class RunningMeanStd(nn.Module):
             if ws > 1:
                 # equal batch sizes per rank: pooled mean / unbiased variance from per-rank moments
                 stats = torch.stack((mean, var * (batch_count - 1) + batch_count * mean * mean))
-                dist.all_reduce(stats, group=group)
+                collectives.all_reduce(stats, "normaliser_moments", group=group)
                 tot = batch_count * ws
                 mean = stats[0] / ws
                 var = (stats[1] - tot * mean * mean) / (tot - 1)

@@ -264,12 +264,56 @@ def self_launch(args, argv):
                           "unit": "env-steps/s", "n_gpus": args.gpus, "error": f"needs {args.gpus} devices, {have} visible",
                           "devices_visible": have, "steps": args.steps, "warmup": args.warmup}), flush=True)
         return 0
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    return subprocess.call(cmd, env=env)
+    base = dict(os.environ)
+    base.setdefault("OMP_NUM_THREADS", "8")
+    # Attempt 1: dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0 - what this image exports; the host driver only supports dmabuf IPC
+    # and RCCL's cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument` without it).  That is a
+    # property of the box, not of this code, so if the N ranks do not produce a result the launcher tries ONCE more with the
+    # variable removed (the runtime's default IPC mode) and the JSON line says which setting the numbers were measured under.
+    attempts = [("0", "HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC)")]
+    if args.device != "cpu":
+        attempts.append((None, "HSA_ENABLE_IPC_MODE_LEGACY unset (runtime default)"))
+    if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] != "0":
+        attempts.insert(0, (os.environ["HSA_ENABLE_IPC_MODE_LEGACY"], "HSA_ENABLE_IPC_MODE_LEGACY as inherited"))
+    last_line, rc, tried = None, 1, []
+    for value, label in attempts:
+        env = dict(base)
+        if value is None:
+            env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+        else:
+            env["HSA_ENABLE_IPC_MODE_LEGACY"] = value
+        env["AIRGYM_BENCH_LAUNCH_ATTEMPT"] = json.dumps({"attempt": len(tried) + 1, "ipc_setting": label, "earlier": tried})
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=args.launch_timeout)
+            rc, out = r.returncode, r.stdout
+        except subprocess.TimeoutExpired as e:
+            rc, out = 124, (e.stdout or "") if isinstance(e.stdout, str) else ""
+        lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+        last_line = lines[-1] if lines else None
+        ok = False
+        if rc == 0 and last_line is not None:
+            try:
+                ok = json.loads(last_line).get("value") is not None
+            except ValueError:
+                ok = False
+        if ok:
+            print(last_line, flush=True)
+            return 0
+        tried.append({"ipc_setting": label, "exit_code": rc,
+                      "error": (json.loads(last_line).get("error") if last_line else "no JSON line from rank 0")})
+    # nothing was measured: ONE parseable line that says what was tried
+    err = {"metric": f"env_steps_per_sec_{args.task}_{args.envs}_envs_per_gpu", "value": None, "unit": "env-steps/s",
+           "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": "no launch attempt produced a result",
+           "launch_attempts": tried}
+    if last_line is not None:
+        try:
+            err["rccl"] = json.loads(last_line).get("rccl")
+        except ValueError:
+            pass
+    print(json.dumps(err), flush=True)
+    return rc if rc != 0 else 1
 
 
 def rccl_probe(agent, world, iters=100):
@@ -295,7 +339,26 @@ def rccl_probe(agent, world, iters=100):
     return {"ranks_seen": dist.get_world_size(), "ranks_counted_by_allreduce": int(ones.item()),
             "backend": dist.get_backend(), "allreduce_us": t.item() / iters * 1e6, "bytes": buf.numel() * buf.element_size(),
             "iters": iters, "per_epoch": agent.mini_epochs_num * agent.num_minibatches,
-            "note": "one all-reduce of the flat gradient (+KL) per optimizer step is the job's only data-path collective"}
+            "ipc_mode_legacy_env": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "launch": json.loads(os.environ.get("AIRGYM_BENCH_LAUNCH_ATTEMPT", "null")),
+            "note": "one all-reduce of the flat gradient (+KL) per optimizer step; during the first mini-epoch the input "
+                    "normaliser's batch moments are all-reduced too, and the value normaliser's twice per epoch - "
+                    "`collectives_per_epoch` is what rank 0 actually issued inside the timed region, counted call by call"}
+
+
+def _failure_line(args, world, exc, stage):
+    """Rank 0's JSON line when an N > 1 run dies: what was asked for, what the process group reported before it died."""
+    seen = backend = None
+    try:
+        if dist.is_initialized():
+            seen, backend = dist.get_world_size(), dist.get_backend()
+    except Exception:
+        pass
+    return {"metric": f"env_steps_per_sec_{args.task}_{args.envs}_envs_per_gpu", "value": None, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "error": f"{stage}: {type(exc).__name__}: {exc}"[:600],
+            "rccl": {"ranks_seen": seen, "backend": backend, "ipc_mode_legacy_env": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                     "launch": json.loads(os.environ.get("AIRGYM_BENCH_LAUNCH_ATTEMPT", "null"))}}
 
 
 def main(argv=None):
@@ -325,6 +388,7 @@ def main(argv=None):
                     help="skip the side lines for BASELINE configs 2 (Tracking / LV) and 4 (Planning / CNN, 16 384 envs)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu = launcher / collective test only (gloo)")
     ap.add_argument("--dist-backend", default=None, help="default: nccl (= RCCL) on cuda, gloo on cpu")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds one self-launched N-rank attempt may take")
     ap.add_argument("--agent", default="airgym_amd.lib.agent.a2c_continuous:A2CAgent",
                     help="module:Class of the agent (tests substitute a stub to exercise the launcher without a GPU)")
     args = ap.parse_args(argv)
@@ -348,15 +412,33 @@ def main(argv=None):
                                   "devices_visible": have, "steps": args.steps, "warmup": args.warmup}), flush=True)
             return
 
+    if world > 1:
+        # an N-rank run that dies (RCCL init, IPC, a missing device) still leaves ONE parseable line from rank 0
+        stage = ["setup"]
+        try:
+            return _run_rank(args, world, rank, on_gpu, stage)
+        except BaseException as e:      # noqa: BLE001 - report, then fail the process
+            if isinstance(e, SystemExit) and not e.code:
+                raise
+            if rank == 0:
+                print(json.dumps(_failure_line(args, world, e, stage[0])), flush=True)
+            raise
+    return _run_rank(args, world, rank, on_gpu, ["setup"])
+
+
+def _run_rank(args, world, rank, on_gpu, stage):
+    from airgym_amd.lib.core import collectives
     A2CAgent = _load_agent_class(args.agent)
     params = build_params(args, world)
     if not on_gpu:
         params["config"]["device"] = "cpu"
         params["config"]["env_config"]["sim_device"] = "cpu"
     params["config"]["dist_backend"] = args.dist_backend or ("nccl" if on_gpu else "gloo")
+    stage[0] = "process group / agent construction"
     agent = A2CAgent("bench", params)
     agent.init_tensors()
     agent.obs = agent.env_reset()
+    stage[0] = "initial parameter broadcast (first collective)"
     agent.broadcast_parameters()
     dev = agent.ppo_device
 
@@ -370,11 +452,15 @@ def main(argv=None):
             dist.barrier()
         sync()
 
+    stage[0] = "gradient all-reduce probe"
     rccl = rccl_probe(agent, world) if world > 1 else None      # before the timed region: also warms the communicator
+    stage[0] = "warm-up epochs"
     for _ in range(args.warmup):
         agent.epoch_num += 1
         agent.train_epoch()
     barrier()
+    stage[0] = "timed epochs"
+    collectives.reset()
     t0 = time.perf_counter()
     play = update = 0.0
     for _ in range(args.steps):
@@ -385,6 +471,8 @@ def main(argv=None):
         last_stats = st
     barrier()
     elapsed = time.perf_counter() - t0
+    counted = collectives.snapshot()
+    stage[0] = "reporting"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -421,6 +509,10 @@ def main(argv=None):
                                           (last_stats["kl"], last_stats["a_loss"], last_stats["c_loss"]))))},
     }
     if rccl is not None:
+        # what rank 0 issued between the two barriers of the timed region, per epoch (every rank issues the same sequence)
+        rccl["collectives_per_epoch"] = {k: {"calls": v["calls"] / args.steps, "bytes": v["bytes"] / args.steps}
+                                         for k, v in counted.items()}
+        rccl["minibatch_hip_graphs"] = bool(getattr(agent, "_graph_update", False))
         out["rccl"] = rccl
     hip = getattr(agent, "_hip_env", None)
     # N > 1: every rank measures its own env kernel at the same time (nobody idles in a barrier while rank 0 works); the

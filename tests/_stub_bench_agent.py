@@ -16,3 +16,11 @@ class StubAgent(A2CAgent):
         c["train_dir"] = __import__("tempfile").mkdtemp(prefix="airgym_bench_stub_")
         params["network"]["mlp"]["units"] = [32, 32]
         super().__init__(name, params)
+
+
+class BrokenCollectiveAgent(StubAgent):
+    """A run whose first collective fails on every rank (what an RCCL / IPC failure looks like to bench.py): the launcher must
+    retry once (on a GPU box: with the other IPC setting) and, when nothing works, still print ONE parseable line."""
+
+    def broadcast_parameters(self):
+        raise RuntimeError("hipIpcGetMemHandle: invalid argument (simulated)")

@@ -31,6 +31,13 @@ def test_self_launch_two_ranks_gloo():
     rc = out["rccl"]
     assert rc["ranks_seen"] == 2 and rc["ranks_counted_by_allreduce"] == 2 and rc["backend"] == "gloo"
     assert rc["allreduce_us"] > 0 and rc["bytes"] > 0 and rc["per_epoch"] == 5 * 2
+    # counted, not derived: 10 gradient all-reduces per epoch; the input normaliser's moments in the first mini-epoch's two
+    # minibatches + the value normaliser's two updates (values, returns) per epoch
+    cpe = rc["collectives_per_epoch"]
+    assert cpe["gradient"]["calls"] == 10 and cpe["gradient"]["bytes"] == 10 * rc["bytes"]
+    assert cpe["normaliser_moments"]["calls"] == 2 + 2
+    assert set(cpe) == {"gradient", "normaliser_moments"}
+    assert rc["launch"]["attempt"] == 1 and rc["launch"]["earlier"] == [] and rc["minibatch_hip_graphs"] is False
     assert out["phases"]["finite"]
     assert "cpu_baseline" not in out and "shipped_ratio" not in out      # N == 1 legs stay out of the N > 1 line
 
@@ -47,3 +54,31 @@ def test_too_few_devices_is_one_json_error_line():
 def test_mismatched_world_size_is_refused():
     r, _ = _run(["--gpus", "2", "--device", "cpu"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_self_launch_eight_ranks_gloo():
+    """The shape of the driver's N = 8 run (one process per GPU of one node), on the CPU test double."""
+    r, lines = _run(["--gpus", "8", "--device", "cpu", "--agent", "tests._stub_bench_agent:StubAgent", "--envs", "8",
+                     "--steps", "1", "--warmup", "1", "--minibatches", "2"], env_extra={"OMP_NUM_THREADS": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["global_envs"] == 64 and out["config"]["parallelism"] == "dp8"
+    rc = out["rccl"]
+    assert rc["ranks_seen"] == 8 and rc["ranks_counted_by_allreduce"] == 8
+    assert rc["collectives_per_epoch"]["gradient"]["calls"] == 10
+    assert abs(out["value"] - 8 * 8 * out["config"]["horizon_length"] / (out["ms_per_step"] / 1e3)) < 1e-6 * out["value"]
+    assert out["phases"]["finite"]
+
+
+def test_failing_collective_leaves_one_json_line_with_what_was_seen():
+    r, lines = _run(["--gpus", "2", "--device", "cpu", "--agent", "tests._stub_bench_agent:BrokenCollectiveAgent", "--envs", "8",
+                     "--steps", "1", "--warmup", "0", "--minibatches", "2"])
+    assert r.returncode != 0
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["n_gpus"] == 2
+    att = out["launch_attempts"]
+    assert len(att) == 1 and att[0]["exit_code"] != 0                  # cpu: one attempt (no IPC setting to flip)
+    assert "hipIpcGetMemHandle" in att[0]["error"] and "initial parameter broadcast" in att[0]["error"]
+    assert out["rccl"]["ranks_seen"] == 2 and out["rccl"]["backend"] == "gloo"      # what the group reported before it died
