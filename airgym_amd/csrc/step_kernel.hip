@@ -156,7 +156,10 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
     __shared__ float tileB[64 * SB];
     __shared__ float tileT[64 * ST];
     __shared__ float tileS[64];
-    __shared__ __attribute__((aligned(16))) float tileA[FUSED ? 64 * SA : 4];
+    // env actions: FUSED: sampled by the noise wave; otherwise LOADED by the noise wave one step ahead (two buffers) - the physics
+    // wave issues no global load inside the step loop, so it never has to wait for its own stores (loads and stores share
+    // vmcnt on gfx950: a wave that consumes a load behind stores waits for the stores too)
+    __shared__ __attribute__((aligned(16))) float tileA[(FUSED ? 1 : 2) * 64 * SA];
     __shared__ float tileR[FUSED ? 64 : 1];
     __shared__ int tileD[FUSED ? 64 : 1];
 
@@ -179,27 +182,48 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
     // physics wave: the env's state lives here across the K steps
     EnvState s;
     CtlState c;
-    float pre_a[A], raw_next[A];
+    float pre_a[A], raw_next[A];          // raw_next: noise wave, non-FUSED: the action of the NEXT step, in flight / landed
+    // action rows of step `step_` -> registers (zeros for padding lanes) / registers -> tileA buffer `buf_`
+#define AG_LOAD_ACTION(step_)                                                                          \
+    do {                                                                                               \
+        if (active) {                                                                                  \
+            const float* an_ = k.actions + (size_t)(step_) * nsz * A;                                  \
+            if (A == 4) {                                                                              \
+                const float4 av_ = reinterpret_cast<const float4*>(an_)[i];                            \
+                raw_next[0] = av_.x; raw_next[1] = av_.y; raw_next[2] = av_.z; raw_next[3] = av_.w;    \
+            } else {                                                                                   \
+                _Pragma("unroll") for (int j = 0; j < A; ++j) raw_next[j] = an_[(size_t)i * A + j];    \
+            }                                                                                          \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < A; ++j) raw_next[j] = 0.0f;                          \
+        }                                                                                              \
+    } while (0)
+#define AG_PUT_ACTION(buf_)                                                                            \
+    do {                                                                                               \
+        float* ta_ = tileA + (buf_) * 64 * SA;                                                         \
+        if (A == 4) {                                                                                  \
+            reinterpret_cast<float4*>(ta_)[lane] = make_float4(raw_next[0], raw_next[1], raw_next[2], raw_next[3]); \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int j = 0; j < A; ++j) ta_[lane * SA + j] = raw_next[j];            \
+        }                                                                                              \
+    } while (0)
     if (wave == 0) {
         load_env(k, i, s);
         load_ctl<CTL>(k, i, c);
         const float4 pa = k.PA[i];
         pre_a[0] = pa.x; pre_a[1] = pa.y; pre_a[2] = pa.z; pre_a[3] = pa.w;
         if (A == 5) pre_a[A - 1] = k.PA4[i];
-        if (!FUSED) {      // step 0's action (steps kk + 1 are requested one step ahead, under step kk's arithmetic)
-            if (active) {
-                if (A == 4) {
-                    const float4 av = reinterpret_cast<const float4*>(k.actions)[i];
-                    raw_next[0] = av.x; raw_next[1] = av.y; raw_next[2] = av.z; raw_next[3] = av.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < A; ++j) raw_next[j] = k.actions[(size_t)i * A + j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < A; ++j) raw_next[j] = 0.0f;
-            }
-        }
+    } else if (!FUSED) {
+        AG_LOAD_ACTION(0);
+        AG_PUT_ACTION(0);                  // step 0's action
+        if (K > 1) AG_LOAD_ACTION(1);      // step 1's is requested now and handed over during step 0
+    }
+    if (!FUSED) {
+        __syncthreads();                   // step 0's action is in tileA[0] (the physics wave's state loads are in flight)
+        // Everything requested so far has landed before the step loop is entered (vmcnt(0); expcnt / lgkmcnt untouched).  Left to
+        // the compiler, the wait for the state loads sits at their first use INSIDE the loop body, where from the second step on
+        // it waits for the previous step's stores instead (loads and stores share the counter): +2 us per step.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
 
 #pragma unroll 1
@@ -220,18 +244,14 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
 #pragma unroll
                     for (int j = 0; j < A; ++j) raw_a[j] = tileA[lane * SA + j];
                 }
-            } else {
+            } else {      // handed over by the noise wave during the previous step (before its barrier 2)
+                const float* ta_ = tileA + (kk & 1) * 64 * SA;
+                if (A == 4) {
+                    const float4 av = reinterpret_cast<const float4*>(ta_)[lane];
+                    raw_a[0] = av.x; raw_a[1] = av.y; raw_a[2] = av.z; raw_a[3] = av.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < A; ++j) raw_a[j] = raw_next[j];
-                if (!last && active) {
-                    const float* an = k.actions + (size_t)(kk + 1) * nsz * A;
-                    if (A == 4) {
-                        const float4 av = reinterpret_cast<const float4*>(an)[i];
-                        raw_next[0] = av.x; raw_next[1] = av.y; raw_next[2] = av.z; raw_next[3] = av.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < A; ++j) raw_next[j] = an[(size_t)i * A + j];
-                    }
+                    for (int j = 0; j < A; ++j) raw_a[j] = ta_[lane * SA + j];
                 }
             }
             StepOut o;
@@ -332,6 +352,12 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
                     for (int j = 0; j < A; ++j) tileA[lane * SA + j] = ea[j];
                 }
                 __syncthreads();   // barrier 0
+            } else if (!last) {
+                // multi-step: step kk + 1's action (requested a whole step ago) goes to the other tileA buffer - the physics
+                // wave reads it behind barrier 2 - and step kk + 2's is requested.  Consume first, then issue: the wait for
+                // the landed load must not cover the new one.
+                AG_PUT_ACTION((kk + 1) & 1);
+                if (kk + 2 < K) AG_LOAD_ACTION(kk + 2);
             }
             // ---- observation noise
             float z[18];
@@ -396,23 +422,30 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
         const int valid = min(64, k.n - block_env0) * NOBS;    // floats of this tile that exist
         float* out = obs_out + (size_t)block_env0 * NOBS;
         constexpr int NV4 = 64 * NOBS / 4;
-        constexpr int ITERS = (NV4 + 127) / 128;
-        const int t2 = wave * 64 + lane;
+        // FUSED (one step per launch): both waves copy the tile out.  Otherwise the physics wave alone: it has no load to wait
+        // for, so its stores never stall it, while a noise wave that stored here would meet them again at its next action load.
+        constexpr int CW = FUSED ? 128 : 64;
+        constexpr int ITERS = (NV4 + CW - 1) / CW;
+        const int t2 = FUSED ? wave * 64 + lane : lane;
+        if (FUSED || wave == 0) {
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int m = t2 + it * 128;
-            if (m < NV4) {
-                const int e = 4 * m;
-                if (e + 3 < valid) {
-                    reinterpret_cast<float4*>(out)[m] = reinterpret_cast<const float4*>(tileO)[m];
-                } else {
-                    for (int q = e; q < e + 4 && q < valid; ++q) out[q] = tileO[q];
+            for (int it = 0; it < ITERS; ++it) {
+                const int m = t2 + it * CW;
+                if (m < NV4) {
+                    const int e = 4 * m;
+                    if (e + 3 < valid) {
+                        reinterpret_cast<float4*>(out)[m] = reinterpret_cast<const float4*>(tileO)[m];
+                    } else {
+                        for (int q = e; q < e + 4 && q < valid; ++q) out[q] = tileO[q];
+                    }
                 }
             }
         }
         // (next step: the physics wave writes tileO / tileT again only after barrier 1, which the noise wave reaches after
         //  the copy-out reads above; the noise wave rewrites tileB only after barrier 2, behind the physics wave's reads)
     }
+#undef AG_LOAD_ACTION
+#undef AG_PUT_ACTION
 }
 
 // ---------------------------------------------------------------------------------------------------

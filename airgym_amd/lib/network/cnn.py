@@ -19,12 +19,57 @@ class CNNFeatureExtractor(nn.Module):
         self.fused_trunk = True         # False: layer by layer (every ReLU + BatchNorm output written and read)
         self.bn_sums_from_weights = True   # the trunk's BatchNorm backward reductions from (w, dw) of the next convolution (exact
                                            # identity, fused_cnn.bn_sums_from_conv; needs BatchNorm weights != 0); False: reduction kernel
+        # ... guarded: the identity recovers dgamma as (sum w dw - beta sum dy) / gamma, which amplifies the float32 rounding of
+        # dw by 1 / |gamma|.  A step whose smallest |gamma_c| (first two BatchNorm layers) is below bn_gamma_guard x the layer's
+        # largest takes the reduction kernels instead (exact for any gamma, 0 included).  The ratio is read from a pinned host
+        # copy that every training forward refreshes asynchronously - no host synchronisation after the first call, the decision
+        # is one step stale (gamma moves by <= lr per step; the threshold has a 2x margin over the 1e-3 the error bound needs).
+        self.bn_gamma_guard = 2e-3
+        self._gamma_ratio_host = None      # pinned [1] float32: min_c |gamma_c| / max_c |gamma_c| over the guarded layers
+        self._gamma_ratio_event = None
+        self.bn_fallback_steps = 0         # training forwards that took the reduction kernels because of the guard
         self.dgrad_epilogue = True      # (with bn_sums_from_weights) the second layer's ReLU + BatchNorm backward in the epilogue of the
                                         # third convolution's input gradient; False: as a pass of its own (ag_relu_bn_bwd_dx)
         self.conv1_wgrad_fused = True   # (with bn_sums_from_weights) conv2's input gradient + layer 1's backward + conv1's weight gradient
                                         # as one kernel; False: two kernels with the 1.9 GB gradient between them
         self.direct_grads = False       # True (set by an owner that zeroes .grad before every backward): the trunk's backward writes
                                         # the parameter gradients into the existing .grad tensors itself (no accumulation launches)
+
+    def reset_gamma_guard(self):
+        """Forget the cached gamma ratio: the next training forward synchronises once and decides on the CURRENT weights (call
+        after writing the BatchNorm weights from outside the optimizer; load_state_dict does it itself)."""
+        self._gamma_ratio_host = None
+        self._gamma_ratio_event = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.reset_gamma_guard()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    @torch.no_grad()
+    def _sums_from_weights_ok(self, device):
+        """True when the (w, dw) identity is well conditioned for this step - see bn_gamma_guard."""
+        if not self.bn_sums_from_weights:
+            return False
+        g1, g2 = self.features[2].weight, self.features[5].weight
+        ratio = torch.minimum(g1.abs().min() / g1.abs().max().clamp_min(1e-30),
+                              g2.abs().min() / g2.abs().max().clamp_min(1e-30)).float().reshape(1)
+        first = self._gamma_ratio_host is None
+        if first:
+            self._gamma_ratio_host = torch.empty(1, dtype=torch.float32).pin_memory()
+            self._gamma_ratio_event = torch.cuda.Event()
+        else:
+            # the value an EARLIER step left (its copy completed long ago; wait only if a caller runs two steps back to back
+            # faster than one tiny copy - then the event wait is microseconds)
+            self._gamma_ratio_event.synchronize()
+            ok = float(self._gamma_ratio_host[0]) >= self.bn_gamma_guard
+        self._gamma_ratio_host.copy_(ratio, non_blocking=True)
+        self._gamma_ratio_event.record(torch.cuda.current_stream(device))
+        if first:      # nothing to go by yet (fresh model, or a restored checkpoint): one synchronisation
+            self._gamma_ratio_event.synchronize()
+            ok = float(self._gamma_ratio_host[0]) >= self.bn_gamma_guard
+        if not ok:
+            self.bn_fallback_steps += 1
+        return ok
 
     def forward(self, x, weights=None, norm=None, index=None):
         """weights [N] (optional, training): image i stands for weights[i] identical images of the minibatch (frame
@@ -37,7 +82,10 @@ class CNNFeatureExtractor(nn.Module):
             # the whole trunk as one autograd node (lib/network/fused_cnn.py): the ReLU + BatchNorm outputs are never written
             from airgym_amd.lib.network import fused_cnn
             if fused_cnn.usable(x, self.features) and (self.features[2].training or not torch.is_grad_enabled()):
-                return self.fc(fused_cnn.trunk(x, self.features, weights, norm, index, self.direct_grads, self.bn_sums_from_weights,
+                fw = self.bn_sums_from_weights
+                if fw and self.features[2].training and torch.is_grad_enabled():
+                    fw = self._sums_from_weights_ok(x.device)
+                return self.fc(fused_cnn.trunk(x, self.features, weights, norm, index, self.direct_grads, fw,
                                                  self.dgrad_epilogue, self.conv1_wgrad_fused))
         if index is not None:
             x = x.index_select(0, index)

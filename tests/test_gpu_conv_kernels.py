@@ -232,6 +232,52 @@ def test_reductions_from_weights_equal_the_reduction_kernel():
         assert (pa.grad - pc.grad).abs().max().item() <= 2e-4 * s + 1e-8, (name, (pa.grad - pc.grad).abs().max().item(), s)
 
 
+def test_small_batchnorm_weights_fall_back_to_the_reduction_kernels():
+    """The (w, dw) identity divides by gamma: a BatchNorm scale near zero would turn the float32 rounding of dw into a huge
+    dgamma for that channel (and, through gradient clipping, starve every other parameter).  With one gamma at 1e-6 and one at
+    exactly 0 the default trunk must notice (bn_gamma_guard) and produce the gradients of the reduction-kernel path - every
+    parameter, to 1e-3 of its scale; the un-guarded identity on the same weights is shown to be off by orders of magnitude."""
+    import copy
+    from airgym_amd.lib.network.cnn import CNNFeatureExtractor
+    torch.manual_seed(5)
+    a = CNNFeatureExtractor(12).cuda().train()
+    with torch.no_grad():
+        for mod in a.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_()
+        a.features[2].weight[3] = 1e-6          # first BatchNorm layer: one tiny scale
+        a.features[5].weight[7] = 0.0           # second: one exactly zero
+    a.reset_gamma_guard()
+    ref = copy.deepcopy(a)
+    ref.bn_sums_from_weights = False            # ag_relu_bn_bwd_reduce passes over the gradients: exact for any gamma
+    raw = copy.deepcopy(a)
+    raw.bn_gamma_guard = 0.0                    # the identity, un-guarded
+    x = torch.rand(9, 1, 212, 120, device="cuda") * 3.0
+    w = torch.tensor([1., 4., 2., 1., 3., 4., 1., 2., 2.], device="cuda")
+    g = torch.randn(9, 12, device="cuda")
+    a(x, w).backward(g)
+    ref(x, w).backward(g)
+    raw(x, w).backward(g)
+    assert a.bn_fallback_steps == 1 and raw.bn_fallback_steps == 0
+    worst_raw = 0.0
+    for (name, pa), (_, pr), (_, pw) in zip(a.named_parameters(), ref.named_parameters(), raw.named_parameters()):
+        s = pr.grad.abs().max().item()
+        assert torch.isfinite(pa.grad).all(), name
+        assert (pa.grad - pr.grad).abs().max().item() <= 1e-3 * s + 1e-8, (name, (pa.grad - pr.grad).abs().max().item(), s)
+        worst_raw = max(worst_raw, ((pw.grad - pr.grad).abs().max().item() / (s + 1e-30)) if torch.isfinite(pw.grad).all() else 1e30)
+    assert worst_raw > 1e-1, worst_raw          # what the guard is there for
+    # healthy weights again: the guard lets the identity back in (one step later: the decision uses the previous step's copy)
+    with torch.no_grad():
+        a.features[2].weight[3] = 1.0
+        a.features[5].weight[7] = 1.0
+    for p in a.parameters():
+        p.grad = None
+    a(x, w).backward(g)          # decided on the stale ratio: still the reduction kernels
+    a(x, w).backward(g)          # now the identity
+    assert a.bn_fallback_steps == 2
+
+
 @pytest.mark.parametrize("shape", [(5, 32, 53, 30), (4, 64, 27, 15)])
 def test_border_sums_in_passing_equal_the_standalone_kernel_and_torch(shape):
     """ag_relu_bn_bwd_dx_weighted's plane / border sums (formed while dx is written) against ag_plane_border_sums on the result and
