@@ -29,8 +29,11 @@ _CTL_ID = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
 
 
 def kernel_name(task, ctl_mode, fused=False):
-    """Symbol (as rocprofv3 prints it) of the env-step kernel: step_kernel_ws2<task, ctl, FUSED> (csrc/step_kernel.hip)."""
-    return "ag::step_kernel_ws2<%d,%d,%s>" % (_TASK_ID[task], _CTL_ID[ctl_mode], "true" if fused else "false")
+    """Symbol (as rocprofv3 prints it) of the env-step kernel (csrc/step_kernel.hip): step_kernel_ws2<task, ctl, true> for
+    ag_step_rollout_fused, step_kernel_multi<task, ctl> for ag_step / ag_step_rollout / ag_step_multi."""
+    if fused:
+        return "ag::step_kernel_ws2<%d,%d,true>" % (_TASK_ID[task], _CTL_ID[ctl_mode])
+    return "ag::step_kernel_multi<%d,%d>" % (_TASK_ID[task], _CTL_ID[ctl_mode])
 
 
 def fused_algo_bytes(task, ctl_mode, num_obs, num_actions):
@@ -119,7 +122,7 @@ def multi_own_bytes(task, ctl_mode, num_obs, num_actions, K):
     return num_actions * 4 + num_obs * 4 + 4 + 1 + (2 * state + 1) / float(K)
 
 
-def measure_env_multi(env, K=24, launches_per_graph=2, replays=52, warmup_replays=3, seed=1):
+def measure_env_multi(env, K=24, launches_per_graph=2, replays=52, warmup_replays=3, seed=1, use_graph=True):
     """ag_step_multi: K env steps per launch (state in registers between them), `launches_per_graph` launches per hipGraph
     (even: device tick ping-pong), HIP events on the launch stream.  Default 24 x 2 x 52 = 2 496 env steps, the same count
     (and the same N(0,1)-clamped actions) as measure_env_kernel, so the 2 400-step time limit fires inside the timed region."""
@@ -141,16 +144,25 @@ def measure_env_multi(env, K=24, launches_per_graph=2, replays=52, warmup_replay
         for j in range(2):
             one(j)
         stream.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-            for j in range(launches_per_graph):
-                one(j)
+        graph = None
+        if use_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+                for j in range(launches_per_graph):
+                    one(j)
+
+        def run():
+            if graph is not None:
+                graph.replay()
+            else:
+                for j in range(launches_per_graph):
+                    one(j)
         for _ in range(warmup_replays):
-            graph.replay()
+            run()
         stream.synchronize()
         start.record(stream)
         for _ in range(replays):
-            graph.replay()
+            run()
         stop.record(stream)
         stop.synchronize()
     launches = launches_per_graph * replays

@@ -16,13 +16,14 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from airgym_amd.lib.agent.a2c_continuous import A2CAgent  # noqa: E402
 from airgym_amd.utils.kernel_bench import (env_kernel_source_sha, kernel_name, measure_env_kernel,  # noqa: E402
-                                           measure_fused_rollout_kernel)
+                                           measure_env_multi, measure_fused_rollout_kernel)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--task", default="hovering")
 ap.add_argument("--ctl", default="rate")
 ap.add_argument("--envs", type=int, default=65536)
-ap.add_argument("--forms", nargs="+", default=["api", "rollout", "fused"])
+ap.add_argument("--forms", nargs="+", default=["api", "rollout", "fused"], help="api | rollout | fused | multi (ag_step_multi)")
+ap.add_argument("--multi-steps", type=int, default=24, help="env steps per ag_step_multi launch")
 ap.add_argument("--replays", type=int, default=20)
 ap.add_argument("--nograph", action="store_true", help="eager launches (rocprofv3 counter passes)")
 a = ap.parse_args()
@@ -45,6 +46,9 @@ for form in a.forms:
             r = dict(r0)
         else:
             r = measure_fused_rollout_kernel(agent, replays=a.replays)
+    elif form == "multi":
+        r = measure_env_multi(env, K=a.multi_steps, launches_per_graph=2, replays=a.replays, use_graph=not a.nograph)
+        r["kernel"] = kernel_name(a.task, a.ctl, False)
     else:
         r = measure_env_kernel(env, replays=a.replays, rollout_form=(form == "rollout"), use_graph=not a.nograph)
         r["kernel"] = kernel_name(a.task, a.ctl, False)
