@@ -283,12 +283,17 @@ def _dp_gpu_worker_body(rank, world, port, q):
     agent = A2CAgent("dp", params)
     agent.init_tensors()
     assert agent.multi_gpu and agent._fused_step is not None and agent._fused_rollout is not None
-    assert agent.env_config["env_id_offset"] == rank * 1024 and not agent._graph_update
+    # 6 144-sample minibatches: the launch-bound regime - minibatch hipGraphs, split at the gradient all-reduce under multi_gpu
+    assert agent.env_config["env_id_offset"] == rank * 1024 and agent._graph_update
     agent.obs = agent.env_reset()
     agent.broadcast_parameters()
     for ep in range(1, 4):
         agent.epoch_num = ep
         st = agent.train_epoch()
+    # epochs 2 and 3 replayed graph A (forward / backward / reductions) + eager all-reduce + graph B (average, clip, Adam) for the
+    # statistics-off minibatches; the first mini-epoch's (normaliser moments all-reduced inside the forward) stayed eager
+    assert "tail" in agent._upd_graphs and any(k != "tail" and k[1] is False for k in agent._upd_graphs)
+    assert not any(k != "tail" and k[1] is True for k in agent._upd_graphs)
     q.put((rank, agent.flat_param.cpu().numpy().copy(), float(agent.optimizer.lr.item()), st["kl"],
            agent.model.running_mean_std.running_mean.cpu().numpy().copy(), agent.actions_buf[0, :4].cpu().numpy().copy()))
     import torch.distributed as dist
