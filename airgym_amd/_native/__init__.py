@@ -182,6 +182,11 @@ SYMBOLS = [
                                                  ctypes.c_int, _P]),
     ("ag_split_gemm_elu_heads", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, _P]),
+    ("ag_mlp_chain_supported", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    ("ag_mlp_chain_image_bytes", ctypes.c_longlong, [ctypes.c_int]),
+    ("ag_mlp_chain_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, ctypes.c_int, _P, _P]),
+    ("ag_mlp_chain_forward", ctypes.c_int, [_P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_planes_per_block", ctypes.c_int, []),
     ("ag_relu_bn_stats", ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_relu_bn_apply", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),

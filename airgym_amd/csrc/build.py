@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 18 translation units compiled in parallel).
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 19 translation units compiled in parallel).
 
     python airgym_amd/csrc/build.py [--force] [--jobs N] [--experiments]
 
@@ -44,7 +44,7 @@ def units(experiments=False):
     for task in (0, 1):
         for ctl in range(5):
             out.append((os.path.join(od, f"step_{task}_{ctl}.o"), "step_kernel.hip", [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}"] + x))
-    for name in ("airgym_hip", "ppo_kernels", "planning_kernel", "rollout_kernels", "split_gemm", "split_wgrad", "cnn_kernels", "conv_kernels"):
+    for name in ("airgym_hip", "ppo_kernels", "planning_kernel", "rollout_kernels", "split_gemm", "split_wgrad", "cnn_kernels", "conv_kernels", "mlp_chain"):
         out.append((os.path.join(od, name + ".o"), name + ".hip", list(x)))
     if experiments:
         out.append((os.path.join(od, "experiments.o"), "experiments.hip", list(x)))

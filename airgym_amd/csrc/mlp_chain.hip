@@ -41,6 +41,19 @@ typedef __attribute__((address_space(3))) void* cl_ptr;
 
 __device__ __forceinline__ int chain_perm(int h, int i) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
+// LDS-DMA of one 1 KiB piece: lane l's 16 bytes at `src` (per-lane global address) land at LDS byte address lds_base + 16 l
+// (lds_base wave-uniform, in M0).  Written as inline assembly on purpose: hipcc treats the builtin's destination as "may alias
+// any LDS read" and puts an `s_waitcnt vmcnt(0)` in front of the first ds_read behind it - the copy of the NEXT block would be
+// waited for at the top of every K step.  Hidden from the compiler, the copies are drained by the explicit vmcnt(0) in front
+// of the K step's barrier instead (chain_dma_wait), a whole K step after they were issued.
+__device__ __forceinline__ void chain_dma16(const uint4* src, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void chain_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+__device__ __forceinline__ uint32_t chain_lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(cl_ptr)(p);
+}
+
 __device__ __forceinline__ float chain_elu(float z) {      // same form as split_gemm.hip sg_elu / ppo_kernels.hip elu1
     return z > 0.f ? z : __builtin_amdgcn_exp2f(z * 1.4426950408889634f) - 1.0f;
 }
@@ -140,26 +153,38 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
     const int ntiles = (a.M + CROWS - 1) / CROWS;
     const bool normalize = a.mean != nullptr;
 
-#define AG_CHAIN_ISSUE_BLOCK(blk_, stg_)                                                               \
+    // The weight stream: block after block of the stream image, wrapping at the end of a tile - a RUNNING scalar pointer (were
+    // the source address a function of the unrolled K-step index, LLVM would hoist all 6 x NB per-lane 64-bit addresses out of
+    // the tile loop: 216 registers, spilled).  One call issues the next block into stage `stg_`.
+    const uint4* dma_src = a.stream_img;
+    int dma_blk = 0;
+    const int lane_unit = wave * 64 + lane;
+    const uint32_t stage_addr = __builtin_amdgcn_readfirstlane(chain_lds_addr(stage));
+#define AG_CHAIN_ISSUE_NEXT(stg_)                                                                      \
     do {                                                                                               \
-        const uint4* src_ = a.stream_img + (size_t)(blk_) * CBLK + wave * 64 + lane;                   \
-        uint4* dst_ = stage + (stg_) * CBLK + wave * 64;                                               \
+        const uint4* src_ = dma_src;                                                                   \
+        const uint32_t dst_ = stage_addr + ((stg_) * CBLK + wave * 64) * 16;                           \
         _Pragma("unroll") for (int it = 0; it < CBLK / 256; ++it)                                      \
-            __builtin_amdgcn_global_load_lds((cg_ptr)(src_ + it * 256), (cl_ptr)(dst_ + it * 256), 16, 0, 0); \
+            chain_dma16(src_ + it * 256 + lane_unit, dst_ + it * 256 * 16);                            \
+        dma_src += CBLK;                                                                               \
+        if (++dma_blk == NB) { dma_blk = 0; dma_src = a.stream_img; }                                  \
     } while (0)
 
     // ---- prologue: resident head image, constants, block 0 of the first tile
+    {
+        const uint32_t wh_addr = __builtin_amdgcn_readfirstlane(chain_lds_addr(whres)) + wave * 64 * 16;
 #pragma unroll
-    for (int it = 0; it < CWH / 256; ++it)
-        __builtin_amdgcn_global_load_lds((cg_ptr)(a.wh_img + it * 256 + wave * 64 + lane), (cl_ptr)(whres + it * 256 + wave * 64), 16, 0, 0);
+        for (int it = 0; it < CWH / 256; ++it) chain_dma16(a.wh_img + it * 256 + lane_unit, wh_addr + it * 256 * 16);
+    }
     fconst[tid] = a.b2[tid];
     if (tid < 64) {
         const bool in = normalize && tid < a.D;
         fconst[256 + tid] = in ? (float)a.mean[tid] : 0.0f;
         fconst[320 + tid] = in ? sqrtf((float)a.var[tid] + a.eps) : 1.0f;
     }
-    if ((int)blockIdx.x < ntiles) AG_CHAIN_ISSUE_BLOCK(0, 0);
-    __syncthreads();              // the constants are visible to every wave (the tile loop reads them before its first barrier)
+    if ((int)blockIdx.x < ntiles) AG_CHAIN_ISSUE_NEXT(0);
+    chain_dma_wait();
+    __syncthreads();              // the head image and the constants are visible to every wave
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row_raw = tile * CROWS + wave * 32 + l31;
@@ -200,11 +225,11 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
 
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
-            // block g has landed for every wave (the compiler puts the vmcnt(0) of the pending LDS-DMA in front of the barrier);
-            // every wave is done with block g - 1, whose stage block g + 1 goes to
+            // block g has landed for every wave (each drains its own LDS-DMA pieces, issued a whole K step ago, before it
+            // arrives); every wave is done with block g - 1, whose stage block g + 1 goes to
+            chain_dma_wait();
             __syncthreads();
-            if (g + 1 < NB) AG_CHAIN_ISSUE_BLOCK(g + 1, (g + 1) & 1);
-            else if (next_tile) AG_CHAIN_ISSUE_BLOCK(0, 0);
+            if (g + 1 < NB || next_tile) AG_CHAIN_ISSUE_NEXT((g + 1) & 1);
             const uint4* st = stage + (g & 1) * CBLK;
             if (g < NB1) {
                 // ---- first layer, K step g: B fragment = this lane's row of (normalised) inputs, k = 16 g + 8 h + i
@@ -294,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
             }
         }
     }
-#undef AG_CHAIN_ISSUE_BLOCK
+#undef AG_CHAIN_ISSUE_NEXT
 }
 
 constexpr size_t chain_fwd_lds_bytes() { return (size_t)(2 * CBLK + CWH) * 16 + (256 + 64 + 64) * 4; }

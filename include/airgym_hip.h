@@ -377,6 +377,24 @@ int ag_split_gemm_input_wgrad_rows(void);
 int ag_split_gemm_input_wgrad_supported(int D);   /* 1 for D in {16, 18, 20, 48} */
 int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
                               float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
+/* The whole actor-critic MLP [D -> 256 -> 256 -> (A + 1)] as ONE launch with the activations in registers
+ * (airgym_amd/csrc/mlp_chain.hip): input normaliser -> Linear + ELU -> Linear + ELU -> mu | value heads
+ * (ModelA2CContinuousLogStd.forward, lib/model/a2c_continuous_logstd_model.py:80-193; MLP, lib/network/mlp.py:36-39; fixed
+ * sigma, shared trunk).  Same float32-accurate arithmetic as ag_split_gemm for all three products.  Replaces
+ * ag_mlp_input_layer + ag_split_gemm_elu_heads in the rollout: neither h1 nor z2 goes through HBM.
+ *   ag_mlp_chain_supported: 1 for C = 256, D + 1 <= 64, A1 in {5, 6}.
+ *   ag_mlp_chain_image_bytes(D): size of the prepared weight image (16-byte aligned buffer).
+ *   ag_mlp_chain_prepare: W1 [256, D], b1 [256], W2 [256, 256], Wh [A1, 256] (row-major f32) -> image.  Once per policy version.
+ *   ag_mlp_chain_forward: heads_dev [M, A1] = Wh ELU(W2 ELU(W1 xn + b1) + b2) + bh with xn = clamp((obs - mean) /
+ *       sqrt(var + eps), +-clip) (mean_dev / var_dev NULL: xn = obs).  Optional outputs (NULL = not written): xn_dev [M, D],
+ *       h1_dev / h2_dev [M, 256] = the two layers' activations (after ELU). */
+int ag_mlp_chain_supported(int D, int C, int A1);
+long long ag_mlp_chain_image_bytes(int D);
+int ag_mlp_chain_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, const float* Wh_dev, int A1,
+                         void* image_dev, void* stream);
+int ag_mlp_chain_forward(const float* obs_dev, const double* mean_dev, const double* var_dev, float eps, float clip,
+                         const void* image_dev, const float* b2_dev, const float* bh_dev, float* heads_dev, float* xn_dev,
+                         float* h1_dev, float* h2_dev, int M, int D, int A1, void* stream);
 int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
                             const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1, void* stream);
 
