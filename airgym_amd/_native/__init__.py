@@ -241,6 +241,7 @@ DEBUG_SYMBOLS = [
     ("ag_debug_planning_render_parts", ctypes.c_int, [_P, ctypes.c_int]),
     ("ag_debug_split_gemm_variant", ctypes.c_int, [ctypes.c_int]),
     ("ag_debug_split_wgrad_ordered", ctypes.c_int, [ctypes.c_int]),
+    ("ag_debug_chain_skip", ctypes.c_int, [ctypes.c_int]),
 ]
 
 _lib = None

@@ -115,16 +115,44 @@ struct ChainFwdArgs {
     float* h1;                 // [M, 256] or null: first-layer activations
     float* h2;                 // [M, 256] or null: second-layer activations
     int M, D;
+    int debug_skip;            // experiments build only: bit0 no weight DMA behind the first block, bit1 no MFMA, bit2 no barriers
 };
+// (a compile-time constant inside the kernel: a run-time test in front of every MFMA group would change the schedule it measures)
+#define AG_CHAIN_DBG(bit_) (DBG & (bit_))
 
 #define AG_CHAIN_MFMA6(acc_, a_, b_)                                                                   \
     do {                                                                                               \
+        if (AG_CHAIN_DBG(2)) { acc_[0] += __builtin_bit_cast(float, (int)a_[0][0] ^ (int)b_[0][0] ^ (int)a_[1][1] ^ (int)b_[1][1] ^ (int)a_[2][2] ^ (int)b_[2][2]); break; } \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[2], b_[0], acc_, 0, 0, 0);                   \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[2], acc_, 0, 0, 0);                   \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], b_[1], acc_, 0, 0, 0);                   \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], b_[0], acc_, 0, 0, 0);                   \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[1], acc_, 0, 0, 0);                   \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[0], acc_, 0, 0, 0);                   \
+    } while (0)
+
+// the same six products for TWO accumulator tiles that share the B fragment, interleaved so that consecutive MFMAs never wait
+// for each other's result (a dependent pair issued back to back is free, but any other instruction between them costs ~43
+// cycles - MI355X_MICROARCH.md - and the compiler does put fillers there)
+#define AG_CHAIN_MFMA6x2(acc0_, acc1_, a0_, a1_, b_)                                                   \
+    do {                                                                                               \
+        if (AG_CHAIN_DBG(2)) {                                                                         \
+            acc0_[0] += __builtin_bit_cast(float, (int)a0_[0][0] ^ (int)b_[0][0] ^ (int)a0_[1][1] ^ (int)b_[1][1] ^ (int)a0_[2][2] ^ (int)b_[2][2]); \
+            acc1_[0] += __builtin_bit_cast(float, (int)a1_[0][0] ^ (int)a1_[1][1] ^ (int)a1_[2][2]);   \
+            break;                                                                                     \
+        }                                                                                              \
+        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[2], b_[0], acc0_, 0, 0, 0);                \
+        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[2], b_[0], acc1_, 0, 0, 0);                \
+        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[0], b_[2], acc0_, 0, 0, 0);                \
+        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[0], b_[2], acc1_, 0, 0, 0);                \
+        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[1], b_[1], acc0_, 0, 0, 0);                \
+        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[1], b_[1], acc1_, 0, 0, 0);                \
+        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[1], b_[0], acc0_, 0, 0, 0);                \
+        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[1], b_[0], acc1_, 0, 0, 0);                \
+        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[0], b_[1], acc0_, 0, 0, 0);                \
+        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[0], b_[1], acc1_, 0, 0, 0);                \
+        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[0], b_[0], acc0_, 0, 0, 0);                \
+        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[0], b_[0], acc1_, 0, 0, 0);                \
     } while (0)
 
 // registers 8 s .. 8 s + 7 of an accumulator tile -> the three bf16x8 pieces of a B (or A) fragment
@@ -139,7 +167,7 @@ __device__ __forceinline__ void chain_split_regs(const f32x16& acc, int s, bf16x
     out[2] = *reinterpret_cast<const bf16x8*>(&p3);
 }
 
-template <int KP1, int A1, bool STORE>
+template <int KP1, int A1, bool STORE, int DBG>
 __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArgs a) {
     constexpr int NB1 = KP1 / 16, NB = NB1 + 16;
     static_assert((NB & 1) == 0, "an even number of blocks per tile keeps the stage parity across tiles");
@@ -158,19 +186,44 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
     // the tile loop: 216 registers, spilled).  One call issues the next block into stage `stg_`.
     const uint4* dma_src = a.stream_img;
     int dma_blk = 0;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    int dma_left = my_tiles * NB;                      // blocks this workgroup still has to request
     const int lane_unit = wave * 64 + lane;
     const uint32_t stage_addr = __builtin_amdgcn_readfirstlane(chain_lds_addr(stage));
 #define AG_CHAIN_ISSUE_NEXT(stg_)                                                                      \
     do {                                                                                               \
-        const uint4* src_ = dma_src;                                                                   \
-        const uint32_t dst_ = stage_addr + ((stg_) * CBLK + wave * 64) * 16;                           \
-        _Pragma("unroll") for (int it = 0; it < CBLK / 256; ++it)                                      \
-            chain_dma16(src_ + it * 256 + lane_unit, dst_ + it * 256 * 16);                            \
+        if (dma_left > 0 && !AG_CHAIN_DBG(1)) {                                                        \
+            const uint4* src_ = dma_src;                                                               \
+            const uint32_t dst_ = stage_addr + ((stg_) * CBLK + wave * 64) * 16;                       \
+            _Pragma("unroll") for (int it = 0; it < CBLK / 256; ++it)                                  \
+                chain_dma16(src_ + it * 256 + lane_unit, dst_ + it * 256 * 16);                        \
+        }                                                                                              \
+        --dma_left;                                                                                    \
         dma_src += CBLK;                                                                               \
         if (++dma_blk == NB) { dma_blk = 0; dma_src = a.stream_img; }                                  \
     } while (0)
+    // A fragments (three planes) of output tiles 2 p and 2 p + 1 out of a landed block
+#define AG_CHAIN_READ_PAIR(w0_, w1_, st_, pair_)                                                       \
+    do {                                                                                               \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                \
+            const uint4 u0_ = (st_)[(p * 2 + h) * CF + 64 * (pair_) + l31];                            \
+            const uint4 u1_ = (st_)[(p * 2 + h) * CF + 64 * (pair_) + 32 + l31];                       \
+            w0_[p] = *reinterpret_cast<const bf16x8*>(&u0_);                                           \
+            w1_[p] = *reinterpret_cast<const bf16x8*>(&u1_);                                           \
+        }                                                                                              \
+    } while (0)
+    // issue order of one tile pair's twelve MFMAs: every MFMA is followed by up to three vector-ALU instructions (the next K
+    // step's ELU / split work), the fragment reads of the next pair lead
+#define AG_CHAIN_ORDER_PAIR()                                                                          \
+    do {                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                             \
+        _Pragma("unroll") for (int q_ = 0; q_ < 12; ++q_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                         \
+        }                                                                                              \
+    } while (0)
 
-    // ---- prologue: resident head image, constants, block 0 of the first tile
+    // ---- prologue: resident head image, constants, the first two blocks
     {
         const uint32_t wh_addr = __builtin_amdgcn_readfirstlane(chain_lds_addr(whres)) + wave * 64 * 16;
 #pragma unroll
@@ -182,9 +235,13 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
         fconst[256 + tid] = in ? (float)a.mean[tid] : 0.0f;
         fconst[320 + tid] = in ? sqrtf((float)a.var[tid] + a.eps) : 1.0f;
     }
-    if ((int)blockIdx.x < ntiles) AG_CHAIN_ISSUE_NEXT(0);
+    AG_CHAIN_ISSUE_NEXT(0);
+    AG_CHAIN_ISSUE_NEXT(1);
     chain_dma_wait();
-    __syncthreads();              // the head image and the constants are visible to every wave
+    __syncthreads();              // head image, constants, blocks 0 and 1 are in LDS for every wave
+    // A fragments of the pair that is multiplied next; read one pair ahead, across K steps and tiles
+    bf16x8 wc0[3], wc1[3], wn0[3], wn1[3];
+    AG_CHAIN_READ_PAIR(wc0, wc1, stage, 0);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row_raw = tile * CROWS + wave * 32 + l31;
@@ -192,8 +249,8 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
         const int row = row_ok ? row_raw : a.M - 1;            // rows past M are computed on a copy of the last row, never stored
         const bool next_tile = tile + (int)gridDim.x < ntiles;
 
-        // this lane's input row, k = 16 g + 8 h + i: all loads issued together (one wait, under the first K step's barrier);
-        // columns past D: the all-ones bias column at D, zeros behind it
+        // this lane's input row, k = 16 g + 8 h + i: all loads issued together; columns past D: the all-ones bias column at D,
+        // zeros behind it
         float xv[NB1][8];
 #pragma unroll
         for (int g = 0; g < NB1; ++g)
@@ -223,91 +280,136 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc1[t][r] = 0.0f; acc2[t][r] = 0.0f; }
 
+        // The B fragment of K step g + 1 is formed DURING K step g (its inputs - the input row, or first-layer registers that
+        // were final long ago - do not depend on this step's products), a QUARTER of it under each tile pair's MFMAs.
+        bf16x8 bcur[3];
+        uint4 qn[3];                       // the next step's fragment under construction (planes 1..3)
+        {
+            uint4 q1, q2, q3;
+            split8(make_float4(xv[0][0], xv[0][1], xv[0][2], xv[0][3]), make_float4(xv[0][4], xv[0][5], xv[0][6], xv[0][7]), q1, q2, q3);
+            bcur[0] = *reinterpret_cast<const bf16x8*>(&q1);
+            bcur[1] = *reinterpret_cast<const bf16x8*>(&q2);
+            bcur[2] = *reinterpret_cast<const bf16x8*>(&q3);
+        }
+        // quarter `q_` of the work that turns first-layer tile `tn_`'s registers into the B fragment of K step (tn_, sn_):
+        //   sn_ = 0: ELU of all 16 registers (4 per quarter; registers 8..15 are used by the FOLLOWING step), the fragment's low
+        //            half in quarter 2, its high half in quarter 3;   sn_ = 1: the two halves in quarters 0 and 1
+#define AG_CHAIN_FRAG_QUARTER(tn_, sn_, q_)                                                            \
+        do {                                                                                           \
+            if ((sn_) == 0) {                                                                          \
+                _Pragma("unroll") for (int r = 4 * (q_); r < 4 * (q_) + 4; ++r) acc1[tn_][r] = chain_elu(acc1[tn_][r]); \
+                if (STORE && a.h1 != nullptr && row_ok)                                                \
+                    *reinterpret_cast<float4*>(a.h1 + (size_t)row * CF + 32 * (tn_) + 8 * (q_) + 4 * h) = \
+                        make_float4(acc1[tn_][4 * (q_)], acc1[tn_][4 * (q_) + 1], acc1[tn_][4 * (q_) + 2], acc1[tn_][4 * (q_) + 3]); \
+                if ((q_) == 2) {                                                                       \
+                    split_pair(acc1[tn_][0], acc1[tn_][1], qn[0].x, qn[1].x, qn[2].x);                 \
+                    split_pair(acc1[tn_][2], acc1[tn_][3], qn[0].y, qn[1].y, qn[2].y);                 \
+                } else if ((q_) == 3) {                                                                \
+                    split_pair(acc1[tn_][4], acc1[tn_][5], qn[0].z, qn[1].z, qn[2].z);                 \
+                    split_pair(acc1[tn_][6], acc1[tn_][7], qn[0].w, qn[1].w, qn[2].w);                 \
+                }                                                                                      \
+            } else if ((q_) == 0) {                                                                    \
+                split_pair(acc1[tn_][8], acc1[tn_][9], qn[0].x, qn[1].x, qn[2].x);                     \
+                split_pair(acc1[tn_][10], acc1[tn_][11], qn[0].y, qn[1].y, qn[2].y);                   \
+            } else if ((q_) == 1) {                                                                    \
+                split_pair(acc1[tn_][12], acc1[tn_][13], qn[0].z, qn[1].z, qn[2].z);                   \
+                split_pair(acc1[tn_][14], acc1[tn_][15], qn[0].w, qn[1].w, qn[2].w);                   \
+            }                                                                                          \
+        } while (0)
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
-            // block g has landed for every wave (each drains its own LDS-DMA pieces, issued a whole K step ago, before it
-            // arrives); every wave is done with block g - 1, whose stage block g + 1 goes to
-            chain_dma_wait();
-            __syncthreads();
-            if (g + 1 < NB || next_tile) AG_CHAIN_ISSUE_NEXT((g + 1) & 1);
+            // K step g multiplies block g (stage g & 1), whose first pair of fragments is already in wc0 / wc1.  The step's ONE
+            // barrier stands in front of its LAST tile pair: by then this wave has read all of block g, so after the barrier the
+            // stage is free for block g + 2 (requested at once: a whole K step to land) and block g + 1 (requested a K step ago,
+            // drained by chain_dma_wait) can be read - its first fragments arrive under the last pair's MFMAs.
             const uint4* st = stage + (g & 1) * CBLK;
-            if (g < NB1) {
-                // ---- first layer, K step g: B fragment = this lane's row of (normalised) inputs, k = 16 g + 8 h + i
-                uint4 q1, q2, q3;
-                split8(make_float4(xv[g][0], xv[g][1], xv[g][2], xv[g][3]), make_float4(xv[g][4], xv[g][5], xv[g][6], xv[g][7]), q1, q2, q3);
-                bf16x8 b[3] = {*reinterpret_cast<const bf16x8*>(&q1), *reinterpret_cast<const bf16x8*>(&q2),
-                               *reinterpret_cast<const bf16x8*>(&q3)};
+            const uint4* stn = stage + ((g + 1) & 1) * CBLK;
+            if (g + 1 < NB1) {              // first layer: the next K step's fragment is the next 16 input columns
+                split8(make_float4(xv[g + 1][0], xv[g + 1][1], xv[g + 1][2], xv[g + 1][3]),
+                       make_float4(xv[g + 1][4], xv[g + 1][5], xv[g + 1][6], xv[g + 1][7]), qn[0], qn[1], qn[2]);
+            }
+            // ---- this step's products: weights = A operand (two output tiles at a time), bcur = B operand.  Every tile pair is
+            //      its own scheduling region (sched_barrier): fragment reads of the NEXT pair first, then twelve MFMAs with the
+            //      quarter of vector-ALU work spread between them.
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    bf16x8 w[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const uint4 u = st[(p * 2 + h) * CF + 32 * t + l31];
-                        w[p] = *reinterpret_cast<const bf16x8*>(&u);
-                    }
-                    AG_CHAIN_MFMA6(acc1[t], w, b);
+            for (int jp = 0; jp < 4; ++jp) {
+                if (jp < 3) {
+                    if (!AG_CHAIN_DBG(16)) AG_CHAIN_READ_PAIR(wn0, wn1, st, jp + 1);
+                } else if (g + 1 < NB || next_tile) {
+                    chain_dma_wait();
+                    if (!AG_CHAIN_DBG(4)) __syncthreads();
+                    AG_CHAIN_ISSUE_NEXT(g & 1);
+                    if (!AG_CHAIN_DBG(16)) AG_CHAIN_READ_PAIR(wn0, wn1, stn, 0);
                 }
-            } else {
-                // ---- second layer, K step c: B fragment = registers 8 s .. 8 s + 7 of first-layer tile t, split where they are
-                const int c = g - NB1, t = c >> 1, s = c & 1;
-                if (s == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc1[t][r] = chain_elu(acc1[t][r]);
-                    if (STORE && a.h1 != nullptr && row_ok) {
-#pragma unroll
-                        for (int r = 0; r < 16; r += 4)
-                            *reinterpret_cast<float4*>(a.h1 + (size_t)row * CF + 32 * t + 8 * (r >> 2) + 4 * h) =
-                                make_float4(acc1[t][r], acc1[t][r + 1], acc1[t][r + 2], acc1[t][r + 3]);
-                    }
+                if (g + 1 < NB && g + 1 > NB1 && !AG_CHAIN_DBG(8)) {
+                    const int cn = g + 1 - NB1;      // second layer, K step cn >= 1: first-layer tile cn >> 1, half cn & 1
+                    AG_CHAIN_FRAG_QUARTER(cn >> 1, cn & 1, jp);
                 }
-                bf16x8 b[3];
-                chain_split_regs(acc1[t], s, b);
+                if (g < NB1) AG_CHAIN_MFMA6x2(acc1[2 * jp], acc1[2 * jp + 1], wc0, wc1, bcur);
+                else AG_CHAIN_MFMA6x2(acc2[2 * jp], acc2[2 * jp + 1], wc0, wc1, bcur);
+                AG_CHAIN_ORDER_PAIR();
+                __builtin_amdgcn_sched_barrier(0);
+                if (!AG_CHAIN_DBG(16)) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    bf16x8 w[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const uint4 u = st[(p * 2 + h) * CF + 32 * j + l31];
-                        w[p] = *reinterpret_cast<const bf16x8*>(&u);
-                    }
-                    AG_CHAIN_MFMA6(acc2[j], w, b);
+                    for (int p = 0; p < 3; ++p) { wc0[p] = wn0[p]; wc1[p] = wn1[p]; }
                 }
+            }
+            if (g + 1 == NB1) {
+                // the first layer has just ended: the first B fragment of the second layer (tile 0, registers 0..7) - the only
+                // one that cannot be formed a step ahead
+                AG_CHAIN_FRAG_QUARTER(0, 0, 0); AG_CHAIN_FRAG_QUARTER(0, 0, 1); AG_CHAIN_FRAG_QUARTER(0, 0, 2); AG_CHAIN_FRAG_QUARTER(0, 0, 3);
+            }
+            if (g + 1 < NB) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bcur[p] = *reinterpret_cast<const bf16x8*>(&qn[p]);
             }
         }
+#undef AG_CHAIN_FRAG_QUARTER
 
         // ---- bias + ELU of the second layer (its registers hold features 32 j + (r & 3) + 8 (r >> 2) + 4 h), then the heads:
-        //      one more transposed product against the resident head image, B fragments again straight from the registers
-        f32x16 acch;
+        //      one more transposed product against the resident head image, B fragments again straight from the registers.
+        //      Two accumulators (even / odd K steps), fragment c + 1 formed while step c multiplies.
+#define AG_CHAIN_H2_HALF(t_, s_)                                                                       \
+        do {                                                                                           \
+            _Pragma("unroll") for (int r = 8 * (s_); r < 8 * (s_) + 8; r += 4) {                       \
+                const float4 bb = *reinterpret_cast<const float4*>(fconst + 32 * (t_) + 8 * (r >> 2) + 4 * h); \
+                acc2[t_][r] = chain_elu(acc2[t_][r] + bb.x);                                           \
+                acc2[t_][r + 1] = chain_elu(acc2[t_][r + 1] + bb.y);                                   \
+                acc2[t_][r + 2] = chain_elu(acc2[t_][r + 2] + bb.z);                                   \
+                acc2[t_][r + 3] = chain_elu(acc2[t_][r + 3] + bb.w);                                   \
+                if (STORE && a.h2 != nullptr && row_ok)                                                \
+                    *reinterpret_cast<float4*>(a.h2 + (size_t)row * CF + 32 * (t_) + 8 * (r >> 2) + 4 * h) = \
+                        make_float4(acc2[t_][r], acc2[t_][r + 1], acc2[t_][r + 2], acc2[t_][r + 3]);   \
+            }                                                                                          \
+        } while (0)
+        f32x16 acch, acch1;
+        bf16x8 bnext[3];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acch[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) { acch[r] = 0.0f; acch1[r] = 0.0f; }
+        AG_CHAIN_H2_HALF(0, 0);
+        chain_split_regs(acc2[0], 0, bcur);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const int t = c >> 1, s = c & 1;
-            if (s == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    const float4 bb = *reinterpret_cast<const float4*>(fconst + 32 * t + 8 * (r >> 2) + 4 * h);
-                    acc2[t][r] = chain_elu(acc2[t][r] + bb.x);
-                    acc2[t][r + 1] = chain_elu(acc2[t][r + 1] + bb.y);
-                    acc2[t][r + 2] = chain_elu(acc2[t][r + 2] + bb.z);
-                    acc2[t][r + 3] = chain_elu(acc2[t][r + 3] + bb.w);
-                }
-                if (STORE && a.h2 != nullptr && row_ok) {
-#pragma unroll
-                    for (int r = 0; r < 16; r += 4)
-                        *reinterpret_cast<float4*>(a.h2 + (size_t)row * CF + 32 * t + 8 * (r >> 2) + 4 * h) =
-                            make_float4(acc2[t][r], acc2[t][r + 1], acc2[t][r + 2], acc2[t][r + 3]);
-                }
+            if (c + 1 < 16) {
+                const int tn = (c + 1) >> 1, sn = (c + 1) & 1;
+                if (sn == 0) AG_CHAIN_H2_HALF(tn, 0); else AG_CHAIN_H2_HALF(tn, 1);
+                chain_split_regs(acc2[tn], sn, bnext);
             }
-            bf16x8 b[3], w[3];
-            chain_split_regs(acc2[t], s, b);
+            bf16x8 w[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const uint4 u = whres[c * (3 * 2 * 32) + (p * 2 + h) * 32 + l31];
                 w[p] = *reinterpret_cast<const bf16x8*>(&u);
             }
-            AG_CHAIN_MFMA6(acch, w, b);
+            if (c & 1) AG_CHAIN_MFMA6(acch1, w, bcur); else AG_CHAIN_MFMA6(acch, w, bcur);
+            if (c + 1 < 16) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bcur[p] = bnext[p];
+            }
         }
+#undef AG_CHAIN_H2_HALF
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acch[r] += acch1[r];
         // heads of batch row n: head index (r & 3) + 8 (r >> 2) + 4 h -> lane n holds heads 0..3 (registers 0..3), lane n + 32
         // heads 4..7 (registers 0..3 again)
         if (row_ok) {
@@ -320,6 +422,8 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
         }
     }
 #undef AG_CHAIN_ISSUE_NEXT
+#undef AG_CHAIN_READ_PAIR
+#undef AG_CHAIN_ORDER_PAIR
 }
 
 constexpr size_t chain_fwd_lds_bytes() { return (size_t)(2 * CBLK + CWH) * 16 + (256 + 64 + 64) * 4; }
@@ -337,10 +441,10 @@ int chain_cus() {
     return cus[dev];
 }
 
-template <int KP1, int A1, bool STORE>
+template <int KP1, int A1, bool STORE, int DBG = 0>
 int launch_chain_fwd(const ChainFwdArgs& a, void* stream) {
     static bool attr_set[64] = {};
-    auto* fn = mlp_chain_fwd_kernel<KP1, A1, STORE>;
+    auto* fn = mlp_chain_fwd_kernel<KP1, A1, STORE, DBG>;
     constexpr size_t lds_bytes = chain_fwd_lds_bytes();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
@@ -356,6 +460,13 @@ int launch_chain_fwd(const ChainFwdArgs& a, void* stream) {
 }
 
 }  // namespace
+
+#ifdef AG_EXPERIMENTS
+static int g_chain_debug_skip = 0;
+extern "C" int ag_debug_chain_skip(int mask) { g_chain_debug_skip = mask; return AG_OK; }
+#else
+constexpr int g_chain_debug_skip = 0;
+#endif
 
 extern "C" int ag_mlp_chain_supported(int D, int C, int A1) {
     return (C == CF && chain_kp1(D) != 0 && (A1 == 5 || A1 == 6)) ? 1 : 0;
@@ -394,7 +505,24 @@ extern "C" int ag_mlp_chain_forward(const float* obs_dev, const double* mean_dev
     a.stream_img = (const uint4*)image_dev;
     a.wh_img = a.stream_img + (size_t)(nb1 + 16) * CBLK;
     a.b2 = b2_dev; a.bh = bh_dev; a.heads = heads_dev; a.xn = xn_dev; a.h1 = h1_dev; a.h2 = h2_dev; a.M = M; a.D = D;
+    a.debug_skip = g_chain_debug_skip;
     const bool store = xn_dev || h1_dev || h2_dev;
+#ifdef AG_EXPERIMENTS
+    if (g_chain_debug_skip != 0 && nb1 == 2 && A1 == 5 && !store) {
+        switch (g_chain_debug_skip) {
+            case 1: return launch_chain_fwd<32, 5, false, 1>(a, stream);
+            case 2: return launch_chain_fwd<32, 5, false, 2>(a, stream);
+            case 3: return launch_chain_fwd<32, 5, false, 3>(a, stream);
+            case 4: return launch_chain_fwd<32, 5, false, 4>(a, stream);
+            case 7: return launch_chain_fwd<32, 5, false, 7>(a, stream);
+            case 8: return launch_chain_fwd<32, 5, false, 8>(a, stream);
+            case 16: return launch_chain_fwd<32, 5, false, 16>(a, stream);
+            case 24: return launch_chain_fwd<32, 5, false, 24>(a, stream);
+            case 29: return launch_chain_fwd<32, 5, false, 29>(a, stream);
+            default: return AG_ERR_INVALID_ARG;
+        }
+    }
+#endif
 #define AG_CHAIN_GO(KP, AV) (store ? launch_chain_fwd<KP, AV, true>(a, stream) : launch_chain_fwd<KP, AV, false>(a, stream))
     if (nb1 == 2) return A1 == 5 ? AG_CHAIN_GO(32, 5) : AG_CHAIN_GO(32, 6);
     return A1 == 5 ? AG_CHAIN_GO(64, 5) : AG_CHAIN_GO(64, 6);

@@ -33,6 +33,10 @@ int ag_debug_split_gemm_variant(int variant);
  * the compiler. */
 int ag_debug_split_wgrad_ordered(int on);
 
+/* ag_mlp_chain_forward with parts of the kernel left out (timing ablations; results are then meaningless): bit0 no weight
+ * LDS-DMA behind the first block, bit1 no MFMA, bit2 no workgroup barriers. */
+int ag_debug_chain_skip(int mask);
+
 /* Next Planning step renders with parts of the render kernel skipped: bit0 ray-cast, bit1 noise passes, bit2 5x5 pass. */
 int ag_debug_planning_render_parts(ag_handle h, int skip_mask);
 

@@ -16,6 +16,7 @@ from airgym_amd.utils.kernel_bench import _time_us  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, nargs="+", default=[65536, 196608])
 ap.add_argument("--D", type=int, default=18)
+ap.add_argument("--ablate", action="store_true", help="AIRGYM_EXPERIMENTS=1 build: time the kernel with DMA / MFMA / barriers left out")
 a = ap.parse_args()
 lib = N.load()
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -50,4 +51,10 @@ for M in a.rows:
         out[name + "_us"] = us
         if name.startswith("chain"):
             out[name + "_bf16_tflops"] = flops / us / 1e6
+    if a.ablate:
+        for mask, label in ((1, "no_dma"), (2, "no_mfma"), (4, "no_barrier"), (8, "no_l2_frag_valu"), (16, "no_frag_reads"),
+                            (24, "no_l2_valu_no_reads"), (29, "mfma_and_heads_only")):
+            lib.ag_debug_chain_skip(mask)
+            out["ablate_" + label + "_us"] = _time_us(lambda: chain(False), iters=20, warmup=3)
+        lib.ag_debug_chain_skip(0)
     print(json.dumps(out), flush=True)
