@@ -369,6 +369,11 @@ class FusedRolloutStep:
         self.split = {li: SplitGemm256(w, backward=False) for li, (w, _) in enumerate(self.layers)
                       if li >= 1 and SplitGemm256.applies(w, agent.config)}
         self.fuse_gemm_heads = bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 in (5, 6)
+        # the whole policy forward as ONE launch with the activations in registers (csrc/mlp_chain.hip): [D -> 256 -> 256] trunks
+        self.chain = None
+        if (bool(agent.config.get("use_mlp_chain", True)) and len(self.layers) == 2 and self.split
+                and tuple(self.layers[0][0].shape) == (256, D) and self.lib.ag_mlp_chain_supported(D, 256, self.A + 1)):
+            self.chain = torch.empty(self.lib.ag_mlp_chain_image_bytes(D), dtype=torch.uint8, device=dev)
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         # per-step, per-block episode sums; reduced over blocks ONCE per rollout (end_rollout)
         self.acct_partials = torch.zeros(agent.horizon_length, self.lib.ag_rollout_account_blocks(n), 4,
@@ -384,6 +389,8 @@ class FusedRolloutStep:
 
     @property
     def launches_per_step(self):
+        if self.chain is not None:
+            return 1 + (1 if self.fuse_tail else 3)
         gemms = len(self.layers) - 1
         return 1 + gemms + (0 if (self.fuse_gemm_heads and self.split) else 1) + (1 if self.fuse_tail else 3)
 
@@ -428,6 +435,12 @@ class FusedRolloutStep:
 
     def refresh_weights(self):
         """Transposed copy of the last hidden layer's weight for the NN-form GEMM (parameters are constant in a rollout)."""
+        if self.chain is not None:
+            (w0, b0), (w1, _) = self.layers
+            N.check(self.lib.ag_mlp_chain_prepare(w0.data_ptr(), b0.data_ptr(), w0.shape[1], w1.data_ptr(),
+                                                  self.agent.heads_w.data_ptr(), self.A + 1, self.chain.data_ptr(), self._stream()),
+                    "ag_mlp_chain_prepare")
+            return
         if self.fuse_heads:
             self.wt_last.copy_(self.layers[-1][0].t())
         for sg in self.split.values():
@@ -447,6 +460,13 @@ class FusedRolloutStep:
         rms = m.running_mean_std if m.normalize_input else None
         w0, b0 = self.layers[0]
         D, C0 = obs.shape[1], w0.shape[0]
+        if self.chain is not None:
+            N.check(lib.ag_mlp_chain_forward(obs.data_ptr(), rms.running_mean.data_ptr() if rms is not None else None,
+                                             rms.running_var.data_ptr() if rms is not None else None,
+                                             float(rms.epsilon) if rms is not None else 0.0, 5.0, self.chain.data_ptr(),
+                                             self.layers[1][1].data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(), None, None,
+                                             None, n, D, A + 1, st), "ag_mlp_chain_forward")
+            return self.heads
         if self.fuse_input:
             N.check(lib.ag_mlp_input_layer(obs.data_ptr(), rms.running_mean.data_ptr() if rms is not None else None,
                                            rms.running_var.data_ptr() if rms is not None else None, w0.data_ptr(),
