@@ -114,6 +114,20 @@ class AgRolloutTail(ctypes.Structure):
     ]
 
 
+class AgLossEpilogue(ctypes.Structure):
+    """ag_loss_epilogue (include/airgym_hip.h)"""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32),
+        ("logstd_dev", ctypes.c_void_p), ("actions_dev", ctypes.c_void_p), ("old_neglogp_dev", ctypes.c_void_p),
+        ("advantages_dev", ctypes.c_void_p), ("returns_dev", ctypes.c_void_p), ("old_values_dev", ctypes.c_void_p),
+        ("old_mu_dev", ctypes.c_void_p), ("old_sigma_dev", ctypes.c_void_p), ("new_mu_dev", ctypes.c_void_p),
+        ("new_sigma_dev", ctypes.c_void_p), ("heads_dev", ctypes.c_void_p), ("loss_partials_dev", ctypes.c_void_p),
+        ("dwh_partials_dev", ctypes.c_void_p), ("db_partials_dev", ctypes.c_void_p),
+        ("e_clip", ctypes.c_float), ("critic_coef", ctypes.c_float), ("bounds_loss_coef", ctypes.c_float),
+        ("clip_value", ctypes.c_int), ("bound_type", ctypes.c_int),
+    ]
+
+
 # every symbol include/airgym_hip.h declares: (name, restype, argtypes)
 _P = ctypes.c_void_p
 class AgSumJob(ctypes.Structure):
@@ -182,6 +196,9 @@ SYMBOLS = [
                                                  ctypes.c_int, _P]),
     ("ag_split_gemm_elu_heads", ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, _P]),
+    ("ag_split_gemm_loss_rows", ctypes.c_int, []),
+    ("ag_split_gemm_loss_heads_bwd", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.POINTER(AgLossEpilogue), ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_mlp_chain_supported", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("ag_mlp_chain_image_bytes", ctypes.c_longlong, [ctypes.c_int]),
     ("ag_mlp_chain_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, ctypes.c_int, _P, _P]),

@@ -24,7 +24,7 @@ ARCH = "gfx950"
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
-HEADERS = ["env_math.hpp", "planning_math.hpp", "kernel_args.hpp", "rollout_math.hpp", "handle.hpp", "split_common.hpp",
+HEADERS = ["env_math.hpp", "planning_math.hpp", "kernel_args.hpp", "rollout_math.hpp", "handle.hpp", "split_common.hpp", "ppo_loss_math.hpp",
            os.path.join("..", "..", "include", "airgym_hip.h")]
 
 

@@ -13,14 +13,15 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/airgym_hip.h"
+#include "ppo_loss_math.hpp"
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kDLogstd0 = 4;                              // a, c, b, kl, dlogstd[<=5], dbias_heads[<=6]
-constexpr int kDBias0 = 4 + AG_MAX_ACTIONS;
-constexpr int kClipCount = 4 + AG_MAX_ACTIONS + AG_MAX_ACTIONS + 1;   // rows whose ratio left [1 - e_clip, 1 + e_clip]
-constexpr int kNumSums = kClipCount + 1;
+using agloss::kClipCount;
+using agloss::kDBias0;
+using agloss::kDLogstd0;
+using agloss::kNumSums;
 
 struct LossArgs {
     const float* heads;      // [M, A+1]
@@ -47,94 +48,31 @@ __global__ __launch_bounds__(kBlock) void ppo_loss_kernel(const LossArgs k) {
     float acc[kNumSums];
 #pragma unroll
     for (int j = 0; j < kNumSums; ++j) acc[j] = 0.0f;
-    float ls[A], sig[A], inv_sig[A];
-    float logstd_sum = 0.0f;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-        ls[a] = k.logstd[a];
-        sig[a] = expf(ls[a]);
-        inv_sig[a] = 1.0f / sig[a];
-        logstd_sum += ls[a];
-    }
-    const float half_log_2pi_a = 0.5f * 1.8378770664093453f * (float)A;
-    // policy_clip_fraction (lib/core/torch_ext.py:168-178): logratio outside [log(1 - e), log(1 + e)]
-    const float log_lo = logf(1.0f - k.e_clip), log_hi = logf(1.0f + k.e_clip);
+    agloss::LossConsts<A> lc;
+    agloss::loss_consts<A>(k.logstd, k.e_clip, lc);
+    const agloss::LossParams lp{k.e_clip, k.critic_coef, k.bounds_loss_coef, k.inv_m, k.clip_value, k.bound_type};
 
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < k.M; i += gridDim.x * kBlock) {
-        const float* h = k.heads + (size_t)i * (A + 1);
-        float mu[A], z[A];
-        float q = 0.0f;
+        float h[A + 1], act[A], om[A], os[A], dhr[A + 1];
+#pragma unroll
+        for (int a = 0; a <= A; ++a) h[a] = k.heads[(size_t)i * (A + 1) + a];
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            mu[a] = h[a];
-            z[a] = (k.actions[(size_t)i * A + a] - mu[a]) * inv_sig[a];
-            q += z[a] * z[a];
+            act[a] = k.actions[(size_t)i * A + a];
+            om[a] = k.old_mu[(size_t)i * A + a];
+            os[a] = k.old_sigma[(size_t)i * A + a];
         }
-        const float v = h[A];
-        const float nlp = 0.5f * q + half_log_2pi_a + logstd_sum;
-        const float adv = k.advantages[i];
-        const float logratio = k.old_neglogp[i] - nlp;
-        const float ratio = expf(logratio);
-        acc[kClipCount] += (logratio < log_lo || logratio > log_hi) ? 1.0f : 0.0f;
-        const float lo = 1.0f - k.e_clip, hi = 1.0f + k.e_clip;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
-        const float l1 = -adv * ratio, l2 = -adv * rc;
-        const float a_loss = fmaxf(l1, l2);
-        // d a / d ratio with torch.max's tie rule (equal -> half to each branch); clamp passes the
-        // gradient on the closed interval [lo, hi]
-        const float in_range = (ratio >= lo && ratio <= hi) ? 1.0f : 0.0f;
-        const float w1 = (l1 > l2) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
-        const float w2 = (l2 > l1) ? 1.0f : ((l1 == l2) ? 0.5f : 0.0f);
-        const float da_dratio = -adv * (w1 + w2 * in_range);
-        const float da_dnlp = da_dratio * (-ratio);      // d ratio / d nlp = -ratio
-        // value loss (common_losses.py:10-20)
-        const float ret = k.returns[i];
-        float c_loss, dc_dv;
-        if (k.clip_value) {
-            const float vp = k.old_values[i];
-            const float dvc = fminf(fmaxf(v - vp, -k.e_clip), k.e_clip);
-            const float vc = vp + dvc;
-            const float u1 = (v - ret) * (v - ret), u2 = (vc - ret) * (vc - ret);
-            c_loss = fmaxf(u1, u2);
-            const float pass = ((v - vp) >= -k.e_clip && (v - vp) <= k.e_clip) ? 1.0f : 0.0f;
-            const float g1 = 2.0f * (v - ret), g2 = 2.0f * (vc - ret) * pass;
-            dc_dv = (u1 > u2) ? g1 : ((u1 == u2) ? 0.5f * (g1 + g2) : g2);
-        } else {
-            c_loss = (ret - v) * (ret - v);
-            dc_dv = 2.0f * (v - ret);
-        }
-        float b_loss = 0.0f, kl = 0.0f;
+        agloss::loss_row<A>(h, act, k.old_neglogp[i], k.advantages[i], k.returns[i], k.old_values[i], om, os, lc, lp, dhr, acc);
         float* dh = k.d_heads + (size_t)i * (A + 1);
 #pragma unroll
-        for (int a = 0; a < A; ++a) {
-            // d nlp / d mu_a = -z_a / sigma_a ;  d nlp / d logstd_a = 1 - z_a^2
-            float dmu = da_dnlp * (-z[a] * inv_sig[a]);
-            acc[kDLogstd0 + a] += da_dnlp * (1.0f - z[a] * z[a]);
-            if (k.bound_type == 1) {
-                const float hi_v = fmaxf(mu[a] - 1.1f, 0.0f), lo_v = fminf(mu[a] + 1.1f, 0.0f);
-                b_loss += lo_v * lo_v + hi_v * hi_v;
-                dmu += k.bounds_loss_coef * 2.0f * (hi_v + lo_v);
-            } else if (k.bound_type == 2) {
-                b_loss += mu[a] * mu[a];
-                dmu += k.bounds_loss_coef * 2.0f * mu[a];
-            }
-            dh[a] = dmu * k.inv_m;
-            acc[kDBias0 + a] += dmu * k.inv_m;
-            // KL(p0 = new || p1 = old), torch_ext.py:27-36
-            const float s1 = k.old_sigma[(size_t)i * A + a], m1 = k.old_mu[(size_t)i * A + a];
-            const float dm = m1 - mu[a];
-            kl += logf(s1 * inv_sig[a] + 1e-5f) + (sig[a] * sig[a] + dm * dm) / (2.0f * (s1 * s1 + 1e-5f)) - 0.5f;
-            if (k.new_mu) {
-                k.new_mu[(size_t)i * A + a] = mu[a];
-                k.new_sigma[(size_t)i * A + a] = sig[a];
+        for (int a = 0; a <= A; ++a) dh[a] = dhr[a];
+        if (k.new_mu) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                k.new_mu[(size_t)i * A + a] = h[a];
+                k.new_sigma[(size_t)i * A + a] = lc.sig[a];
             }
         }
-        dh[A] = 0.5f * k.critic_coef * dc_dv * k.inv_m;
-        acc[kDBias0 + A] += dh[A];
-        acc[0] += a_loss;
-        acc[1] += c_loss;
-        acc[2] += b_loss;
-        acc[3] += kl;
     }
     // block reduction: wave shuffle, then LDS across the 4 waves
 #pragma unroll

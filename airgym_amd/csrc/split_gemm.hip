@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "../../include/airgym_hip.h"
+#include "ppo_loss_math.hpp"
 #include "split_common.hpp"
 
 namespace {
@@ -174,9 +175,24 @@ struct SplitEpilogue {
     const float* x;            // input wgrad: [M, DIN] (normalised) network inputs
     float* dw_partials;        // input wgrad: [tiles, 256, DIN]
     float* db_partials;        // input wgrad: [tiles, 256]
+    // LOSS (ag_split_gemm_loss_heads_bwd): the minibatch rows of the PPO loss and where the head layer's backward goes
+    const float* logstd;       // [A]
+    const float* actions;      // [M, A]
+    const float* old_neglogp;  // [M]
+    const float* advantages;   // [M]
+    const float* returns;      // [M]
+    const float* old_values;   // [M]
+    const float* old_mu;       // [M, A]
+    const float* old_sigma;    // [M, A]
+    float* new_mu;             // [M, A] or null
+    float* new_sigma;          // [M, A] or null
+    float* loss_partials;      // [tiles, agloss::kNumSums]
+    float* dwh_partials;       // [tiles, A1, 256] head weight gradient of the tile's rows
+    float* db2_partials;       // [tiles, 256] column sums of dz (bias gradient of this layer)
+    agloss::LossParams lp;
 };
 
-template <bool HAS_BIAS, int A1, int DIN, int WM>
+template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false>
 __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
                                                                   float* __restrict__ C, int M, const SplitEpilogue ep) {
     constexpr int BM = WM * 64, NT = WM * 128;               // rows per tile, threads per workgroup
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = acc[i * 4 + j][r];
-                    if (live) C[(size_t)(m0 + rloc) * BN + wn * 128 + j * 32 + l31] = v;
+                    if (!LOSS && live) C[(size_t)(m0 + rloc) * BN + wn * 128 + j * 32 + l31] = v;
                     const float e = sg_elu(v + bcol[j]);
 #pragma unroll
                     for (int a = 0; a < A1; ++a) part[a] = fmaf(e, wcol[a][j], part[a]);
@@ -330,10 +346,137 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
             }
         }
         __syncthreads();
-        if (tid < BM && m0 + tid < M) {
+        if constexpr (!LOSS) {
+            if (tid < BM && m0 + tid < M) {
 #pragma unroll
-            for (int a = 0; a < A1; ++a)
-                heads[(size_t)(m0 + tid) * A1 + a] = hs[tid * A1 + a] + hs[(BM + tid) * A1 + a] + bh[a];
+                for (int a = 0; a < A1; ++a)
+                    heads[(size_t)(m0 + tid) * A1 + a] = hs[tid * A1 + a] + hs[(BM + tid) * A1 + a] + bh[a];
+            }
+        } else {
+            // ---- the PPO loss of the tile's rows (one thread per row; ppo_loss_math.hpp = ag_ppo_loss's arithmetic), then the
+            //      head layer's backward from the activations still in the accumulators: dz = (d_heads Wh) * ELU'(h) written where
+            //      the pre-activation would have gone, the head weight gradient dWh[a, c] = sum_m d_heads[m, a] h[m, c] and this
+            //      layer's bias gradient db[c] = sum_m dz[m, c] as one partial per tile.  Replaces ag_ppo_loss +
+            //      ag_heads_bwd_elu_wgrad: heads / d_heads never leave the LDS, z is neither written nor re-read.
+            constexpr int AA = A1 - 1;
+            float* dhs = hs + 2 * BM * A1;                      // [row BM][A1] d loss / d heads
+            float* lred = dhs + BM * A1;                        // [4 waves][kNumSums]
+            float* red2 = hs + 6144;                            // [wm WM][khalf 2][col BN][A1 + 1] (floats 6144 ..)
+            static_assert((6144 + WM * 2 * BN * (A1 + 1)) * 4 <= 2 * stage_units(BM) * 16, "loss epilogue exceeds the stages");
+            float lacc[agloss::kNumSums];
+#pragma unroll
+            for (int q = 0; q < agloss::kNumSums; ++q) lacc[q] = 0.0f;
+            // the constants of the state-independent sigma: once per tile (wave 7, lane 0), through LDS
+            float* lcs = lred + 4 * agloss::kNumSums;           // LossConsts<AA> as floats
+            static_assert(sizeof(agloss::LossConsts<AA>) % 4 == 0, "LossConsts is an array of floats");
+            static_assert(2 * BM * A1 + BM * A1 + 4 * agloss::kNumSums + (int)sizeof(agloss::LossConsts<AA>) / 4 <= 6144, "LDS");
+            if (tid == NT - 1) {
+                agloss::LossConsts<AA> lc0;
+                agloss::loss_consts<AA>(ep.logstd, ep.lp.e_clip, lc0);
+                *reinterpret_cast<agloss::LossConsts<AA>*>(lcs) = lc0;
+            }
+            __syncthreads();
+            if (tid < BM) {
+                const int row = m0 + tid;
+                float dh[A1];
+#pragma unroll
+                for (int a = 0; a < A1; ++a) dh[a] = 0.0f;
+                if (row < M) {
+                    const agloss::LossConsts<AA> lc = *reinterpret_cast<const agloss::LossConsts<AA>*>(lcs);
+                    float hv[A1], act[AA], om[AA], os[AA];
+#pragma unroll
+                    for (int a = 0; a < A1; ++a) hv[a] = hs[tid * A1 + a] + hs[(BM + tid) * A1 + a] + bh[a];
+#pragma unroll
+                    for (int a = 0; a < AA; ++a) {
+                        act[a] = ep.actions[(size_t)row * AA + a];
+                        om[a] = ep.old_mu[(size_t)row * AA + a];
+                        os[a] = ep.old_sigma[(size_t)row * AA + a];
+                    }
+                    if (heads != nullptr) {
+#pragma unroll
+                        for (int a = 0; a < A1; ++a) heads[(size_t)row * A1 + a] = hv[a];
+                    }
+                    if (ep.new_mu != nullptr) {
+#pragma unroll
+                        for (int a = 0; a < AA; ++a) {
+                            ep.new_mu[(size_t)row * AA + a] = hv[a];
+                            ep.new_sigma[(size_t)row * AA + a] = lc.sig[a];
+                        }
+                    }
+                    agloss::loss_row<AA, true>(hv, act, ep.old_neglogp[row], ep.advantages[row], ep.returns[row], ep.old_values[row],
+                                               om, os, lc, ep.lp, dh, lacc);
+                }
+#pragma unroll
+                for (int a = 0; a < A1; ++a) dhs[tid * A1 + a] = dh[a];      // rows past M: zeros (they add nothing below)
+#pragma unroll
+                for (int q = 0; q < agloss::kNumSums; ++q) {
+                    float x = lacc[q];
+                    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+                    if (lane == 0) lred[wave * agloss::kNumSums + q] = x;
+                }
+            }
+            __syncthreads();
+            if (tid < agloss::kNumSums) {
+                float x = 0.0f;
+                for (int w = 0; w < BM / 64; ++w) x += lred[w * agloss::kNumSums + tid];
+                ep.loss_partials[(size_t)tile * agloss::kNumSums + tid] = x;
+            }
+            int late2 = 0;       // opaque zero born HERE: or the 128 row addresses of the dz stores are formed in front of the
+            asm volatile("" : "+s"(late2) : : "memory");      // loss phase and spilled across it
+            const int m0b = m0 + late2;
+            float bcol2[4];      // the bias again, opaque: the activations are RECOMPUTED below (as values common to both passes
+#pragma unroll                   // LLVM keeps all 128 of them alive across the loss phase - spilled)
+            for (int j = 0; j < 4; ++j) bcol2[j] = bcol[j] + (float)late2;
+            float gw[A1][4], db[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                db[j] = 0.0f;
+#pragma unroll
+                for (int a = 0; a < A1; ++a) gw[a][j] = 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rloc = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;      // (M is a multiple of the tile)
+                    float d[A1];
+#pragma unroll
+                    for (int a = 0; a < A1; ++a) d[a] = dhs[rloc * A1 + a];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float e = sg_elu(acc[i * 4 + j][r] + bcol2[j]);
+                        float g = 0.0f;
+#pragma unroll
+                        for (int a = 0; a < A1; ++a) {
+                            g = fmaf(d[a], wcol[a][j], g);
+                            gw[a][j] = fmaf(d[a], e, gw[a][j]);
+                        }
+                        const float o = g * (e > 0.0f ? 1.0f : e + 1.0f);
+                        C[(size_t)(m0b + rloc) * BN + wn * 128 + j * 32 + l31] = o;
+                        db[j] += o;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the two row halves of a wave and the WM row blocks in a fixed order: deterministic
+            {
+                float* mine = red2 + (((size_t)wm * 2 + khalf) * BN + wn * 128 + l31) * (A1 + 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int a = 0; a < A1; ++a) mine[(j * 32) * (A1 + 1) + a] = gw[a][j];
+                    mine[(j * 32) * (A1 + 1) + A1] = db[j];
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < BN * (A1 + 1); idx += NT) {
+                const int c = idx / (A1 + 1), q = idx - c * (A1 + 1);
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WM * 2; ++w) v += red2[((size_t)w * BN + c) * (A1 + 1) + q];
+                if (q < A1) ep.dwh_partials[((size_t)tile * A1 + q) * BN + c] = v;
+                else ep.db2_partials[(size_t)tile * BN + c] = v;
+            }
         }
     } else if constexpr (DIN > 0) {
         constexpr int RW = DIN + 1;                         // reduction row: DIN weight-gradient entries + the bias gradient
@@ -467,10 +610,10 @@ constexpr size_t split_lds_bytes() {
     return stages > epi ? stages : epi;
 }
 
-template <bool HAS_BIAS, int A1, int DIN, int WM>
+template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false>
 static int launch_split_any(const float* A_dev, const void* planes_dev, float* C_dev, int M, const SplitEpilogue& ep, void* stream) {
     static bool attr_set[64] = {};      // per device ordinal: the dynamic-LDS limit is an attribute of (function, device)
-    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM>;
+    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM, LOSS>;
     constexpr size_t lds_bytes = split_lds_bytes<DIN, WM>();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
@@ -506,6 +649,32 @@ extern "C" int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_de
     if (A1 == 5) return AG_SG_DISPATCH(AG_SGH(5, 2), AG_SGH(5, 4));
     return AG_SG_DISPATCH(AG_SGH(6, 2), AG_SGH(6, 4));
 #undef AG_SGH
+}
+
+extern "C" int ag_split_gemm_loss_rows(void) { return g_split_wm * 64; }
+
+extern "C" int ag_split_gemm_loss_heads_bwd(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
+                                            const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* L, int M, int n, int k, int A1,
+                                            void* stream) {
+    if (!A_dev || !planes_dev || !bias_dev || !Wh_dev || !bh_dev || !dZ_dev || !L || M <= 0) return AG_ERR_INVALID_ARG;
+    if (L->struct_size != sizeof(ag_loss_epilogue)) return AG_ERR_INVALID_ARG;
+    if (n != BN || k != KDIM || A1 != 5) return AG_ERR_UNSUPPORTED;      // four actions + the value head
+    if (M % (g_split_wm * 64) != 0) return AG_ERR_UNSUPPORTED;           // whole row tiles only (the dZ stores are unguarded)
+    if (!L->logstd_dev || !L->actions_dev || !L->old_neglogp_dev || !L->advantages_dev || !L->returns_dev || !L->old_values_dev ||
+        !L->old_mu_dev || !L->old_sigma_dev || !L->loss_partials_dev || !L->dwh_partials_dev || !L->db_partials_dev)
+        return AG_ERR_INVALID_ARG;
+    if ((L->new_mu_dev == nullptr) != (L->new_sigma_dev == nullptr)) return AG_ERR_INVALID_ARG;
+    if (((uintptr_t)A_dev & 15) || ((uintptr_t)planes_dev & 15)) return AG_ERR_INVALID_ARG;
+    SplitEpilogue ep = {};
+    ep.bias = bias_dev; ep.Wh = Wh_dev; ep.bh = bh_dev; ep.heads = L->heads_dev;
+    ep.logstd = L->logstd_dev; ep.actions = L->actions_dev; ep.old_neglogp = L->old_neglogp_dev; ep.advantages = L->advantages_dev;
+    ep.returns = L->returns_dev; ep.old_values = L->old_values_dev; ep.old_mu = L->old_mu_dev; ep.old_sigma = L->old_sigma_dev;
+    ep.new_mu = L->new_mu_dev; ep.new_sigma = L->new_sigma_dev; ep.loss_partials = L->loss_partials_dev;
+    ep.dwh_partials = L->dwh_partials_dev; ep.db2_partials = L->db_partials_dev;
+    ep.lp = agloss::LossParams{L->e_clip, L->critic_coef, L->bounds_loss_coef, 1.0f / (float)M, L->clip_value, L->bound_type};
+#define AG_SGL(W) launch_split_any<true, 5, 0, W, true>(A_dev, planes_dev, dZ_dev, M, ep, stream)
+    return AG_SG_DISPATCH(AG_SGL(2), AG_SGL(4));
+#undef AG_SGL
 }
 
 extern "C" int ag_split_gemm_input_wgrad_rows(void) { return g_split_wm * 64; }

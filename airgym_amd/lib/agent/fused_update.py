@@ -66,6 +66,14 @@ class SplitGemm256:
                                                  heads_b.data_ptr(), z.data_ptr(), heads.data_ptr(), x.shape[0], 256, 256,
                                                  heads_w.shape[0], self._stream()), "ag_split_gemm_elu_heads")
 
+    def forward_loss_heads_bwd(self, x, dz, bias, heads_w, heads_b, loss):
+        """The GEMM of forward_elu_heads with the PPO loss and the head layer's backward in its epilogue
+        (ag_split_gemm_loss_heads_bwd): dz [M, 256] = (d_heads heads_w) * ELU'(h) and the per-tile partials named in `loss`
+        (an AgLossEpilogue) - heads, d_heads and the pre-activation never go through HBM."""
+        N.check(self.lib.ag_split_gemm_loss_heads_bwd(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr(), heads_w.data_ptr(),
+                                                      heads_b.data_ptr(), dz.data_ptr(), ctypes.byref(loss), x.shape[0], 256, 256,
+                                                      heads_w.shape[0], self._stream()), "ag_split_gemm_loss_heads_bwd")
+
     def backward_input_wgrad(self, dz, h_prev, x_prev, dw_partials, db_partials):
         """dX = dz W of this layer, consumed in the epilogue by the PREVIOUS (first) layer's backward: ELU'(h_prev), then
         dw_partials [tiles, 256, D] / db_partials [tiles, 256] against its inputs x_prev [M, D] (ag_split_gemm_input_wgrad)."""
@@ -106,11 +114,20 @@ class FusedMLPStep:
         self.heads = torch.empty(M, self.A + 1, **f)
         self.d_heads = torch.empty(M, self.A + 1, **f)
         self.nsums = self.lib.ag_ppo_loss_num_sums()
-        self.loss_partials = torch.empty(self.lib.ag_ppo_loss_max_blocks(), self.nsums, **f)
+        self.loss_partials = torch.empty(max(self.lib.ag_ppo_loss_max_blocks(), (M + 63) // 64), self.nsums, **f)
         L = len(self.layers)
         erows = self.lib.ag_elu_bwd_bias_rows_per_block()
         wrows, irows = self.lib.ag_wgrad_rows_per_block(0), max(1, self.lib.ag_input_wgrad_rows(D))
         self.wg_blocks = (M + wrows - 1) // wrows
+        # ... or, with the loss and the head layer's backward in the last GEMM's epilogue (ag_split_gemm_loss_heads_bwd), one
+        # partial per GEMM row tile
+        lrows = self.lib.ag_split_gemm_loss_rows()
+        self.fuse_gemm_loss = (L >= 2 and bool(agent.config.get("fuse_gemm_loss", True))
+                               and bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 == 5
+                               and SplitGemm256.applies(self.layers[-1][0], agent.config) and M % lrows == 0
+                               and 64 <= self.layers[-1][0].shape[0] <= 256)
+        if self.fuse_gemm_loss:
+            self.wg_blocks = M // lrows
         # small weight gradients folded into the ELU' passes (head: always; first layer: D in {16,18,20}, >= 2 layers)
         # ... and for a [D -> 256 -> 256] trunk the first layer's whole backward rides in the epilogue of the second layer's
         # dX GEMM (ag_split_gemm_input_wgrad): dh1 / dz1 are never written, one partial per row tile (D = 18: Hovering, 48: Tracking)
@@ -228,7 +245,7 @@ class FusedMLPStep:
         inputs.append(x)
         x = self.h[0]
         last = len(self.layers) - 1
-        heads_done = False
+        heads_done = loss_done = False
         for sg in self.split.values():          # the weights moved in the previous optimizer step
             sg.prepare()
         for li in range(1, len(self.layers)):
@@ -236,7 +253,29 @@ class FusedMLPStep:
             inputs.append(x)
             h = self.h[li]
             sg = self.split.get(li)
-            if li == last and self.fuse_heads and sg is not None:
+            if li == last and self.fuse_heads and sg is not None and self.fuse_gemm_loss:
+                # GEMM + heads + PPO loss + the head layer's backward in one launch: dz of this layer comes out directly
+                Lp = N.AgLossEpilogue()
+                Lp.struct_size = ctypes.sizeof(N.AgLossEpilogue)
+                Lp.logstd_dev = m.logstd.data_ptr()
+                Lp.actions_dev = mb["actions"].data_ptr()
+                Lp.old_neglogp_dev = mb["old_logp_actions"].data_ptr()
+                Lp.advantages_dev = mb["advantages"].data_ptr()
+                Lp.returns_dev = mb["returns"].data_ptr()
+                Lp.old_values_dev = mb["old_values"].data_ptr()
+                Lp.old_mu_dev = Lp.new_mu_dev = mb["mu"].data_ptr()
+                Lp.old_sigma_dev = Lp.new_sigma_dev = mb["sigma"].data_ptr()
+                Lp.heads_dev = None
+                Lp.loss_partials_dev = self.loss_partials.data_ptr()
+                Lp.dwh_partials_dev = self.head_wg_partials.data_ptr()
+                Lp.db_partials_dev = self.bias_partials[li].data_ptr()
+                Lp.e_clip, Lp.critic_coef = float(ag.e_clip), float(ag.critic_coef)
+                Lp.bounds_loss_coef = float(ag.bounds_loss_coef or 0.0)
+                Lp.clip_value = int(bool(ag.clip_value))
+                Lp.bound_type = int(BOUND_TYPES[ag.bound_loss_type] if ag.bounds_loss_coef is not None else 0)
+                sg.forward_loss_heads_bwd(x, self.dz[:M * w.shape[0]].view(M, w.shape[0]), b, ag.heads_w, ag.heads_b, Lp)
+                heads_done = loss_done = True
+            elif li == last and self.fuse_heads and sg is not None:
                 if self.fuse_gemm_heads:            # heads formed in the GEMM epilogue; h keeps the bias-free pre-activation
                     sg.forward_elu_heads(x, h, b, ag.heads_w, ag.heads_b, self.heads)
                 else:
@@ -267,12 +306,15 @@ class FusedMLPStep:
         bcoef = float(ag.bounds_loss_coef or 0.0)
         bt = BOUND_TYPES[ag.bound_loss_type] if ag.bounds_loss_coef is not None else 0
         logstd = m.logstd
-        N.check(lib.ag_ppo_loss(self.heads.data_ptr(), logstd.data_ptr(), mb["actions"].data_ptr(),
-                                mb["old_logp_actions"].data_ptr(), mb["advantages"].data_ptr(), mb["returns"].data_ptr(),
-                                mb["old_values"].data_ptr(), mb["mu"].data_ptr(), mb["sigma"].data_ptr(), M, A,
-                                float(ag.e_clip), float(ag.critic_coef), bcoef, int(bool(ag.clip_value)), int(bt),
-                                self.d_heads.data_ptr(), mb["mu"].data_ptr(), mb["sigma"].data_ptr(),
-                                self.loss_partials.data_ptr(), ctypes.byref(nb), st), "ag_ppo_loss")
+        if loss_done:
+            nb.value = self.wg_blocks      # one row of loss sums per GEMM row tile
+        else:
+            N.check(lib.ag_ppo_loss(self.heads.data_ptr(), logstd.data_ptr(), mb["actions"].data_ptr(),
+                                    mb["old_logp_actions"].data_ptr(), mb["advantages"].data_ptr(), mb["returns"].data_ptr(),
+                                    mb["old_values"].data_ptr(), mb["mu"].data_ptr(), mb["sigma"].data_ptr(), M, A,
+                                    float(ag.e_clip), float(ag.critic_coef), bcoef, int(bool(ag.clip_value)), int(bt),
+                                    self.d_heads.data_ptr(), mb["mu"].data_ptr(), mb["sigma"].data_ptr(),
+                                    self.loss_partials.data_ptr(), ctypes.byref(nb), st), "ag_ppo_loss")
         if stats_out is not None:
             stats = stats_out
         else:
@@ -291,7 +333,9 @@ class FusedMLPStep:
             C, K = w.shape
             dz = self.dz[:M * C].view(M, C)
             parts = self.bias_partials[li]
-            if li == last:
+            if li == last and loss_done:
+                pass      # dz, the head weight-gradient partials and this layer's bias partials came out of the forward launch
+            elif li == last:
                 N.check(lib.ag_heads_bwd_elu_wgrad(self.d_heads.data_ptr(), ag.heads_w.data_ptr(), h.data_ptr(), dz.data_ptr(),
                                                    parts.data_ptr(), self.head_wg_partials.data_ptr(), M, C, A + 1,
                                                    int(heads_done), self.layers[li][1].data_ptr() if heads_done else None, st),

@@ -395,6 +395,39 @@ int ag_mlp_chain_prepare(const float* W1_dev, const float* b1_dev, int D, const 
 int ag_mlp_chain_forward(const float* obs_dev, const double* mean_dev, const double* var_dev, float eps, float clip,
                          const void* image_dev, const float* b2_dev, const float* bh_dev, float* heads_dev, float* xn_dev,
                          float* h1_dev, float* h2_dev, int M, int D, int A1, void* stream);
+/* The last hidden layer's forward, the PPO loss and the head layer's backward in ONE launch (calc_gradients,
+ * lib/agent/a2c_continuous.py:299-369, around lib/network/mlp.py:36-39): the GEMM of ag_split_gemm_elu_heads, then - in its
+ * epilogue, with the activations h = ELU(z + bias) still in the accumulators and the heads in LDS - ag_ppo_loss's per-row
+ * arithmetic (csrc/ppo_loss_math.hpp: the same expressions) and ag_heads_bwd_elu_wgrad's: dZ_dev [M, 256] = (d_heads Wh) *
+ * ELU'(h) is written where the pre-activation would have gone, and one partial per row tile of the head weight gradient
+ * dwh_partials [tiles, A1, 256], of this layer's bias gradient db_partials [tiles, 256] (column sums of dZ) and of the loss
+ * sums loss_partials [tiles, ag_ppo_loss_num_sums()] (feed ag_ppo_loss_finalize with num_blocks = tiles).  tiles =
+ * ceil(M / ag_split_gemm_loss_rows()).  Neither the pre-activation nor the heads nor d_heads goes through HBM (heads_dev, if not
+ * NULL, receives the heads anyway); new_mu_dev / new_sigma_dev: the rows' (mu, sigma) written back (PPODataset.update_mu_sigma,
+ * lib/core/datasets.py:20-24) or NULL.  A1 = 5 (four actions + value). */
+typedef struct ag_loss_epilogue {
+    uint32_t struct_size;              /* = sizeof(ag_loss_epilogue), ABI guard */
+    const float* logstd_dev;           /* [A] */
+    const float* actions_dev;          /* [M, A] */
+    const float* old_neglogp_dev;      /* [M] */
+    const float* advantages_dev;       /* [M] */
+    const float* returns_dev;          /* [M] */
+    const float* old_values_dev;       /* [M] */
+    const float* old_mu_dev;           /* [M, A] */
+    const float* old_sigma_dev;        /* [M, A] */
+    float* new_mu_dev;                 /* [M, A] or NULL (may alias old_mu_dev) */
+    float* new_sigma_dev;              /* [M, A] or NULL (may alias old_sigma_dev) */
+    float* heads_dev;                  /* [M, A1] or NULL */
+    float* loss_partials_dev;          /* [tiles, ag_ppo_loss_num_sums()] */
+    float* dwh_partials_dev;           /* [tiles, A1, 256] */
+    float* db_partials_dev;            /* [tiles, 256] */
+    float e_clip, critic_coef, bounds_loss_coef;
+    int clip_value, bound_type;        /* as ag_ppo_loss */
+} ag_loss_epilogue;
+int ag_split_gemm_loss_rows(void);
+int ag_split_gemm_loss_heads_bwd(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
+                                 const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* loss, int M, int n, int k, int A1,
+                                 void* stream);
 int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
                             const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1, void* stream);
 
