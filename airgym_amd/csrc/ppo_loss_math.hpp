@@ -52,6 +52,10 @@ template <int A, bool SERIAL = false>
 __device__ __forceinline__ void loss_row(const float* h, const float* act, float old_neglogp, float adv, float ret, float old_value,
                                          const float* old_mu, const float* old_sigma, const LossConsts<A>& c, const LossParams& k,
                                          float* dh, float* acc) {
+    // no FMA contraction in here: the KL term is a difference of O(1) quantities that leaves O(1e-5); whether `a * a + b * b`
+    // became an fma used to depend on the kernel the function was inlined into (0.6 % of the minibatch KL between the two).
+    // Unfused, both evaluate what the reference's eager torch ops evaluate (torch_ext.py:27-36).
+#pragma clang fp contract(off)
     float mu[A], z[A];
     float q = 0.0f;
 #pragma unroll
