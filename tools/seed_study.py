@@ -20,6 +20,10 @@ ARMS = {
     "epilogues_off": {"fuse_gemm_heads": False, "fuse_gemm_input_wgrad": False},
     "split_gemm_off": {"use_split_gemm": False},
     "fix_time_outs": {"_env": {"fix_time_outs": True}},
+    # opt-in: a full reset starts every env at its own progress, so the 2 400-step time limit does not end (nearly) all
+    # episodes of the shard inside the same rollouts (AG_FLAG_STAGGER_PHASE)
+    "stagger": {"_env": {"stagger_episode_phase": True}},
+    "stagger_fix_time_outs": {"_env": {"stagger_episode_phase": True, "fix_time_outs": True}},
 }
 CONFIGS = {"headline_196608": 8, "ratio_32768": 48}
 

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Re-wrap the prose lines of a markdown file to <= WIDTH columns (tables, code fences and headings are left alone; list items
+keep their hanging indent).    python tools/wrap_md.py FILE [WIDTH]"""
+import re
+import sys
+import textwrap
+
+path = sys.argv[1]
+width = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+out, fence = [], False
+for line in open(path).read().split("\n"):
+    if line.lstrip().startswith("```"):
+        fence = not fence
+    if fence or len(line) <= width or line.lstrip().startswith("|") or line.startswith("#"):
+        out.append(line)
+        continue
+    m = re.match(r"^(\s*(?:[-*+]|\d+\.)\s+|\s*>\s*|\s*)", line)
+    lead = m.group(1)
+    hang = " " * len(lead) if lead.strip() not in (">",) else lead
+    out.extend(textwrap.wrap(line[len(lead):], width=width, initial_indent=lead, subsequent_indent=hang,
+                             break_long_words=False, break_on_hyphens=False))
+open(path, "w").write("\n".join(out))
