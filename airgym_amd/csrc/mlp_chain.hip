@@ -507,7 +507,7 @@ extern "C" int ag_mlp_chain_forward(const float* obs_dev, const double* mean_dev
     a.b2 = b2_dev; a.bh = bh_dev; a.heads = heads_dev; a.xn = xn_dev; a.h1 = h1_dev; a.h2 = h2_dev; a.M = M; a.D = D;
     a.debug_skip = g_chain_debug_skip;
     const bool store = xn_dev || h1_dev || h2_dev;
-#ifdef AG_EXPERIMENTS
+#if defined(AG_EXPERIMENTS) && defined(AG_CHAIN_ABLATIONS)      // (nine more instantiations: ~15 min of compile time; opt-in)
     if (g_chain_debug_skip != 0 && nb1 == 2 && A1 == 5 && !store) {
         switch (g_chain_debug_skip) {
             case 1: return launch_chain_fwd<32, 5, false, 1>(a, stream);

@@ -1,7 +1,10 @@
 """Does the fast path LEARN?  Regression for the headline configuration (Hovering / CTBR, 65 536 envs, MLP(256,256), 196 608-sample
-minibatches; split-bf16 GEMMs, fused epilogues, fused rollout step, hipGraph rollout): the mean episode reward must reach 2 000
-within 120 epochs on at least 4 of 5 seeds.  The 5-seed x 8-arm study this bar comes from is profiles/r03_seed_study.md: there
-all five seeds of this arm reach 6 700-7 700 by epoch 120 (random policy: ~20; hover for the whole 2 400-step episode: ~8 000)."""
+minibatches; split-bf16 GEMMs, fused epilogues incl. the loss, chain forward + fused rollout step, hipGraph rollout): the mean
+episode reward must reach 2 000 within 120 epochs on at least 4 of 5 seeds, and 80 epochs later - past the point where every
+arm of the seed studies dips (profiles/r03_seed_study.md, r04_seed_study.md: the 2 400-step time limit; desynchronising it does
+not help) - at least 4 of 5 seeds must still be above 150 (random policy: ~20; hover for the whole episode: ~8 000; lowest
+default-arm seed of the round-4 study at epoch 200: 808).  The second bound is a guard against a TOTAL collapse, which is what a
+broken kernel would look like; the dip itself is a property of the configuration at 10x the reference's training budget."""
 import os
 import sys
 
@@ -17,12 +20,16 @@ def test_headline_configuration_learns_on_4_of_5_seeds():
     assert torch.cuda.is_available()
     sys.path.insert(0, REPO)
     from tools.learning_curves import run
-    best = []
+    best, final = [], []
     for seed in range(5):
-        out = run(f"headline seed {seed}", 65536, 8, 120, 10, seed=seed)
-        best.append(max((c["reward"] or 0.0) for c in out["curve"]))
+        out = run(f"headline seed {seed}", 65536, 8, 200, 10, seed=seed)
+        best.append(max((c["reward"] or 0.0) for c in out["curve"] if c["epoch"] <= 120))
+        final.append(out["curve"][-1]["reward"] or 0.0)
+        assert out["curve"][-1]["epoch"] == 200
         assert all(c["kl"] == c["kl"] and c["c_loss"] == c["c_loss"] for c in out["curve"]), "NaN in the losses"
+    print("best by epoch 120:", best, "at epoch 200:", final, "median at 200:", sorted(final)[2])
     assert sum(b >= 2000.0 for b in best) >= 4, best
+    assert sum(f >= 150.0 for f in final) >= 4, final
 
 
 def test_planning_cnn_policy_learns_on_the_hand_written_trunk():
