@@ -428,6 +428,28 @@ def measure_update_kernels(agent, iters=20):
             us = _time_us(lambda: sg.forward_elu_heads(x, fs.dz[:M * C].view(M, C), b, agent.heads_w, agent.heads_b, fs.heads), iters)
             mfma("ag_split_gemm_elu_heads (update forward of the last hidden layer + ELU + heads, as the step runs it)", us,
                  flops + 2.0 * M * C * A1, "replaces ag_split_gemm + ag_elu_heads (one pass over z less)")
+        if getattr(fs, "fuse_gemm_loss", False):
+            lrows = lib.ag_split_gemm_loss_rows()
+            tiles = M // lrows
+            f = dict(dtype=torch.float32, device=x.device)
+            zeros = lambda *s: torch.zeros(*s, **f)
+            Lp = N.AgLossEpilogue()
+            Lp.struct_size = ctypes.sizeof(N.AgLossEpilogue)
+            keep = {"act": zeros(M, fs.A), "nlp": zeros(M), "adv": zeros(M), "ret": zeros(M), "val": zeros(M), "mu": zeros(M, fs.A),
+                    "sig": torch.ones(M, fs.A, **f), "lp": torch.empty(tiles, lib.ag_ppo_loss_num_sums(), **f),
+                    "dwh": torch.empty(tiles, A1, C, **f), "db": torch.empty(tiles, C, **f)}
+            Lp.logstd_dev = agent.model.logstd.data_ptr()
+            Lp.actions_dev, Lp.old_neglogp_dev, Lp.advantages_dev = keep["act"].data_ptr(), keep["nlp"].data_ptr(), keep["adv"].data_ptr()
+            Lp.returns_dev, Lp.old_values_dev = keep["ret"].data_ptr(), keep["val"].data_ptr()
+            Lp.old_mu_dev, Lp.old_sigma_dev, Lp.new_mu_dev, Lp.new_sigma_dev = keep["mu"].data_ptr(), keep["sig"].data_ptr(), None, None
+            Lp.heads_dev = None
+            Lp.loss_partials_dev, Lp.dwh_partials_dev, Lp.db_partials_dev = keep["lp"].data_ptr(), keep["dwh"].data_ptr(), keep["db"].data_ptr()
+            Lp.e_clip, Lp.critic_coef, Lp.bounds_loss_coef, Lp.clip_value, Lp.bound_type = 0.2, 2.0, 1e-4, 0, 1
+            us = _time_us(lambda: sg.forward_loss_heads_bwd(x, fs.dz[:M * C].view(M, C), b, agent.heads_w, agent.heads_b, Lp), iters)
+            mfma("ag_split_gemm_loss_heads_bwd (forward of the last hidden layer + ELU + heads + PPO loss + head backward, as the "
+                 "step runs it)", us, flops + 4.0 * M * C * A1,
+                 "replaces ag_split_gemm_elu_heads + ag_ppo_loss + ag_heads_bwd_elu_wgrad: z, heads and d_heads never touch HBM")
+            del keep
         if getattr(fs, "fuse_gemm_input_wgrad", False):
             D0 = fs.layers[0][0].shape[1]
             us = _time_us(lambda: sg.backward_input_wgrad(h, fs.h[0], fs.xn, fs.wgrad_partials[0], fs.bias_partials[0]), iters)
@@ -444,11 +466,17 @@ def measure_update_kernels(agent, iters=20):
                                             fs.heads.data_ptr(), M, C, A1, 0, None, st), iters)
     hbm("ag_elu_heads (ELU + head product, pre-activation kept)" + (" - folded into the GEMM epilogue in the step, shown for reference"
         if getattr(fs, "fuse_gemm_heads", False) and getattr(fs, "split", None) else ""), us, 4.0 * M * (C + A1))
-    parts = fs.bias_partials[-1]
+    # partial buffers of ITS block count (the step's own are sized for whichever kernel the step runs: with the loss in the
+    # GEMM epilogue they hold one row per 256-row GEMM tile, this kernel writes one per 128 rows)
+    hb_blocks = (M + lib.ag_wgrad_rows_per_block(0) - 1) // lib.ag_wgrad_rows_per_block(0)
+    parts = torch.empty(hb_blocks, C, dtype=torch.float32, device=x.device)
+    hparts = torch.empty(hb_blocks, A1, C, dtype=torch.float32, device=x.device)
     us = _time_us(lambda: lib.ag_heads_bwd_elu_wgrad(fs.d_heads.data_ptr(), agent.heads_w.data_ptr(), h.data_ptr(),
-                                                      scratch.data_ptr(), parts.data_ptr(), fs.head_wg_partials.data_ptr(),
+                                                      scratch.data_ptr(), parts.data_ptr(), hparts.data_ptr(),
                                                       M, C, A1, 1, None, st), iters)
-    hbm("ag_heads_bwd_elu_wgrad (head dX + ELU' + head wgrad)", us, 4.0 * M * (2 * C + A1))
+    hbm("ag_heads_bwd_elu_wgrad (head dX + ELU' + head wgrad)" + (" - folded into the forward GEMM's epilogue in the step, shown for "
+        "reference" if getattr(fs, "fuse_gemm_loss", False) else ""), us, 4.0 * M * (2 * C + A1))
+    del parts, hparts
     if fs.fuse_input_wgrad and lib.ag_input_wgrad_rows(fs.layers[0][0].shape[1]) > 0:
         D = fs.layers[0][0].shape[1]
         C0 = fs.layers[0][0].shape[0]
