@@ -6,7 +6,7 @@ R=$(pwd)
 cd /tmp; export TMPDIR=/tmp
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-shipped-ratio --no-side-configs"
 rm -rf /tmp/trace_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/trace_$TAG -o t -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-shipped-ratio --no-side-configs > $R/gpurun_out/${TAG}_trace_bench.json 2> $R/gpurun_out/${TAG}_trace_bench.err
+timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d /tmp/trace_$TAG -o t -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-shipped-ratio --no-side-configs > $R/gpurun_out/${TAG}_trace_bench.json 2> $R/gpurun_out/${TAG}_trace_bench.err
 DB=$(find /tmp/trace_$TAG -name "*results.db" | head -1)
 python $R/tools/rocprof_summary.py $DB $R/gpurun_out/${TAG}_bench_kernel_trace.md "rocprofv3 --kernel-trace --stats -- $CMD"
 head -40 $R/gpurun_out/${TAG}_bench_kernel_trace.md | cut -c1-200
