@@ -253,6 +253,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
 
     const int l31 = lane & 31, khalf = lane >> 5;
     constexpr int NCHUNK = KDIM / BK;
+#ifdef AG_SPLIT_SETPRIO
+    // static priority for the later-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md, "two waves per SIMD" item 4)
+    if (WM == 4 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     // WM x 2 waves: wave (wm, wn) owns rows 64 wm .. +63 and columns 128 wn .. +127 (2 x 4 tiles of 32 x 32): 18 fragment
     // reads per chunk (every B fragment feeds two row tiles).  Products smallest first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1.
     const int wm = wave >> 1, wn = wave & 1;

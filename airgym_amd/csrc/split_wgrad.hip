@@ -161,6 +161,9 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_kernel(const float* __rest
         AG_WG_GROUP(0); AG_WG_GROUP(0); AG_WG_GROUP(0);                                                \
     } while (0)
 
+#ifdef AG_SPLIT_SETPRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // static priority for the later-dispatched half (two waves per SIMD)
+#endif
     // ---- prologue: chunks 0 and 1 requested, chunk 0 into stage 0
     if (n > 0) AG_WG_LOAD(0, va, nva);
     if (n > 1) AG_WG_LOAD(1, vb, nvb);
