@@ -429,7 +429,8 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
             asm volatile("" : "+s"(late2) : : "memory");      // loss phase and spilled across it
             const int m0b = m0 + late2;
             float bcol2[4];      // the bias again, opaque: the activations are RECOMPUTED below (as values common to both passes
-#pragma unroll                   // LLVM keeps all 128 of them alive across the loss phase - spilled)
+#pragma unroll                   // LLVM keeps all 128 of them alive across the loss phase - spilled; writing them over the
+                                 // accumulators in pass 1 instead: 58 registers spilled in the epilogue, epoch +0.45 ms)
             for (int j = 0; j < 4; ++j) bcol2[j] = bcol[j] + (float)late2;
             float gw[A1][4], db[4];
 #pragma unroll
