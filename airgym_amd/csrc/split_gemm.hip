@@ -215,8 +215,43 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     const int a_grow = min(m0 + a_row, M - 1);                          // rows past M are computed, never stored
     const float4* a_src = reinterpret_cast<const float4*>(A + (size_t)a_grow * KDIM + a_half * 8);
     float4 ra0, ra1;
+#ifndef AG_SPLIT_B_STAGED
+    // The B planes are the LDS image already, so they go global -> LDS directly (global_load_lds_dwordx4: a wave's 64 units land
+    // at M0 + 16 lane): no staging registers, no ds_write (-DAG_SPLIT_B_STAGED restores the copy through registers: epoch +0.4 %).
+    // Issued from inline assembly: told about an LDS-DMA, hipcc waits for vmcnt(0) in front of the next ds_read.  Its own vmcnt
+    // counts for the A loads stay correct (an unseen younger operation can only make a wait longer).  DMA(c + 1) is issued at the
+    // top of chunk c (every wave is past the barrier behind that stage's last reader) and drained by an explicit vmcnt(0) behind
+    // the chunk's stores, before the next A loads are issued.
+    const uint32_t lds_b0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds +
+                                                           (A_UNITS + wave * 64) * 16);
+#define AG_SG_DMA(c, stage)                                                            \
+    do {                                                                               \
+        const uint4* bsrc_ = Bp + (size_t)(c) * B_UNITS + tid;                         \
+        _Pragma("unroll") for (int it = 0; it < BPT; ++it)                             \
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"   \
+                         : : "v"(bsrc_ + it * NT), "s"(lds_b0 + ((stage) * STAGE_UNITS + it * NT) * 16) : "memory"); \
+    } while (0)
+#define AG_SG_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" : : : "memory")
+#define AG_SG_LOAD(c)                                                                  \
+    do {                                                                               \
+        ra0 = a_src[(c) * (BK / 4)];                                                   \
+        ra1 = a_src[(c) * (BK / 4) + 1];                                               \
+    } while (0)
+#define AG_SG_STORE(stage)                                                             \
+    do {                                                                               \
+        uint4* sa_ = lds + (stage) * STAGE_UNITS;                                      \
+        uint4 p1_, p2_, p3_;                                                           \
+        split8(ra0, ra1, p1_, p2_, p3_);                                               \
+        sa_[(0 * 2 + a_half) * BM + a_row] = p1_;                                      \
+        sa_[(1 * 2 + a_half) * BM + a_row] = p2_;                                      \
+        sa_[(2 * 2 + a_half) * BM + a_row] = p3_;                                      \
+    } while (0)
+    AG_SG_DMA(0, 0);
+#else
     uint4 rb0, rb1, rb2, rb3, rb4, rb5;                                 // (rb3..5: 4-wave tiles only; named, not an array: LLVM
     static_assert(BPT == 3 || BPT == 6, "B copy per thread");           //  left an indexed array in scratch)
+#define AG_SG_DMA(c, stage) do { } while (0)
+#define AG_SG_DMA_WAIT() do { } while (0)
 #define AG_SG_LOAD(c)                                                                  \
     do {                                                                               \
         ra0 = a_src[(c) * (BK / 4)];                                                   \
@@ -237,9 +272,11 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         sb_[0] = rb0; sb_[NT] = rb1; sb_[2 * NT] = rb2;                                \
         if (BPT == 6) { sb_[3 * NT] = rb3; sb_[4 * NT] = rb4; sb_[5 * NT] = rb5; }     \
     } while (0)
+#endif
 
     AG_SG_LOAD(0);
     AG_SG_STORE(0);
+    AG_SG_DMA_WAIT();
     int c1 = 1;      // opaque, so that chunk 1's loads stay BEHIND chunk 0's stores and reuse its staging registers (hoisted to
     asm volatile("" : "+s"(c1) : : "memory");      // the top they need a second set: spills, each behind an s_waitcnt vmcnt(0))
     AG_SG_LOAD(c1);
@@ -295,8 +332,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
 #pragma unroll 1
     for (int c = 0; c < NCHUNK - 1; ++c) {
         const int stage = c & 1;
+        AG_SG_DMA(c + 1, stage ^ 1);
         AG_SG_COMPUTE(stage);
         AG_SG_STORE(stage ^ 1);                             // chunk c + 1; that stage was last read before the previous barrier
+        AG_SG_DMA_WAIT();
         const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;      // (the last trip reloads a chunk it does not need)
         AG_SG_LOAD(cn);
         __syncthreads();
@@ -306,6 +345,8 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
 #undef AG_SG_COMPUTE
 #undef AG_SG_LOAD
 #undef AG_SG_STORE
+#undef AG_SG_DMA
+#undef AG_SG_DMA_WAIT
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if constexpr (A1 > 0) {
