@@ -28,10 +28,6 @@
 #include "ppo_loss_math.hpp"
 #include "split_common.hpp"
 
-#ifndef AG_FIN_DIAG
-#define AG_FIN_DIAG 0
-#endif
-
 namespace {
 
 constexpr int BN = 256, BK = 16, KDIM = 256;
@@ -194,25 +190,9 @@ struct SplitEpilogue {
     float* dwh_partials;       // [tiles, A1, 256] head weight gradient of the tile's rows
     float* db2_partials;       // [tiles, 256] column sums of dz (bias gradient of this layer)
     agloss::LossParams lp;
-    // FIN (ag_split_gemm_input_loss_heads_bwd): the FIRST layer formed on the fly as this GEMM's A operand; A = the raw observations
-    const double* in_mean;     // [FIN] running mean / variance of the input normaliser, or null (A is used as it is)
-    const double* in_var;
-    const float* W1;           // [256, FIN] first-layer weight, row-major
-    const float* b1;           // [256]
-    float* xn_out;             // [M, FIN] normalised inputs (null iff in_mean is null)
-    float* h1_out;             // [M, 256] first-layer activations (the backward reads them)
-    float in_eps, in_clip;
 };
 
-//
-// FIN > 0: the first layer of a [FIN -> 256 -> 256] trunk inside this launch (replaces ag_mlp_input_layer in the update).  The
-// thread that would load and split a 32-byte piece of h1 (row r, 8 consecutive k) COMPUTES it instead: the row's FIN normalised
-// inputs stay in registers for the whole tile, the 8 x FIN weights of a chunk are wave-uniform (k-halves are assigned per wave:
-// scalar loads, v_fmac with an SGPR operand), h1 = ELU(b1 + sum_d x_d W1[k][d]) in the order of input_layer_reg_kernel
-// (bit-identical), written to HBM as a by-product (the backward needs it) and split into the LDS planes as before.  The GEMM no
-// longer reads 201 MB of activations it could have produced itself, and the write-bound producer launch (61 us) is gone; its
-// stores now happen under this kernel's MFMAs.
-template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0>
+template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false>
 __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
                                                                   float* __restrict__ C, int M, const SplitEpilogue ep) {
     constexpr int BM = WM * 64, NT = WM * 128;               // rows per tile, threads per workgroup
@@ -221,7 +201,6 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     static_assert(WM == 2 || WM == 4, "4 or 8 waves");
     static_assert(A1 == 0 || DIN == 0, "one fused epilogue at a time");
     static_assert((DIN & 1) == 0 && DIN <= 62, "input width: even, at most two 32-wide tiles with the bias column");
-    static_assert(FIN == 0 || (WM == 4 && (FIN & 1) == 0 && FIN <= 20), "fused first layer: 256-row tiles, small even widths");
     const float* __restrict__ bias = ep.bias;
     const float* __restrict__ Wh = ep.Wh;
     const float* __restrict__ bh = ep.bh;
@@ -232,9 +211,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     const int m0 = tile * BM;
 
     // ---- global -> register staging for one K chunk
-    // BM rows x 2 k-halves: one 32-byte piece per thread (FIN: the k-half is the same for a whole wave)
-    const int a_row = FIN > 0 ? (tid & (BM - 1)) : (tid >> 1);
-    const int a_half = FIN > 0 ? __builtin_amdgcn_readfirstlane(tid / BM) : (tid & 1);
+    const int a_row = tid >> 1, a_half = tid & 1;                       // BM rows x 2 k-halves: one 32-byte piece per thread
     const int a_grow = min(m0 + a_row, M - 1);                          // rows past M are computed, never stored
     const float4* a_src = reinterpret_cast<const float4*>(A + (size_t)a_grow * KDIM + a_half * 8);
     float4 ra0, ra1;
@@ -271,7 +248,6 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     } while (0)
     AG_SG_DMA(0, 0);
 #else
-    static_assert(FIN == 0, "the fused first layer goes with the LDS-DMA B planes");
     uint4 rb0, rb1, rb2, rb3, rb4, rb5;                                 // (rb3..5: 4-wave tiles only; named, not an array: LLVM
     static_assert(BPT == 3 || BPT == 6, "B copy per thread");           //  left an indexed array in scratch)
 #define AG_SG_DMA(c, stage) do { } while (0)
@@ -298,92 +274,13 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     } while (0)
 #endif
 
-    // FIN: this thread's row of (normalised) inputs, and the producer of one 32-byte piece of h1
-    // (weights and bias through the constant address space: a wave-uniform address then becomes a scalar load; as plain global
-    // pointers hipcc issued 35 vector loads per chunk, each group behind an s_waitcnt vmcnt(0))
-    typedef const float __attribute__((address_space(4))) sg_cfloat;
-    sg_cfloat* const w1c = (sg_cfloat*)(uintptr_t)ep.W1;
-    sg_cfloat* const b1c = (sg_cfloat*)(uintptr_t)ep.b1;
-    float xr[FIN > 0 ? FIN : 1];
-    float4 hq0, hq1;                                                    // the piece last produced (stored to HBM a step later)
-#if AG_FIN_DIAG == 1          /* timing probe: no FMAs */
-#define AG_FIN_BODY                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) hv_[i] = sg_elu(b1c[k0_ + i] + xr[i]);
-#elif AG_FIN_DIAG == 2        /* timing probe: packed FMAs over output pairs, weights read as a [FIN][256] image */
-#define AG_FIN_BODY                                                                    \
-        {                                                                              \
-            f32x2 s2_[4];                                                              \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) s2_[i] = f32x2{b1c[k0_ + 2 * i], b1c[k0_ + 2 * i + 1]}; \
-            _Pragma("unroll") for (int d = 0; d < FIN; ++d)                            \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i)                          \
-                    s2_[i] = __builtin_elementwise_fma(f32x2{xr[d], xr[d]},            \
-                                                       f32x2{w1c[d * 256 + k0_ + 2 * i], w1c[d * 256 + k0_ + 2 * i + 1]}, s2_[i]); \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) { hv_[2 * i] = sg_elu(s2_[i].x); hv_[2 * i + 1] = sg_elu(s2_[i].y); } \
-        }
-#else
-#define AG_FIN_BODY                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
-            float s_ = b1c[k0_ + i];                                                   \
-            _Pragma("unroll") for (int d = 0; d < FIN; ++d) s_ = fmaf(xr[d], w_[i * FIN + d], s_); \
-            hv_[i] = sg_elu(s_);                                                       \
-        }
-#endif
-#define AG_SG_PRODUCE(c, stage)                                                        \
-    do {                                                                               \
-        const int k0_ = (c) * BK + a_half * 8;                                         \
-        const sg_cfloat* w_ = w1c + (size_t)k0_ * FIN;      /* wave-uniform: s_load */ \
-        float hv_[8];                                                                  \
-        AG_FIN_BODY                                                                    \
-        hq0 = make_float4(hv_[0], hv_[1], hv_[2], hv_[3]);                             \
-        hq1 = make_float4(hv_[4], hv_[5], hv_[6], hv_[7]);                             \
-        uint4* sa_ = lds + (stage) * STAGE_UNITS;                                      \
-        uint4 p1_, p2_, p3_;                                                           \
-        split8(hq0, hq1, p1_, p2_, p3_);                                               \
-        sa_[(0 * 2 + a_half) * BM + a_row] = p1_;                                      \
-        sa_[(1 * 2 + a_half) * BM + a_row] = p2_;                                      \
-        sa_[(2 * 2 + a_half) * BM + a_row] = p3_;                                      \
-    } while (0)
-    // ... and its store, issued BEHIND the step's vmcnt(0) (which then finds only stores a whole chunk old)
-#define AG_SG_H1STORE(c)                                                               \
-    do {                                                                               \
-        if (m0 + a_row < M) {                                                          \
-            float4* dst_ = reinterpret_cast<float4*>(ep.h1_out + (size_t)(m0 + a_row) * KDIM + (c) * BK + a_half * 8); \
-            dst_[0] = hq0;                                                             \
-            dst_[1] = hq1;                                                             \
-        }                                                                              \
-    } while (0)
-    if constexpr (FIN > 0) {
-        const bool norm = ep.in_mean != nullptr;
-        const float2* xsrc = reinterpret_cast<const float2*>(A + (size_t)a_grow * FIN);
-#pragma unroll
-        for (int d2 = 0; d2 < FIN / 2; ++d2) {
-            const float2 v2 = xsrc[d2];
-            float v[2] = {v2.x, v2.y};
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int d = 2 * d2 + e;
-                if (norm) {      // ag_mlp_input_layer's arithmetic (running_mean_std.py:78-79)
-                    v[e] = (v[e] - (float)ep.in_mean[d]) / sqrtf((float)ep.in_var[d] + ep.in_eps);
-                    v[e] = fminf(fmaxf(v[e], -ep.in_clip), ep.in_clip);
-                }
-                xr[d] = v[e];
-            }
-            if (norm && a_half == 0 && m0 + a_row < M)
-                reinterpret_cast<float2*>(ep.xn_out + (size_t)(m0 + a_row) * FIN)[d2] = make_float2(v[0], v[1]);
-        }
-        AG_SG_PRODUCE(0, 0);
-        AG_SG_DMA_WAIT();
-        AG_SG_H1STORE(0);
-        __syncthreads();
-    } else {
-        AG_SG_LOAD(0);
-        AG_SG_STORE(0);
-        AG_SG_DMA_WAIT();
-        int c1 = 1;      // opaque, so that chunk 1's loads stay BEHIND chunk 0's stores and reuse its staging registers (hoisted to
-        asm volatile("" : "+s"(c1) : : "memory");      // the top they need a second set: spills, each behind an s_waitcnt vmcnt(0))
-        AG_SG_LOAD(c1);
-        __syncthreads();
-    }
+    AG_SG_LOAD(0);
+    AG_SG_STORE(0);
+    AG_SG_DMA_WAIT();
+    int c1 = 1;      // opaque, so that chunk 1's loads stay BEHIND chunk 0's stores and reuse its staging registers (hoisted to
+    asm volatile("" : "+s"(c1) : : "memory");      // the top they need a second set: spills, each behind an s_waitcnt vmcnt(0))
+    AG_SG_LOAD(c1);
+    __syncthreads();
 
     f32x16 acc[8];
 #pragma unroll
@@ -437,16 +334,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         const int stage = c & 1;
         AG_SG_DMA(c + 1, stage ^ 1);
         AG_SG_COMPUTE(stage);
-        if constexpr (FIN > 0) {
-            AG_SG_PRODUCE(c + 1, stage ^ 1);                // chunk c + 1 of h1: computed, not loaded
-            AG_SG_DMA_WAIT();
-            AG_SG_H1STORE(c + 1);
-        } else {
-            AG_SG_STORE(stage ^ 1);                         // chunk c + 1; that stage was last read before the previous barrier
-            AG_SG_DMA_WAIT();
-            const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;      // (the last trip reloads a chunk it does not need)
-            AG_SG_LOAD(cn);
-        }
+        AG_SG_STORE(stage ^ 1);                             // chunk c + 1; that stage was last read before the previous barrier
+        AG_SG_DMA_WAIT();
+        const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;      // (the last trip reloads a chunk it does not need)
+        AG_SG_LOAD(cn);
         __syncthreads();
     }
     AG_SG_COMPUTE((NCHUNK - 1) & 1);
@@ -456,9 +347,6 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
 #undef AG_SG_STORE
 #undef AG_SG_DMA
 #undef AG_SG_DMA_WAIT
-#undef AG_SG_PRODUCE
-#undef AG_SG_H1STORE
-#undef AG_FIN_BODY
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if constexpr (A1 > 0) {
@@ -768,10 +656,10 @@ constexpr size_t split_lds_bytes() {
     return stages > epi ? stages : epi;
 }
 
-template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0>
+template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false>
 static int launch_split_any(const float* A_dev, const void* planes_dev, float* C_dev, int M, const SplitEpilogue& ep, void* stream) {
     static bool attr_set[64] = {};      // per device ordinal: the dynamic-LDS limit is an attribute of (function, device)
-    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM, LOSS, FIN>;
+    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM, LOSS>;
     constexpr size_t lds_bytes = split_lds_bytes<DIN, WM>();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
@@ -833,44 +721,6 @@ extern "C" int ag_split_gemm_loss_heads_bwd(const float* A_dev, const void* plan
 #define AG_SGL(W) launch_split_any<true, 5, 0, W, true>(A_dev, planes_dev, dZ_dev, M, ep, stream)
     return AG_SG_DISPATCH(AG_SGL(2), AG_SGL(4));
 #undef AG_SGL
-}
-
-// widths with the first layer formed inside the forward GEMM (Hovering's 18 and the neighbouring even widths); 256-row tiles only
-extern "C" int ag_split_gemm_input_fwd_supported(int D) { return (g_split_wm == 4 && (D == 16 || D == 18 || D == 20)) ? 1 : 0; }
-
-extern "C" int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void* planes_dev, const float* bias_dev,
-                                                  const float* Wh_dev, const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* L,
-                                                  int M, int n, int k, int A1, void* stream) {
-    if (!in || !planes_dev || !bias_dev || !Wh_dev || !bh_dev || !dZ_dev || !L || M <= 0) return AG_ERR_INVALID_ARG;
-    if (in->struct_size != sizeof(ag_input_layer_args) || L->struct_size != sizeof(ag_loss_epilogue)) return AG_ERR_INVALID_ARG;
-    if (!in->obs_dev || !in->W1_dev || !in->b1_dev || !in->h1_dev) return AG_ERR_INVALID_ARG;
-    const bool norm = in->mean_dev != nullptr;
-    if (norm != (in->var_dev != nullptr) || norm != (in->xn_dev != nullptr)) return AG_ERR_INVALID_ARG;
-    if (n != BN || k != KDIM || A1 != 5 || !ag_split_gemm_input_fwd_supported(in->D)) return AG_ERR_UNSUPPORTED;
-    if (M % 256 != 0) return AG_ERR_UNSUPPORTED;                          // whole row tiles only
-    if (!L->logstd_dev || !L->actions_dev || !L->old_neglogp_dev || !L->advantages_dev || !L->returns_dev || !L->old_values_dev ||
-        !L->old_mu_dev || !L->old_sigma_dev || !L->loss_partials_dev || !L->dwh_partials_dev || !L->db_partials_dev)
-        return AG_ERR_INVALID_ARG;
-    if ((L->new_mu_dev == nullptr) != (L->new_sigma_dev == nullptr)) return AG_ERR_INVALID_ARG;
-    if (((uintptr_t)in->obs_dev & 7) || ((uintptr_t)in->h1_dev & 15) || ((uintptr_t)planes_dev & 15) ||
-        (norm && ((uintptr_t)in->xn_dev & 7)))
-        return AG_ERR_INVALID_ARG;
-    SplitEpilogue ep = {};
-    ep.bias = bias_dev; ep.Wh = Wh_dev; ep.bh = bh_dev; ep.heads = L->heads_dev;
-    ep.logstd = L->logstd_dev; ep.actions = L->actions_dev; ep.old_neglogp = L->old_neglogp_dev; ep.advantages = L->advantages_dev;
-    ep.returns = L->returns_dev; ep.old_values = L->old_values_dev; ep.old_mu = L->old_mu_dev; ep.old_sigma = L->old_sigma_dev;
-    ep.new_mu = L->new_mu_dev; ep.new_sigma = L->new_sigma_dev; ep.loss_partials = L->loss_partials_dev;
-    ep.dwh_partials = L->dwh_partials_dev; ep.db2_partials = L->db_partials_dev;
-    ep.lp = agloss::LossParams{L->e_clip, L->critic_coef, L->bounds_loss_coef, 1.0f / (float)M, L->clip_value, L->bound_type};
-    ep.in_mean = in->mean_dev; ep.in_var = in->var_dev; ep.W1 = in->W1_dev; ep.b1 = in->b1_dev; ep.xn_out = in->xn_dev;
-    ep.h1_out = in->h1_dev; ep.in_eps = in->eps; ep.in_clip = in->clip;
-#define AG_SGF(F) launch_split_any<true, 5, 0, 4, true, F>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream)
-    switch (in->D) {
-        case 16: return AG_SGF(16);
-        case 18: return AG_SGF(18);
-        default: return AG_SGF(20);
-    }
-#undef AG_SGF
 }
 
 extern "C" int ag_split_gemm_input_wgrad_rows(void) { return g_split_wm * 64; }

@@ -9,7 +9,6 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['ms_per_step'],3), 'ms/epoch')"
 }
 for i in $(seq 1 $N); do
-  unset AIRGYM_EXP_LIB; AIRGYM_EXPERIMENTS=1 run "base(no-fin)" "--fuse-gemm-input 0"
-  AIRGYM_EXPERIMENTS=1 run "fin" ""
+  unset AIRGYM_EXP_LIB; AIRGYM_EXPERIMENTS=1 run "base" "$BASE_FLAGS"
   for T in $TAGS; do AIRGYM_EXPERIMENTS=1 AIRGYM_EXP_LIB=$(pwd)/airgym_amd/_native/libairgym_hip_exp_$T.so run $T ""; done
 done
