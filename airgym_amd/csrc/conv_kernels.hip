@@ -19,10 +19,8 @@
 // applied while staging (y = max(x, 0) * scale[c] + shift[c]; padding stays 0), so the normalised activation never exists in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/airgym_hip.h"
-#include "split_common.hpp"
 
 namespace {
 
@@ -279,198 +277,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) t += (&s_red[w][0][0])[u];
             stats[(size_t)blockIdx.x * COUT * 2 + u] = t;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------------
-// Forward of the SECOND layer (16 -> 32 channels, 106 x 60 -> 53 x 30) on the bf16 matrix cores at float32 accuracy: every f32
-// operand split exactly three ways, six v_mfma_f32_32x32x16_bf16 per product (split_gemm.hip has the error analysis): 2.67 x the
-// rate of the f32 instruction the kernel above uses.  What makes it a different kernel rather than a different instruction:
-//   * K = 16 of one instruction = the 16 input channels at ONE tap, so a pixel's channels must sit together: the staging thread
-//     gathers 8 channels of a column pair (8 coalesced plane reads; adjacent threads = adjacent columns), applies the previous
-//     layer's ReLU + BatchNorm, splits ONCE (a pixel feeds ~2.25 taps: splitting per fragment read would make the kernel
-//     ALU-bound) and writes three 16-byte units per pixel into a channel-innermost image
-//         s_in[plane 3][channel half 2][band row 9][E: even columns 0..29 | O': left padding, odd columns 1..59] x 16 B;
-//     a B fragment (lane = output column, 8 channels per lane half) is then three conflict-free ds_read_b128 per tap.
-//   * the whole weight set of the layer (9 taps x 3 planes = 108 registers per lane as A fragments, lane = output channel) stays
-//     in registers of PERSISTENT workgroups: only pixel fragments are read from LDS, 3 reads per 6 MFMAs.
-// Workgroup = 4 waves, item = (image, band of 4 output rows), wave w owns output row 4 band + w (32 channels x 30 of 32 columns).
-// The next item's loads are in flight during the current item's MFMAs.  Same interface and statistics as conv_s2_fwd_kernel.
-constexpr int kC2Rows = 4, kC2InRows = 2 * kC2Rows + 1;
-constexpr int kC2OB = 32;                       // O' region of a band row starts here (units)
-constexpr int kC2RS = 66;                       // units per band row: E[0..31], O'[0..33]
-constexpr int kC2PS = 600;                      // units per (plane, channel half): 9 x 66 = 594, padded to a multiple of 8 (128 B)
-
-// weight image of the split forward: wp[(tap, 16-channel block)][plane 3][h 2][co] x 16 B (8 input channels 16 kb + 8 h + i)
-__global__ void pack_fwd_split_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int cin, int cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int KB = cin / 16;
-    if (i >= 9 * KB * 2 * cout) return;
-    const int co = i % cout;
-    int r = i / cout;
-    const int h = r % 2; r /= 2;
-    const int kb = r % KB;
-    const int tap = r / KB;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = w[((size_t)co * cin + 16 * kb + 8 * h + e) * 9 + tap];
-    uint4 p1, p2, p3;
-    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
-    uint4* base = wp + (size_t)(tap * KB + kb) * 3 * 2 * cout;
-    base[(0 * 2 + h) * cout + co] = p1;
-    base[(1 * 2 + h) * cout + co] = p2;
-    base[(2 * 2 + h) * cout + co] = p3;
-}
-
-// sum over each 32-lane half of the wave (fixed order); valid in lanes 16..31 and 48..63
-__device__ __forceinline__ float half_sum32(float v) {
-    v = row_sum16(v);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast15
-    return v;
-}
-
-template <bool APPLY>
-__global__ __launch_bounds__(256, 2) void conv2_fwd_split_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                                 const float* __restrict__ bias, const float* __restrict__ scale,
-                                                                 const float* __restrict__ shift, float* __restrict__ y,
-                                                                 float* __restrict__ stats, int items, int bands, int dbg) {
-    constexpr int CIN = 16, COUT = 32, HIN = 106, WIN = 60, HO = 53, WO = 30;
-    constexpr int NT = 256, SLOTS = kC2InRows * (WIN / 2) * 2, NS = (SLOTS + NT - 1) / NT;      // 540 staging slots, 3 per thread
-    __shared__ uint4 s_in[6 * kC2PS];
-    __shared__ float s_red[kC2Rows][COUT][2];
-    __shared__ float s_ss[2 * CIN];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n31 = lane & 31, h = lane >> 5;
-
-    // the layer's weights: A fragments of every tap, for good
-    bf16x8 a[9][3];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const uint4 u = wp[((t * 3 + p) * 2 + h) * COUT + n31];
-            a[t][p] = *reinterpret_cast<const bf16x8*>(&u);
-        }
-    float bco[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bco[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * h];
-    for (int u = tid; u < 6 * kC2PS; u += NT) s_in[u] = make_uint4(0u, 0u, 0u, 0u);      // paddings stay zero for good
-    if (APPLY) {
-        for (int u = tid; u < CIN; u += NT) { s_ss[u] = scale[u]; s_ss[CIN + u] = shift[u]; }
-    }
-    // staging slots of this thread (the same for every item): (channel half, band row, column pair)
-    int s_hh[NS], s_r[NS], s_j[NS];
-    bool s_act[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const int sl = tid + k * NT;
-        s_act[k] = sl < SLOTS;
-        const int slc = s_act[k] ? sl : 0;
-        s_hh[k] = slc / (kC2InRows * (WIN / 2));
-        const int rem = slc - s_hh[k] * (kC2InRows * (WIN / 2));
-        s_r[k] = rem / (WIN / 2);
-        s_j[k] = rem - s_r[k] * (WIN / 2);
-    }
-    float2 vin[NS][8];
-    bool v_in[NS];
-    auto fetch = [&](int item) {
-        const int n = item / bands, band = item - n * bands;
-        const __amdgpu_buffer_rsrc_t rx = buf_of(x + (size_t)n * CIN * HIN * WIN, CIN * HIN * WIN * 4);
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int iy = 2 * band * kC2Rows - 1 + s_r[k];
-            v_in[k] = s_act[k] && iy >= 0 && iy < HIN;
-            const unsigned off = v_in[k] ? (unsigned)(((8 * s_hh[k] * HIN + iy) * WIN + 2 * s_j[k]) * 4) : kOob;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) vin[k][i] = buf_f2(rx, off, i * (HIN * WIN * 4));
-        }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            if (!s_act[k]) continue;
-            float e[8], o[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                e[i] = vin[k][i].x;
-                o[i] = vin[k][i].y;
-                if (APPLY) {
-                    if (v_in[k]) {
-                        const float sc = s_ss[8 * s_hh[k] + i], sh = s_ss[CIN + 8 * s_hh[k] + i];
-                        e[i] = fmaxf(e[i], 0.f) * sc + sh;
-                        o[i] = fmaxf(o[i], 0.f) * sc + sh;
-                    }
-                }
-            }
-            uint4 pe[3], po[3];
-            split8(make_float4(e[0], e[1], e[2], e[3]), make_float4(e[4], e[5], e[6], e[7]), pe[0], pe[1], pe[2]);
-            split8(make_float4(o[0], o[1], o[2], o[3]), make_float4(o[4], o[5], o[6], o[7]), po[0], po[1], po[2]);
-            uint4* dst = s_in + s_hh[k] * kC2PS + s_r[k] * kC2RS + s_j[k];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                dst[p * 2 * kC2PS] = pe[p];                          // E[j]: column 2 j
-                dst[p * 2 * kC2PS + kC2OB + 1] = po[p];              // O'[j + 1]: column 2 j + 1
-            }
-        }
-    };
-
-    int item = blockIdx.x;
-    if (item < items) fetch(item);
-    for (; item < items; item += gridDim.x) {
-        __syncthreads();                         // every wave is done with the previous band (and with s_red)
-        if (!(dbg & 4)) stash();
-        __syncthreads();
-        const int next = item + gridDim.x;
-        if (next < items && !(dbg & 8)) fetch(next);
-        __builtin_amdgcn_sched_barrier(0);       // the loads stay ahead of the MFMA loop
-        const int n = item / bands, band = item - n * bands;
-        const int oy = band * kC2Rows + wave;
-        const bool row_ok = oy < HO;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (row_ok && !(dbg & 1)) {
-            const uint4* bb = s_in + h * kC2PS + (2 * wave) * kC2RS + n31;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ky = t / 3, kx = t % 3;
-                const int uo = ky * kC2RS + (kx == 1 ? 0 : kC2OB + (kx == 2 ? 1 : 0));
-                bf16x8 b[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const uint4 u = bb[p * 2 * kC2PS + uo];
-                    b[p] = *reinterpret_cast<const bf16x8*>(&u);
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][2], b[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][1], b[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t][0], b[0], acc, 0, 0, 0);
-            }
-        }
-        // epilogue: + bias, store (C layout: column = lane & 31, channel = (reg & 3) + 8 (reg >> 2) + 4 h), statistics of relu(y)
-        const bool ok = row_ok && n31 < WO;
-        float* yrow = y + (((size_t)n * COUT) * HO + oy) * WO + n31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = acc[r] + bco[r];
-            if (ok) yrow[(size_t)co * HO * WO] = v;
-            if (stats && !(dbg & 2)) {
-                const float rl = ok ? fmaxf(v, 0.f) : 0.f;
-                const float s1 = half_sum32(rl), s2 = half_sum32(rl * rl);
-                if (n31 == 31) { s_red[wave][co][0] = s1; s_red[wave][co][1] = s2; }
-            }
-        }
-        if (stats) {
-            __syncthreads();
-            if (tid < COUT * 2) {
-                float t = 0.f;
-#pragma unroll
-                for (int w = 0; w < kC2Rows; ++w) t += (&s_red[w][0][0])[tid];
-                stats[(size_t)item * COUT * 2 + tid] = t;
-            }
         }
     }
 }
@@ -1300,15 +1106,6 @@ inline int layer_of(int cin, int cout, int hin, int win) {
 // output rows per band = 2 x waves: 53 = 7 bands of 8 (-3), 27 = 2 bands of 14 (-1); 2 / 7 and 4 / 5 waves measured slower
 constexpr int kL2Waves = 4, kL3Waves = 7;
 constexpr int kWgradWorkgroups = 512;              // persistent 12-wave workgroups: two per CU where registers allow (conv2), else they queue
-// which passes run on the bf16 matrix cores with the exact 3-way split (bit 0: the second layer's forward); the experiments build
-// reads AIRGYM_CONV_SPLIT for A/B timing
-constexpr int kDefaultConvSplit = 1;
-#ifdef AG_EXPERIMENTS
-static const int g_conv_split = [] { const char* e = getenv("AIRGYM_CONV_SPLIT"); return e ? atoi(e) : kDefaultConvSplit; }();
-#else
-constexpr int g_conv_split = kDefaultConvSplit;
-#endif
-constexpr int kC2SplitWorkgroups = 512;            // persistent, two per CU
 
 }  // namespace
 
@@ -1316,7 +1113,7 @@ constexpr int kC2SplitWorkgroups = 512;            // persistent, two per CU
 
 extern "C" int ag_cnn_conv_workspace_floats(int cin, int cout) {
     if (cin == 1 && cout == 16) return 400;
-    return 9 * cin * cout * 3 / 2;      // the split forward's weight image: three bf16 planes = 6 bytes per weight
+    return 9 * cin * cout;
 }
 
 extern "C" int ag_cnn_conv1_fwd(const float* x_dev, const long long* index_dev, const float* norm_mean_dev, const float* norm_std_dev,
@@ -1362,7 +1159,7 @@ extern "C" int ag_cnn_conv_supported(int cin, int cout, int hin, int win) { retu
 
 extern "C" int ag_cnn_conv_fwd_bands(int cin, int cout, int hin, int win) {
     const int layer = layer_of(cin, cout, hin, win);
-    if (layer == 2) return (g_conv_split & 1) ? (53 + kC2Rows - 1) / kC2Rows : (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
+    if (layer == 2) return (53 + 2 * kL2Waves - 1) / (2 * kL2Waves);
     if (layer == 3) return (27 + 2 * kL3Waves - 1) / (2 * kL3Waves);
     return AG_ERR_UNSUPPORTED;
 }
@@ -1374,23 +1171,10 @@ extern "C" int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const
     const int layer = layer_of(cin, cout, hin, win);
     if (!layer) return AG_ERR_UNSUPPORTED;
     const int tot = 9 * cin * cout;
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, cin, cout);
     const bool apply = scale_dev != nullptr;
     const int bands = ag_cnn_conv_fwd_bands(cin, cout, hin, win);
     if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
-    if (layer == 2 && (g_conv_split & 1)) {      // bf16 matrix cores, exact 3-way split (conv2_fwd_split_kernel)
-        if ((uintptr_t)workspace_dev & 15) return AG_ERR_INVALID_ARG;
-        uint4* wp = reinterpret_cast<uint4*>(workspace_dev);
-        hipLaunchKernelGGL(pack_fwd_split_kernel, dim3((9 * 2 * cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, wp, cin, cout);
-        const int items = n * bands, grid = items < kC2SplitWorkgroups ? items : kC2SplitWorkgroups;
-        if (apply)
-            hipLaunchKernelGGL(conv2_fwd_split_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_dev, wp, b_dev, scale_dev,
-                               shift_dev, y_dev, stats_dev, items, bands, g_conv_split >> 8);
-        else
-            hipLaunchKernelGGL(conv2_fwd_split_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_dev, wp, b_dev, scale_dev,
-                               shift_dev, y_dev, stats_dev, items, bands, g_conv_split >> 8);
-        return AG_CONV_LAUNCH_OK();
-    }
-    hipLaunchKernelGGL(pack_fwd_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, workspace_dev, cin, cout);
 #define AG_CF(CIN_, COUT_, HIN_, WIN_, WAVES_, APPLY_)                                                                           \
     hipLaunchKernelGGL((conv_s2_fwd_kernel<CIN_, COUT_, HIN_, WIN_, WAVES_, APPLY_>), dim3(n * bands), dim3(WAVES_ * 64), 0,      \
                        (hipStream_t)stream, x_dev, workspace_dev, b_dev, scale_dev, shift_dev, y_dev, stats_dev, bands)
