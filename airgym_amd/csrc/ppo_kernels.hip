@@ -258,8 +258,12 @@ struct AdamArgs {
 constexpr int kAdamBlocks = 64;
 constexpr int kAdamThreads = 256;
 
-__global__ __launch_bounds__(kAdamThreads) void adam_norm_kernel(const float* __restrict__ g, int n, float* __restrict__ partial) {
+// Block 0 also snapshots {lr, step} into `snap`: phase 2 reads the snapshot and publishes the new pair straight into the caller's
+// slot (no block of phase 2 reads what block 0 of phase 2 writes) - the 16-byte device-to-device copy that used to follow is gone.
+__global__ __launch_bounds__(kAdamThreads) void adam_norm_kernel(const float* __restrict__ g, int n, float* __restrict__ partial,
+                                                                  const double* __restrict__ state, double* __restrict__ snap) {
     __shared__ float red[kAdamThreads / 64];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { snap[0] = state[0]; snap[1] = state[1]; }
     float ss = 0.f;
     for (int i = blockIdx.x * kAdamThreads + threadIdx.x; i < n; i += kAdamBlocks * kAdamThreads) {
         const float x = g[i];
@@ -275,8 +279,8 @@ __global__ __launch_bounds__(kAdamThreads) void adam_norm_kernel(const float* __
     }
 }
 
-// Phase 2: every block re-reduces the 64 partials (deterministic order), reads {lr, step} from state_in, updates its
-// slice; block 0 publishes {new lr, step + 1} to state_out (ping-pong: no block reads what block 0 writes).
+// Phase 2: every block re-reduces the 64 partials (deterministic order), reads {lr, step} from state_in (phase 1's snapshot),
+// updates its slice; block 0 publishes {new lr, step + 1} to state_out (the caller's slot: no block reads what block 0 writes).
 __global__ __launch_bounds__(kAdamThreads) void adam_clip_step_kernel(const AdamArgs k, const float* __restrict__ partial,
                                                                        const double* __restrict__ state_in,
                                                                        double* __restrict__ state_out) {
@@ -332,15 +336,13 @@ extern "C" int ag_adam_clip_step(float* param, float* grad, float* exp_avg, floa
     if (!param || !grad || !exp_avg || !exp_avg_sq || !state || n <= 0) return AG_ERR_INVALID_ARG;
     AdamArgs k{param, grad, exp_avg, exp_avg_sq, state, n, beta1, beta2, eps, weight_decay, max_grad_norm,
                kl_threshold, min_lr, max_lr};
-    // state_dev layout: double[2 + 2 + 64 floats]: {lr, step} | scratch {lr, step} | 64 float partials
-    double* scratch = state + 2;
+    // state_dev layout: double[2 + 2 + 64 floats]: {lr, step} | snapshot of {lr, step} taken by phase 1 | 64 float partials
+    double* snap = state + 2;
     float* partial = reinterpret_cast<float*>(state + 4);
-    hipLaunchKernelGGL(adam_norm_kernel, dim3(kAdamBlocks), dim3(kAdamThreads), 0, (hipStream_t)stream, grad, n, partial);
+    hipLaunchKernelGGL(adam_norm_kernel, dim3(kAdamBlocks), dim3(kAdamThreads), 0, (hipStream_t)stream, grad, n, partial,
+                       (const double*)state, snap);
     hipLaunchKernelGGL(adam_clip_step_kernel, dim3(kAdamBlocks), dim3(kAdamThreads), 0, (hipStream_t)stream, k, partial,
-                       (const double*)state, scratch);
-    // publish {lr, step} back to the caller-visible slot (stream-ordered 16-byte copy)
-    if (hipMemcpyAsync(state, scratch, 2 * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
-        return AG_ERR_HIP;
+                       (const double*)snap, state);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
