@@ -990,11 +990,25 @@ __global__ __launch_bounds__(256) void rms_moments_kernel(const float* __restric
     const int c = threadIdx.x % D, g = threadIdx.x / D;
     double s = 0.0, q = 0.0;
     if (g < groups) {
-        for (long long r = (long long)blockIdx.x * groups + g; r < rows; r += (long long)kRmsBlocks * groups) {
+        // four rows in flight per thread (one dependent load per trip made this launch latency-bound: 23 us for 14 MB)
+        const long long stride = (long long)kRmsBlocks * groups;
+        long long r = (long long)blockIdx.x * groups + g;
+        double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+        for (; r + 3 * stride < rows; r += 4 * stride) {
+            const float a0 = x[r * D + c], a1 = x[(r + stride) * D + c], a2 = x[(r + 2 * stride) * D + c], a3 = x[(r + 3 * stride) * D + c];
+            const double v0 = (double)a0, v1 = (double)a1, v2 = (double)a2, v3 = (double)a3;
+            s += v0; q += v0 * v0;
+            s1 += v1; q1 += v1 * v1;
+            s2 += v2; q2 += v2 * v2;
+            s3 += v3; q3 += v3 * v3;
+        }
+        for (; r < rows; r += stride) {
             const double v = (double)x[r * D + c];
             s += v;
             q += v * v;
         }
+        s = (s + s1) + (s2 + s3);
+        q = (q + q1) + (q2 + q3);
         sh[(g * 2 + 0) * D + c] = s;
         sh[(g * 2 + 1) * D + c] = q;
     }
@@ -1013,13 +1027,30 @@ __global__ __launch_bounds__(256) void rms_moments_kernel(const float* __restric
 __global__ __launch_bounds__(256) void rms_merge_kernel(const double* __restrict__ partial, long long rows, int D,
                                                         double* __restrict__ mean, double* __restrict__ var,
                                                         double* __restrict__ count) {
+    __shared__ double shs[256], shq[256];
     const double cnt = *count;
-    __syncthreads();                     // everyone has read the old count before thread 0 overwrites it
-    for (int c = threadIdx.x; c < D; c += 256) {
+    // the blocks' partials: 256 / D lanes per column (D <= 256), then a fixed-order sum over the lanes (D serial chains of
+    // 2 x kRmsBlocks dependent loads made this launch 20 us)
+    const int lanes = 256 / D;
+    {
+        const int c = (int)threadIdx.x % D, l = (int)threadIdx.x / D;
+        double ps = 0.0, pq = 0.0;
+        if (l < lanes) {
+            for (int b = l; b < kRmsBlocks; b += lanes) {
+                ps += partial[((size_t)b * 2 + 0) * D + c];
+                pq += partial[((size_t)b * 2 + 1) * D + c];
+            }
+        }
+        shs[threadIdx.x] = ps;
+        shq[threadIdx.x] = pq;
+    }
+    __syncthreads();                     // (also: everyone has read the old count before thread 0 overwrites it)
+    if ((int)threadIdx.x < D) {
+        const int c = threadIdx.x;
         double s = 0.0, q = 0.0;
-        for (int b = 0; b < kRmsBlocks; ++b) {
-            s += partial[((size_t)b * 2 + 0) * D + c];
-            q += partial[((size_t)b * 2 + 1) * D + c];
+        for (int k = 0; k < lanes; ++k) {
+            s += shs[k * D + c];
+            q += shq[k * D + c];
         }
         const double n = (double)rows;
         const double bmean = s / n;

@@ -526,6 +526,7 @@ def test_host_reset_of_a_subset_matches_oracle(Handle, task):
 def test_host_reset_subset_through_the_task_class(Handle):
     """Hovering.reset_idx(env_ids) of the drop-in class no longer raises for a subset."""
     from argparse import Namespace
+    import airgym_amd.envs  # noqa: F401  (registers the tasks, as `from airgym.envs import *` does in the reference's scripts)
     from airgym_amd.utils.task_registry import task_registry
     env, _ = task_registry.make_env("hovering", Namespace(num_envs=128, ctl_mode="rate", seed=3, sim_device="cuda:0", headless=True))
     env.reset()

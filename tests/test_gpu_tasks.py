@@ -193,6 +193,7 @@ def test_drop_in_api_and_short_ppo_run(Handle, task, use_image):
     import yaml
     from argparse import Namespace
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    import airgym_amd.envs  # noqa: F401  (registers the tasks, as `from airgym.envs import *` does in the reference's scripts)
     from airgym_amd.utils.task_registry import task_registry
     env, cfg = task_registry.make_env(task, Namespace(num_envs=64, ctl_mode="rate", seed=3, sim_device="cuda:0", headless=True))
     obs, priv = env.reset()
