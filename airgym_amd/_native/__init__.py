@@ -128,6 +128,16 @@ class AgLossEpilogue(ctypes.Structure):
     ]
 
 
+class AgInputLayerArgs(ctypes.Structure):
+    """ag_input_layer_args (include/airgym_hip.h)"""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("D", ctypes.c_int),
+        ("obs_dev", ctypes.c_void_p), ("mean_dev", ctypes.c_void_p), ("var_dev", ctypes.c_void_p),
+        ("xn_dev", ctypes.c_void_p), ("h1_dev", ctypes.c_void_p),
+        ("eps", ctypes.c_float), ("clip", ctypes.c_float),
+    ]
+
+
 # every symbol include/airgym_hip.h declares: (name, restype, argtypes)
 _P = ctypes.c_void_p
 class AgSumJob(ctypes.Structure):
@@ -199,6 +209,12 @@ SYMBOLS = [
     ("ag_split_gemm_loss_rows", ctypes.c_int, []),
     ("ag_split_gemm_loss_heads_bwd", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.POINTER(AgLossEpilogue), ctypes.c_int,
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_split_gemm_input_fwd_supported", ctypes.c_int, [ctypes.c_int]),
+    ("ag_split_gemm_input_image_bytes", ctypes.c_longlong, []),
+    ("ag_split_gemm_input_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),
+    ("ag_split_gemm_input_loss_heads_bwd", ctypes.c_int, [ctypes.POINTER(AgInputLayerArgs), _P, _P, _P, _P, _P,
+                                                          ctypes.POINTER(AgLossEpilogue), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                          ctypes.c_int, _P]),
     ("ag_mlp_chain_supported", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("ag_mlp_chain_image_bytes", ctypes.c_longlong, [ctypes.c_int]),
     ("ag_mlp_chain_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, ctypes.c_int, _P, _P]),

@@ -62,6 +62,47 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
     chunk[(2 * 2 + h) * BN + n] = p3;
 }
 
+// Images of ag_split_gemm_input_prepare (the fused first layer, FIN > 0):
+//   [0, kInImageW1Bytes): W1ext [block 8][K step 2][plane 3][h 2][feature 32] x 16 B, W1ext[f][d] = W1[f][d] (d < D), b1[f] (d = D), 0
+//   then the forward planes of W2 in the chain's K order, laid out like ag_split_gemm_prepare's
+constexpr int kInImageW1Bytes = 8 * 2 * 3 * 2 * 32 * 16;
+__global__ __launch_bounds__(256) void split_in_prepare_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D,
+                                                               const float* __restrict__ W2, uint4* __restrict__ img) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 8 * 2 * 2 * 32) {                               // W1ext: one (block, step, h, feature) unit triple per thread
+        const int m = t & 31, h = (t >> 5) & 1, st = (t >> 6) & 1, b = t >> 7;
+        const int f = 32 * b + m;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = 16 * st + 8 * h + i;
+            v[i] = d < D ? W1[(size_t)f * D + d] : (d == D ? b1[f] : 0.0f);
+        }
+        uint4 p1, p2, p3;
+        split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
+        uint4* base = img + (size_t)((b * 2 + st) * 3) * 64 + h * 32 + m;
+        base[0] = p1;
+        base[64] = p2;
+        base[128] = p3;
+        return;
+    }
+    const int unit = t - 8 * 2 * 2 * 32;                    // W2 planes, chain K order: one (chunk, k-half, n) unit triple per thread
+    if (unit >= 16 * 2 * BN) return;
+    const int n = unit % BN, h = (unit / BN) & 1, c = unit / (2 * BN);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = 32 * (c >> 1) + 16 * (c & 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
+        v[i] = W2[(size_t)n * KDIM + f];
+    }
+    uint4 p1, p2, p3;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
+    uint4* chunk = img + kInImageW1Bytes / 16 + (size_t)c * B_UNITS;
+    chunk[(0 * 2 + h) * BN + n] = p1;
+    chunk[(1 * 2 + h) * BN + n] = p2;
+    chunk[(2 * 2 + h) * BN + n] = p3;
+}
+
 // A1 > 0: the forward of the LAST hidden layer with the actor/critic heads folded into the epilogue
 // (lib/network/mlp.py:36-39 followed by the mu / value Linear of a2c_continuous.py's model): C keeps the bias-free
 // pre-activation z (the backward wants it), and heads[m, a] = sum_c ELU(z[m,c] + bias[c]) Wh[a,c] + bh[a] is formed from the
@@ -190,9 +231,22 @@ struct SplitEpilogue {
     float* dwh_partials;       // [tiles, A1, 256] head weight gradient of the tile's rows
     float* db2_partials;       // [tiles, 256] column sums of dz (bias gradient of this layer)
     agloss::LossParams lp;
+    // FIN (ag_split_gemm_input_loss_heads_bwd): the FIRST layer formed on the fly as this GEMM's A operand; A = the raw observations
+    const double* in_mean;     // [FIN] running mean / variance of the input normaliser, or null (A is used as it is)
+    const double* in_var;
+    const uint4* w1img;        // first-layer weight + bias image (ag_split_gemm_input_prepare)
+    float* xn_out;             // [M, FIN] normalised inputs (null iff in_mean is null)
+    float* h1_out;             // [M, 256] first-layer activations (the backward reads them)
+    float in_eps, in_clip;
 };
 
-template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false>
+//
+// FIN > 0: the first layer of a [FIN -> 256 -> 256] trunk inside this launch (replaces ag_mlp_input_layer in the update): the A
+// operand of the main product is PRODUCED, not loaded - see the FIN block in the kernel.  h1 still goes to HBM (the backward reads
+// it), but as stores under this kernel's MFMAs instead of a write-bound launch of its own, and the 201 MB read of it is gone.  The
+// W2 planes of this launch are in the chain's K order (chunk 2 b + q, k-half h, slot i <-> feature 32 b + 16 q + (i & 3) + 8 (i >> 2)
+// + 4 h).  A version that formed the piece on the vector ALU (144 FMAs per thread and chunk) was 0.7 ms per epoch SLOWER.
+template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0>
 __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
                                                                   float* __restrict__ C, int M, const SplitEpilogue ep) {
     constexpr int BM = WM * 64, NT = WM * 128;               // rows per tile, threads per workgroup
@@ -201,6 +255,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     static_assert(WM == 2 || WM == 4, "4 or 8 waves");
     static_assert(A1 == 0 || DIN == 0, "one fused epilogue at a time");
     static_assert((DIN & 1) == 0 && DIN <= 62, "input width: even, at most two 32-wide tiles with the bias column");
+    static_assert(FIN == 0 || (WM == 4 && (FIN & 1) == 0 && FIN >= 16 && FIN <= 20), "fused first layer: 256-row tiles, widths 16 / 18 / 20");
     const float* __restrict__ bias = ep.bias;
     const float* __restrict__ Wh = ep.Wh;
     const float* __restrict__ bh = ep.bh;
@@ -248,6 +303,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     } while (0)
     AG_SG_DMA(0, 0);
 #else
+    static_assert(FIN == 0, "the fused first layer goes with the LDS-DMA B planes");
     uint4 rb0, rb1, rb2, rb3, rb4, rb5;                                 // (rb3..5: 4-wave tiles only; named, not an array: LLVM
     static_assert(BPT == 3 || BPT == 6, "B copy per thread");           //  left an indexed array in scratch)
 #define AG_SG_DMA(c, stage) do { } while (0)
@@ -274,13 +330,121 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     } while (0)
 #endif
 
-    AG_SG_LOAD(0);
-    AG_SG_STORE(0);
-    AG_SG_DMA_WAIT();
-    int c1 = 1;      // opaque, so that chunk 1's loads stay BEHIND chunk 0's stores and reuse its staging registers (hoisted to
-    asm volatile("" : "+s"(c1) : : "memory");      // the top they need a second set: spills, each behind an s_waitcnt vmcnt(0))
-    AG_SG_LOAD(c1);
-    __syncthreads();
+    // ---- FIN: the first layer on the matrix cores, TRANSPOSED (the chain kernel's first layer, mlp_chain.hip): wave w produces
+    // rows 32 w .. + 31 of the tile; per block of 32 features  h1^T[f, row] = W1ext[f, :] . x_ext[row, :]  (K = 32: the FIN inputs, an
+    // all-ones column that carries the bias, zeros) as 2 x 6 split MFMAs with the weights as A operand (image in LDS) and the lane's row
+    // of inputs as B operand (registers, for the whole tile).  Lane (row, h) then holds features 32 b + (r & 3) + 8 (r >> 2) + 4 h in
+    // register r: registers 0..7 and 8..15 ARE one 16-byte A unit each of the main product (chunks 2 b and 2 b + 1, k-half h) in the K
+    // order the W2 planes of this launch are prepared in (ag_split_gemm_input_prepare) - bias + ELU + split in registers, no shuffle.
+    bf16x8 xq[2][3];
+    f32x16 hacc;
+    float4 hs0, hs1;
+    int hoff = 0;
+    uint4* const w1s = lds + 2 * STAGE_UNITS;           // [block 8][K step 2][plane 3][h 2][feature 32] x 16 B (FIN only)
+    const int frow = wave * 32 + (lane & 31), fh = lane >> 5;
+#define AG_FIN_MFMA(b_)                                                                                \
+    do {                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;                                 \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                             \
+            bf16x8 wa_[3];                                                                             \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                            \
+                const uint4 u_ = w1s[((((b_) * 2 + s_) * 3 + p) * 2 + fh) * 32 + (lane & 31)];         \
+                wa_[p] = *reinterpret_cast<const bf16x8*>(&u_);                                        \
+            }                                                                                          \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[2], xq[s_][0], hacc, 0, 0, 0);          \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[0], xq[s_][2], hacc, 0, 0, 0);          \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[1], xq[s_][1], hacc, 0, 0, 0);          \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[1], xq[s_][0], hacc, 0, 0, 0);          \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[0], xq[s_][1], hacc, 0, 0, 0);          \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[0], xq[s_][0], hacc, 0, 0, 0);          \
+        }                                                                                              \
+    } while (0)
+    // half q of the block (registers 8 q .. 8 q + 7) -> chunk 2 b + q: ELU, split, the three plane units of (row, k-half h)
+#define AG_FIN_EMIT(b_, q_, stage_)                                                                    \
+    do {                                                                                               \
+        float e_[8];                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) e_[i] = sg_elu(hacc[8 * (q_) + i]);              \
+        hs0 = make_float4(e_[0], e_[1], e_[2], e_[3]);                                                 \
+        hs1 = make_float4(e_[4], e_[5], e_[6], e_[7]);                                                 \
+        hoff = 32 * (b_) + 16 * (q_) + 4 * fh;                                                         \
+        uint4* sa_ = lds + (stage_) * STAGE_UNITS;                                                     \
+        uint4 p1_, p2_, p3_;                                                                           \
+        split8(hs0, hs1, p1_, p2_, p3_);                                                               \
+        sa_[(0 * 2 + fh) * BM + frow] = p1_;                                                           \
+        sa_[(1 * 2 + fh) * BM + frow] = p2_;                                                           \
+        sa_[(2 * 2 + fh) * BM + frow] = p3_;                                                           \
+    } while (0)
+    // ... and the same values to HBM (the backward reads h1), issued BEHIND the step's vmcnt(0) (which then finds only stores a
+    // whole chunk old): features hoff .. + 3 and hoff + 8 .. + 11 of the lane's row
+#define AG_FIN_STORE()                                                                                 \
+    do {                                                                                               \
+        if (m0 + frow < M) {                                                                           \
+            float* d_ = ep.h1_out + (size_t)(m0 + frow) * KDIM + hoff;                                 \
+            *reinterpret_cast<float4*>(d_) = hs0;                                                      \
+            *reinterpret_cast<float4*>(d_ + 8) = hs1;                                                  \
+        }                                                                                              \
+    } while (0)
+    if constexpr (FIN > 0) {
+        for (int u = tid; u < 8 * 2 * 3 * 2 * 32; u += NT) w1s[u] = ep.w1img[u];
+        const bool norm = ep.in_mean != nullptr;
+        const int grow = min(m0 + frow, M - 1);
+        const float* xrow = A + (size_t)grow * FIN;
+        float xv[2][8];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {                    // K step 0: inputs 8 h .. 8 h + 7 (all below FIN >= 16)
+            const float2 v2 = reinterpret_cast<const float2*>(xrow + 8 * fh)[i2];
+            xv[0][2 * i2] = v2.x;
+            xv[0][2 * i2 + 1] = v2.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[1][i] = 0.0f;         // K step 1: inputs 16 .. FIN - 1, the bias column at FIN, zeros
+        if (fh == 0) {
+#pragma unroll
+            for (int i2 = 0; i2 < (FIN - 16) / 2; ++i2) {
+                const float2 v2 = reinterpret_cast<const float2*>(xrow + 16)[i2];
+                xv[1][2 * i2] = v2.x;
+                xv[1][2 * i2 + 1] = v2.y;
+            }
+        }
+        if (norm) {      // ag_mlp_input_layer's arithmetic (running_mean_std.py:78-79)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int d = 16 * s_ + 8 * fh + i;
+                    if (d < FIN) {
+                        float v = (xv[s_][i] - (float)ep.in_mean[d]) / sqrtf((float)ep.in_var[d] + ep.in_eps);
+                        v = fminf(fmaxf(v, -ep.in_clip), ep.in_clip);
+                        xv[s_][i] = v;
+                        if (m0 + frow < M) ep.xn_out[(size_t)(m0 + frow) * FIN + d] = v;
+                    }
+                }
+        }
+        if (fh == 0) xv[1][FIN - 16] = 1.0f;                // the all-ones column: W1ext[f, FIN] = b1[f]
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            uint4 q1, q2, q3;
+            split8(make_float4(xv[s_][0], xv[s_][1], xv[s_][2], xv[s_][3]), make_float4(xv[s_][4], xv[s_][5], xv[s_][6], xv[s_][7]),
+                   q1, q2, q3);
+            xq[s_][0] = *reinterpret_cast<const bf16x8*>(&q1);
+            xq[s_][1] = *reinterpret_cast<const bf16x8*>(&q2);
+            xq[s_][2] = *reinterpret_cast<const bf16x8*>(&q3);
+        }
+        __syncthreads();                                     // the W1 image is in LDS
+        AG_FIN_MFMA(0);
+        AG_FIN_EMIT(0, 0, 0);
+        AG_SG_DMA_WAIT();
+        AG_FIN_STORE();
+        __syncthreads();
+    } else {
+        AG_SG_LOAD(0);
+        AG_SG_STORE(0);
+        AG_SG_DMA_WAIT();
+        int c1 = 1;      // opaque, so that chunk 1's loads stay BEHIND chunk 0's stores and reuse its staging registers (hoisted to
+        asm volatile("" : "+s"(c1) : : "memory");      // the top they need a second set: spills, each behind an s_waitcnt vmcnt(0))
+        AG_SG_LOAD(c1);
+        __syncthreads();
+    }
 
     f32x16 acc[8];
 #pragma unroll
@@ -329,24 +493,55 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     // fill were drained into LDS: issued at the top of the chunk that precedes their use, LLVM sinks them into the store block
     // (same condition, only user there) and every chunk ends waiting for HBM; here they have a full chunk to land and cost
     // no extra registers.
+    if constexpr (FIN > 0) {
+        // chunk pairs: the even chunk's step emits the second half of the current feature block, the odd chunk's step produces the
+        // next block (12 MFMAs) and emits its first half
 #pragma unroll 1
-    for (int c = 0; c < NCHUNK - 1; ++c) {
-        const int stage = c & 1;
-        AG_SG_DMA(c + 1, stage ^ 1);
-        AG_SG_COMPUTE(stage);
-        AG_SG_STORE(stage ^ 1);                             // chunk c + 1; that stage was last read before the previous barrier
+        for (int cc = 0; cc < NCHUNK / 2 - 1; ++cc) {
+            AG_SG_DMA(2 * cc + 1, 1);
+            AG_SG_COMPUTE(0);
+            AG_FIN_EMIT(cc, 1, 1);
+            AG_SG_DMA_WAIT();
+            AG_FIN_STORE();
+            __syncthreads();
+            AG_SG_DMA(2 * cc + 2, 0);
+            AG_SG_COMPUTE(1);
+            AG_FIN_MFMA(cc + 1);
+            AG_FIN_EMIT(cc + 1, 0, 0);
+            AG_SG_DMA_WAIT();
+            AG_FIN_STORE();
+            __syncthreads();
+        }
+        AG_SG_DMA(NCHUNK - 1, 1);
+        AG_SG_COMPUTE(0);
+        AG_FIN_EMIT(NCHUNK / 2 - 1, 1, 1);
         AG_SG_DMA_WAIT();
-        const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;      // (the last trip reloads a chunk it does not need)
-        AG_SG_LOAD(cn);
+        AG_FIN_STORE();
         __syncthreads();
+        AG_SG_COMPUTE(1);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < NCHUNK - 1; ++c) {
+            const int stage = c & 1;
+            AG_SG_DMA(c + 1, stage ^ 1);
+            AG_SG_COMPUTE(stage);
+            AG_SG_STORE(stage ^ 1);                         // chunk c + 1; that stage was last read before the previous barrier
+            AG_SG_DMA_WAIT();
+            const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;      // (the last trip reloads a chunk it does not need)
+            AG_SG_LOAD(cn);
+            __syncthreads();
+        }
+        AG_SG_COMPUTE((NCHUNK - 1) & 1);
     }
-    AG_SG_COMPUTE((NCHUNK - 1) & 1);
     if (A1 > 0 || DIN > 0) __syncthreads();                 // the fused epilogues reuse the stages
 #undef AG_SG_COMPUTE
 #undef AG_SG_LOAD
 #undef AG_SG_STORE
 #undef AG_SG_DMA
 #undef AG_SG_DMA_WAIT
+#undef AG_FIN_MFMA
+#undef AG_FIN_EMIT
+#undef AG_FIN_STORE
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if constexpr (A1 > 0) {
@@ -656,11 +851,11 @@ constexpr size_t split_lds_bytes() {
     return stages > epi ? stages : epi;
 }
 
-template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false>
+template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0>
 static int launch_split_any(const float* A_dev, const void* planes_dev, float* C_dev, int M, const SplitEpilogue& ep, void* stream) {
     static bool attr_set[64] = {};      // per device ordinal: the dynamic-LDS limit is an attribute of (function, device)
-    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM, LOSS>;
-    constexpr size_t lds_bytes = split_lds_bytes<DIN, WM>();
+    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM, LOSS, FIN>;
+    constexpr size_t lds_bytes = split_lds_bytes<DIN, WM>() + (FIN > 0 ? (size_t)kInImageW1Bytes : 0);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
@@ -721,6 +916,56 @@ extern "C" int ag_split_gemm_loss_heads_bwd(const float* A_dev, const void* plan
 #define AG_SGL(W) launch_split_any<true, 5, 0, W, true>(A_dev, planes_dev, dZ_dev, M, ep, stream)
     return AG_SG_DISPATCH(AG_SGL(2), AG_SGL(4));
 #undef AG_SGL
+}
+
+// widths with the first layer formed inside the forward GEMM (Hovering's 18 and the neighbouring even widths); 256-row tiles only
+extern "C" int ag_split_gemm_input_fwd_supported(int D) { return (g_split_wm == 4 && (D == 16 || D == 18 || D == 20)) ? 1 : 0; }
+
+extern "C" long long ag_split_gemm_input_image_bytes(void) { return (long long)kInImageW1Bytes + (long long)(KDIM / BK) * B_UNITS * 16; }
+
+extern "C" int ag_split_gemm_input_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev,
+                                           void* stream) {
+    if (!W1_dev || !b1_dev || !W2_dev || !image_dev) return AG_ERR_INVALID_ARG;
+    if (!ag_split_gemm_input_fwd_supported(D)) return AG_ERR_UNSUPPORTED;
+    if ((uintptr_t)image_dev & 15) return AG_ERR_INVALID_ARG;
+    const int threads = 8 * 2 * 2 * 32 + 16 * 2 * BN;
+    hipLaunchKernelGGL(split_in_prepare_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1_dev, b1_dev, D, W2_dev,
+                       (uint4*)image_dev);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void* image_dev, const float* bias_dev,
+                                                  const float* Wh_dev, const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* L,
+                                                  int M, int n, int k, int A1, void* stream) {
+    if (!in || !image_dev || !bias_dev || !Wh_dev || !bh_dev || !dZ_dev || !L || M <= 0) return AG_ERR_INVALID_ARG;
+    if (in->struct_size != sizeof(ag_input_layer_args) || L->struct_size != sizeof(ag_loss_epilogue)) return AG_ERR_INVALID_ARG;
+    if (!in->obs_dev || !in->h1_dev) return AG_ERR_INVALID_ARG;
+    const bool norm = in->mean_dev != nullptr;
+    if (norm != (in->var_dev != nullptr) || norm != (in->xn_dev != nullptr)) return AG_ERR_INVALID_ARG;
+    if (n != BN || k != KDIM || A1 != 5 || !ag_split_gemm_input_fwd_supported(in->D)) return AG_ERR_UNSUPPORTED;
+    if (M % 256 != 0) return AG_ERR_UNSUPPORTED;                          // whole row tiles only
+    if (!L->logstd_dev || !L->actions_dev || !L->old_neglogp_dev || !L->advantages_dev || !L->returns_dev || !L->old_values_dev ||
+        !L->old_mu_dev || !L->old_sigma_dev || !L->loss_partials_dev || !L->dwh_partials_dev || !L->db_partials_dev)
+        return AG_ERR_INVALID_ARG;
+    if ((L->new_mu_dev == nullptr) != (L->new_sigma_dev == nullptr)) return AG_ERR_INVALID_ARG;
+    if (((uintptr_t)in->obs_dev & 7) || ((uintptr_t)in->h1_dev & 15) || ((uintptr_t)image_dev & 15)) return AG_ERR_INVALID_ARG;
+    SplitEpilogue ep = {};
+    ep.bias = bias_dev; ep.Wh = Wh_dev; ep.bh = bh_dev; ep.heads = L->heads_dev;
+    ep.logstd = L->logstd_dev; ep.actions = L->actions_dev; ep.old_neglogp = L->old_neglogp_dev; ep.advantages = L->advantages_dev;
+    ep.returns = L->returns_dev; ep.old_values = L->old_values_dev; ep.old_mu = L->old_mu_dev; ep.old_sigma = L->old_sigma_dev;
+    ep.new_mu = L->new_mu_dev; ep.new_sigma = L->new_sigma_dev; ep.loss_partials = L->loss_partials_dev;
+    ep.dwh_partials = L->dwh_partials_dev; ep.db2_partials = L->db_partials_dev;
+    ep.lp = agloss::LossParams{L->e_clip, L->critic_coef, L->bounds_loss_coef, 1.0f / (float)M, L->clip_value, L->bound_type};
+    ep.in_mean = in->mean_dev; ep.in_var = in->var_dev; ep.w1img = reinterpret_cast<const uint4*>(image_dev); ep.xn_out = in->xn_dev;
+    ep.h1_out = in->h1_dev; ep.in_eps = in->eps; ep.in_clip = in->clip;
+    const void* planes_dev = reinterpret_cast<const char*>(image_dev) + kInImageW1Bytes;
+#define AG_SGF(F) launch_split_any<true, 5, 0, 4, true, F>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream)
+    switch (in->D) {
+        case 16: return AG_SGF(16);
+        case 18: return AG_SGF(18);
+        default: return AG_SGF(20);
+    }
+#undef AG_SGF
 }
 
 extern "C" int ag_split_gemm_input_wgrad_rows(void) { return g_split_wm * 64; }

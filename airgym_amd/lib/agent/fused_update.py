@@ -42,6 +42,7 @@ class SplitGemm256:
         nbytes = self.lib.ag_split_gemm_plane_bytes()
         self.fwd = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
         self.bwd = torch.empty(nbytes, dtype=torch.uint8, device=weight.device) if backward else None
+        self.in_image = None      # (prepare_input_image: the fused first layer's weights + chain-ordered forward planes)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.w.device).cuda_stream)
@@ -73,6 +74,22 @@ class SplitGemm256:
         N.check(self.lib.ag_split_gemm_loss_heads_bwd(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr(), heads_w.data_ptr(),
                                                       heads_b.data_ptr(), dz.data_ptr(), ctypes.byref(loss), x.shape[0], 256, 256,
                                                       heads_w.shape[0], self._stream()), "ag_split_gemm_loss_heads_bwd")
+
+    def prepare_input_image(self, w1, b1):
+        """One image per optimizer step for forward_input_loss_heads_bwd: the first layer's weights + bias as MFMA fragments and this
+        layer's forward planes in the K order the fused launch produces its A operand in (ag_split_gemm_input_prepare)."""
+        if self.in_image is None:
+            self.in_image = torch.empty(self.lib.ag_split_gemm_input_image_bytes(), dtype=torch.uint8, device=self.w.device)
+        N.check(self.lib.ag_split_gemm_input_prepare(w1.data_ptr(), b1.data_ptr(), w1.shape[1], self.w.data_ptr(),
+                                                     self.in_image.data_ptr(), self._stream()), "ag_split_gemm_input_prepare")
+
+    def forward_input_loss_heads_bwd(self, inp, M, dz, bias, heads_w, heads_b, loss):
+        """forward_loss_heads_bwd with the FIRST layer formed inside the launch (ag_split_gemm_input_loss_heads_bwd): `inp` is an
+        AgInputLayerArgs (observations, normaliser statistics; xn and h1 are written as by-products); weights: prepare_input_image."""
+        N.check(self.lib.ag_split_gemm_input_loss_heads_bwd(ctypes.byref(inp), self.in_image.data_ptr(), bias.data_ptr(),
+                                                            heads_w.data_ptr(), heads_b.data_ptr(), dz.data_ptr(), ctypes.byref(loss),
+                                                            M, 256, 256, heads_w.shape[0], self._stream()),
+                "ag_split_gemm_input_loss_heads_bwd")
 
     def backward_input_wgrad(self, dz, h_prev, x_prev, dw_partials, db_partials):
         """dX = dz W of this layer, consumed in the epilogue by the PREVIOUS (first) layer's backward: ELU'(h_prev), then
@@ -128,6 +145,10 @@ class FusedMLPStep:
                                and 64 <= self.layers[-1][0].shape[0] <= 256)
         if self.fuse_gemm_loss:
             self.wg_blocks = M // lrows
+        # ... and, for a [D -> 256 -> 256] trunk, with the first layer formed inside that launch as well (no ag_mlp_input_layer)
+        self.fuse_gemm_input = (self.fuse_gemm_loss and L == 2 and bool(agent.config.get("fuse_gemm_input", True))
+                                and self.layers[0][0].shape[0] == 256 and M % 256 == 0
+                                and bool(self.lib.ag_split_gemm_input_fwd_supported(D)))
         # small weight gradients folded into the ELU' passes (head: always; first layer: D in {16,18,20}, >= 2 layers)
         # ... and for a [D -> 256 -> 256] trunk the first layer's whole backward rides in the epilogue of the second layer's
         # dX GEMM (ag_split_gemm_input_wgrad): dh1 / dz1 are never written, one partial per row tile (D = 18: Hovering, 48: Tracking)
@@ -226,7 +247,19 @@ class FusedMLPStep:
         w0, b0 = self.layers[0][0], self.layers[0][1]
         D, C0 = obs.shape[1], w0.shape[0]
         inputs = []
-        if self.fuse_input:       # normalise + Linear(D -> C0) + ELU in one pass
+        in_args = None
+        if self.fuse_gemm_input:      # the first layer is formed inside the last GEMM's launch (which writes xn and h[0])
+            in_args = N.AgInputLayerArgs()
+            in_args.struct_size = ctypes.sizeof(N.AgInputLayerArgs)
+            in_args.D = D
+            in_args.obs_dev = obs.data_ptr()
+            in_args.mean_dev = rms.running_mean.data_ptr() if rms is not None else None
+            in_args.var_dev = rms.running_var.data_ptr() if rms is not None else None
+            in_args.xn_dev = self.xn.data_ptr() if rms is not None else None
+            in_args.h1_dev = self.h[0].data_ptr()
+            in_args.eps, in_args.clip = (float(rms.epsilon) if rms is not None else 0.0), 5.0
+            x = self.xn if rms is not None else obs
+        elif self.fuse_input:       # normalise + Linear(D -> C0) + ELU in one pass
             mean_p = rms.running_mean.data_ptr() if rms is not None else None
             var_p = rms.running_var.data_ptr() if rms is not None else None
             N.check(lib.ag_mlp_input_layer(obs.data_ptr(), mean_p, var_p, w0.data_ptr(), b0.data_ptr(),
@@ -248,6 +281,8 @@ class FusedMLPStep:
         heads_done = loss_done = False
         for sg in self.split.values():          # the weights moved in the previous optimizer step
             sg.prepare()
+        if in_args is not None:
+            self.split[len(self.layers) - 1].prepare_input_image(w0, b0)
         for li in range(1, len(self.layers)):
             w, b = self.layers[li][0], self.layers[li][1]
             inputs.append(x)
@@ -273,7 +308,11 @@ class FusedMLPStep:
                 Lp.bounds_loss_coef = float(ag.bounds_loss_coef or 0.0)
                 Lp.clip_value = int(bool(ag.clip_value))
                 Lp.bound_type = int(BOUND_TYPES[ag.bound_loss_type] if ag.bounds_loss_coef is not None else 0)
-                sg.forward_loss_heads_bwd(x, self.dz[:M * w.shape[0]].view(M, w.shape[0]), b, ag.heads_w, ag.heads_b, Lp)
+                dz_out = self.dz[:M * w.shape[0]].view(M, w.shape[0])
+                if in_args is not None:
+                    sg.forward_input_loss_heads_bwd(in_args, M, dz_out, b, ag.heads_w, ag.heads_b, Lp)
+                else:
+                    sg.forward_loss_heads_bwd(x, dz_out, b, ag.heads_w, ag.heads_b, Lp)
                 heads_done = loss_done = True
             elif li == last and self.fuse_heads and sg is not None:
                 if self.fuse_gemm_heads:            # heads formed in the GEMM epilogue; h keeps the bias-free pre-activation

@@ -67,6 +67,7 @@ def build_params(args, world_size):
     c["fuse_gemm_input_wgrad"] = bool(getattr(args, "fuse_gemm_input_wgrad", 1))
     c["use_mlp_chain"] = bool(getattr(args, "mlp_chain", 1))
     c["fuse_gemm_loss"] = bool(getattr(args, "fuse_gemm_loss", 1))
+    c["fuse_gemm_input"] = bool(getattr(args, "fuse_gemm_input", 1))
     params["seed"] = 0
     return params
 
@@ -380,6 +381,8 @@ def main(argv=None):
     ap.add_argument("--fuse-gemm-input-wgrad", type=int, default=1, help="first layer's backward in the dX GEMM's epilogue")
     ap.add_argument("--fuse-gemm-loss", type=int, default=1,
                     help="PPO loss + head layer backward in the last hidden layer's GEMM epilogue (ag_split_gemm_loss_heads_bwd)")
+    ap.add_argument("--fuse-gemm-input", type=int, default=1,
+                    help="first layer formed inside that launch as well (ag_split_gemm_input_loss_heads_bwd; no ag_mlp_input_layer)")
     ap.add_argument("--mlp-chain", type=int, default=1,
                     help="rollout policy forward as ONE launch with the activations in registers (ag_mlp_chain_forward)")
     ap.add_argument("--fuse-rollout-tail", type=int, default=1,

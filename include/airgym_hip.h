@@ -431,6 +431,31 @@ int ag_split_gemm_loss_heads_bwd(const float* A_dev, const void* planes_dev, con
 int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
                             const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1, void* stream);
 
+/* The same launch with the FIRST layer of a [D -> 256 -> 256] trunk formed inside it (lib/network/mlp.py:36-39, first Linear + ELU,
+ * behind the input normaliser of lib/core/running_mean_std.py:78-79): replaces ag_mlp_input_layer + ag_split_gemm_loss_heads_bwd in
+ * the update.  h1 is produced on the matrix cores (the same exact 3-way split; bias through an all-ones input column) straight into
+ * the GEMM's A operand - it is not read back - and written to h1_dev as a by-product (the backward reads it); xn_dev receives the
+ * normalised inputs (the first layer's weight gradient needs them).  Weights come as ONE image made once per optimizer step:
+ * ag_split_gemm_input_prepare(W1 [256, D], b1 [256], D, W2 [256, 256], image) - ag_split_gemm_input_image_bytes() bytes.
+ * D in {16, 18, 20} (ag_split_gemm_input_fwd_supported), M a multiple of 256, A1 = 5.  Float32-accurate like the other split
+ * products (not bit-identical to ag_mlp_input_layer's FMA chain). */
+typedef struct ag_input_layer_args {
+    uint32_t struct_size;              /* = sizeof(ag_input_layer_args), ABI guard */
+    int D;                             /* input width */
+    const float* obs_dev;              /* [M, D] observations (raw when mean/var are given) */
+    const double* mean_dev;            /* [D] running mean or NULL (no normaliser: obs is used as it is) */
+    const double* var_dev;             /* [D] running variance or NULL */
+    float* xn_dev;                     /* [M, D] out: clamp((obs - mean) / sqrt(var + eps), +-clip); NULL iff mean_dev is NULL */
+    float* h1_dev;                     /* [M, 256] out: ELU(xn W1^T + b1) */
+    float eps, clip;
+} ag_input_layer_args;
+int ag_split_gemm_input_fwd_supported(int D);
+long long ag_split_gemm_input_image_bytes(void);
+int ag_split_gemm_input_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev, void* stream);
+int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void* image_dev, const float* bias_dev,
+                                       const float* Wh_dev, const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* loss, int M,
+                                       int n, int k, int A1, void* stream);
+
 /* ReLU followed by BatchNorm2d on [N, C, H, W] float32 (NCHW, C <= 64) for the depth-image feature extractor (reference:
  * lib/network/cnn.py:3-33: Conv2d -> ReLU -> BatchNorm2d, three times) - airgym_amd/csrc/cnn_kernels.hip.  The ReLU output is
  * never materialised; x is the CONVOLUTION output.  HW = H * W.  blocks = ceil(N * C / ag_relu_bn_planes_per_block()).

@@ -368,10 +368,11 @@ def test_tracking_full_size_properties(Handle):
     env.close()
 
 
-@pytest.mark.parametrize("task,ctl,units,gemm_loss", [
-    ("hovering", "rate", [256, 256], True), ("hovering", "rate", [256, 256], False), ("hovering", "rate", [128, 64, 32], True),
-    ("hovering", "rate", [512], True), ("tracking", "vel", [256, 256], True)])
-def test_hand_scheduled_update_matches_autograd(Handle, task, ctl, units, gemm_loss):
+@pytest.mark.parametrize("task,ctl,units,gemm_loss,gemm_input", [
+    ("hovering", "rate", [256, 256], True, True), ("hovering", "rate", [256, 256], True, False),
+    ("hovering", "rate", [256, 256], False, False), ("hovering", "rate", [128, 64, 32], True, True),
+    ("hovering", "rate", [512], True, True), ("tracking", "vel", [256, 256], True, True)])
+def test_hand_scheduled_update_matches_autograd(Handle, task, ctl, units, gemm_loss, gemm_input):
     """FusedMLPStep (hand-scheduled forward/backward writing into the flat gradient buffer) == the autograd path on the
     same minibatch: every gradient, the KL slot, the logged scalars and the mu/sigma write-back."""
     import os
@@ -388,12 +389,15 @@ def test_hand_scheduled_update_matches_autograd(Handle, task, ctl, units, gemm_l
     params["config"]["bounds_loss_coef"] = 1e-4
     params["network"]["mlp"]["units"] = units
     params["config"]["fuse_gemm_loss"] = gemm_loss
+    params["config"]["fuse_gemm_input"] = gemm_input
     agent = A2CAgent("t", params)
     assert agent._fused_step is not None, "the bench configuration must take the hand-scheduled path"
     if units == [256, 256]:     # Hovering's 18-wide and Tracking's 48-wide first layer: backward in the dX GEMM's epilogue
         assert agent._fused_step.fuse_gemm_input_wgrad and agent._fused_step.split_wgrad == {1}
         # ... and the PPO loss + the head layer's backward in the forward GEMM's epilogue (ag_split_gemm_loss_heads_bwd)
         assert agent._fused_step.fuse_gemm_loss == gemm_loss
+        # ... with the first layer formed inside that launch too (Hovering's 18 inputs; Tracking's 48 keep ag_mlp_input_layer)
+        assert agent._fused_step.fuse_gemm_input == (gemm_input and gemm_loss and task == "hovering")
     agent.init_tensors()
     agent.obs = agent.env_reset()
     agent.epoch_num = 1
