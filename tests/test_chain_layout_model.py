@@ -150,3 +150,71 @@ def test_chain_forward_backward_layouts():
                 f = 32 * J + (l & 31)
                 want = dW1[f, d] if d < D else (db1[f] if d == D else 0.0)
                 assert abs(G[l, r] - want) < 1e-10
+
+
+def test_first_layer_inside_the_update_gemm_layouts():
+    """csrc/split_gemm.hip, FIN > 0 (ag_split_gemm_input_loss_heads_bwd): the update's forward GEMM keeps its NATURAL orientation
+    (A = activations, lane = batch row; B = W2 planes, lane = output column) but produces its A operand itself, transposed:
+    per block b of 32 features  h1^T[f, row] = W1ext[f, :] . x_ext[row, :]  (weights as A fragments, the lane's input row as B
+    fragments).  Registers 8 q .. 8 q + 7 of that block are then ONE A unit of the main product - chunk 2 b + q, k-half h, slot i
+    <-> feature 32 b + 16 q + perm(h, i) - provided the W2 planes enumerate K the same way (split_in_prepare_kernel)."""
+    rng = np.random.default_rng(1)
+    D, F, R = 18, 256, 32
+    x = rng.normal(size=(R, D)); W1 = rng.normal(size=(F, D)) * 0.3; b1 = rng.normal(size=F) * 0.1
+    W2 = rng.normal(size=(F, F)) * 0.08
+    z1 = x @ W1.T + b1
+    h1 = elu(z1)
+    ref = h1 @ W2.T                                    # [row, out column]
+
+    def feat(c, h, i):                                 # K enumeration of the launch: chunk c, k-half h, slot i -> feature
+        return 32 * (c >> 1) + 16 * (c & 1) + perm(h, i)
+    assert sorted(feat(c, h, i) for c in range(16) for h in range(2) for i in range(8)) == list(range(F))
+
+    # W1ext image as split_in_prepare_kernel lays it out: unit (block b, K step s, h, feature m) = W1ext[32 b + m][16 s + 8 h + i];
+    # (s, h) = (1, 1) - inputs 24..31 - does not exist for D <= 23: the kernel's B fragment is all zero there
+    def w1_unit(b, s, h, m):
+        out = np.zeros(8)
+        for i in range(8):
+            d = 16 * s + 8 * h + i
+            out[i] = W1[32 * b + m, d] if d < D else (b1[32 * b + m] if d == D else 0.0)
+        return out
+
+    def x_unit(row, s, h):                             # the lane's row of inputs, the all-ones column at D
+        out = np.zeros(8)
+        for i in range(8):
+            d = 16 * s + 8 * h + i
+            out[i] = x[row, d] if d < D else (1.0 if d == D else 0.0)
+        return out
+
+    a_units = {}                                       # (chunk, k-half, row) -> the 8 values the producing lane writes to the A stage
+    for b in range(8):
+        hacc = np.zeros((64, 16))
+        for s in range(2):
+            a = np.stack([w1_unit(b, s, l >> 5, l & 31) for l in range(64)])
+            bb = np.stack([x_unit(l & 31, s, l >> 5) for l in range(64)])
+            hacc = mfma(a, bb, hacc)
+        for l in range(64):                            # lane = batch row, register r = feature 32 b + row_of_reg(r, h)
+            for r in range(16):
+                assert abs(hacc[l, r] - z1[l & 31, 32 * b + row_of_reg(r, l >> 5)]) < 1e-12
+        e = elu(hacc)
+        for l in range(64):
+            for q in range(2):
+                a_units[(2 * b + q, l >> 5, l & 31)] = e[l, 8 * q:8 * q + 8]
+                for i in range(8):                     # ... which are exactly the features the launch's K order puts in that unit
+                    assert abs(e[l, 8 * q + i] - h1[l & 31, feat(2 * b + q, l >> 5, i)]) < 1e-12
+    # the h1 rows the kernel writes back: lane (row, h) stores registers 8 q .. + 3 at feature 32 b + 16 q + 4 h and 8 q + 4 .. + 7 at + 8
+    for q in range(2):
+        for h in range(2):
+            assert [perm(h, i) for i in range(4)] == [4 * h + j for j in range(4)]
+            assert [perm(h, i) for i in range(4, 8)] == [8 + 4 * h + j for j in range(4)]
+
+    # main product, natural orientation: one 32 x 32 output tile per column block, K in 16 chunks of 16 slots
+    for nt in range(2):                                # two of the eight column tiles are enough
+        acc = np.zeros((64, 16))
+        for c in range(16):
+            a = np.stack([a_units[(c, l >> 5, l & 31)] for l in range(64)])                        # fragment read: (row, k-half)
+            bfrag = np.stack([[W2[32 * nt + (l & 31), feat(c, l >> 5, i)] for i in range(8)] for l in range(64)])   # chain-ordered planes
+            acc = mfma(a, bfrag, acc)
+        for l in range(64):
+            for r in range(16):
+                assert abs(acc[l, r] - ref[row_of_reg(r, l >> 5), 32 * nt + (l & 31)]) < 1e-10
