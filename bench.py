@@ -510,6 +510,10 @@ def _run_rank(args, world, rank, on_gpu, stage):
                    "hip_graph_rollout": bool(args.graph),
                    "rollout_launches_per_step": getattr(getattr(agent, "_fused_rollout", None), "launches_per_step", None),
                    "hidden_layer_gemm": getattr(fs, "gemm_description", "library f32 GEMM"),
+                   "update_forward_launch": ("first layer + hidden layer + heads + PPO loss + head backward in ONE launch "
+                                             "(ag_split_gemm_input_loss_heads_bwd)" if getattr(fs, "fuse_gemm_input", False) else
+                                             ("hidden layer + heads + PPO loss + head backward in one launch behind ag_mlp_input_layer"
+                                              if getattr(fs, "fuse_gemm_loss", False) else "separate launches")),
                    "gemm_selection": ("TunableOp table airgym_amd/assets/tunableop_gfx950.csv (hipBLASLt / rocBLAS fp32)"
                                       if getattr(agent, "tuned_gemms", False) else "hipBLASLt default heuristic (fp32)")},
         "phases": {"rollout_host_enqueue_s": play, "update_s": update, "final_lr": agent.last_lr,
