@@ -148,3 +148,37 @@ def test_ppo_kernel_entry_points_validate_arguments_before_any_launch(lib):
     assert lib.ag_sum_rows_multi(jobs, 1, p, 1 << 20, None) == unsupported                           # n % 4 != 0
     jobs[0] = N.AgSumJob(p.value, p.value, 4, 8)
     assert lib.ag_sum_rows_multi(jobs, 1, p, 4, None) == inval                                       # scratch too small
+
+
+def test_ctypes_mirrors_of_the_argument_structs_match_the_header(tmp_path):
+    """The structs passed BY POINTER (ag_loss_epilogue, ag_input_layer_args, ag_sum_job, ag_config): size and every field offset of
+    the ctypes mirrors in airgym_amd/_native against what a C compiler makes of include/airgym_hip.h - without a GPU."""
+    import shutil
+    import subprocess
+    from airgym_amd import _native
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    mirrors = {"ag_loss_epilogue": _native.AgLossEpilogue, "ag_input_layer_args": _native.AgInputLayerArgs,
+               "ag_sum_job": _native.AgSumJob, "ag_config": _native.AgConfig}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for cname, mirror in mirrors.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-std=c99", "-o", str(exe), str(src)], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.strip().splitlines():
+        cname, what, val = line.split()
+        mirror = mirrors[cname]
+        if what == "size":
+            assert ctypes.sizeof(mirror) == int(val), (cname, ctypes.sizeof(mirror), val)
+        else:
+            assert getattr(mirror, what).offset == int(val), (cname, what, getattr(mirror, what).offset, val)
+        seen += 1
+    assert seen == sum(len(m._fields_) + 1 for m in mirrors.values())
