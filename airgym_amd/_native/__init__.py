@@ -200,6 +200,12 @@ SYMBOLS = [
     ("ag_split_gemm", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_wgrad_slices", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_wgrad", ctypes.c_int, [_P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_split_wgrad_input_supported", ctypes.c_int, [ctypes.c_int]),
+    ("ag_split_wgrad_input_slices", ctypes.c_int, [ctypes.c_int]),
+    ("ag_split_wgrad_input", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_split_gemm_input_wgrad_recompute_supported", ctypes.c_int, [ctypes.c_int]),
+    ("ag_split_gemm_input_wgrad_recompute", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                           ctypes.c_int, _P]),
     ("ag_split_gemm_input_wgrad_rows", ctypes.c_int, []),
     ("ag_split_gemm_input_wgrad_supported", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_gemm_input_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,

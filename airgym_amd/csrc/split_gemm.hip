@@ -207,6 +207,14 @@ __device__ __forceinline__ void input_wgrad_tile(const f32x16 (&acc)[8], const f
         }
 }
 
+// LDS layout of the recomputing dX epilogue (RC, DIN > 0): [x image, K = rows order: 3 x 4 x XS units][red: WM x 256 x (DIN + 1)
+// floats] over the (idle) stages, then the first-layer image (loaded once, at kernel start) behind whichever is larger
+template <int DIN, int WM>
+constexpr int rc_w1_offset_units() {
+    constexpr int epi = 3 * 4 * (WM * 2 * (DIN + 2)) + (WM * BN * (DIN + 1) * 4 + 15) / 16;
+    return epi > 2 * stage_units(WM * 64) ? epi : 2 * stage_units(WM * 64);
+}
+
 struct SplitEpilogue {
     const float* bias;         // [256] layer bias: added to C (plain), or inside the ELU only (heads)
     const float* Wh;           // heads: [A1, 256]
@@ -246,7 +254,10 @@ struct SplitEpilogue {
 // it), but as stores under this kernel's MFMAs instead of a write-bound launch of its own, and the 201 MB read of it is gone.  The
 // W2 planes of this launch are in the chain's K order (chunk 2 b + q, k-half h, slot i <-> feature 32 b + 16 q + (i & 3) + 8 (i >> 2)
 // + 4 h).  A version that formed the piece on the vector ALU (144 FMAs per thread and chunk) was 0.7 ms per epoch SLOWER.
-template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0>
+// RC (round 5: h1 is recomputed, not stored): with FIN > 0 the launch does not write h1_out; with DIN > 0 the epilogue forms
+// ELU'(h1) from a natural-orientation recomputation of h1 = ELU(W1ext x_ext) on the matrix cores (rc_input_wgrad below) instead of
+// reading the stored activations.
+template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0, bool RC = false>
 __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
                                                                   float* __restrict__ C, int M, const SplitEpilogue ep) {
     constexpr int BM = WM * 64, NT = WM * 128;               // rows per tile, threads per workgroup
@@ -256,6 +267,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     static_assert(A1 == 0 || DIN == 0, "one fused epilogue at a time");
     static_assert((DIN & 1) == 0 && DIN <= 62, "input width: even, at most two 32-wide tiles with the bias column");
     static_assert(FIN == 0 || (WM == 4 && (FIN & 1) == 0 && FIN >= 16 && FIN <= 20), "fused first layer: 256-row tiles, widths 16 / 18 / 20");
+    static_assert(!RC || FIN > 0 || (DIN > 0 && WM == 4 && DIN <= 18), "recomputed h1: the fused forward, or the 256-row dX epilogue (widths <= 18)");
     const float* __restrict__ bias = ep.bias;
     const float* __restrict__ Wh = ep.Wh;
     const float* __restrict__ bh = ep.bh;
@@ -264,6 +276,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
     const int m0 = tile * BM;
+    if constexpr (DIN > 0 && RC) {      // the first-layer image, behind the stages / the epilogue's buffers (visible after the first barrier)
+        uint4* w1d = lds + rc_w1_offset_units<DIN, WM>();
+        for (int u = tid; u < kInImageW1Bytes / 16; u += NT) w1d[u] = ep.w1img[u];
+    }
 
     // ---- global -> register staging for one K chunk
     const int a_row = tid >> 1, a_half = tid & 1;                       // BM rows x 2 k-halves: one 32-byte piece per thread
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     // whole chunk old): features hoff .. + 3 and hoff + 8 .. + 11 of the lane's row
 #define AG_FIN_STORE()                                                                                 \
     do {                                                                                               \
-        if (m0 + frow < M) {                                                                           \
+        if (!RC && m0 + frow < M) {                                                                           \
             float* d_ = ep.h1_out + (size_t)(m0 + frow) * KDIM + hoff;                                 \
             *reinterpret_cast<float4*>(d_) = hs0;                                                      \
             *reinterpret_cast<float4*>(d_ + 8) = hs1;                                                  \
@@ -719,6 +735,146 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
                 else ep.db2_partials[(size_t)tile * BN + c] = v;
             }
         }
+    } else if constexpr (DIN > 0 && RC) {
+        // ---- first-layer backward with h1 RECOMPUTED (round 5; h1 is no longer stored).  Per row tile i and column tile J of the
+        // wave: z1[row, f] = x_ext[row, :] . W1ext[f, :] as a natural-orientation MFMA tile (K = 32: inputs, ones column = bias,
+        // zeros; 2 x 6 split MFMAs; A = the lane's row of x, split once per row tile; B = the first-layer image, the same units the
+        // forward reads as its A operand) lands in exactly the accumulator layout of dh1 (lane = column, registers = rows), so
+        // dz1 = dh1 * ELU'(z1), ELU'(z) = z > 0 ? 1 : e^z, is formed register by register and feeds the K = rows products of
+        // input_wgrad_tile unchanged.  +96 MFMAs per wave and tile; the 128 strided h1 loads per lane (201 MB per launch) are gone.
+        constexpr int RW = DIN + 1;                         // reduction row: DIN weight-gradient entries + the bias gradient
+        constexpr int DW = RW + 1;                          // units per (wm, h): d < RW real, d = RW zeros (lanes >= RW read that one)
+        constexpr int XS = WM * 2 * DW;                     // units per (plane, step)
+        uint4* xp = lds;                                    // [plane 3][step 4][wm WM][h 2][d DW] x 16 B: x, split, in K = rows order
+        float* red = reinterpret_cast<float*>(lds + 3 * 4 * XS);       // [wm WM][BN][RW]
+        const uint4* w1s = lds + rc_w1_offset_units<DIN, WM>();        // [block 8][K step 2][plane 3][h 2][feature 32] x 16 B
+        int late = 0;                                       // (opaque zero, as above)
+        asm volatile("" : "+s"(late) : : "memory");
+        const int m0e = m0 + late;
+        // the lane's rows of x for the two row tiles (natural A fragments: lane = row, K step 0 = inputs 8 h .. 8 h + 7, K step 1 =
+        // inputs 16 .. DIN - 1, the ones column, zeros - lane half 1 holds zeros there)
+        float xr0[2][8], xr1[2][DIN - 16 > 0 ? DIN - 16 : 1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = min(m0e + wm * 64 + i * 32 + l31, M - 1);
+            const float* xrow = ep.x + (size_t)row * DIN;
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                const float2 v2 = reinterpret_cast<const float2*>(xrow + 8 * khalf)[i2];
+                xr0[i][2 * i2] = v2.x;
+                xr0[i][2 * i2 + 1] = v2.y;
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < (DIN - 16) / 2; ++i2) {
+                const float2 v2 = reinterpret_cast<const float2*>(xrow + 16)[i2];
+                xr1[i][2 * i2] = v2.x;
+                xr1[i][2 * i2 + 1] = v2.y;
+            }
+        }
+        for (int u = tid; u < 4 * XS; u += NT) {
+            const int d = u % DW, h = (u / DW) & 1, w2 = (u / (2 * DW)) % WM, st = u / XS;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int row = m0e + w2 * 64 + (st >> 1) * 32 + (e & 3) + 8 * (e >> 2) + 16 * (st & 1) + 4 * h;
+                const float xv = (d < DIN) ? ep.x[(size_t)min(row, M - 1) * DIN + d] : (d == DIN ? 1.0f : 0.0f);
+                v[e] = row < M ? xv : 0.0f;
+            }
+            uint4 p1, p2, p3;
+            split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
+            xp[(0 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p1;
+            xp[(1 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p2;
+            xp[(2 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p3;
+        }
+        __syncthreads();
+        const uint4* xp_lane = xp + (wm * 2 + khalf) * DW + min(l31, RW);
+        float* mine = red + ((size_t)wm * BN + wn * 128 + l31) * RW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 xq[2][3];
+            {
+                float x1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x1[e] = 0.0f;
+#pragma unroll
+                for (int e = 0; e < DIN - 16; ++e) x1[e] = khalf == 0 ? xr1[i][e] : 0.0f;
+                x1[DIN - 16] = khalf == 0 ? 1.0f : 0.0f;
+                uint4 q1, q2, q3;
+                split8(make_float4(xr0[i][0], xr0[i][1], xr0[i][2], xr0[i][3]), make_float4(xr0[i][4], xr0[i][5], xr0[i][6], xr0[i][7]),
+                       q1, q2, q3);
+                xq[0][0] = *reinterpret_cast<const bf16x8*>(&q1);
+                xq[0][1] = *reinterpret_cast<const bf16x8*>(&q2);
+                xq[0][2] = *reinterpret_cast<const bf16x8*>(&q3);
+                split8(make_float4(x1[0], x1[1], x1[2], x1[3]), make_float4(x1[4], x1[5], x1[6], x1[7]), q1, q2, q3);
+                xq[1][0] = *reinterpret_cast<const bf16x8*>(&q1);
+                xq[1][1] = *reinterpret_cast<const bf16x8*>(&q2);
+                xq[1][2] = *reinterpret_cast<const bf16x8*>(&q3);
+            }
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                const int blk = wn * 4 + J;                 // feature block of this column tile
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    bf16x8 wb[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const uint4 u_ = w1s[(((blk * 2 + st) * 3 + p) * 2 + khalf) * 32 + l31];
+                        wb[p] = *reinterpret_cast<const bf16x8*>(&u_);
+                    }
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][0], wb[2], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][2], wb[0], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][1], wb[1], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][0], wb[1], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][1], wb[0], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][0], wb[0], z, 0, 0, 0);
+                }
+                f32x16 g;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float dz[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float zz = z[8 * ks + e];
+                        dz[e] = acc[i * 4 + J][8 * ks + e] * (zz > 0.0f ? 1.0f : __builtin_amdgcn_exp2f(zz * 1.4426950408889634f));
+                    }
+                    uint4 b1, b2, b3;                       // rows past M need no masking here: their x rows are zero
+                    split8(make_float4(dz[0], dz[1], dz[2], dz[3]), make_float4(dz[4], dz[5], dz[6], dz[7]), b1, b2, b3);
+                    const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(&b1), c2 = *reinterpret_cast<const bf16x8*>(&b2),
+                                 c3 = *reinterpret_cast<const bf16x8*>(&b3);
+                    const int s = 2 * i + ks;
+                    const uint4 ua1 = xp_lane[(0 * 4 + s) * XS], ua2 = xp_lane[(1 * 4 + s) * XS], ua3 = xp_lane[(2 * 4 + s) * XS];
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1), a2 = *reinterpret_cast<const bf16x8*>(&ua2),
+                                 a3 = *reinterpret_cast<const bf16x8*>(&ua3);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, c1, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c3, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c2, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c1, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c2, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c1, g, 0, 0, 0);
+                }
+                // g: column c = this lane's column of tile J, rows d = (r & 3) + 8 (r >> 2) + 4 h; d = DIN: the bias gradient.  The
+                // second row tile adds to the first one's entry (lane-private slot, fixed order: deterministic)
+                float* dst = mine + J * 32 * RW;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (d < RW) dst[d] = (i == 0) ? g[r] : dst[d] + g[r];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one column tile at a time
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BN * RW; idx += NT) {     // the WM row blocks in a fixed order
+            const int c = idx / RW, d = idx - c * RW;
+            const float v = ((red[idx] + red[BN * RW + idx]) + red[2 * BN * RW + idx]) + red[3 * BN * RW + idx];
+            if (d < DIN) ep.dw_partials[((size_t)tile * BN + c) * DIN + d] = v;
+            else ep.db_partials[(size_t)tile * BN + c] = v;
+        }
     } else if constexpr (DIN > 0) {
         constexpr int RW = DIN + 1;                         // reduction row: DIN weight-gradient entries + the bias gradient
         constexpr int NDT = (RW + 31) / 32;                 // 32-wide tiles of input columns (1: Hovering's 18; 2: Tracking's 48)
@@ -851,11 +1007,13 @@ constexpr size_t split_lds_bytes() {
     return stages > epi ? stages : epi;
 }
 
-template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0>
+template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0, bool RC = false>
 static int launch_split_any(const float* A_dev, const void* planes_dev, float* C_dev, int M, const SplitEpilogue& ep, void* stream) {
     static bool attr_set[64] = {};      // per device ordinal: the dynamic-LDS limit is an attribute of (function, device)
-    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM, LOSS, FIN>;
-    constexpr size_t lds_bytes = split_lds_bytes<DIN, WM>() + (FIN > 0 ? (size_t)kInImageW1Bytes : 0);
+    auto* fn = split_gemm_kernel<HAS_BIAS, A1, DIN, WM, LOSS, FIN, RC>;
+    constexpr size_t lds_bytes = (DIN > 0 && RC) ? (size_t)rc_w1_offset_units<DIN, WM>() * 16 + (size_t)kInImageW1Bytes
+                                                 : split_lds_bytes<DIN, WM>() + (FIN > 0 ? (size_t)kInImageW1Bytes : 0);
+    static_assert(lds_bytes <= 160 * 1024, "LDS per workgroup");
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
@@ -939,7 +1097,7 @@ extern "C" int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in,
                                                   int M, int n, int k, int A1, void* stream) {
     if (!in || !image_dev || !bias_dev || !Wh_dev || !bh_dev || !dZ_dev || !L || M <= 0) return AG_ERR_INVALID_ARG;
     if (in->struct_size != sizeof(ag_input_layer_args) || L->struct_size != sizeof(ag_loss_epilogue)) return AG_ERR_INVALID_ARG;
-    if (!in->obs_dev || !in->h1_dev) return AG_ERR_INVALID_ARG;
+    if (!in->obs_dev) return AG_ERR_INVALID_ARG;          // h1_dev NULL: h1 is not written (the backward recomputes it)
     const bool norm = in->mean_dev != nullptr;
     if (norm != (in->var_dev != nullptr) || norm != (in->xn_dev != nullptr)) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM || A1 != 5 || !ag_split_gemm_input_fwd_supported(in->D)) return AG_ERR_UNSUPPORTED;
@@ -959,7 +1117,8 @@ extern "C" int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in,
     ep.in_mean = in->mean_dev; ep.in_var = in->var_dev; ep.w1img = reinterpret_cast<const uint4*>(image_dev); ep.xn_out = in->xn_dev;
     ep.h1_out = in->h1_dev; ep.in_eps = in->eps; ep.in_clip = in->clip;
     const void* planes_dev = reinterpret_cast<const char*>(image_dev) + kInImageW1Bytes;
-#define AG_SGF(F) launch_split_any<true, 5, 0, 4, true, F>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream)
+#define AG_SGF(F) (in->h1_dev ? launch_split_any<true, 5, 0, 4, true, F, false>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream) \
+                              : launch_split_any<true, 5, 0, 4, true, F, true>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream))
     switch (in->D) {
         case 16: return AG_SGF(16);
         case 18: return AG_SGF(18);
@@ -988,6 +1147,23 @@ extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes
         default: return AG_SG_DISPATCH(AG_SGI(48, 2), AG_SGI(48, 4));
     }
 #undef AG_SGI
+}
+
+// widths whose first-layer backward can recompute h1 in the dX epilogue (256-row tiles; the LDS layout holds D + 2 <= 20 columns)
+extern "C" int ag_split_gemm_input_wgrad_recompute_supported(int D) { return (g_split_wm == 4 && (D == 16 || D == 18)) ? 1 : 0; }
+
+extern "C" int ag_split_gemm_input_wgrad_recompute(const float* dZ_dev, const void* planes_dev, const void* image_dev, const float* x_dev,
+                                                   float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D,
+                                                   void* stream) {
+    if (!dZ_dev || !planes_dev || !image_dev || !x_dev || !dw_partials_dev || !db_partials_dev || M <= 0) return AG_ERR_INVALID_ARG;
+    if (n != BN || k != KDIM || !ag_split_gemm_input_wgrad_recompute_supported(D)) return AG_ERR_UNSUPPORTED;
+    if (((uintptr_t)dZ_dev & 15) || ((uintptr_t)planes_dev & 15) || ((uintptr_t)image_dev & 15) || ((uintptr_t)x_dev & 7))
+        return AG_ERR_INVALID_ARG;
+    SplitEpilogue ep = {};
+    ep.x = x_dev; ep.dw_partials = dw_partials_dev; ep.db_partials = db_partials_dev;
+    ep.w1img = reinterpret_cast<const uint4*>(image_dev);
+    if (D == 16) return launch_split_any<false, 0, 16, 4, false, 0, true>(dZ_dev, planes_dev, nullptr, M, ep, stream);
+    return launch_split_any<false, 0, 18, 4, false, 0, true>(dZ_dev, planes_dev, nullptr, M, ep, stream);
 }
 
 extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,

@@ -225,6 +225,336 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// split_wgrad_fin_kernel: the same weight gradient with its X operand - the first layer's activations h1 = ELU(W1 xn + b1) of a
+// [FIN -> 256 -> 256] trunk - PRODUCED on the matrix cores from the FIN-wide network input instead of read from HBM (round 5:
+// h1 [M, 256] is no longer stored by the forward launch; 201 MB of the 403 MB this kernel read per minibatch are gone, the other
+// 201 MB write of the forward with them).
+//
+//   * 8 waves as 1 x 8: wave w owns ALL 256 rows (co) of dW and the 32 columns ci = 32 w .. 32 w + 31 (eight 32 x 32 accumulator
+//     tiles, 128 registers).  Then the X operand never touches LDS: h1 for a block of 32 minibatch rows x the wave's 32 features
+//     is one natural-orientation MFMA tile D[row, feature] = x_ext[row, :] . W1ext[feature, :]  (K = 32: the FIN inputs, an all-ones
+//     column that carries the bias, zeros; exact 3-way split, 2 x 6 MFMAs - the first layer of split_gemm.hip's FIN block with the
+//     operand roles swapped), and a lane of that tile holds for ITS column (feature l31) the rows (r & 3) + 8 (r >> 2) + 4 h:
+//     registers 0..7 / 8..15 are, after ELU and the split, exactly the B fragment (K = rows, N = feature) of the first / second
+//     16-row chunk of the block, in the K order  slot e <-> row (e & 3) + 8 (e >> 2) + 4 h  of the chunk.
+//   * The dZ image (A operand, K = rows) is staged as in split_wgrad_kernel, with its loaders fetching rows in that same order
+//     (wave (q, lh, lg): rows 16 q + 4 lh + 8 lg .. + 3 of the 32-row block), all eight waves loading one 4-row quad per block.
+//   * The loop runs over 32-row blocks (two chunks), one barrier per block; LDS = 4 chunk slots of the dZ image (96 KB) + the
+//     48 KB first-layer image of ag_split_gemm_input_prepare (read as B fragments: same content as the forward's A fragments).
+//   * +12.5 % MFMAs (12 per 96), no X-side loads, splits or LDS stores; every wave reads all eight dZ row tiles of a chunk
+//     (24 fragment reads per 48 MFMAs instead of 18).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kW1ImageUnits = 8 * 2 * 3 * 2 * 32;                       // [block 8][K step 2][plane 3][h 2][feature 32] x 16 B
+constexpr size_t kWgradFinLds = (size_t)(4 * OP_UNITS + kW1ImageUnits) * 16;      // 144 KB
+
+__device__ __forceinline__ float wg_elu(float z) {      // split_gemm.hip sg_elu
+    return z > 0.f ? z : __builtin_amdgcn_exp2f(z * 1.4426950408889634f) - 1.0f;
+}
+
+template <int FIN>
+__global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __restrict__ dZ, const float* __restrict__ X,
+                                                                  const uint4* __restrict__ w1img, float* __restrict__ partials, int M,
+                                                                  int blocks_per_slice) {
+    static_assert((FIN & 1) == 0 && FIN >= 16 && FIN <= 30, "input width: even, 16 .. 30 (+ the bias column: K = 32)");
+    extern __shared__ uint4 lds[];           // [4 chunk slots][OP_UNITS] dZ image | [kW1ImageUnits] first-layer image
+    uint4* const w1s = lds + 4 * OP_UNITS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int total_blocks = M / 32;         // M is a multiple of 32 (checked by the host): no ragged block, no row guards
+    const int b_begin = min((int)blockIdx.x * blocks_per_slice, total_blocks);
+    const int n = min(b_begin + blocks_per_slice, total_blocks) - b_begin;      // 32-row blocks of this slice (may be 0)
+
+    for (int u = tid; u < kW1ImageUnits; u += 512) w1s[u] = w1img[u];
+
+    // ---- dZ loader role: chunk q of the block, k-half lh, slot group lg -> rows 16 q + 4 lh + 8 lg .. + 3
+    const int lq = wave >> 2, lh = (wave >> 1) & 1, lg = wave & 1;
+    float4 v[4];
+#define AG_WF_LOAD(t_)                                                                               \
+    do {                                                                                             \
+        const float* src_ = dZ + (size_t)((b_begin + (t_)) * 32 + 16 * lq + 4 * lh + 8 * lg) * WN;   \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                \
+            v[r] = reinterpret_cast<const float4*>(src_ + (size_t)r * WN)[lane];                     \
+    } while (0)
+#define AG_WF_HALF(x0, x1, x2, x3, q_)                                                               \
+    do {                                                                                             \
+        uint2 h1_, h2_, h3_;                                                                         \
+        split_pair(x0, x1, h1_.x, h2_.x, h3_.x);                                                     \
+        split_pair(x2, x3, h1_.y, h2_.y, h3_.y);                                                     \
+        dst_[(0 * 2 * WN + (q_) * 64) * 2] = h1_;                                                    \
+        dst_[(1 * 2 * WN + (q_) * 64) * 2] = h2_;                                                    \
+        dst_[(2 * 2 * WN + (q_) * 64) * 2] = h3_;                                                    \
+    } while (0)
+    // block slot bs (0 / 1) -> chunk slots 2 bs, 2 bs + 1
+#define AG_WF_WRITE(bs_)                                                                             \
+    do {                                                                                             \
+        uint2* dst_ = reinterpret_cast<uint2*>(lds + (2 * (bs_) + lq) * OP_UNITS + lh * WN + lane) + lg; \
+        AG_WF_HALF(v[0].x, v[1].x, v[2].x, v[3].x, 0);                                               \
+        AG_WF_HALF(v[0].y, v[1].y, v[2].y, v[3].y, 1);                                               \
+        AG_WF_HALF(v[0].z, v[1].z, v[2].z, v[3].z, 2);                                               \
+        AG_WF_HALF(v[0].w, v[1].w, v[2].w, v[3].w, 3);                                               \
+    } while (0)
+
+    // ---- X producer role: the lane's row (l31 of the block) of network inputs, K step 0 = inputs 8 h .. 8 h + 7, K step 1 =
+    //      inputs 16 .. FIN - 1, the all-ones column at FIN, zeros (lane half 1: all zeros)
+    float xr0[8], xr1[FIN - 16 > 0 ? FIN - 16 : 1];
+#define AG_WF_XLOAD(t_)                                                                              \
+    do {                                                                                             \
+        const float* xrow_ = X + (size_t)((b_begin + (t_)) * 32 + l31) * FIN;                        \
+        _Pragma("unroll") for (int i2 = 0; i2 < 4; ++i2) {                                           \
+            const float2 v2_ = reinterpret_cast<const float2*>(xrow_ + 8 * khalf)[i2];               \
+            xr0[2 * i2] = v2_.x;                                                                     \
+            xr0[2 * i2 + 1] = v2_.y;                                                                 \
+        }                                                                                            \
+        _Pragma("unroll") for (int i2 = 0; i2 < (FIN - 16) / 2; ++i2) {                              \
+            const float2 v2_ = reinterpret_cast<const float2*>(xrow_ + 16)[i2];                      \
+            xr1[2 * i2] = v2_.x;                                                                     \
+            xr1[2 * i2 + 1] = v2_.y;                                                                 \
+        }                                                                                            \
+    } while (0)
+    bf16x8 xq[2][3], bfrag[2][3];
+    f32x16 hacc;
+#define AG_WF_XSPLIT()                                                                               \
+    do {                                                                                             \
+        float x1_[8];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) x1_[i] = 0.0f;                                 \
+        _Pragma("unroll") for (int i = 0; i < FIN - 16; ++i) x1_[i] = khalf == 0 ? xr1[i] : 0.0f;    \
+        x1_[FIN - 16] = khalf == 0 ? 1.0f : 0.0f;                                                    \
+        uint4 q1_, q2_, q3_;                                                                         \
+        split8(make_float4(xr0[0], xr0[1], xr0[2], xr0[3]), make_float4(xr0[4], xr0[5], xr0[6], xr0[7]), q1_, q2_, q3_); \
+        xq[0][0] = *reinterpret_cast<const bf16x8*>(&q1_);                                           \
+        xq[0][1] = *reinterpret_cast<const bf16x8*>(&q2_);                                           \
+        xq[0][2] = *reinterpret_cast<const bf16x8*>(&q3_);                                           \
+        split8(make_float4(x1_[0], x1_[1], x1_[2], x1_[3]), make_float4(x1_[4], x1_[5], x1_[6], x1_[7]), q1_, q2_, q3_); \
+        xq[1][0] = *reinterpret_cast<const bf16x8*>(&q1_);                                           \
+        xq[1][1] = *reinterpret_cast<const bf16x8*>(&q2_);                                           \
+        xq[1][2] = *reinterpret_cast<const bf16x8*>(&q3_);                                           \
+    } while (0)
+    // h1 tile of the block (natural orientation: A = x, B = W1ext; same product order as the forward), ELU, split -> the B
+    // fragments of the block's two chunks
+#define AG_WF_PRODUCE_MFMA()                                                                         \
+    do {                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;                               \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                           \
+            bf16x8 wb_[3];                                                                           \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                          \
+                const uint4 u_ = w1s[(((wave * 2 + s_) * 3 + p) * 2 + khalf) * 32 + l31];            \
+                wb_[p] = *reinterpret_cast<const bf16x8*>(&u_);                                      \
+            }                                                                                        \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb_[2], hacc, 0, 0, 0);        \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][2], wb_[0], hacc, 0, 0, 0);        \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb_[1], hacc, 0, 0, 0);        \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb_[1], hacc, 0, 0, 0);        \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb_[0], hacc, 0, 0, 0);        \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb_[0], hacc, 0, 0, 0);        \
+        }                                                                                            \
+    } while (0)
+    // ELU + split of the tile -> the B fragments of its block's two chunks
+#define AG_WF_PRODUCE_FINISH(dst)                                                                    \
+    do {                                                                                             \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                           \
+            float e_[8];                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) e_[i] = wg_elu(hacc[8 * q_ + i]);          \
+            uint4 p1_, p2_, p3_;                                                                     \
+            split8(make_float4(e_[0], e_[1], e_[2], e_[3]), make_float4(e_[4], e_[5], e_[6], e_[7]), p1_, p2_, p3_); \
+            dst[q_][0] = *reinterpret_cast<const bf16x8*>(&p1_);                                     \
+            dst[q_][1] = *reinterpret_cast<const bf16x8*>(&p2_);                                     \
+            dst[q_][2] = *reinterpret_cast<const bf16x8*>(&p3_);                                     \
+        }                                                                                            \
+    } while (0)
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    // one chunk: the eight dZ row tiles against the chunk's B fragment (registers); products smallest first
+#define AG_WF_COMPUTE(slot_, q_)                                                                     \
+    do {                                                                                             \
+        const uint4* sa_ = lds + (slot_) * OP_UNITS + khalf * WN + l31;                              \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                              \
+            const uint4 ua0_ = sa_[(0 * 2) * WN + i * 32];                                           \
+            const uint4 ua1_ = sa_[(1 * 2) * WN + i * 32];                                           \
+            const uint4 ua2_ = sa_[(2 * 2) * WN + i * 32];                                           \
+            const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(&ua0_);                              \
+            const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(&ua1_);                              \
+            const bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(&ua2_);                              \
+            f32x16& d_ = acc[i];                                                                     \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[q_][0], d_, 0, 0, 0);            \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][2], d_, 0, 0, 0);            \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[q_][1], d_, 0, 0, 0);            \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[q_][0], d_, 0, 0, 0);            \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][1], d_, 0, 0, 0);            \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][0], d_, 0, 0, 0);            \
+        }                                                                                            \
+    } while (0)
+
+    // the same in pieces, for the hand-ordered main loop: one dZ row tile of a chunk (3 fragment reads + 6 MFMAs), optionally with
+    // three MFMAs of the next block's production riding between its pairs
+#define AG_WF_TILE_READ(slot_, i_)                                                                   \
+        const uint4* sa_ = lds + (slot_) * OP_UNITS + khalf * WN + l31;                              \
+        const uint4 ua0_ = sa_[(0 * 2) * WN + (i_) * 32];                                            \
+        const uint4 ua1_ = sa_[(1 * 2) * WN + (i_) * 32];                                            \
+        const uint4 ua2_ = sa_[(2 * 2) * WN + (i_) * 32];                                            \
+        const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(&ua0_);                                  \
+        const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(&ua1_);                                  \
+        const bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(&ua2_);                                  \
+        f32x16& d_ = acc[i_]
+#define AG_WF_TILE(slot_, q_, i_)                                                                    \
+    do {                                                                                             \
+        AG_WF_TILE_READ(slot_, i_);                                                                  \
+        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[q_][0], d_, 0, 0, 0);                \
+        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][2], d_, 0, 0, 0);                \
+        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[q_][1], d_, 0, 0, 0);                \
+        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[q_][0], d_, 0, 0, 0);                \
+        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][1], d_, 0, 0, 0);                \
+        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][0], d_, 0, 0, 0);                \
+    } while (0)
+    // production MFMAs k .. k + 2 (of 6) of K step s_: (x1 w3, x3 w1, x2 w2 | x1 w2, x2 w1, x1 w1), the forward's order
+#define AG_WF_PROD3(s_, half_)                                                                       \
+    do {                                                                                             \
+        if ((half_) == 0) {                                                                          \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][2], hacc, 0, 0, 0);     \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][2], wb[s_][0], hacc, 0, 0, 0);     \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][1], hacc, 0, 0, 0);     \
+        } else {                                                                                     \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][1], hacc, 0, 0, 0);     \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][0], hacc, 0, 0, 0);     \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][0], hacc, 0, 0, 0);     \
+        }                                                                                            \
+    } while (0)
+#define AG_WF_WREAD(s_)                                                                              \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                  \
+        const uint4 u_ = w1s[(((wave * 2 + (s_)) * 3 + p) * 2 + khalf) * 32 + l31];                  \
+        wb[s_][p] = *reinterpret_cast<const bf16x8*>(&u_);                                           \
+    }
+    // issue-order groups (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read, 0x200 DS write, 0x020 VMEM read)
+#define AG_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0)
+
+    // ---- prologue: block 0 staged and its B fragments produced; block 1 requested
+    if (n > 0) {
+        AG_WF_LOAD(0);
+        AG_WF_XLOAD(0);
+        AG_WF_WRITE(0);
+        AG_WF_XSPLIT();
+        const int t1 = min(1, n - 1);
+        AG_WF_LOAD(t1);
+        AG_WF_XLOAD(t1);
+    }
+    __syncthreads();                         // (also: the first-layer image is in LDS)
+    if (n > 0) {
+        AG_WF_PRODUCE_MFMA();
+        AG_WF_PRODUCE_FINISH(bfrag);
+    }
+    // ---- main loop over 32-row blocks, software-pipelined: while block t is multiplied out of slot t & 1, block t + 1's X side is
+    //      produced (its 12 MFMAs ride among the first chunk's 48, its ELU + split among the second chunk's) and its dZ side is
+    //      split into the other slot (second chunk); the loads of block t + 2 follow the registers they refill.  One basic block
+    //      per trip; the last trips re-stage the last block (harmless: nobody reads it).
+#pragma unroll 1
+    for (int t = 0; t < n; ++t) {
+        const int bs = t & 1;
+        const int t2 = min(t + 2, n - 1);
+        // ---- first chunk: tiles 0 .. 3 carry the split of block t + 1's inputs (VALU), tiles 4 .. 7 its 12 production MFMAs
+        AG_WF_TILE(2 * bs, 0, 0);
+        AG_WF_TILE(2 * bs, 0, 1);
+        AG_WF_TILE(2 * bs, 0, 2);
+        AG_WF_TILE(2 * bs, 0, 3);
+        AG_WF_XSPLIT();                         // x of block t + 1 (requested a block ago)
+        AG_WF_XLOAD(t2);
+        bf16x8 wb[2][3];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
+        AG_WF_WREAD(0);
+        AG_WF_WREAD(1);
+#define AG_WF_TILE_P(i_, s_)                                                                         \
+        do {                                                                                         \
+            AG_WF_TILE_READ(2 * bs, i_);                                                             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[0][0], d_, 0, 0, 0);             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][2], d_, 0, 0, 0);             \
+            AG_WF_PROD3(s_, (i_) & 1);                                                               \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][1], d_, 0, 0, 0);             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][0], d_, 0, 0, 0);             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][1], d_, 0, 0, 0);             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][0], d_, 0, 0, 0);             \
+        } while (0)
+        AG_WF_TILE_P(4, 0);
+        AG_WF_TILE_P(5, 0);
+        AG_WF_TILE_P(6, 1);
+        AG_WF_TILE_P(7, 1);
+#undef AG_WF_TILE_P
+        AG_SGB(0x100, 6);                       // fragments of tiles 0, 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {           // tiles 0 .. 3: one MFMA, three VALU (the 60-odd of the input split + addresses)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                AG_SGB(0x008, 1);
+                AG_SGB(0x002, 3);
+            }
+            AG_SGB(0x100, 3);                   // fragments of tile i + 2
+        }
+        AG_SGB(0x020, 4 + (FIN - 16) / 2);      // the next-but-one block's inputs (their registers were just split)
+        AG_SGB(0x100, 6);                       // first-layer fragments (both K steps)
+#pragma unroll
+        for (int i = 4; i < 8; ++i) {           // tiles 4 .. 7: nine MFMAs each (six of the chunk, three of the production)
+            AG_SGB(0x008, 9);
+            if (i < 6) AG_SGB(0x100, 3);        // fragments of tile i + 2
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- second chunk: ELU + split of the produced tile (B fragments of block t + 1) and the split of its dZ quad into the
+        //      other slot, spread under the 48 MFMAs; then the loads that refill the quad's registers
+        bf16x8 bnext[2][3];
+        AG_WF_PRODUCE_FINISH(bnext);
+        AG_WF_COMPUTE(2 * bs + 1, 1);
+        AG_WF_WRITE(bs ^ 1);                    // dZ of block t + 1 (requested at the end of the previous trip)
+        AG_WF_LOAD(t2);
+        AG_SGB(0x100, 6);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                AG_SGB(0x008, 1);
+                AG_SGB(0x002, 5);
+            }
+            if (i < 6) AG_SGB(0x100, 3);
+            if (i >= 2) AG_SGB(0x200, 2);
+        }
+        AG_SGB(0x020, 4);
+#pragma unroll
+        for (int q_ = 0; q_ < 2; ++q_)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfrag[q_][p] = bnext[q_][p];
+        __syncthreads();
+    }
+#undef AG_SGB
+#undef AG_WF_WREAD
+#undef AG_WF_PROD3
+#undef AG_WF_TILE
+#undef AG_WF_TILE_READ
+#undef AG_WF_COMPUTE
+#undef AG_WF_PRODUCE_FINISH
+#undef AG_WF_PRODUCE_MFMA
+#undef AG_WF_XSPLIT
+#undef AG_WF_XLOAD
+#undef AG_WF_WRITE
+#undef AG_WF_HALF
+#undef AG_WF_LOAD
+
+    // ---- epilogue.  A-image unit u holds logical row co = 4 (u & 63) + (u >> 6); this wave's columns are ci = 32 wave + l31
+    float* __restrict__ out = partials + (size_t)blockIdx.x * WN * WN + 32 * wave + l31;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int co = 4 * (u & 63) + (u >> 6);
+            out[(size_t)co * WN] = acc[i][r];
+        }
+    }
+}
+
+
 int device_cus() {
     static int cus[64] = {};
     int dev = 0;
@@ -275,5 +605,50 @@ extern "C" int ag_split_wgrad(const float* dZ_dev, const float* X_dev, float* pa
     else
         hipLaunchKernelGGL(split_wgrad_kernel<false>, dim3(slices), dim3(512), kWgradLds, (hipStream_t)stream, dZ_dev, X_dev,
                            partials_dev, M, cps);
+    return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+// ---- the weight gradient with its X operand produced from the network input (split_wgrad_fin_kernel)
+extern "C" int ag_split_wgrad_input_supported(int D) { return (D == 16 || D == 18 || D == 20) ? 1 : 0; }
+
+// one workgroup per CU, never more slices than 32-row blocks
+extern "C" int ag_split_wgrad_input_slices(int M) {
+    if (M <= 0) return 0;
+    const int blocks = (M + 31) / 32;
+    const int s = device_cus();
+    return blocks < s ? blocks : s;
+}
+
+extern "C" int ag_split_wgrad_input(const float* dZ_dev, const float* x_dev, const void* image_dev, float* partials_dev, int M, int n,
+                                    int k, int D, int slices, void* stream) {
+    if (!dZ_dev || !x_dev || !image_dev || !partials_dev || M <= 0 || slices <= 0) return AG_ERR_INVALID_ARG;
+    if (n != WN || k != WN || !ag_split_wgrad_input_supported(D)) return AG_ERR_UNSUPPORTED;
+    if (((uintptr_t)dZ_dev | (uintptr_t)image_dev | (uintptr_t)partials_dev) & 15) return AG_ERR_INVALID_ARG;
+    if ((uintptr_t)x_dev & 7) return AG_ERR_INVALID_ARG;
+    if (M % 32 != 0) return AG_ERR_UNSUPPORTED;      // whole 32-row blocks only
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kWgradFinLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<18>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kWgradFinLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<20>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kWgradFinLds) != hipSuccess)
+            return AG_ERR_HIP;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const int blocks = M / 32;
+    const int bps = (blocks + slices - 1) / slices;
+#define AG_WF_LAUNCH(F)                                                                                                        \
+    hipLaunchKernelGGL(split_wgrad_fin_kernel<F>, dim3(slices), dim3(512), kWgradFinLds, (hipStream_t)stream, dZ_dev, x_dev,   \
+                       (const uint4*)image_dev, partials_dev, M, bps)
+    switch (D) {
+        case 16: AG_WF_LAUNCH(16); break;
+        case 18: AG_WF_LAUNCH(18); break;
+        default: AG_WF_LAUNCH(20); break;
+    }
+#undef AG_WF_LAUNCH
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }

@@ -264,7 +264,8 @@ class A2CAgent:
         self.schedule_type = config.get("schedule_type", "legacy")
         if self.is_adaptive_lr:
             self.kl_threshold = config["kl_threshold"]
-            self.scheduler = schedulers.AdaptiveScheduler(self.kl_threshold)
+            self.scheduler = schedulers.AdaptiveScheduler(self.kl_threshold, min_lr=config.get("min_lr", 1e-6),
+                                                          max_lr=config.get("max_lr", 1e-2))
         elif self.linear_lr:
             self.scheduler = schedulers.LinearScheduler(float(config["learning_rate"]),
                                                         max_steps=self.max_epochs if self.max_epochs != -1 else self.max_frames,

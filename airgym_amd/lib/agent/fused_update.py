@@ -156,6 +156,12 @@ class FusedMLPStep:
                                       and SplitGemm256.applies(self.layers[1][0], agent.config)
                                       and self.layers[0][0].shape[0] == 256
                                       and bool(self.lib.ag_split_gemm_input_wgrad_supported(D)))
+        # ... and (round 5) with h1 never stored: the forward launch skips the 201 MB write, the dX epilogue and the weight gradient
+        # RECOMPUTE it from the D-wide inputs on the matrix cores (ag_split_gemm_input_wgrad_recompute, ag_split_wgrad_input)
+        self.recompute_h1 = (self.fuse_gemm_input and self.fuse_gemm_input_wgrad and bool(agent.config.get("recompute_h1", True))
+                             and self._split_wgrad_ok(self.layers[1][0], agent.config) and M % 32 == 0
+                             and bool(self.lib.ag_split_gemm_input_wgrad_recompute_supported(D))
+                             and bool(self.lib.ag_split_wgrad_input_supported(D)))
         self.fuse_input_wgrad = L >= 2 and (self.lib.ag_input_wgrad_rows(D) > 0 or self.fuse_gemm_input_wgrad)
         if self.fuse_gemm_input_wgrad:
             irows = self.lib.ag_split_gemm_input_wgrad_rows()
@@ -176,7 +182,8 @@ class FusedMLPStep:
                 self.wgrad_partials.append(torch.empty(self.in_wg_blocks, C, K, **f))
             elif self._split_wgrad_ok(w, agent.config):
                 # ag_split_wgrad: one partial per row slice (= per CU), each operand read once (csrc/split_wgrad.hip)
-                self.wgrad_partials.append(torch.empty(self.lib.ag_split_wgrad_slices(M), C, K, **f))
+                ns = self.lib.ag_split_wgrad_input_slices(M) if (li == 1 and self.recompute_h1) else self.lib.ag_split_wgrad_slices(M)
+                self.wgrad_partials.append(torch.empty(ns, C, K, **f))
                 self.split_wgrad.add(li)
             else:
                 self.wgrad_partials.append(torch.empty(SPLIT_K, C, K, **f))
@@ -256,7 +263,7 @@ class FusedMLPStep:
             in_args.mean_dev = rms.running_mean.data_ptr() if rms is not None else None
             in_args.var_dev = rms.running_var.data_ptr() if rms is not None else None
             in_args.xn_dev = self.xn.data_ptr() if rms is not None else None
-            in_args.h1_dev = self.h[0].data_ptr()
+            in_args.h1_dev = None if self.recompute_h1 else self.h[0].data_ptr()
             in_args.eps, in_args.clip = (float(rms.epsilon) if rms is not None else 0.0), 5.0
             x = self.xn if rms is not None else obs
         elif self.fuse_input:       # normalise + Linear(D -> C0) + ELU in one pass
@@ -387,6 +394,16 @@ class FusedMLPStep:
             else:
                 N.check(lib.ag_elu_bwd_bias(dh.data_ptr(), h.data_ptr(), dz.data_ptr(), parts.data_ptr(), M, C, st),
                         "ag_elu_bwd_bias")
+            if li == 1 and self.recompute_h1:
+                # X operand (h1) and ELU'(h1) are produced from the network inputs + the first-layer image of the forward launch
+                wp, img = self.wgrad_partials[1], self.split[1].in_image
+                N.check(lib.ag_split_wgrad_input(dz.data_ptr(), inputs[0].data_ptr(), img.data_ptr(), wp.data_ptr(), M, C, K,
+                                                 inputs[0].shape[1], wp.shape[0], st), "ag_split_wgrad_input")
+                N.check(lib.ag_split_gemm_input_wgrad_recompute(dz.data_ptr(), self.split[1].bwd.data_ptr(), img.data_ptr(),
+                                                                inputs[0].data_ptr(), self.wgrad_partials[0].data_ptr(),
+                                                                self.bias_partials[0].data_ptr(), M, 256, 256, inputs[0].shape[1], st),
+                        "ag_split_gemm_input_wgrad_recompute")
+                break
             if li in self.split_wgrad:
                 wp = self.wgrad_partials[li]
                 N.check(lib.ag_split_wgrad(dz.data_ptr(), xin.data_ptr(), wp.data_ptr(), M, C, K, wp.shape[0], st), "ag_split_wgrad")

@@ -13,9 +13,11 @@ class IdentityScheduler(RLScheduler):
 
 
 class AdaptiveScheduler(RLScheduler):
-    def __init__(self, kl_threshold=0.008):
-        self.min_lr = 1e-6
-        self.max_lr = 1e-2
+    def __init__(self, kl_threshold=0.008, min_lr=1e-6, max_lr=1e-2):
+        # bounds: the reference hard-codes [1e-6, 1e-2] (lib/core/schedulers.py:19-23); here they are also YAML keys
+        # (`min_lr`, `max_lr` beside `kl_threshold`), defaults unchanged
+        self.min_lr = float(min_lr)
+        self.max_lr = float(max_lr)
         self.kl_threshold = kl_threshold
 
     def update(self, current_lr, entropy_coef, epoch, frames, kl_dist, **kwargs):

@@ -68,6 +68,7 @@ def build_params(args, world_size):
     c["use_mlp_chain"] = bool(getattr(args, "mlp_chain", 1))
     c["fuse_gemm_loss"] = bool(getattr(args, "fuse_gemm_loss", 1))
     c["fuse_gemm_input"] = bool(getattr(args, "fuse_gemm_input", 1))
+    c["recompute_h1"] = bool(getattr(args, "recompute_h1", 1))
     params["seed"] = 0
     return params
 
@@ -381,6 +382,8 @@ def main(argv=None):
     ap.add_argument("--fuse-gemm-input-wgrad", type=int, default=1, help="first layer's backward in the dX GEMM's epilogue")
     ap.add_argument("--fuse-gemm-loss", type=int, default=1,
                     help="PPO loss + head layer backward in the last hidden layer's GEMM epilogue (ag_split_gemm_loss_heads_bwd)")
+    ap.add_argument("--recompute-h1", type=int, default=1,
+                    help="h1 is not stored by the update's forward launch; the two backward kernels recompute it on the matrix cores")
     ap.add_argument("--fuse-gemm-input", type=int, default=1,
                     help="first layer formed inside that launch as well (ag_split_gemm_input_loss_heads_bwd; no ag_mlp_input_layer)")
     ap.add_argument("--mlp-chain", type=int, default=1,

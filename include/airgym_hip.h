@@ -377,6 +377,25 @@ int ag_split_gemm_input_wgrad_rows(void);
 int ag_split_gemm_input_wgrad_supported(int D);   /* 1 for D in {16, 18, 20, 48} */
 int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
                               float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
+/* Round 5 - the first layer's activations h1 = ELU(x W1^T + b1) are RECOMPUTED on the matrix cores wherever the backward of a
+ * [D -> 256 -> 256] trunk needs them, instead of stored by the forward and read back twice (autograd keeps them as saved tensors,
+ * lib/network/mlp.py:36-39 under lib/agent/a2c_continuous.py:299-369; 201 MB written + 402 MB read per 196 608-row minibatch):
+ *   ag_split_gemm_input_wgrad_recompute: ag_split_gemm_input_wgrad with ELU'(h1) formed from a recomputation of the
+ *       pre-activation z1 = x_ext W1ext^T (exact 3-way split, K = 32, natural orientation: it lands in the accumulator layout of
+ *       dh1) - image_dev = the image of ag_split_gemm_input_prepare (its first-layer part), x_dev [M, D] the (normalised) network
+ *       inputs.  D in {16, 18} (ag_split_gemm_input_wgrad_recompute_supported).  Same outputs as ag_split_gemm_input_wgrad.
+ *   ag_split_wgrad_input: ag_split_wgrad for dW2 = dZ^T h1 with the X operand h1 produced from x_dev [M, D] and the same image
+ *       (8 waves as 1 x 8; a wave's h1 tile IS its B fragment: the X operand never touches LDS or HBM).  M a multiple of 32,
+ *       D in {16, 18, 20} (ag_split_wgrad_input_supported); slices = ag_split_wgrad_input_slices(M) (one workgroup per CU, at
+ *       most one per 32 rows); partials_dev [slices, 256, 256], summed over dim 0 by the caller like ag_split_wgrad's.
+ * With both, ag_split_gemm_input_loss_heads_bwd may be given h1_dev = NULL: it then does not write h1 at all. */
+int ag_split_gemm_input_wgrad_recompute_supported(int D);
+int ag_split_gemm_input_wgrad_recompute(const float* dZ_dev, const void* planes_dev, const void* image_dev, const float* x_dev,
+                                        float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
+int ag_split_wgrad_input_supported(int D);
+int ag_split_wgrad_input_slices(int M);
+int ag_split_wgrad_input(const float* dZ_dev, const float* x_dev, const void* image_dev, float* partials_dev, int M, int n, int k,
+                         int D, int slices, void* stream);
 /* The whole actor-critic MLP [D -> 256 -> 256 -> (A + 1)] as ONE launch with the activations in registers
  * (airgym_amd/csrc/mlp_chain.hip): input normaliser -> Linear + ELU -> Linear + ELU -> mu | value heads
  * (ModelA2CContinuousLogStd.forward, lib/model/a2c_continuous_logstd_model.py:80-193; MLP, lib/network/mlp.py:36-39; fixed
@@ -446,7 +465,7 @@ typedef struct ag_input_layer_args {
     const double* mean_dev;            /* [D] running mean or NULL (no normaliser: obs is used as it is) */
     const double* var_dev;             /* [D] running variance or NULL */
     float* xn_dev;                     /* [M, D] out: clamp((obs - mean) / sqrt(var + eps), +-clip); NULL iff mean_dev is NULL */
-    float* h1_dev;                     /* [M, 256] out: ELU(xn W1^T + b1) */
+    float* h1_dev;                     /* [M, 256] out: ELU(xn W1^T + b1), or NULL: not written (the backward recomputes it) */
     float eps, clip;
 } ag_input_layer_args;
 int ag_split_gemm_input_fwd_supported(int D);

@@ -21,7 +21,36 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 
-def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=None, env_extra=None):
+def evaluate_population(agent, steps=None):
+    """Return of the FIRST episode of EVERY env from a fresh full reset, under the training policy (sampled actions, as in the
+    rollout): what players.py reports for n_games = all envs.  The reference's training meter (AverageMeter over the last 100
+    episodes that ENDED, a2c_base.py:100-102) cannot show this at 65 536 envs: once the policy stops crashing, the only episodes
+    that end between two time-limit waves are the few that crashed.  Uses the agent's own rollout (hipGraph replay) and reads
+    its raw-reward / done buffers; training must not be continued on this agent afterwards (the env was reset)."""
+    import math
+    H, n = agent.horizon_length, agent.num_actors * agent.num_agents
+    max_len = int(getattr(agent.vec_env.env, "max_episode_length", 2400))
+    steps = steps or max_len
+    agent.obs = agent.env_reset()
+    dev = agent.ppo_device
+    ret = torch.zeros(n, dtype=torch.float64, device=dev)
+    length = torch.zeros(n, dtype=torch.float64, device=dev)
+    alive = torch.ones(n, dtype=torch.float64, device=dev)
+    for _ in range(math.ceil(steps / H)):
+        agent.play_steps()
+        rr = agent.raw_rewards_buf.double().view(H, n)
+        dn = agent.dones_buf[1:H + 1].double().view(H, n)
+        for t in range(H):
+            ret += alive * rr[t]
+            length += alive
+            alive = alive * (1.0 - dn[t])
+    full = (length >= max_len - 1).double().mean()
+    return {"eval_return": round(float(ret.mean()), 2), "eval_return_p10": round(float(ret.quantile(0.10)), 2),
+            "eval_length": round(float(length.mean()), 1), "eval_full_length_frac": round(float(full), 4),
+            "eval_still_alive_frac": round(float(alive.mean()), 4), "eval_steps": steps, "eval_envs": n}
+
+
+def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=None, env_extra=None, evaluate=False):
     class A:
         pass
     A.envs, A.minibatches, A.graph, A.task, A.ctl, A.tuned_gemms = envs, minibatches, 1, "hovering", "rate", 1
@@ -53,6 +82,8 @@ def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=
     out = {"run": name, "envs": envs, "minibatch_size": agent.minibatch_size,
            "optimizer_steps_per_epoch": agent.mini_epochs_num * agent.num_minibatches, "mlp": list(units), "epochs": epochs,
            "wall_s": round(wall, 2), "env_steps_per_s": round(epochs * envs * agent.horizon_length / wall), "curve": curve}
+    if evaluate:
+        out["eval"] = evaluate_population(agent)
     agent.vec_env.env.hip.close()
     return out
 
