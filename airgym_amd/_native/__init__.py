@@ -218,6 +218,7 @@ SYMBOLS = [
     ("ag_split_gemm_input_fwd_supported", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_gemm_input_image_bytes", ctypes.c_longlong, []),
     ("ag_split_gemm_input_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P]),
+    ("ag_split_gemm_input_prepare_pair", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, _P, _P]),
     ("ag_split_gemm_input_loss_heads_bwd", ctypes.c_int, [ctypes.POINTER(AgInputLayerArgs), _P, _P, _P, _P, _P,
                                                           ctypes.POINTER(AgLossEpilogue), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                           ctypes.c_int, _P]),

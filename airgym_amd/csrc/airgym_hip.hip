@@ -300,7 +300,7 @@ void bind_tick(ag_env* h, ag::KArgs& k) {
 int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int64_t* reset_out,
             const float* noise, const float* uniforms, void* stream, uint8_t* done_u8 = nullptr,
             float* term_sums = nullptr, bool rollout_form = false, const ag::TailArgs* tail = nullptr, int num_steps = 1,
-            uint8_t* timeout_steps = nullptr) {
+            uint8_t* timeout_steps = nullptr, bool force_multi = false) {
     if (!h) return fail(AG_ERR_INVALID_ARG, "handle is NULL");
     if (!actions && !tail) return fail(AG_ERR_INVALID_ARG, "actions_dev is NULL");
     if (actions && h->num_actions == 4 && ((uintptr_t)actions & 15)) return fail(AG_ERR_INVALID_ARG, "actions_dev must be 16-byte aligned");
@@ -357,6 +357,7 @@ int do_step(ag_env* h, const float* actions, float* obs_out, float* rew_out, int
         k.cmd = nullptr;
     }
     k.num_steps = num_steps;
+    k.force_multi = force_multi ? 1 : 0;
     k.timeout_steps = timeout_steps;
     bind_tick(h, k);
     h->tick += (uint64_t)(num_steps - 1);      // the launch advances the device tick by num_steps
@@ -467,6 +468,7 @@ int ag_create(const ag_config* cfg, void* arena_dev, ag_handle* out) {
     }
     k.n = cfg->num_envs;
     k.num_steps = 1;
+    k.force_multi = 0;
     fill_params(h);
     h->tick = 0;
     h->parity = 0;
@@ -570,7 +572,7 @@ int ag_step_multi(ag_handle h, const float* actions_dev, int num_steps, float* o
         return fail(AG_ERR_UNSUPPORTED, "ag_step_multi with num_steps > 1 needs num_envs * num_obs to be a multiple of 4 "
                                         "(16-byte aligned observation slices)");
     return do_step(h, actions_dev, obs_out_dev, rew_out_dev, nullptr, nullptr, nullptr, stream, done_out_dev, term_sums_dev, true,
-                   nullptr, num_steps, timeout_out_dev);
+                   nullptr, num_steps, timeout_out_dev, /*force_multi=*/true);
 }
 
 int ag_step_rollout_fused(ag_handle h, const ag_rollout_tail* t, float* obs_out_dev, float* rew_out_dev, uint8_t* done_out_dev,

@@ -38,6 +38,7 @@ struct KArgs {
     // K env steps per launch (ag_step_multi): actions / obs / rew / reset_u8 / term_sums / timeout_steps are [K, ...] arrays,
     // step kk at offset kk * n * width; the state is loaded before step 0 and stored after step K - 1
     int num_steps;               // >= 1
+    int force_multi;             // ag_step_multi: always the K-step kernel (num_steps == 1 otherwise takes the one-step kernel)
     uint8_t* timeout_steps;      // [K, n] or null: per-step time-out flags (`timeout` [n] keeps the LAST step's)
     float* term_sums;            // [ceil(n/64), 12] or null: sums over the tile's envs of terms[0..8]
     // parity / inspection mode (ag_eval_obs_reward): processed actions + controller output supplied by the caller

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
 //   then the forward planes of W2 in the chain's K order, laid out like ag_split_gemm_prepare's
 constexpr int kInImageW1Bytes = 8 * 2 * 3 * 2 * 32 * 16;
 __global__ __launch_bounds__(256) void split_in_prepare_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D,
-                                                               const float* __restrict__ W2, uint4* __restrict__ img) {
+                                                               const float* __restrict__ W2, uint4* __restrict__ img,
+                                                               uint4* __restrict__ planes_t) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < 8 * 2 * 2 * 32) {                               // W1ext: one (block, step, h, feature) unit triple per thread
         const int m = t & 31, h = (t >> 5) & 1, st = (t >> 6) & 1, b = t >> 7;
@@ -86,18 +87,24 @@ __global__ __launch_bounds__(256) void split_in_prepare_kernel(const float* __re
         base[128] = p3;
         return;
     }
-    const int unit = t - 8 * 2 * 2 * 32;                    // W2 planes, chain K order: one (chunk, k-half, n) unit triple per thread
-    if (unit >= 16 * 2 * BN) return;
+    int unit = t - 8 * 2 * 2 * 32;                          // W2 planes: one (chunk, k-half, n) unit triple per thread
+    const bool bwd = unit >= 16 * 2 * BN;                   // ... then (planes_t != null) the backward image: B[n][k] = W2[k][n], natural K
+    if (bwd) unit -= 16 * 2 * BN;
+    if (unit >= 16 * 2 * BN || (bwd && planes_t == nullptr)) return;
     const int n = unit % BN, h = (unit / BN) & 1, c = unit / (2 * BN);
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int f = 32 * (c >> 1) + 16 * (c & 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
-        v[i] = W2[(size_t)n * KDIM + f];
+        if (bwd) {
+            v[i] = W2[(size_t)(c * BK + h * 8 + i) * BN + n];
+        } else {                                            // forward image in the chain's K order
+            const int f = 32 * (c >> 1) + 16 * (c & 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
+            v[i] = W2[(size_t)n * KDIM + f];
+        }
     }
     uint4 p1, p2, p3;
     split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
-    uint4* chunk = img + kInImageW1Bytes / 16 + (size_t)c * B_UNITS;
+    uint4* chunk = (bwd ? planes_t : img + kInImageW1Bytes / 16) + (size_t)c * B_UNITS;
     chunk[(0 * 2 + h) * BN + n] = p1;
     chunk[(1 * 2 + h) * BN + n] = p2;
     chunk[(2 * 2 + h) * BN + n] = p3;
@@ -1081,15 +1088,28 @@ extern "C" int ag_split_gemm_input_fwd_supported(int D) { return (g_split_wm == 
 
 extern "C" long long ag_split_gemm_input_image_bytes(void) { return (long long)kInImageW1Bytes + (long long)(KDIM / BK) * B_UNITS * 16; }
 
-extern "C" int ag_split_gemm_input_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev,
-                                           void* stream) {
+static int launch_in_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev, void* planes_t_dev,
+                             void* stream) {
     if (!W1_dev || !b1_dev || !W2_dev || !image_dev) return AG_ERR_INVALID_ARG;
     if (!ag_split_gemm_input_fwd_supported(D)) return AG_ERR_UNSUPPORTED;
-    if ((uintptr_t)image_dev & 15) return AG_ERR_INVALID_ARG;
-    const int threads = 8 * 2 * 2 * 32 + 16 * 2 * BN;
+    if (((uintptr_t)image_dev | (uintptr_t)planes_t_dev) & 15) return AG_ERR_INVALID_ARG;
+    const int threads = 8 * 2 * 2 * 32 + (planes_t_dev ? 2 : 1) * 16 * 2 * BN;
     hipLaunchKernelGGL(split_in_prepare_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1_dev, b1_dev, D, W2_dev,
-                       (uint4*)image_dev);
+                       (uint4*)image_dev, (uint4*)planes_t_dev);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_split_gemm_input_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev,
+                                           void* stream) {
+    return launch_in_prepare(W1_dev, b1_dev, D, W2_dev, image_dev, nullptr, stream);
+}
+
+// ... and, in the same launch, the backward planes of W2 (what ag_split_gemm_prepare(transpose = 1) writes): one weight-image launch per
+// optimizer step instead of two
+extern "C" int ag_split_gemm_input_prepare_pair(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev,
+                                                void* planes_t_dev, void* stream) {
+    if (!planes_t_dev) return AG_ERR_INVALID_ARG;
+    return launch_in_prepare(W1_dev, b1_dev, D, W2_dev, image_dev, planes_t_dev, stream);
 }
 
 extern "C" int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void* image_dev, const float* bias_dev,

@@ -10,8 +10,9 @@
 //   one __ballot per wavefront publishes the done mask (hovering.py:300 nonzero) and lets a wavefront with no done
 //   lane skip the reset path entirely.
 //
-// Three kernels live here:
-//   step_kernel_ws2<TASK, CTL, false>  ag_step / ag_step_into / ag_step_rollout    (the env step alone)
+// Kernels that live here:
+//   step_kernel_ws2<TASK, CTL, false>  ag_step / ag_step_into / ag_step_rollout    (the env step alone, one step per launch)
+//   step_kernel_multi<TASK, CTL>       ag_step_multi: K steps per launch, state in registers between them
 //   step_kernel_ws2<TASK, CTL, true>   ag_step_rollout_fused: the same step with the rollout's policy sampling in front
 //                                      of it and its reward / episode accounting behind it, in the same launch
 //   step_kernel_ext<TASK, CTL>         ag_step_with_inputs (parity mode: random numbers supplied by the caller)
@@ -123,6 +124,27 @@ __global__ __launch_bounds__(64) void step_kernel_ext(const KArgs k) {
     }
 }
 
+// Sum over the 64 lanes of a wave in ONE fixed order, shared by every step kernel (so that the per-tile reward-term sums - the
+// Episode/<term> logs - are bit-identical whichever kernel produced them).  row_bcast15 / row_bcast31 are gfx9 DPP controls.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "sm_wave_sum uses the gfx9 row_bcast DPP controls"
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float sm_dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(moved);
+}
+// sum over the 64 lanes in a fixed order; valid in lane 63
+__device__ __forceinline__ float sm_wave_sum(float v) {
+    v = sm_dpp_add<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v = sm_dpp_add<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    v = sm_dpp_add<0x141, 0xF>(v);       // row_half_mirror
+    v = sm_dpp_add<0x140, 0xF>(v);       // row_mirror
+    v = sm_dpp_add<0x142, 0xA>(v);       // row_bcast15: rows 1, 3 += lane 15 of rows 0, 2
+    v = sm_dpp_add<0x143, 0xC>(v);       // row_bcast31: rows 2, 3 += lane 31
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The shipped kernel.  128-thread workgroup = two wavefronts for the same 64 envs:
 //   physics wave: state I/O, controller, RK4, reward / termination, reset; after barrier 1 it forms
@@ -155,7 +177,6 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
     __shared__ __attribute__((aligned(16))) float tileO[64 * NOBS];   // final observation rows, HBM order
     __shared__ float tileB[64 * SB];
     __shared__ float tileT[64 * ST];
-    __shared__ float tileS[64];
     __shared__ __attribute__((aligned(16))) float tileA[FUSED ? 64 * SA : 4];
     __shared__ float tileR[FUSED ? 64 : 1];
     __shared__ int tileD[FUSED ? 64 : 1];
@@ -222,6 +243,7 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
             if (k.reset_u8 != nullptr) k.reset_u8[i] = (uint8_t)o.done;
             else k.reset[i] = (long long)o.done;
             k.timeout[i] = (uint8_t)o.timeout;
+            if (k.timeout_steps != nullptr) k.timeout_steps[i] = (uint8_t)o.timeout;
             if (lane == 0) k.mask[i >> 6] = ballot;
             if (k.cmd != nullptr) {
                 k.cmd[i] = make_float4(o.cmd[0], o.cmd[1], o.cmd[2], o.cmd[3]);
@@ -308,21 +330,13 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
         for (int j = 0; j < 18; ++j) tileB[lane * SB + j] = noise_sigma(j) * z[j];
         __syncthreads();   // barrier 1
         // ---- between the barriers (the physics wave is adding the noise): reductions over the tile
-        if (want_terms) {  // per-tile sums of the reward terms, fixed order: 7 row groups x 9 terms, then 7 -> 1
-            const int term = lane % 9, part = lane / 9;          // lanes 0..62
-            const int r0 = (part == 0) ? 0 : 9 * part + 1, r1 = 9 * part + 10;   // row groups of 10,9,9,9,9,9,9
-            float acc = 0.0f;
-            if (lane < 63) {
-                for (int r = r0; r < r1; ++r) acc += tileT[r * ST + term];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 63) tileS[lane] = acc;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 9) {
-                float tot = 0.0f;
+        if (want_terms) {  // per-tile sums of the nine reward terms: nine wave sums, fixed order (as step_kernel_multi)
+            float tsum[9];
 #pragma unroll
-                for (int p = 0; p < 7; ++p) tot += tileS[p * 9 + lane];
-                k.term_sums[(size_t)blockIdx.x * 12 + lane] = tot;
+            for (int t = 0; t < 9; ++t) tsum[t] = sm_wave_sum(tileT[lane * ST + t]);
+            if (lane == 63) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) k.term_sums[(size_t)blockIdx.x * 12 + t] = tsum[t];
             }
         }
         if (FUSED) {       // rollout tail: reward shaping + episode accounting (a2c_base.py:668-695)
@@ -392,22 +406,6 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
 // noise wave works on step kk's while the physics wave fills step kk + 1's, and reaches barrier kk + 1 only when it is done.
 // Results: bit-identical for any split of a step sequence into launches (one instantiation serves every K).
 // ---------------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float sm_dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-    return v + __int_as_float(moved);
-}
-// sum over the 64 lanes in a fixed order; valid in lane 63
-__device__ __forceinline__ float sm_wave_sum(float v) {
-    v = sm_dpp_add<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
-    v = sm_dpp_add<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
-    v = sm_dpp_add<0x141, 0xF>(v);       // row_half_mirror
-    v = sm_dpp_add<0x140, 0xF>(v);       // row_mirror
-    v = sm_dpp_add<0x142, 0xA>(v);       // row_bcast15: rows 1, 3 += lane 15 of rows 0, 2
-    v = sm_dpp_add<0x143, 0xC>(v);       // row_bcast31: rows 2, 3 += lane 31
-    return v;
-}
-
 template <int TASK, int CTL>
 __global__ __launch_bounds__(128) void step_kernel_multi(const KArgs k) {
     constexpr int NOBS = TaskTraits<TASK>::kNumObs;
@@ -665,6 +663,11 @@ hipError_t AG_CAT(AG_TASK, AG_CTL)(const KArgs& k, const TailArgs* tail, hipStre
         hipLaunchKernelGGL((step_kernel_ext<AG_TASK, AG_CTL>), g64, dim3(64), 0, stream, k);
     } else if (tail != nullptr) {
         hipLaunchKernelGGL((step_kernel_ws2<AG_TASK, AG_CTL, true>), g64, dim3(128), 0, stream, k, *tail);
+    } else if (k.num_steps == 1 && !k.force_multi) {
+        // one step per launch (ag_step / ag_step_into / ag_step_rollout): the dedicated two-wave kernel - the physics wave reads
+        // its action itself (no hand-over barrier in front of the physics, no double-buffered tiles); bit-identical to
+        // step_kernel_multi with K = 1 (tests/test_gpu_step_multi.py), 8 % faster per launch
+        hipLaunchKernelGGL((step_kernel_ws2<AG_TASK, AG_CTL, false>), g64, dim3(128), 0, stream, k, TailArgs{});
     } else {
         hipLaunchKernelGGL((step_kernel_multi<AG_TASK, AG_CTL>), g64, dim3(128), 0, stream, k);
     }

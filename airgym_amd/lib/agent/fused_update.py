@@ -80,6 +80,11 @@ class SplitGemm256:
         layer's forward planes in the K order the fused launch produces its A operand in (ag_split_gemm_input_prepare)."""
         if self.in_image is None:
             self.in_image = torch.empty(self.lib.ag_split_gemm_input_image_bytes(), dtype=torch.uint8, device=self.w.device)
+        if self.bwd is not None:      # the backward planes of this layer ride in the same launch (no separate prepare())
+            N.check(self.lib.ag_split_gemm_input_prepare_pair(w1.data_ptr(), b1.data_ptr(), w1.shape[1], self.w.data_ptr(),
+                                                              self.in_image.data_ptr(), self.bwd.data_ptr(), self._stream()),
+                    "ag_split_gemm_input_prepare_pair")
+            return
         N.check(self.lib.ag_split_gemm_input_prepare(w1.data_ptr(), b1.data_ptr(), w1.shape[1], self.w.data_ptr(),
                                                      self.in_image.data_ptr(), self._stream()), "ag_split_gemm_input_prepare")
 
@@ -286,9 +291,10 @@ class FusedMLPStep:
         x = self.h[0]
         last = len(self.layers) - 1
         heads_done = loss_done = False
-        for sg in self.split.values():          # the weights moved in the previous optimizer step
-            sg.prepare()
-        if in_args is not None:
+        for li_, sg in self.split.items():      # the weights moved in the previous optimizer step
+            if in_args is None or li_ != len(self.layers) - 1:
+                sg.prepare()
+        if in_args is not None:                 # one launch: first-layer image + chain-ordered forward planes + backward planes
             self.split[len(self.layers) - 1].prepare_input_image(w0, b0)
         for li in range(1, len(self.layers)):
             w, b = self.layers[li][0], self.layers[li][1]

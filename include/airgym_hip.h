@@ -471,6 +471,9 @@ typedef struct ag_input_layer_args {
 int ag_split_gemm_input_fwd_supported(int D);
 long long ag_split_gemm_input_image_bytes(void);
 int ag_split_gemm_input_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev, void* stream);
+/* ... the same plus the backward planes of W2 (= ag_split_gemm_prepare(W2, planes_t_dev, 256, 256, transpose = 1)) in one launch */
+int ag_split_gemm_input_prepare_pair(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev,
+                                     void* planes_t_dev, void* stream);
 int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void* image_dev, const float* bias_dev,
                                        const float* Wh_dev, const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* loss, int M,
                                        int n, int k, int A1, void* stream);

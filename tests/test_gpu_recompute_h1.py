@@ -241,3 +241,22 @@ def test_update_step_with_and_without_stored_h1(recompute):
     scale = g_auto[:-1].abs().max()
     assert (g_fused - g_auto)[:-1].abs().max() <= 2e-5 * scale + 1e-9, ((g_fused - g_auto).abs().max(), scale)
     agent.vec_env.env.hip.close()
+
+
+def test_weight_images_of_the_step_in_one_launch(lib):
+    """ag_split_gemm_input_prepare_pair == ag_split_gemm_input_prepare + ag_split_gemm_prepare(transpose = 1), bit for bit."""
+    from airgym_amd import _native as N
+    g = torch.Generator(device="cuda").manual_seed(9)
+    f = dict(device="cuda", dtype=torch.float32)
+    D = 18
+    W1, b1, W2 = torch.randn(256, D, generator=g, **f), torch.randn(256, generator=g, **f), torch.randn(256, 256, generator=g, **f)
+    img0 = torch.zeros(lib.ag_split_gemm_input_image_bytes(), dtype=torch.uint8, device="cuda")
+    img1 = torch.ones_like(img0)
+    pt0 = torch.zeros(lib.ag_split_gemm_plane_bytes(), dtype=torch.uint8, device="cuda")
+    pt1 = torch.ones_like(pt0)
+    N.check(lib.ag_split_gemm_input_prepare(W1.data_ptr(), b1.data_ptr(), D, W2.data_ptr(), img0.data_ptr(), _stream()), "prepare")
+    N.check(lib.ag_split_gemm_prepare(W2.data_ptr(), pt0.data_ptr(), 256, 256, 1, _stream()), "prepare_t")
+    N.check(lib.ag_split_gemm_input_prepare_pair(W1.data_ptr(), b1.data_ptr(), D, W2.data_ptr(), img1.data_ptr(), pt1.data_ptr(),
+                                                 _stream()), "prepare_pair")
+    assert torch.equal(img0, img1) and torch.equal(pt0, pt1)
+    assert lib.ag_split_gemm_input_prepare_pair(W1.data_ptr(), b1.data_ptr(), D, W2.data_ptr(), img1.data_ptr(), None, _stream()) == -1

@@ -1,5 +1,6 @@
-"""ag_step_multi (K env steps per launch, state in registers between them; csrc/step_kernel.hip step_kernel_ws2<.., false>
-with KArgs.num_steps = K) against K calls of ag_step_rollout on a twin handle: `for t in range(K): env.step(actions[t])`
+"""ag_step_multi (K env steps per launch, state in registers between them; csrc/step_kernel.hip step_kernel_multi) against K
+calls of ag_step_rollout (since round 5 the dedicated one-step kernel step_kernel_ws2<.., false>: TWO instantiations are compared
+here, for every K including K = 1) on a twin handle: `for t in range(K): env.step(actions[t])`
 (Hovering.step, hovering.py:286-308) must come out IDENTICAL, bit for bit - observations (noise included: Philox tick
 tick0 + t), rewards, done flags, per-tile reward-term sums, the time-out flags, the state left behind and the ballot mask /
 reset ids of the last step - with in-step resets happening inside the launch."""
@@ -29,7 +30,10 @@ def _bufs(env, K, lib):
 
 
 @pytest.mark.parametrize("task,ctl,n,K,max_len,fix", [
-    ("hovering", "rate", 1000, 1, 0, False),      # K = 1 is ag_step_rollout itself; ragged tail tile
+    ("hovering", "rate", 1000, 1, 0, False),      # K = 1: the K-step kernel against the one-step kernel; ragged tail tile
+    ("hovering", "rate", 4096, 1, 3, True),       # K = 1 with the time limit firing every third launch
+    ("tracking", "vel", 520, 1, 0, False),        # K = 1, 48 observations
+    ("hovering", "atti", 200, 1, 5, False),       # K = 1, five actions
     ("hovering", "rate", 1000, 4, 0, False),
     ("hovering", "rate", 4096, 24, 16, True),     # the time limit fires inside the launch (twice per env), flags on
     ("hovering", "atti", 130, 24, 9, False),      # 5 actions (scalar action loads), resets
