@@ -43,9 +43,14 @@ def units(experiments=False):
     out = []
     for task in (0, 1):
         for ctl in range(5):
-            out.append((os.path.join(od, f"step_{task}_{ctl}.o"), "step_kernel.hip", [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}"] + x))
+            # -ffp-contract=on: a*b+c fuses only inside ONE source expression (decided by the front end), never across statements
+            # (the default `fast` lets the back end fuse whatever ends up adjacent after inlining, which differs between the
+            # kernels that share env_math.hpp): every step kernel then runs the same arithmetic, bit for bit
+            out.append((os.path.join(od, f"step_{task}_{ctl}.o"), "step_kernel.hip",
+                        [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}", "-ffp-contract=on"] + x))
     for name in ("airgym_hip", "ppo_kernels", "planning_kernel", "rollout_kernels", "split_gemm", "split_wgrad", "cnn_kernels", "conv_kernels", "mlp_chain"):
-        out.append((os.path.join(od, name + ".o"), name + ".hip", list(x)))
+        # rollout_kernels.hip shares rollout_math.hpp with the fused step kernel (policy sampling, reward shaping): same rule
+        out.append((os.path.join(od, name + ".o"), name + ".hip", (["-ffp-contract=on"] if name == "rollout_kernels" else []) + list(x)))
     if experiments:
         out.append((os.path.join(od, "experiments.o"), "experiments.hip", list(x)))
     return out

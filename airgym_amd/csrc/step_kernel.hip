@@ -263,8 +263,8 @@ __global__ __launch_bounds__(128) void step_kernel_ws2(const KArgs k, const Tail
         // obs = (clean + sigma*z) - target for the 18 noisy columns (hovering.py:343-345), clean elsewhere
 #pragma unroll
         for (int j = 0; j < 18; ++j) {
-            float v = obs[j] + tileB[lane * SB + j];
-            if (TASK == TASK_HOVERING) v -= P.target[j];
+            float v = __fadd_rn(obs[j], tileB[lane * SB + j]);      // an add of its own (never contracted with the product that
+            if (TASK == TASK_HOVERING) v -= P.target[j];            // formed obs[j]): the K-step kernel adds it in another wave
             obs[j] = v;
         }
         if (NOBS % 4 == 0) {

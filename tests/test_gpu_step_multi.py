@@ -32,7 +32,7 @@ def _bufs(env, K, lib):
 @pytest.mark.parametrize("task,ctl,n,K,max_len,fix", [
     ("hovering", "rate", 1000, 1, 0, False),      # K = 1: the K-step kernel against the one-step kernel; ragged tail tile
     ("hovering", "rate", 4096, 1, 3, True),       # K = 1 with the time limit firing every third launch
-    ("tracking", "vel", 520, 1, 0, False),        # K = 1, 48 observations
+    ("tracking", "vel", 520, 1, 2, False),        # K = 1, 48 observations
     ("hovering", "atti", 200, 1, 5, False),       # K = 1, five actions
     ("hovering", "rate", 1000, 4, 0, False),
     ("hovering", "rate", 4096, 24, 16, True),     # the time limit fires inside the launch (twice per env), flags on
