@@ -464,6 +464,33 @@ class A2CAgent:
         self._fused_rollout = FusedRolloutStep(self) if FusedRolloutStep.supported(self) else None
         if self._fused_rollout is not None and getattr(self, "_restored_noise_counter", None) is not None:
             self._fused_rollout.counter.fill_(int(self._restored_noise_counter))
+        if self.config.get("print_paths", True) and getattr(self, "global_rank", 0) == 0:
+            # which implementation THIS configuration got (the hand-written GEMMs cover 256-wide layers; everything else
+            # runs the library): one line on stderr at start-up, and `config.paths` of bench.py's JSON line
+            import json
+            import sys
+            print("[airgym_amd] compute paths: " + json.dumps(self.compute_paths()), file=sys.stderr, flush=True)
+
+    def compute_paths(self):
+        """{'rollout': ..., 'update': {layer: {forward, dW / backward, dX}}} - what runs for this network / config."""
+        fr, fs = self._fused_rollout, self._fused_step
+        if fr is None:
+            rollout = "generic: model forward (torch) + env.step per rollout step"
+        elif fr.chain is not None:
+            rollout = ("ag_mlp_chain_forward (whole policy forward, one launch, activations in registers) + "
+                       + ("ag_step_rollout_fused" if fr.fuse_tail else "ag_policy_sample + ag_step_rollout + ag_rollout_account"))
+        else:
+            gemm = "ag_split_gemm_elu_heads" if (fr.split and fr.fuse_gemm_heads) else "library f32 GEMMs (torch.addmm / torch.mm)"
+            rollout = (("ag_mlp_input_layer + " if fr.fuse_input else "library first layer + ") + gemm + " + "
+                       + ("ag_step_rollout_fused" if fr.fuse_tail else "ag_policy_sample + ag_step_rollout + ag_rollout_account"))
+        if fs is None:
+            update = "generic: autograd (torch) + fused PPO loss kernel where supported"
+        else:
+            update = fs.describe_paths()
+        return {"rollout_step": rollout, "update": update,
+                "optimizer": "ag_adam_clip_step (HIP)" if self.config.get("use_fused_adam", True) and str(self.ppo_device).startswith("cuda")
+                else "FlatAdam (torch)",
+                "minibatch_hip_graphs": bool(getattr(self, "_graph_update", False))}
 
     def _dedup_ok(self):
         m = self.model

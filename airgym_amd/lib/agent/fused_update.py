@@ -218,6 +218,51 @@ class FusedMLPStep:
         self.fuse_gemm_heads = bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 in (5, 6)
         self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 8, **f)
         self.k = 0
+        self.last_launches = {}       # the step's dominant launches as (entry point, replayable closure) - for bench.py
+
+    def describe_paths(self):
+        """Which implementation each layer of the update took (bench.py `config.paths`; printed once at agent start-up)."""
+        L = len(self.layers)
+        lib_gemm = "library f32 GEMM (torch.addmm / torch.mm: hipBLASLt / rocBLAS)"
+        out = {}
+        for li, (w, _, _, _) in enumerate(self.layers):
+            C, K = w.shape
+            key = f"layer{li} [{K}->{C}]"
+            if li == 0:
+                if self.fuse_gemm_input:
+                    fwd = "inside the next layer's forward launch, on the matrix cores (ag_split_gemm_input_loss_heads_bwd)"
+                elif self.fuse_input:
+                    fwd = "ag_mlp_input_layer (normalise + Linear + ELU, HIP, vector ALU)"
+                else:
+                    fwd = lib_gemm
+                if self.recompute_h1:
+                    bwd = "in the dX launch's epilogue with h1 recomputed (ag_split_gemm_input_wgrad_recompute); h1 never stored"
+                elif self.fuse_gemm_input_wgrad:
+                    bwd = "in the dX launch's epilogue (ag_split_gemm_input_wgrad), h1 read back"
+                elif self.fuse_input_wgrad:
+                    bwd = "ag_elu_bwd_input_wgrad (HIP, vector ALU)"
+                else:
+                    bwd = lib_gemm + " split-K bmm"
+                out[key] = {"forward": fwd, "backward": bwd}
+                continue
+            sg = li in self.split
+            if li == L - 1 and sg and self.fuse_heads and self.fuse_gemm_loss:
+                fwd = "split-bf16 GEMM + ELU + heads + PPO loss + head backward in one launch (ag_split_gemm_*loss_heads_bwd)"
+            elif li == L - 1 and sg and self.fuse_heads and self.fuse_gemm_heads:
+                fwd = "split-bf16 GEMM + ELU + heads (ag_split_gemm_elu_heads); loss and head backward as separate HIP launches"
+            elif sg:
+                fwd = "split-bf16 GEMM (ag_split_gemm)"
+            else:
+                fwd = lib_gemm
+            if li == 1 and self.recompute_h1:
+                dw = "split-bf16, X operand produced on chip (ag_split_wgrad_input)"
+            elif li in self.split_wgrad:
+                dw = "split-bf16 (ag_split_wgrad)"
+            else:
+                dw = lib_gemm + " split-K bmm"
+            dx = ("split-bf16 GEMM (ag_split_gemm / ..._input_wgrad*)" if sg else lib_gemm)
+            out[key] = {"forward": fwd, "dW": dw, "dX": dx}
+        return out
 
     @staticmethod
     def _split_wgrad_ok(weight, config):
@@ -323,9 +368,13 @@ class FusedMLPStep:
                 Lp.bound_type = int(BOUND_TYPES[ag.bound_loss_type] if ag.bounds_loss_coef is not None else 0)
                 dz_out = self.dz[:M * w.shape[0]].view(M, w.shape[0])
                 if in_args is not None:
-                    sg.forward_input_loss_heads_bwd(in_args, M, dz_out, b, ag.heads_w, ag.heads_b, Lp)
+                    fwd = ("ag_split_gemm_input_loss_heads_bwd" + (" (h1 not stored)" if self.recompute_h1 else ""),
+                           lambda sg=sg, a=in_args, d=dz_out, b=b, L=Lp: sg.forward_input_loss_heads_bwd(a, M, d, b, ag.heads_w, ag.heads_b, L))
                 else:
-                    sg.forward_loss_heads_bwd(x, dz_out, b, ag.heads_w, ag.heads_b, Lp)
+                    fwd = ("ag_split_gemm_loss_heads_bwd",
+                           lambda sg=sg, x=x, d=dz_out, b=b, L=Lp: sg.forward_loss_heads_bwd(x, d, b, ag.heads_w, ag.heads_b, L))
+                fwd[1]()
+                self.last_launches["forward"] = fwd      # (entry point, replayable launch): bench.py times what the step ran
                 heads_done = loss_done = True
             elif li == last and self.fuse_heads and sg is not None:
                 if self.fuse_gemm_heads:            # heads formed in the GEMM epilogue; h keeps the bias-free pre-activation
@@ -402,21 +451,32 @@ class FusedMLPStep:
                         "ag_elu_bwd_bias")
             if li == 1 and self.recompute_h1:
                 # X operand (h1) and ELU'(h1) are produced from the network inputs + the first-layer image of the forward launch
-                wp, img = self.wgrad_partials[1], self.split[1].in_image
-                N.check(lib.ag_split_wgrad_input(dz.data_ptr(), inputs[0].data_ptr(), img.data_ptr(), wp.data_ptr(), M, C, K,
-                                                 inputs[0].shape[1], wp.shape[0], st), "ag_split_wgrad_input")
-                N.check(lib.ag_split_gemm_input_wgrad_recompute(dz.data_ptr(), self.split[1].bwd.data_ptr(), img.data_ptr(),
-                                                                inputs[0].data_ptr(), self.wgrad_partials[0].data_ptr(),
-                                                                self.bias_partials[0].data_ptr(), M, 256, 256, inputs[0].shape[1], st),
-                        "ag_split_gemm_input_wgrad_recompute")
+                wp, img, x0 = self.wgrad_partials[1], self.split[1].in_image, inputs[0]
+                wg = ("ag_split_wgrad_input", lambda dz=dz, wp=wp, img=img, x0=x0: N.check(lib.ag_split_wgrad_input(
+                    dz.data_ptr(), x0.data_ptr(), img.data_ptr(), wp.data_ptr(), M, C, K, x0.shape[1], wp.shape[0], st),
+                    "ag_split_wgrad_input"))
+                dx = ("ag_split_gemm_input_wgrad_recompute", lambda dz=dz, img=img, x0=x0: N.check(
+                    lib.ag_split_gemm_input_wgrad_recompute(dz.data_ptr(), self.split[1].bwd.data_ptr(), img.data_ptr(), x0.data_ptr(),
+                                                            self.wgrad_partials[0].data_ptr(), self.bias_partials[0].data_ptr(), M, 256,
+                                                            256, x0.shape[1], st), "ag_split_gemm_input_wgrad_recompute"))
+                wg[1]()
+                dx[1]()
+                self.last_launches["wgrad"], self.last_launches["dx"] = wg, dx
                 break
             if li in self.split_wgrad:
                 wp = self.wgrad_partials[li]
-                N.check(lib.ag_split_wgrad(dz.data_ptr(), xin.data_ptr(), wp.data_ptr(), M, C, K, wp.shape[0], st), "ag_split_wgrad")
+                wg = ("ag_split_wgrad", lambda dz=dz, xin=xin, wp=wp: N.check(lib.ag_split_wgrad(
+                    dz.data_ptr(), xin.data_ptr(), wp.data_ptr(), M, C, K, wp.shape[0], st), "ag_split_wgrad"))
+                wg[1]()
+                if li == last:
+                    self.last_launches["wgrad"] = wg
             else:
                 torch.bmm(dz.view(S, M // S, C).transpose(1, 2), xin.view(S, M // S, K), out=self.wgrad_partials[li])
             if li == 1 and self.fuse_gemm_input_wgrad:
-                self.split[1].backward_input_wgrad(dz, self.h[0], inputs[0], self.wgrad_partials[0], self.bias_partials[0])
+                dx = ("ag_split_gemm_input_wgrad", lambda dz=dz, x0=inputs[0]: self.split[1].backward_input_wgrad(
+                    dz, self.h[0], x0, self.wgrad_partials[0], self.bias_partials[0]))
+                dx[1]()
+                self.last_launches["dx"] = dx
                 break
             if li > 0:
                 dh = self.dh[:M * K].view(M, K)

@@ -28,11 +28,14 @@ _TASK_ID = {"hovering": 0, "tracking": 1}
 _CTL_ID = {"pos": 0, "vel": 1, "atti": 2, "rate": 3, "prop": 4}
 
 
-def kernel_name(task, ctl_mode, fused=False):
+def kernel_name(task, ctl_mode, fused=False, single=False):
     """Symbol (as rocprofv3 prints it) of the env-step kernel (csrc/step_kernel.hip): step_kernel_ws2<task, ctl, true> for
-    ag_step_rollout_fused, step_kernel_multi<task, ctl> for ag_step / ag_step_rollout / ag_step_multi."""
+    ag_step_rollout_fused, step_kernel_ws2<task, ctl, false> for the one-step launches (ag_step / ag_step_into / ag_step_rollout),
+    step_kernel_multi<task, ctl> for ag_step_multi."""
     if fused:
         return "ag::step_kernel_ws2<%d,%d,true>" % (_TASK_ID[task], _CTL_ID[ctl_mode])
+    if single:
+        return "ag::step_kernel_ws2<%d,%d,false>" % (_TASK_ID[task], _CTL_ID[ctl_mode])
     return "ag::step_kernel_multi<%d,%d>" % (_TASK_ID[task], _CTL_ID[ctl_mode])
 
 
@@ -294,7 +297,7 @@ def roofline_object(agent, hip, args, repo):
     traffic1, tsrc1 = traffic, tsrc
     if args.envs == 65536:
         traffic, tsrc = pmc_traffic(repo, f"{task}_{ctl}_multi{K}", kname)
-        traffic1, tsrc1 = pmc_traffic(repo, f"{task}_{ctl}", kname)
+        traffic1, tsrc1 = pmc_traffic(repo, f"{task}_{ctl}", kernel_name(task, ctl, False, True))
     copy_gbps = measure_copy_ceiling(agent.ppo_device)
     # The dominant env kernel, launched the way the env-only metric of SURVEY 8(d) launches it (actions pre-generated on the
     # device): ag_step_multi, K steps per launch.  `achieved` = 8(d)'s 287 B x the env-steps one launch processes (envs x K)
@@ -303,8 +306,11 @@ def roofline_object(agent, hip, args, repo):
     roof = {
         "bound": "hbm", "achieved": m["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": m["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
-        "kernel": kname, "entry_point": f"ag_step_multi, {K} env steps per launch (same kernel as ag_step_rollout with the "
-                                        f"state held in registers between the steps; bit-identical results)",
+        "kernel": kname, "entry_point": f"ag_step_multi, {K} env steps per launch (the state held in registers between the "
+                                        f"steps; bit-identical to {K} one-step launches)",
+        "note": "env step ALONE with pre-generated actions (SURVEY 8(d) env-only metric).  The headline's timed region does NOT "
+                "launch this form: with a policy in the loop the rollout issues one ag_step_rollout_fused per step - see "
+                "`in_loop` (same object as `rollout_fused`)",
         "us_per_launch": m["us_per_launch"], "launches_timed": m["launches_timed"], "steps_per_launch": K,
         "us_per_env_step_batch": m["us_per_step"],
         "algo_bytes_per_env_step": m["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
@@ -315,6 +321,7 @@ def roofline_object(agent, hip, args, repo):
         "copy_ceiling_gbps": copy_gbps, "frac_of_copy_ceiling": m["gbps_algorithmic"] / copy_gbps,
         "single_step_launch": {
             "entry_point": "ag_step_rollout (one env step per launch: what a policy in the loop allows)",
+            "kernel": kernel_name(task, ctl, False, True),
             "us_per_launch": r["us_per_step"], "launches_timed": r["steps_timed"], "achieved": r["gbps_algorithmic"],
             "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": traffic1, "traffic_source": tsrc1},
         "drop_in_ag_step": {"us_per_launch": r_api["us_per_step"], "frac": r_api["gbps_algorithmic"] / HBM_PEAK_GBPS,
@@ -339,6 +346,10 @@ def roofline_object(agent, hip, args, repo):
             "us_per_launch": rf["us_per_step"], "launches_timed": rf["steps_timed"],
             "algo_bytes_per_env_step": rf["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
             "frac_of_copy_ceiling": rf["gbps_algorithmic"] / copy_gbps}
+        # the launch the HEADLINE's timed region really issues for the env step (one per rollout step, behind the policy forward)
+        roof["in_loop"] = dict(roof["rollout_fused"], note="what the PPO rollout of the timed region launches (policy in the loop): "
+                               "ag_step_rollout_fused, one env step per launch; `roofline` itself describes ag_step_multi, the "
+                               "env-only form")
     return out
 
 
@@ -357,6 +368,60 @@ def _time_us(fn, iters=20, warmup=3):
     stop.record(s)
     stop.synchronize()
     return start.elapsed_time(stop) * 1e3 / iters
+
+
+@torch.no_grad()
+def measure_update_sequence(agent, iters=30):
+    """The launches that dominate an optimizer step, EXACTLY as FusedMLPStep.step issued them (its own closures, its own live
+    buffers), replayed in the step's order - forward (+ loss + head backward), weight gradient, dX (+ first-layer backward) -
+    with HIP events around every launch, so that each kernel finds the caches as its predecessor leaves them.  Per kernel BOTH
+    rooflines: matrix-core FLOPs at 6 bf16 MFMAs per f32 product (incl. the first layer / recomputation products the launch
+    carries) against the dense bf16 peak, and algorithmic HBM bytes against 8 TB/s."""
+    import statistics
+    fs = getattr(agent, "_fused_step", None)
+    if fs is None or not all(k in fs.last_launches for k in ("forward", "wgrad", "dx")):
+        return []
+    M, A1 = fs.M, fs.A + 1
+    D = fs.layers[0][0].shape[1]
+    order = [fs.last_launches[k] for k in ("forward", "wgrad", "dx")]
+    s = torch.cuda.current_stream()
+    for _ in range(3):
+        for _, fn in order:
+            fn()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(iters)]
+    for it in range(iters):
+        ev[it][0].record(s)
+        for j, (_, fn) in enumerate(order):
+            fn()
+            ev[it][j + 1].record(s)
+    torch.cuda.synchronize()
+    us = [statistics.median(ev[it][j].elapsed_time(ev[it][j + 1]) * 1e3 for it in range(iters)) for j in range(3)]
+    act, io = 4.0 * M * 256, 4.0 * M * D
+    main = 2.0 * M * 256 * 256
+    small = 2.0 * M * 32 * 256                 # one K = 32 (or K = rows x 32 columns) product: first layer, its recomputation, dW1
+    rc, fin = bool(getattr(fs, "recompute_h1", False)), bool(getattr(fs, "fuse_gemm_input", False))
+    S = fs.wgrad_partials[1].shape[0] if len(fs.wgrad_partials) > 1 else 0
+    tiles = fs.wgrad_partials[0].shape[0]
+    flops = [main + (small if fin else 0.0), main + (small if rc else 0.0), main + small + (small if rc else 0.0)]
+    nbytes = [(2 * io if fin else act) + act + (0.0 if (rc or not fin) else act),        # obs in, xn out (or h1 in), dz out, h1 out
+              act + (io if rc else act) + 4.0 * S * 65536,                                 # dz in, x / h1 in, slice partials out
+              act + io + (0.0 if rc else act) + 4.0 * tiles * 256 * (D + 1)]               # dz in, x in, h1 in, tile partials out
+    what = ["forward of both hidden layers + ELU + heads + PPO loss + head backward" if fin else
+            "forward of the last hidden layer + ELU + heads + PPO loss + head backward",
+            "weight gradient dW2 = dz2^T h1" + (" (h1 produced on chip from the network inputs)" if rc else ""),
+            "dX of layer 2 + ELU' + dW1 / db1 in its epilogue" + (" (h1 recomputed on chip)" if rc else "")]
+    out = []
+    for (name, _), u, fl, nb, w in zip(order, us, flops, nbytes, what):
+        out.append({"kernel": f"{name}: {w} - as the step runs it (timed in the step's launch order, {iters} rounds, median)",
+                    "entry_point": name.split(" ")[0], "in_step": True, "us_per_launch": u, "bound": "mfma",
+                    "achieved": 6.0 * fl / u / 1e6, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": 6.0 * fl / u / 1e6 / BF16_MFMA_PEAK_TFLOPS, "f32_equivalent_tflops": fl / u / 1e6,
+                    "matrix_core_gflop_f32_equivalent": fl / 1e9,
+                    "hbm": {"algo_bytes": nb, "achieved": nb / u / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": nb / u / 1e3 / HBM_PEAK_GBPS}})
+    out.append({"kernel": "sum of the three launches above", "in_step": True, "us_per_launch": sum(us),
+                "hbm": {"algo_bytes": sum(nbytes), "note": "algorithmic HBM bytes of the three launches per optimizer step"}})
+    return out
 
 
 @torch.no_grad()
@@ -408,7 +473,9 @@ def measure_update_kernels(agent, iters=20):
         us = _time_us(lambda: N.check(lib.ag_split_wgrad(dzm.data_ptr(), x.data_ptr(), wp.data_ptr(), M, C, K, wp.shape[0], st),
                                       "ag_split_wgrad"), iters)
         out.append({"kernel": f"ag_split_wgrad dW[{C}x{K}] = dZ^T X over {M} rows ({wp.shape[0]} row slices, 6 bf16 MFMAs per f32 "
-                              f"product, f32-accurate), as the step runs it", "bound": "mfma", "achieved": 6.0 * flops / us / 1e6,
+                              f"product, f32-accurate), stored-h1 form"
+                              + (" - for reference (the step runs ag_split_wgrad_input)" if getattr(fs, "recompute_h1", False) else ""),
+                    "bound": "mfma", "achieved": 6.0 * flops / us / 1e6,
                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 6.0 * flops / us / 1e6 / BF16_MFMA_PEAK_TFLOPS,
                     "us_per_launch": us, "f32_equivalent_tflops": flops / us / 1e6,
                     "note": "each operand read from HBM once; slice partials summed by ag_sum_rows_multi (fixed order)"})
@@ -426,7 +493,8 @@ def measure_update_kernels(agent, iters=20):
         mfma(f"ag_split_gemm [{M}x{K}]x[{K}x{C}] (6 bf16 MFMAs per f32 product, f32-accurate), plain", us, flops, peak_note)
         if getattr(fs, "fuse_gemm_heads", False) and fs.fuse_heads:
             us = _time_us(lambda: sg.forward_elu_heads(x, fs.dz[:M * C].view(M, C), b, agent.heads_w, agent.heads_b, fs.heads), iters)
-            mfma("ag_split_gemm_elu_heads (update forward of the last hidden layer + ELU + heads, as the step runs it)", us,
+            mfma("ag_split_gemm_elu_heads (forward of the last hidden layer + ELU + heads; the rollout's form without the chain "
+                 "kernel) - for reference", us,
                  flops + 2.0 * M * C * A1, "replaces ag_split_gemm + ag_elu_heads (one pass over z less)")
         if getattr(fs, "fuse_gemm_loss", False):
             lrows = lib.ag_split_gemm_loss_rows()
@@ -446,14 +514,16 @@ def measure_update_kernels(agent, iters=20):
             Lp.loss_partials_dev, Lp.dwh_partials_dev, Lp.db_partials_dev = keep["lp"].data_ptr(), keep["dwh"].data_ptr(), keep["db"].data_ptr()
             Lp.e_clip, Lp.critic_coef, Lp.bounds_loss_coef, Lp.clip_value, Lp.bound_type = 0.2, 2.0, 1e-4, 0, 1
             us = _time_us(lambda: sg.forward_loss_heads_bwd(x, fs.dz[:M * C].view(M, C), b, agent.heads_w, agent.heads_b, Lp), iters)
-            mfma("ag_split_gemm_loss_heads_bwd (forward of the last hidden layer + ELU + heads + PPO loss + head backward, as the "
-                 "step runs it)", us, flops + 4.0 * M * C * A1,
+            mfma("ag_split_gemm_loss_heads_bwd (forward of the last hidden layer + ELU + heads + PPO loss + head backward; h1 read "
+                 "from HBM)" + (" - for reference (the step runs the fused-first-layer form, first entries)"
+                                if getattr(fs, "fuse_gemm_input", False) else ""), us, flops + 4.0 * M * C * A1,
                  "replaces ag_split_gemm_elu_heads + ag_ppo_loss + ag_heads_bwd_elu_wgrad: z, heads and d_heads never touch HBM")
             del keep
         if getattr(fs, "fuse_gemm_input_wgrad", False):
             D0 = fs.layers[0][0].shape[1]
             us = _time_us(lambda: sg.backward_input_wgrad(h, fs.h[0], fs.xn, fs.wgrad_partials[0], fs.bias_partials[0]), iters)
-            mfma("ag_split_gemm_input_wgrad (dX of layer 2 + ELU' + dW1 / db1 on the matrix cores, as the step runs it)", us,
+            mfma("ag_split_gemm_input_wgrad (dX of layer 2 + ELU' + dW1 / db1 on the matrix cores, stored-h1 form)"
+                 + (" - for reference (the step runs ag_split_gemm_input_wgrad_recompute)" if getattr(fs, "recompute_h1", False) else ""), us,
                  flops + 2.0 * M * C * 32, "replaces ag_split_gemm + ag_elu_bwd_input_wgrad; dh1 / dz1 never written; the "
                  "epilogue's K = rows products are counted at their padded size (32 input columns)")
     scratch = fs.dz[:M * C].view(M, C)

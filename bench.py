@@ -208,6 +208,14 @@ def side_config_tracking(args, epochs=3, warmup=2):
                       "num_obs": 48, "horizon_length": agent.horizon_length, "mini_epochs": agent.mini_epochs_num,
                       "minibatch_size": agent.minibatch_size, "policy": "MLP(256,256) actor-critic, fixed sigma"},
            "last_kl": st["kl"], "finite": bool(st["kl"] == st["kl"] and st["a_loss"] == st["a_loss"])}
+    out["config"]["paths"] = agent.compute_paths()
+    try:      # the env kernels of THIS configuration against its own 543 B / env-step: env-only and in-loop forms
+        from airgym_amd.utils.kernel_bench import roofline_object
+        ro = roofline_object(agent, agent._hip_env, a, REPO)
+        out["roofline"] = ro["roofline"]
+        out["env_only"] = ro["env_only"]
+    except Exception as e:
+        out["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     agent.vec_env.env.hip.close()
     return out
 
@@ -517,6 +525,7 @@ def _run_rank(args, world, rank, on_gpu, stage):
                                              "(ag_split_gemm_input_loss_heads_bwd)" if getattr(fs, "fuse_gemm_input", False) else
                                              ("hidden layer + heads + PPO loss + head backward in one launch behind ag_mlp_input_layer"
                                               if getattr(fs, "fuse_gemm_loss", False) else "separate launches")),
+                   "paths": (agent.compute_paths() if hasattr(agent, "compute_paths") else None),
                    "gemm_selection": ("TunableOp table airgym_amd/assets/tunableop_gfx950.csv (hipBLASLt / rocBLAS fp32)"
                                       if getattr(agent, "tuned_gemms", False) else "hipBLASLt default heuristic (fp32)")},
         "phases": {"rollout_host_enqueue_s": play, "update_s": update, "final_lr": agent.last_lr,
@@ -544,10 +553,11 @@ def _run_rank(args, world, rank, on_gpu, stage):
         if roof is not None:
             out.update(roof)
             if world == 1:
-                from airgym_amd.utils.kernel_bench import measure_update_kernels
-                uk = measure_update_kernels(agent)      # where the epoch's time actually goes
+                from airgym_amd.utils.kernel_bench import measure_update_kernels, measure_update_sequence
+                # where the epoch's time actually goes: first the launches the step really issues, in its order, then reference legs
+                uk = measure_update_sequence(agent) + measure_update_kernels(agent)
                 for e in uk:
-                    if e["bound"] == "hbm":
+                    if e.get("bound") == "hbm":
                         e["frac_of_copy_ceiling"] = e["achieved"] / out["roofline"]["copy_ceiling_gbps"]
                 out["update_kernels"] = uk
         if (world == 1 and on_gpu and not args.no_side_configs and (args.task, args.ctl) == ("hovering", "rate")

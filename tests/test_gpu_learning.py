@@ -1,10 +1,16 @@
 """Does the fast path LEARN?  Regression for the headline configuration (Hovering / CTBR, 65 536 envs, MLP(256,256), 196 608-sample
-minibatches; split-bf16 GEMMs, fused epilogues incl. the loss, chain forward + fused rollout step, hipGraph rollout): the mean
-episode reward must reach 2 000 within 120 epochs on at least 4 of 5 seeds, and 80 epochs later - past the point where every
-arm of the seed studies dips (profiles/r03_seed_study.md, r04_seed_study.md: the 2 400-step time limit; desynchronising it does
-not help) - at least 4 of 5 seeds must still be above 150 (random policy: ~20; hover for the whole episode: ~8 000; lowest
-default-arm seed of the round-4 study at epoch 200: 808).  The second bound is a guard against a TOTAL collapse, which is what a
-broken kernel would look like; the dip itself is a property of the configuration at 10x the reference's training budget."""
+minibatches; split-bf16 GEMMs with h1 recomputed, fused epilogues incl. the loss, chain forward + fused rollout step, hipGraph
+rollout).
+
+What is asserted, and why not the reference's meter at epoch 200 (profiles/r05_collapse_trace.md): the meter averages the last
+100 episodes that ENDED; once the policy keeps all 65 536 envs alive the only episodes that end between two time-limit waves are
+the few that crash, so the meter drops to a few hundred while the population flies better than ever.  So:
+  * default configuration: the meter must reach 2 000 within 120 epochs on >= 4 of 5 seeds (learning speed), and at epoch 200
+    the mean raw reward per env-step over the WHOLE last rollout must be >= 3.0 on every seed (a random policy collects ~1.3, a
+    perfect hover ~3.6; the round-5 trace has 3.53-3.57 on all five) - a regression in any kernel of the path shows here;
+  * opt-in `max_lr: 1e-3` (the arm that keeps the recovery-from-reset skill through the reset-free phase): every env's FIRST
+    episode from a fresh full reset under the final policy (tools/learning_curves.py evaluate_population, 65 536 episodes) must
+    average >= 6 000 on >= 4 of 5 seeds and >= 3 000 on all five (trace: 7 699 / 7 674 / 7 124 / 7 177 / 6 422; ~8 000 = perfect)."""
 import os
 import sys
 
@@ -20,16 +26,32 @@ def test_headline_configuration_learns_on_4_of_5_seeds():
     assert torch.cuda.is_available()
     sys.path.insert(0, REPO)
     from tools.learning_curves import run
-    best, final = [], []
+    best, final, step_reward = [], [], []
     for seed in range(5):
         out = run(f"headline seed {seed}", 65536, 8, 200, 10, seed=seed)
         best.append(max((c["reward"] or 0.0) for c in out["curve"] if c["epoch"] <= 120))
         final.append(out["curve"][-1]["reward"] or 0.0)
+        step_reward.append(out["final_step_reward"])
         assert out["curve"][-1]["epoch"] == 200
         assert all(c["kl"] == c["kl"] and c["c_loss"] == c["c_loss"] for c in out["curve"]), "NaN in the losses"
-    print("best by epoch 120:", best, "at epoch 200:", final, "median at 200:", sorted(final)[2])
+    print("meter: best by epoch 120:", best, "at epoch 200:", final, "| whole-population reward per env-step at epoch 200:", step_reward)
     assert sum(b >= 2000.0 for b in best) >= 4, best
-    assert sum(f >= 150.0 for f in final) >= 4, final
+    assert all(r >= 3.0 for r in step_reward), step_reward
+
+
+def test_opt_in_max_lr_arm_keeps_the_whole_population_flying_at_epoch_200():
+    assert torch.cuda.is_available()
+    sys.path.insert(0, REPO)
+    from tools.learning_curves import run
+    returns, lengths = [], []
+    for seed in range(5):
+        out = run(f"max_lr 1e-3 seed {seed}", 65536, 8, 200, 50, seed=seed, extra={"max_lr": 1e-3}, evaluate=True)
+        returns.append(out["eval"]["eval_return"])
+        lengths.append(out["eval"]["eval_length"])
+        assert out["eval"]["eval_envs"] == 65536
+    print("whole-population first-episode return at epoch 200 (max_lr 1e-3):", returns, "lengths:", lengths)
+    assert sum(r >= 6000.0 for r in returns) >= 4, returns
+    assert all(r >= 3000.0 for r in returns), returns
 
 
 def test_planning_cnn_policy_learns_on_the_hand_written_trunk():

@@ -97,14 +97,17 @@ def run(arm, seed, epochs, envs=65536, minibatches=8, extra=None):
 
 
 def summarise(path):
-    by, evals = {}, {}
+    by, evals, run_no = {}, {}, {}
     for line in open(path):
         line = line.strip()
         if not line.startswith("{"):
             continue
         r = json.loads(line)
         if "epoch" in r:
-            by.setdefault((r["arm"], r["seed"]), []).append(r)
+            if r["epoch"] == 1:                      # a new run of this (arm, seed) starts (e.g. the 120-epoch runs behind the 200-epoch ones)
+                run_no[(r["arm"], r["seed"])] = run_no.get((r["arm"], r["seed"]), -1) + 1
+            by.setdefault((r["arm"] + ("" if run_no[(r["arm"], r["seed"])] == 0 else f" (run {run_no[(r['arm'], r['seed'])] + 1})"),
+                           r["seed"]), []).append(r)
         elif "run_done" in r and "eval_return" in r["run_done"]:
             d = r["run_done"]
             evals.setdefault((d["arm"], d["epochs"]), []).append(d)

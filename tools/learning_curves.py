@@ -44,7 +44,7 @@ def evaluate_population(agent, steps=None):
             ret += alive * rr[t]
             length += alive
             alive = alive * (1.0 - dn[t])
-    full = (length >= max_len - 1).double().mean()
+    full = (length >= 0.99 * max_len).double().mean()      # flew (practically) to the time limit
     return {"eval_return": round(float(ret.mean()), 2), "eval_return_p10": round(float(ret.quantile(0.10)), 2),
             "eval_length": round(float(length.mean()), 1), "eval_full_length_frac": round(float(full), 4),
             "eval_still_alive_frac": round(float(alive.mean()), 4), "eval_steps": steps, "eval_envs": n}
@@ -81,7 +81,9 @@ def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=
     wall = time.time() - t0
     out = {"run": name, "envs": envs, "minibatch_size": agent.minibatch_size,
            "optimizer_steps_per_epoch": agent.mini_epochs_num * agent.num_minibatches, "mlp": list(units), "epochs": epochs,
-           "wall_s": round(wall, 2), "env_steps_per_s": round(epochs * envs * agent.horizon_length / wall), "curve": curve}
+           "wall_s": round(wall, 2), "env_steps_per_s": round(epochs * envs * agent.horizon_length / wall), "curve": curve,
+           # mean raw reward per env-step over ALL samples of the last rollout (the whole population, not the episodes that ended)
+           "final_step_reward": round(float(agent.raw_rewards_buf.mean()), 4) if hasattr(agent, "raw_rewards_buf") else None}
     if evaluate:
         out["eval"] = evaluate_population(agent)
     agent.vec_env.env.hip.close()
