@@ -340,10 +340,13 @@ class A2CAgent:
         from airgym_amd.lib.agent.fused_update import FusedMLPStep
         self._fused_step = FusedMLPStep(self) if FusedMLPStep.supported(self) else None
         self._graphs = {}
-        # minibatch graphs: only where launches dominate (small minibatches).  No collective is ever captured: with
-        # multi_gpu the capture is split at the gradient all-reduce (graph A: forward / backward / reductions; the
-        # all-reduce eager; graph B: average + clip + Adam + LR rule), and a minibatch whose forward all-reduces the
-        # normaliser moments (first mini-epoch, sync_normalizers) runs eagerly
+        # minibatch graphs: only where launches dominate (small minibatches).  With multi_gpu the gradient all-reduce is captured
+        # inside the graph when RCCL allows it (`capture_gradient_allreduce`; train_actor_critic falls back to a capture split
+        # at the all-reduce - graph A: forward / backward / reductions; the all-reduce eager; graph B: average + clip + Adam +
+        # LR rule - if the capture throws); a minibatch whose forward all-reduces the normaliser moments (first mini-epoch,
+        # sync_normalizers) runs eagerly
+        self._capture_collective = bool(config.get("capture_gradient_allreduce", True))
+        self.collective_capture_error = None
         self._graph_update = bool(self._fused_step is not None and self.use_hip_graph
                                   and config.get("use_hip_graph_update", self.minibatch_size <= 32768))
         self._upd_graphs = {}
@@ -865,18 +868,38 @@ class A2CAgent:
             if self._graph_update and self.epoch_num >= 2 and not collective_in_forward:
                 # launch-bound regime (small minibatches): forward + backward + reductions + Adam of this minibatch as ONE
                 # hipGraph, one graph per (minibatch index, statistics-on/off); captured on first use, then replayed.
-                # multi_gpu: the graph ends in front of the gradient all-reduce; that runs eagerly, and the rank average +
-                # clip + Adam + LR rule behind it are a second graph shared by every minibatch (same buffers).
+                # multi_gpu (round 5): the gradient all-reduce is captured INSIDE that graph when RCCL allows it
+                # (`capture_gradient_allreduce`, default on) - N > 1 then replays one graph per optimizer step exactly like N = 1.
+                # If the capture throws, the round-4 structure is the fallback: the graph ends in front of the all-reduce, which
+                # runs eagerly, and rank average + clip + Adam + LR rule are a second graph shared by every minibatch.
                 key = (idx, stats_on)
                 entry = self._upd_graphs.get(key)
                 if entry is None:
                     row = torch.zeros(8, dtype=torch.float32, device=self.ppo_device)
+                    if self.multi_gpu and self._capture_collective and dist.get_backend(self.group) != "nccl":
+                        # gloo moves the buffer through the host: not capturable (tests run two ranks on one GPU over gloo)
+                        self._capture_collective = False
+                        self.collective_capture_error = f"backend {dist.get_backend(self.group)}: host-side collective, not capturable"
+                    whole = (not self.multi_gpu) or self._capture_collective
 
-                    def body():
+                    def body(whole=whole):
                         self._fused_step.step(mb, stats_out=row)
                         if not self.multi_gpu:
                             self._reduce_clip_step(need_kl=False)
-                    entry = (self._capture(body, warmup=False), row, mb)      # mb kept alive: the graph reads its views
+                        elif whole:
+                            collectives.all_reduce(self.flat_grad, "gradient", group=self.group, counted=False)
+                            self._reduce_clip_step(need_kl=False, reduced=True)
+                    try:
+                        graph = self._capture(body, warmup=False)
+                    except Exception as e:      # RCCL refused the capture: remember why, fall back to the split graphs
+                        if not (self.multi_gpu and whole):
+                            raise
+                        self._capture_collective = False
+                        self.collective_capture_error = f"{type(e).__name__}: {e}"[:300]
+                        torch.cuda.synchronize()
+                        whole = False
+                        graph = self._capture(lambda: body(False), warmup=False)
+                    entry = (graph, row, mb, whole)      # mb kept alive: the graph reads its views
                     self._upd_graphs[key] = entry
                 entry[0].replay()
                 st = self._fused_step.next_stats_row()
@@ -884,6 +907,9 @@ class A2CAgent:
                 self._last_clip = st[6]
                 if not self.multi_gpu:
                     return st[0], st[1], st[2], st[3], st[4]
+                if entry[3]:      # the all-reduce, the rank average, clip, Adam and the LR rule were part of the replay
+                    collectives.count("gradient", self.flat_grad.numel() * self.flat_grad.element_size())
+                    return st[0], st[1], st[2], st[3], self.flat_grad[-1].double()
                 collectives.all_reduce(self.flat_grad, "gradient", group=self.group)
                 tail = self._upd_graphs.get("tail")
                 if tail is None:
@@ -968,9 +994,9 @@ class A2CAgent:
                     b_losses.append(b)
             av_kls = torch_ext.mean_list(ep_kls)
             if self.is_adaptive_lr and self.schedule_type == "standard":
-                if self.multi_gpu:
-                    collectives.all_reduce(av_kls, "epoch_kl", group=self.group)
-                    av_kls /= self.world_size
+                # (the reference all-reduces av_kls here, a2c_continuous.py:120-122: its per-minibatch KL is rank-local.  Here every
+                # minibatch's KL rode in the gradient all-reduce - flat_grad's last slot - and is the rank average already, so the
+                # mean of them is identical on every rank: no collective.)
                 self.last_lr, self.entropy_coef = self.scheduler.update(self.optimizer.lr.item(), self.entropy_coef,
                                                                         self.epoch_num, 0, av_kls.item())
                 self.optimizer.lr.fill_(self.last_lr)
@@ -1061,9 +1087,15 @@ class A2CAgent:
                     print("MAX FRAMES NUM!")
                     should_exit = True
             if self.multi_gpu:
-                t = torch.tensor(float(should_exit), device=self.ppo_device)
-                collectives.broadcast(t, 0, "should_exit")
-                should_exit = bool(t.item())
+                # epoch and frame counters advance identically on every rank: those two exits need no collective.  Only
+                # `score_to_win` depends on rank 0's episode meter (a2c_continuous.py:281-286 broadcasts should_exit every epoch);
+                # one scalar per epoch, issued only when the YAML sets that key, outside the update's hot path
+                local = ((epoch_num >= self.max_epochs and self.max_epochs != -1) or (self.frame >= self.max_frames and self.max_frames != -1))
+                if "score_to_win" in self.config:
+                    t = torch.tensor(float(should_exit), device=self.ppo_device)
+                    collectives.broadcast(t, 0, "should_exit")
+                    should_exit = bool(t.item())
+                should_exit = should_exit or local
             if should_exit:
                 return self.last_mean_rewards, epoch_num
 

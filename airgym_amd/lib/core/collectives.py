@@ -19,9 +19,18 @@ def snapshot():
     return {k: {"calls": int(v), "bytes": int(BYTES[k])} for k, v in sorted(COUNTS.items())}
 
 
-def all_reduce(tensor, tag, op=None, group=None):
-    COUNTS[tag] += 1
-    BYTES[tag] += tensor.numel() * tensor.element_size()
+def count(tag, nbytes, calls=1):
+    """Account for collectives that were issued without passing through all_reduce(): the replay of a hipGraph that CONTAINS
+    a captured all-reduce issues it on the device each time - the caller counts it here, once per replay."""
+    COUNTS[tag] += calls
+    BYTES[tag] += nbytes * calls
+
+
+def all_reduce(tensor, tag, op=None, group=None, counted=True):
+    """counted=False: inside a graph capture (the capture pass itself moves no data; replays are counted with count())."""
+    if counted:
+        COUNTS[tag] += 1
+        BYTES[tag] += tensor.numel() * tensor.element_size()
     return dist.all_reduce(tensor, op=op if op is not None else dist.ReduceOp.SUM, group=group)
 
 

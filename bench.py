@@ -538,6 +538,11 @@ def _run_rank(args, world, rank, on_gpu, stage):
         rccl["collectives_per_epoch"] = {k: {"calls": v["calls"] / args.steps, "bytes": v["bytes"] / args.steps}
                                          for k, v in counted.items()}
         rccl["minibatch_hip_graphs"] = bool(getattr(agent, "_graph_update", False))
+        ents = [v for k, v in getattr(agent, "_upd_graphs", {}).items() if k != "tail"]
+        rccl["minibatch_graph_mode"] = (None if not ents else
+                                        ("one graph per optimizer step, gradient all-reduce captured inside" if all(len(e) > 3 and e[3] for e in ents)
+                                         else "split at the gradient all-reduce (graph A, eager all-reduce, graph B)"))
+        rccl["collective_capture_error"] = getattr(agent, "collective_capture_error", None)
         out["rccl"] = rccl
     hip = getattr(agent, "_hip_env", None)
     # N > 1: every rank measures its own env kernel at the same time (nobody idles in a barrier while rank 0 works); the

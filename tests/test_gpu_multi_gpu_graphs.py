@@ -1,5 +1,6 @@
-"""The data-parallel update path on ONE GPU (world_size 1 over RCCL): with multi_gpu the minibatch hipGraph is split at the
-gradient all-reduce (graph A: forward / backward / reductions; eager all-reduce; graph B: rank average + clip + Adam + LR rule,
+"""The data-parallel update path on ONE GPU (world_size 1 over RCCL): with multi_gpu the minibatch hipGraph either CONTAINS the
+gradient all-reduce (round 5, default: one replay per optimizer step, as at N = 1) or is split at it (round 4 form, the
+fallback: graph A: forward / backward / reductions; eager all-reduce; graph B: rank average + clip + Adam + LR rule;
 reference: trancate_gradients_and_step, lib/agent/a2c_base.py:293-316).  A one-rank group makes the all-reduce the identity and
 the division a division by 1.0, so nothing changes numerically; the run with the split graphs must equal, bit for bit, the same data-parallel run with the
 update launched eagerly (use_hip_graph_update: false) - which checks the split capture, the eager collective between two
@@ -16,7 +17,7 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _params(multi_gpu, graph_update=True):
+def _params(multi_gpu, graph_update=True, capture_collective=True):
     with open(os.path.join(REPO, "scripts", "config", "ppo_hovering.yaml")) as f:
         params = yaml.safe_load(f)["params"]
     c = params["config"]
@@ -24,17 +25,18 @@ def _params(multi_gpu, graph_update=True):
     envs = 4096
     c.update(num_actors=envs, minibatch_size=envs * c["horizon_length"] // 24, device="cuda:0", multi_gpu=multi_gpu,
              max_epochs=-1, write_summaries=False, print_stats=False, save_frequency=0, save_best_after=10 ** 9,
-             use_hip_graph=True, use_hip_graph_update=graph_update, dist_backend="nccl")
+             use_hip_graph=True, use_hip_graph_update=graph_update, dist_backend="nccl",
+             capture_gradient_allreduce=capture_collective)
     c["env_config"] = {"use_image": False, "num_envs": envs, "ctl_mode": "rate", "seed": 0, "sim_device": "cuda:0", "headless": True}
     params["seed"] = 0
     return params
 
 
-def _run(multi_gpu, epochs=4, graph_update=True):
+def _run(multi_gpu, epochs=4, graph_update=True, capture_collective=True):
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
     from airgym_amd.lib.core import collectives
     torch.manual_seed(0)
-    agent = A2CAgent("mg", _params(multi_gpu, graph_update))
+    agent = A2CAgent("mg", _params(multi_gpu, graph_update, capture_collective))
     agent.init_tensors()
     agent.obs = agent.env_reset()
     agent.broadcast_parameters()
@@ -44,13 +46,17 @@ def _run(multi_gpu, epochs=4, graph_update=True):
         agent.epoch_num += 1
         kls.append(agent.train_epoch()["kl"])
     out = {"param": agent.flat_param.clone(), "lr": agent.last_lr, "kls": kls, "graphs": dict(agent._upd_graphs),
-           "graph_update": agent._graph_update, "counts": collectives.snapshot(),
+           "graph_update": agent._graph_update, "counts": collectives.snapshot(), "capture_error": agent.collective_capture_error,
            "rms": agent.model.running_mean_std.running_mean.clone()}
     agent.vec_env.env.hip.close()
     return out
 
 
-def test_split_minibatch_graph_under_multi_gpu_equals_the_eager_update():
+def test_minibatch_graphs_under_multi_gpu_equal_the_eager_update():
+    """Three data-parallel runs on a one-rank RCCL group: the update eager; minibatch graphs split at the gradient all-reduce
+    (round 4); ONE graph per optimizer step with the all-reduce captured inside it (round 5, the default).  All three must be the
+    same run bit for bit, and each must have issued the same number of gradient all-reduces (counted at the call site for the
+    eager / split forms, once per replay for the captured form)."""
     assert torch.cuda.is_available()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}
@@ -58,7 +64,8 @@ def test_split_minibatch_graph_under_multi_gpu_equals_the_eager_update():
     os.environ.update(env)
     try:
         eager = _run(True, graph_update=False)
-        multi = _run(True, graph_update=True)
+        split = _run(True, graph_update=True, capture_collective=False)
+        whole = _run(True, graph_update=True, capture_collective=True)
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -67,16 +74,23 @@ def test_split_minibatch_graph_under_multi_gpu_equals_the_eager_update():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    assert multi["graph_update"] and not eager["graph_update"] and not eager["graphs"]
-    assert "tail" in multi["graphs"]
+    assert split["graph_update"] and whole["graph_update"] and not eager["graph_update"] and not eager["graphs"]
+    assert "tail" in split["graphs"] and all(not e[3] for k, e in split["graphs"].items() if k != "tail")
     # graphs exist for the statistics-off minibatches; the first mini-epoch's (whose forward all-reduces the normaliser
     # moments when there is more than one rank) stayed eager
-    assert any(k != "tail" and k[1] is False for k in multi["graphs"])
-    assert not any(k != "tail" and k[1] is True for k in multi["graphs"])
-    # 4 epochs x 5 mini-epochs x 24 minibatches gradient all-reduces, each issued eagerly, in both runs
-    assert multi["counts"]["gradient"]["calls"] == 4 * 5 * 24 == eager["counts"]["gradient"]["calls"]
-    assert "normaliser_moments" not in multi["counts"]          # a one-rank group has nothing to merge (running_mean_std.py)
-    # same kernels in the same order on the same data: the split-graph run IS the eager run
-    assert torch.equal(eager["rms"], multi["rms"])
-    assert torch.equal(eager["param"], multi["param"]), (eager["param"] - multi["param"]).abs().max().item()
-    assert eager["lr"] == multi["lr"] and eager["kls"] == multi["kls"]
+    for run in (split, whole):
+        assert any(k != "tail" and k[1] is False for k in run["graphs"])
+        assert not any(k != "tail" and k[1] is True for k in run["graphs"])
+    # RCCL captured: no tail graph, every minibatch graph contains its all-reduce.  (If this stack refuses the capture the agent
+    # falls back to the split form and says why - that is a finding to record, so fail loudly here with the reason.)
+    assert whole["capture_error"] is None, whole["capture_error"]
+    assert "tail" not in whole["graphs"] and all(e[3] for e in whole["graphs"].values())
+    # 4 epochs x 5 mini-epochs x 24 minibatches gradient all-reduces in every run
+    for run in (eager, split, whole):
+        assert run["counts"]["gradient"]["calls"] == 4 * 5 * 24
+        assert set(run["counts"]) == {"gradient"}, run["counts"]      # a one-rank group has no normaliser moments to merge; no epoch_kl
+    # same kernels in the same order on the same data
+    for run in (split, whole):
+        assert torch.equal(eager["rms"], run["rms"])
+        assert torch.equal(eager["param"], run["param"]), (eager["param"] - run["param"]).abs().max().item()
+        assert eager["lr"] == run["lr"] and eager["kls"] == run["kls"]
