@@ -7,7 +7,7 @@ distance of the 16-dim observation statistics to the input normaliser stored in 
 produced during training).  The world- vs body-frame hypothesis for the angular velocity handed to the rate loop is a compile-time
 variant of the experiments build (-DAG_EXP_CASCADE=1: tools/cascade_sweep.py runs under whatever library AIRGYM_EXP_LIB names).
 
-    python tools/cascade_sweep.py --checkpoint runs/ref_ckpt/planning_cnn_rate.pth --signs +++ -++ +-+ ++- --+ -+- +-- ---
+    python tools/cascade_sweep.py --checkpoint /root/reference/trained/planning_cnn_rate.pth   (this container only; the file is never copied) --signs +++ -++ +-+ ++- --+ -+- +-- ---
 """
 import argparse
 import json
