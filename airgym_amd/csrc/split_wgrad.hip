@@ -412,6 +412,27 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][1], d_, 0, 0, 0);                \
         d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][0], d_, 0, 0, 0);                \
     } while (0)
+    // two dZ row tiles at a time, their MFMAs alternating (consecutive MFMAs never share an accumulator: a wave alone on the
+    // pipe - its partner in a VALU / wait phase - is then not paced by the accumulation latency)
+#define AG_WF_PAIR_READ(slot_, i_)                                                                   \
+        const uint4* sa_ = lds + (slot_) * OP_UNITS + khalf * WN + l31;                              \
+        const uint4 ua0_ = sa_[(0 * 2) * WN + (i_) * 32], ub0_ = sa_[(0 * 2) * WN + (i_) * 32 + 32];  \
+        const uint4 ua1_ = sa_[(1 * 2) * WN + (i_) * 32], ub1_ = sa_[(1 * 2) * WN + (i_) * 32 + 32];  \
+        const uint4 ua2_ = sa_[(2 * 2) * WN + (i_) * 32], ub2_ = sa_[(2 * 2) * WN + (i_) * 32 + 32];  \
+        const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(&ua0_), b0_ = *reinterpret_cast<const bf16x8*>(&ub0_); \
+        const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(&ua1_), b1_ = *reinterpret_cast<const bf16x8*>(&ub1_); \
+        const bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(&ua2_), b2_ = *reinterpret_cast<const bf16x8*>(&ub2_); \
+        f32x16& d_ = acc[i_];                                                                        \
+        f32x16& e_ = acc[(i_) + 1]
+#define AG_WF_PAIR_STEP(pa_, pb_, q_)                                                                \
+        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a##pa_##_, bfrag[q_][pb_], d_, 0, 0, 0);        \
+        e_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b##pa_##_, bfrag[q_][pb_], e_, 0, 0, 0)
+#define AG_WF_PAIR(slot_, q_, i_)                                                                    \
+    do {                                                                                             \
+        AG_WF_PAIR_READ(slot_, i_);                                                                  \
+        AG_WF_PAIR_STEP(2, 0, q_); AG_WF_PAIR_STEP(0, 2, q_); AG_WF_PAIR_STEP(1, 1, q_);             \
+        AG_WF_PAIR_STEP(1, 0, q_); AG_WF_PAIR_STEP(0, 1, q_); AG_WF_PAIR_STEP(0, 0, q_);             \
+    } while (0)
     // production MFMAs k .. k + 2 (of 6) of K step s_: (x1 w3, x3 w1, x2 w2 | x1 w2, x2 w1, x1 w1), the forward's order
 #define AG_WF_PROD3(s_, half_)                                                                       \
     do {                                                                                             \
@@ -457,10 +478,8 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         const int bs = t & 1;
         const int t2 = min(t + 2, n - 1);
         // ---- first chunk: tiles 0 .. 3 carry the split of block t + 1's inputs (VALU), tiles 4 .. 7 its 12 production MFMAs
-        AG_WF_TILE(2 * bs, 0, 0);
-        AG_WF_TILE(2 * bs, 0, 1);
-        AG_WF_TILE(2 * bs, 0, 2);
-        AG_WF_TILE(2 * bs, 0, 3);
+        AG_WF_PAIR(2 * bs, 0, 0);
+        AG_WF_PAIR(2 * bs, 0, 2);
         AG_WF_XSPLIT();                         // x of block t + 1 (requested a block ago)
         AG_WF_XLOAD(t2);
         bf16x8 wb[2][3];
@@ -468,57 +487,62 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
         AG_WF_WREAD(0);
         AG_WF_WREAD(1);
-#define AG_WF_TILE_P(i_, s_)                                                                         \
+        // tiles 4 .. 7 in pairs, a production MFMA behind every pair of chunk MFMAs (12 + 6 per pair of tiles)
+#define AG_WF_PAIR_P(i_, s_)                                                                         \
         do {                                                                                         \
-            AG_WF_TILE_READ(2 * bs, i_);                                                             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[0][0], d_, 0, 0, 0);             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][2], d_, 0, 0, 0);             \
-            AG_WF_PROD3(s_, (i_) & 1);                                                               \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][1], d_, 0, 0, 0);             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][0], d_, 0, 0, 0);             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][1], d_, 0, 0, 0);             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][0], d_, 0, 0, 0);             \
+            AG_WF_PAIR_READ(2 * bs, i_);                                                             \
+            AG_WF_PAIR_STEP(2, 0, 0);                                                                \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][2], hacc, 0, 0, 0);     \
+            AG_WF_PAIR_STEP(0, 2, 0);                                                                \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][2], wb[s_][0], hacc, 0, 0, 0);     \
+            AG_WF_PAIR_STEP(1, 1, 0);                                                                \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][1], hacc, 0, 0, 0);     \
+            AG_WF_PAIR_STEP(1, 0, 0);                                                                \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][1], hacc, 0, 0, 0);     \
+            AG_WF_PAIR_STEP(0, 1, 0);                                                                \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][0], hacc, 0, 0, 0);     \
+            AG_WF_PAIR_STEP(0, 0, 0);                                                                \
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][0], hacc, 0, 0, 0);     \
         } while (0)
-        AG_WF_TILE_P(4, 0);
-        AG_WF_TILE_P(5, 0);
-        AG_WF_TILE_P(6, 1);
-        AG_WF_TILE_P(7, 1);
-#undef AG_WF_TILE_P
+        AG_WF_PAIR_P(4, 0);
+        AG_WF_PAIR_P(6, 1);
+#undef AG_WF_PAIR_P
         AG_SGB(0x100, 6);                       // fragments of tiles 0, 1
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {           // tiles 0 .. 3: one MFMA, three VALU (the 60-odd of the input split + addresses)
+        for (int i = 0; i < 2; ++i) {           // tile pairs (0, 1), (2, 3): one MFMA, three VALU (the input split + addresses)
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
+            for (int m = 0; m < 12; ++m) {
                 AG_SGB(0x008, 1);
                 AG_SGB(0x002, 3);
             }
-            AG_SGB(0x100, 3);                   // fragments of tile i + 2
+            AG_SGB(0x100, 6);                   // fragments of the next pair
         }
         AG_SGB(0x020, 4 + (FIN - 16) / 2);      // the next-but-one block's inputs (their registers were just split)
         AG_SGB(0x100, 6);                       // first-layer fragments (both K steps)
-#pragma unroll
-        for (int i = 4; i < 8; ++i) {           // tiles 4 .. 7: nine MFMAs each (six of the chunk, three of the production)
-            AG_SGB(0x008, 9);
-            if (i < 6) AG_SGB(0x100, 3);        // fragments of tile i + 2
-        }
+        AG_SGB(0x008, 18);                      // tiles 4, 5 + the production's first K step
+        AG_SGB(0x100, 6);                       // fragments of tiles 6, 7
+        AG_SGB(0x008, 18);
         __builtin_amdgcn_sched_barrier(0);
         // ---- second chunk: ELU + split of the produced tile (B fragments of block t + 1) and the split of its dZ quad into the
         //      other slot, spread under the 48 MFMAs; then the loads that refill the quad's registers
         bf16x8 bnext[2][3];
         AG_WF_PRODUCE_FINISH(bnext);
-        AG_WF_COMPUTE(2 * bs + 1, 1);
+        AG_WF_PAIR(2 * bs + 1, 1, 0);
+        AG_WF_PAIR(2 * bs + 1, 1, 2);
+        AG_WF_PAIR(2 * bs + 1, 1, 4);
+        AG_WF_PAIR(2 * bs + 1, 1, 6);
         AG_WF_WRITE(bs ^ 1);                    // dZ of block t + 1 (requested at the end of the previous trip)
         AG_WF_LOAD(t2);
         AG_SGB(0x100, 6);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
+            for (int m = 0; m < 12; ++m) {
                 AG_SGB(0x008, 1);
                 AG_SGB(0x002, 5);
             }
-            if (i < 6) AG_SGB(0x100, 3);
-            if (i >= 2) AG_SGB(0x200, 2);
+            if (i < 3) AG_SGB(0x100, 6);
+            if (i >= 1) AG_SGB(0x200, 4);
         }
         AG_SGB(0x020, 4);
 #pragma unroll
@@ -530,6 +554,9 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
 #undef AG_SGB
 #undef AG_WF_WREAD
 #undef AG_WF_PROD3
+#undef AG_WF_PAIR
+#undef AG_WF_PAIR_STEP
+#undef AG_WF_PAIR_READ
 #undef AG_WF_TILE
 #undef AG_WF_TILE_READ
 #undef AG_WF_COMPUTE
