@@ -252,7 +252,7 @@ __device__ __forceinline__ float wg_elu(float z) {      // split_gemm.hip sg_elu
     return z > 0.f ? z : __builtin_amdgcn_exp2f(z * 1.4426950408889634f) - 1.0f;
 }
 
-template <int FIN>
+template <int FIN, bool PIPE>
 __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __restrict__ dZ, const float* __restrict__ X,
                                                                   const uint4* __restrict__ w1img, float* __restrict__ partials, int M,
                                                                   int blocks_per_slice) {
@@ -412,27 +412,6 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][1], d_, 0, 0, 0);                \
         d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][0], d_, 0, 0, 0);                \
     } while (0)
-    // two dZ row tiles at a time, their MFMAs alternating (consecutive MFMAs never share an accumulator: a wave alone on the
-    // pipe - its partner in a VALU / wait phase - is then not paced by the accumulation latency)
-#define AG_WF_PAIR_READ(slot_, i_)                                                                   \
-        const uint4* sa_ = lds + (slot_) * OP_UNITS + khalf * WN + l31;                              \
-        const uint4 ua0_ = sa_[(0 * 2) * WN + (i_) * 32], ub0_ = sa_[(0 * 2) * WN + (i_) * 32 + 32];  \
-        const uint4 ua1_ = sa_[(1 * 2) * WN + (i_) * 32], ub1_ = sa_[(1 * 2) * WN + (i_) * 32 + 32];  \
-        const uint4 ua2_ = sa_[(2 * 2) * WN + (i_) * 32], ub2_ = sa_[(2 * 2) * WN + (i_) * 32 + 32];  \
-        const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(&ua0_), b0_ = *reinterpret_cast<const bf16x8*>(&ub0_); \
-        const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(&ua1_), b1_ = *reinterpret_cast<const bf16x8*>(&ub1_); \
-        const bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(&ua2_), b2_ = *reinterpret_cast<const bf16x8*>(&ub2_); \
-        f32x16& d_ = acc[i_];                                                                        \
-        f32x16& e_ = acc[(i_) + 1]
-#define AG_WF_PAIR_STEP(pa_, pb_, q_)                                                                \
-        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a##pa_##_, bfrag[q_][pb_], d_, 0, 0, 0);        \
-        e_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b##pa_##_, bfrag[q_][pb_], e_, 0, 0, 0)
-#define AG_WF_PAIR(slot_, q_, i_)                                                                    \
-    do {                                                                                             \
-        AG_WF_PAIR_READ(slot_, i_);                                                                  \
-        AG_WF_PAIR_STEP(2, 0, q_); AG_WF_PAIR_STEP(0, 2, q_); AG_WF_PAIR_STEP(1, 1, q_);             \
-        AG_WF_PAIR_STEP(1, 0, q_); AG_WF_PAIR_STEP(0, 1, q_); AG_WF_PAIR_STEP(0, 0, q_);             \
-    } while (0)
     // production MFMAs k .. k + 2 (of 6) of K step s_: (x1 w3, x3 w1, x2 w2 | x1 w2, x2 w1, x1 w1), the forward's order
 #define AG_WF_PROD3(s_, half_)                                                                       \
     do {                                                                                             \
@@ -454,6 +433,33 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
     // issue-order groups (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read, 0x200 DS write, 0x020 VMEM read)
 #define AG_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0)
 
+    if constexpr (!PIPE) {
+        // ---- the plain schedule (AIRGYM_WGRAD_PIPE=0; kept for A/B): block t's X side is produced at the top of trip t, the next
+        //      block's loads follow it, its dZ side is split under the second chunk
+        if (n > 0) {
+            AG_WF_LOAD(0);
+            AG_WF_XLOAD(0);
+            AG_WF_WRITE(0);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < n; ++t) {
+            const int bs = t & 1;
+            AG_WF_XSPLIT();
+            AG_WF_PRODUCE_MFMA();
+            AG_WF_PRODUCE_FINISH(bfrag);
+            __builtin_amdgcn_sched_barrier(0);
+            const int tn = min(t + 1, n - 1);
+            AG_WF_LOAD(tn);
+            AG_WF_XLOAD(tn);
+            __builtin_amdgcn_sched_barrier(0);
+            AG_WF_COMPUTE(2 * bs, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            AG_WF_COMPUTE(2 * bs + 1, 1);
+            AG_WF_WRITE(bs ^ 1);
+            __syncthreads();
+        }
+    } else {
     // ---- prologue: block 0 staged and its B fragments produced; block 1 requested
     if (n > 0) {
         AG_WF_LOAD(0);
@@ -478,8 +484,10 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         const int bs = t & 1;
         const int t2 = min(t + 2, n - 1);
         // ---- first chunk: tiles 0 .. 3 carry the split of block t + 1's inputs (VALU), tiles 4 .. 7 its 12 production MFMAs
-        AG_WF_PAIR(2 * bs, 0, 0);
-        AG_WF_PAIR(2 * bs, 0, 2);
+        AG_WF_TILE(2 * bs, 0, 0);
+        AG_WF_TILE(2 * bs, 0, 1);
+        AG_WF_TILE(2 * bs, 0, 2);
+        AG_WF_TILE(2 * bs, 0, 3);
         AG_WF_XSPLIT();                         // x of block t + 1 (requested a block ago)
         AG_WF_XLOAD(t2);
         bf16x8 wb[2][3];
@@ -487,62 +495,57 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
         AG_WF_WREAD(0);
         AG_WF_WREAD(1);
-        // tiles 4 .. 7 in pairs, a production MFMA behind every pair of chunk MFMAs (12 + 6 per pair of tiles)
-#define AG_WF_PAIR_P(i_, s_)                                                                         \
+#define AG_WF_TILE_P(i_, s_)                                                                         \
         do {                                                                                         \
-            AG_WF_PAIR_READ(2 * bs, i_);                                                             \
-            AG_WF_PAIR_STEP(2, 0, 0);                                                                \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][2], hacc, 0, 0, 0);     \
-            AG_WF_PAIR_STEP(0, 2, 0);                                                                \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][2], wb[s_][0], hacc, 0, 0, 0);     \
-            AG_WF_PAIR_STEP(1, 1, 0);                                                                \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][1], hacc, 0, 0, 0);     \
-            AG_WF_PAIR_STEP(1, 0, 0);                                                                \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][1], hacc, 0, 0, 0);     \
-            AG_WF_PAIR_STEP(0, 1, 0);                                                                \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][0], hacc, 0, 0, 0);     \
-            AG_WF_PAIR_STEP(0, 0, 0);                                                                \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][0], hacc, 0, 0, 0);     \
+            AG_WF_TILE_READ(2 * bs, i_);                                                             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[0][0], d_, 0, 0, 0);             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][2], d_, 0, 0, 0);             \
+            AG_WF_PROD3(s_, (i_) & 1);                                                               \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][1], d_, 0, 0, 0);             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][0], d_, 0, 0, 0);             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][1], d_, 0, 0, 0);             \
+            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][0], d_, 0, 0, 0);             \
         } while (0)
-        AG_WF_PAIR_P(4, 0);
-        AG_WF_PAIR_P(6, 1);
-#undef AG_WF_PAIR_P
+        AG_WF_TILE_P(4, 0);
+        AG_WF_TILE_P(5, 0);
+        AG_WF_TILE_P(6, 1);
+        AG_WF_TILE_P(7, 1);
+#undef AG_WF_TILE_P
         AG_SGB(0x100, 6);                       // fragments of tiles 0, 1
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {           // tile pairs (0, 1), (2, 3): one MFMA, three VALU (the input split + addresses)
+        for (int i = 0; i < 4; ++i) {           // tiles 0 .. 3: one MFMA, three VALU (the 60-odd of the input split + addresses)
 #pragma unroll
-            for (int m = 0; m < 12; ++m) {
+            for (int m = 0; m < 6; ++m) {
                 AG_SGB(0x008, 1);
                 AG_SGB(0x002, 3);
             }
-            AG_SGB(0x100, 6);                   // fragments of the next pair
+            AG_SGB(0x100, 3);                   // fragments of tile i + 2
         }
         AG_SGB(0x020, 4 + (FIN - 16) / 2);      // the next-but-one block's inputs (their registers were just split)
         AG_SGB(0x100, 6);                       // first-layer fragments (both K steps)
-        AG_SGB(0x008, 18);                      // tiles 4, 5 + the production's first K step
-        AG_SGB(0x100, 6);                       // fragments of tiles 6, 7
-        AG_SGB(0x008, 18);
+#pragma unroll
+        for (int i = 4; i < 8; ++i) {           // tiles 4 .. 7: nine MFMAs each (six of the chunk, three of the production)
+            AG_SGB(0x008, 9);
+            if (i < 6) AG_SGB(0x100, 3);        // fragments of tile i + 2
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- second chunk: ELU + split of the produced tile (B fragments of block t + 1) and the split of its dZ quad into the
         //      other slot, spread under the 48 MFMAs; then the loads that refill the quad's registers
         bf16x8 bnext[2][3];
         AG_WF_PRODUCE_FINISH(bnext);
-        AG_WF_PAIR(2 * bs + 1, 1, 0);
-        AG_WF_PAIR(2 * bs + 1, 1, 2);
-        AG_WF_PAIR(2 * bs + 1, 1, 4);
-        AG_WF_PAIR(2 * bs + 1, 1, 6);
+        AG_WF_COMPUTE(2 * bs + 1, 1);
         AG_WF_WRITE(bs ^ 1);                    // dZ of block t + 1 (requested at the end of the previous trip)
         AG_WF_LOAD(t2);
         AG_SGB(0x100, 6);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
 #pragma unroll
-            for (int m = 0; m < 12; ++m) {
+            for (int m = 0; m < 6; ++m) {
                 AG_SGB(0x008, 1);
                 AG_SGB(0x002, 5);
             }
-            if (i < 3) AG_SGB(0x100, 6);
-            if (i >= 1) AG_SGB(0x200, 4);
+            if (i < 6) AG_SGB(0x100, 3);
+            if (i >= 2) AG_SGB(0x200, 2);
         }
         AG_SGB(0x020, 4);
 #pragma unroll
@@ -551,12 +554,10 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
             for (int p = 0; p < 3; ++p) bfrag[q_][p] = bnext[q_][p];
         __syncthreads();
     }
+    }
 #undef AG_SGB
 #undef AG_WF_WREAD
 #undef AG_WF_PROD3
-#undef AG_WF_PAIR
-#undef AG_WF_PAIR_STEP
-#undef AG_WF_PAIR_READ
 #undef AG_WF_TILE
 #undef AG_WF_TILE_READ
 #undef AG_WF_COMPUTE
@@ -636,6 +637,8 @@ extern "C" int ag_split_wgrad(const float* dZ_dev, const float* X_dev, float* pa
 }
 
 // ---- the weight gradient with its X operand produced from the network input (split_wgrad_fin_kernel)
+#include <stdlib.h>
+static const int g_wgrad_pipe = [] { const char* e = getenv("AIRGYM_WGRAD_PIPE"); return (e && atoi(e) == 0) ? 0 : 1; }();
 extern "C" int ag_split_wgrad_input_supported(int D) { return (D == 16 || D == 18 || D == 20) ? 1 : 0; }
 
 // one workgroup per CU, never more slices than 32-row blocks
@@ -657,11 +660,17 @@ extern "C" int ag_split_wgrad_input(const float* dZ_dev, const float* x_dev, con
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return AG_ERR_HIP;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kWgradFinLds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<18>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<18, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kWgradFinLds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<20>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<20, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kWgradFinLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kWgradFinLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<18, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kWgradFinLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(split_wgrad_fin_kernel<20, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kWgradFinLds) != hipSuccess)
             return AG_ERR_HIP;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
@@ -669,8 +678,14 @@ extern "C" int ag_split_wgrad_input(const float* dZ_dev, const float* x_dev, con
     const int blocks = M / 32;
     const int bps = (blocks + slices - 1) / slices;
 #define AG_WF_LAUNCH(F)                                                                                                        \
-    hipLaunchKernelGGL(split_wgrad_fin_kernel<F>, dim3(slices), dim3(512), kWgradFinLds, (hipStream_t)stream, dZ_dev, x_dev,   \
-                       (const uint4*)image_dev, partials_dev, M, bps)
+    do {                                                                                                                       \
+        if (g_wgrad_pipe)                                                                                                      \
+            hipLaunchKernelGGL((split_wgrad_fin_kernel<F, true>), dim3(slices), dim3(512), kWgradFinLds, (hipStream_t)stream, dZ_dev, \
+                               x_dev, (const uint4*)image_dev, partials_dev, M, bps);                                          \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((split_wgrad_fin_kernel<F, false>), dim3(slices), dim3(512), kWgradFinLds, (hipStream_t)stream, dZ_dev, \
+                               x_dev, (const uint4*)image_dev, partials_dev, M, bps);                                          \
+    } while (0)
     switch (D) {
         case 16: AG_WF_LAUNCH(16); break;
         case 18: AG_WF_LAUNCH(18); break;

@@ -45,10 +45,29 @@ class CNNFeatureExtractor(nn.Module):
         self.reset_gamma_guard()
         return super()._load_from_state_dict(*args, **kwargs)
 
+    # the guard's pinned buffer and HIP event are per-process scratch, not model state: copy.deepcopy / pickle of the module must
+    # work after a training forward (a torch.cuda.Event cannot be pickled), and the copy decides afresh on its first step
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_gamma_ratio_host"] = None
+        state["_gamma_ratio_event"] = None
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in ("_gamma_ratio_host", "_gamma_ratio_event") else copy.deepcopy(v, memo)
+        return new
+
     @torch.no_grad()
     def _sums_from_weights_ok(self, device):
         """True when the (w, dw) identity is well conditioned for this step - see bn_gamma_guard."""
         if not self.bn_sums_from_weights:
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            # event.synchronize() + a pinned host copy cannot be part of a hipGraph: inside a capture take the reduction kernels
             return False
         g1, g2 = self.features[2].weight, self.features[5].weight
         ratio = torch.minimum(g1.abs().min() / g1.abs().max().clamp_min(1e-30),
