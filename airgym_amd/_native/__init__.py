@@ -292,6 +292,13 @@ def _build():
     return _b.build(verbose=False, experiments=EXPERIMENTS)
 
 
+# mixed_precision twins (one bf16 MFMA per product; csrc/split_common.hpp AG_SPLIT_PLANES = 1): same signatures, suffix _bf16
+BF16_TWINS = ("ag_split_gemm", "ag_split_wgrad", "ag_split_wgrad_input", "ag_split_gemm_input_wgrad_recompute",
+              "ag_split_gemm_input_wgrad", "ag_split_gemm_elu_heads", "ag_split_gemm_loss_heads_bwd",
+              "ag_split_gemm_input_loss_heads_bwd", "ag_mlp_chain_forward")
+SYMBOLS = SYMBOLS + [(n + "_bf16", r, a) for (n, r, a) in SYMBOLS if n in BF16_TWINS]
+
+
 def load(rebuild_if_missing=True):
     """Load (building first if needed) libairgym_hip.so.  Raises RuntimeError when the HIP library is
     unavailable - the environments never fall back to a CPU implementation."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 19 translation units compiled in parallel).
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 22 translation units compiled in parallel).
 
     python airgym_amd/csrc/build.py [--force] [--jobs N] [--experiments]
 
@@ -51,6 +51,10 @@ def units(experiments=False):
     for name in ("airgym_hip", "ppo_kernels", "planning_kernel", "rollout_kernels", "split_gemm", "split_wgrad", "cnn_kernels", "conv_kernels", "mlp_chain"):
         # rollout_kernels.hip shares rollout_math.hpp with the fused step kernel (policy sampling, reward shaping): same rule
         out.append((os.path.join(od, name + ".o"), name + ".hip", (["-ffp-contract=on"] if name == "rollout_kernels" else []) + list(x)))
+    # mixed_precision: the three matrix-core sources once more with ONE bf16 plane per operand (one MFMA per product, f32
+    # accumulate); their compute entry points are exported with the suffix _bf16 (split_common.hpp)
+    for name in ("split_gemm", "split_wgrad", "mlp_chain"):
+        out.append((os.path.join(od, name + "_bf16.o"), name + ".hip", ["-DAG_SPLIT_PLANES=1"] + list(x)))
     if experiments:
         out.append((os.path.join(od, "experiments.o"), "experiments.hip", list(x)))
     return out

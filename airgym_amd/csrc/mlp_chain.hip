@@ -123,11 +123,13 @@ struct ChainFwdArgs {
 #define AG_CHAIN_MFMA6(acc_, a_, b_)                                                                   \
     do {                                                                                               \
         if (AG_CHAIN_DBG(2)) { acc_[0] += __builtin_bit_cast(float, (int)a_[0][0] ^ (int)b_[0][0] ^ (int)a_[1][1] ^ (int)b_[1][1] ^ (int)a_[2][2] ^ (int)b_[2][2]); break; } \
-        acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[2], b_[0], acc_, 0, 0, 0);                   \
-        acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[2], acc_, 0, 0, 0);                   \
-        acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], b_[1], acc_, 0, 0, 0);                   \
-        acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], b_[0], acc_, 0, 0, 0);                   \
-        acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[1], acc_, 0, 0, 0);                   \
+        if (kPlanes == 3) {                                                                            \
+            acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[2], b_[0], acc_, 0, 0, 0);               \
+            acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[2], acc_, 0, 0, 0);               \
+            acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], b_[1], acc_, 0, 0, 0);               \
+            acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], b_[0], acc_, 0, 0, 0);               \
+            acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[1], acc_, 0, 0, 0);               \
+        }                                                                                              \
         acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[0], acc_, 0, 0, 0);                   \
     } while (0)
 
@@ -141,16 +143,18 @@ struct ChainFwdArgs {
             acc1_[0] += __builtin_bit_cast(float, (int)a1_[0][0] ^ (int)a1_[1][1] ^ (int)a1_[2][2]);   \
             break;                                                                                     \
         }                                                                                              \
-        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[2], b_[0], acc0_, 0, 0, 0);                \
-        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[2], b_[0], acc1_, 0, 0, 0);                \
-        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[0], b_[2], acc0_, 0, 0, 0);                \
-        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[0], b_[2], acc1_, 0, 0, 0);                \
-        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[1], b_[1], acc0_, 0, 0, 0);                \
-        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[1], b_[1], acc1_, 0, 0, 0);                \
-        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[1], b_[0], acc0_, 0, 0, 0);                \
-        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[1], b_[0], acc1_, 0, 0, 0);                \
-        acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[0], b_[1], acc0_, 0, 0, 0);                \
-        acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[0], b_[1], acc1_, 0, 0, 0);                \
+        if (kPlanes == 3) {                                                                            \
+            acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[2], b_[0], acc0_, 0, 0, 0);            \
+            acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[2], b_[0], acc1_, 0, 0, 0);            \
+            acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[0], b_[2], acc0_, 0, 0, 0);            \
+            acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[0], b_[2], acc1_, 0, 0, 0);            \
+            acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[1], b_[1], acc0_, 0, 0, 0);            \
+            acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[1], b_[1], acc1_, 0, 0, 0);            \
+            acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[1], b_[0], acc0_, 0, 0, 0);            \
+            acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[1], b_[0], acc1_, 0, 0, 0);            \
+            acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[0], b_[1], acc0_, 0, 0, 0);            \
+            acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[0], b_[1], acc1_, 0, 0, 0);            \
+        }                                                                                              \
         acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_[0], b_[0], acc0_, 0, 0, 0);                \
         acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_[0], b_[0], acc1_, 0, 0, 0);                \
     } while (0)
@@ -463,21 +467,28 @@ int launch_chain_fwd(const ChainFwdArgs& a, void* stream) {
 
 #ifdef AG_EXPERIMENTS
 static int g_chain_debug_skip = 0;
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_debug_chain_skip(int mask) { g_chain_debug_skip = mask; return AG_OK; }
+#endif
 #else
 constexpr int g_chain_debug_skip = 0;
 #endif
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_mlp_chain_supported(int D, int C, int A1) {
     return (C == CF && chain_kp1(D) != 0 && (A1 == 5 || A1 == 6)) ? 1 : 0;
 }
+#endif
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" long long ag_mlp_chain_image_bytes(int D) {
     const int kp1 = chain_kp1(D);
     if (kp1 == 0) return 0;
     return ((long long)(kp1 / 16 + 16) * CBLK + CWH) * 16;
 }
+#endif
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_mlp_chain_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, const float* Wh_dev, int A1,
                                     void* image_dev, void* stream) {
     if (!W1_dev || !b1_dev || !W2_dev || !Wh_dev || !image_dev) return AG_ERR_INVALID_ARG;
@@ -491,8 +502,9 @@ extern "C" int ag_mlp_chain_prepare(const float* W1_dev, const float* b1_dev, in
                        W2_dev, Wh_dev, A1, stream_img, wh_img);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
+#endif
 
-extern "C" int ag_mlp_chain_forward(const float* obs_dev, const double* mean_dev, const double* var_dev, float eps, float clip,
+extern "C" int AG_PREC(ag_mlp_chain_forward)(const float* obs_dev, const double* mean_dev, const double* var_dev, float eps, float clip,
                                     const void* image_dev, const float* b2_dev, const float* bh_dev, float* heads_dev, float* xn_dev,
                                     float* h1_dev, float* h2_dev, int M, int D, int A1, void* stream) {
     if (!obs_dev || !image_dev || !b2_dev || !bh_dev || !heads_dev || M <= 0) return AG_ERR_INVALID_ARG;

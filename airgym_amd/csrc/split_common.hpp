@@ -5,7 +5,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// AG_SPLIT_PLANES = 3 (default): the exact 3-way split, six bf16 MFMAs per f32 product - float32-accurate.
+// AG_SPLIT_PLANES = 1: `mixed_precision: true` (the reference's torch.cuda.amp.autocast switch, lib/agent/a2c_base.py:236-237,566,582):
+// ONE bf16 MFMA per product - operands rounded to bf16 (round to nearest), f32 accumulate, f32 master weights; the same sources
+// are compiled a second time with this setting and every compute entry point exported with the suffix _bf16 (csrc/build.py).
+// Planes 2 and 3 of the prepared weight images are simply not read; activation planes 2 and 3 are neither formed nor stored.
+#ifndef AG_SPLIT_PLANES
+#define AG_SPLIT_PLANES 3
+#endif
+#if AG_SPLIT_PLANES != 1 && AG_SPLIT_PLANES != 3
+#error "AG_SPLIT_PLANES: 1 or 3"
+#endif
+#define AG_CAT2_(a, b) a##b
+#define AG_CAT2(a, b) AG_CAT2_(a, b)
+#if AG_SPLIT_PLANES == 3
+#define AG_PREC(name) name                       /* compute entry points: ag_xyz / ag_xyz_bf16 */
+#else
+#define AG_PREC(name) AG_CAT2(name, _bf16)       /* (size / capability / weight-image exports exist once, in the 3-plane build) */
+#endif
+
 namespace {
+
+constexpr int kPlanes = AG_SPLIT_PLANES;
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,3 +61,22 @@ __device__ __forceinline__ void split8(const float4 lo, const float4 hi, uint4& 
 }
 
 }  // namespace
+
+// d += a * b for split operands (planes 1..3 of each): the six kept cross products, smallest first - or, with one plane, a1 b1
+#if AG_SPLIT_PLANES == 3
+#define AG_MFMA_SPLIT(d, a1, a2, a3, b1, b2, b3)                                  \
+    do {                                                                          \
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, d, 0, 0, 0);          \
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, d, 0, 0, 0);          \
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, d, 0, 0, 0);          \
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, d, 0, 0, 0);          \
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, d, 0, 0, 0);          \
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, d, 0, 0, 0);          \
+    } while (0)
+#else
+#define AG_MFMA_SPLIT(d, a1, a2, a3, b1, b2, b3)                                  \
+    do {                                                                          \
+        (void)(a2); (void)(a3); (void)(b2); (void)(b3);                           \
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, d, 0, 0, 0);          \
+    } while (0)
+#endif

@@ -189,12 +189,7 @@ __device__ __forceinline__ void input_wgrad_tile(const f32x16 (&acc)[8], const f
                         ua3 = xp_lane[(2 * 4 + s) * XS + 32 * t];
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1), a2 = *reinterpret_cast<const bf16x8*>(&ua2),
                          a3 = *reinterpret_cast<const bf16x8*>(&ua3);
-            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, c1, g[t], 0, 0, 0);
-            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c3, g[t], 0, 0, 0);
-            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c2, g[t], 0, 0, 0);
-            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c1, g[t], 0, 0, 0);
-            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c2, g[t], 0, 0, 0);
-            g[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c1, g[t], 0, 0, 0);
+            AG_MFMA_SPLIT(g[t], a1, a2, a3, c1, c2, c3);
             asm volatile("" : "+v"(g[t]));                  // this step's products stay in this step (see the head epilogue)
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -305,7 +300,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
 #define AG_SG_DMA(c, stage)                                                            \
     do {                                                                               \
         const uint4* bsrc_ = Bp + (size_t)(c) * B_UNITS + tid;                         \
-        _Pragma("unroll") for (int it = 0; it < BPT; ++it)                             \
+        _Pragma("unroll") for (int it = 0; it < BPT * kPlanes / 3; ++it)               \
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"   \
                          : : "v"(bsrc_ + it * NT), "s"(lds_b0 + ((stage) * STAGE_UNITS + it * NT) * 16) : "memory"); \
     } while (0)
@@ -321,8 +316,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         uint4 p1_, p2_, p3_;                                                           \
         split8(ra0, ra1, p1_, p2_, p3_);                                               \
         sa_[(0 * 2 + a_half) * BM + a_row] = p1_;                                      \
-        sa_[(1 * 2 + a_half) * BM + a_row] = p2_;                                      \
-        sa_[(2 * 2 + a_half) * BM + a_row] = p3_;                                      \
+        if (kPlanes == 3) {                                                            \
+            sa_[(1 * 2 + a_half) * BM + a_row] = p2_;                                  \
+            sa_[(2 * 2 + a_half) * BM + a_row] = p3_;                                  \
+        }                                                                              \
     } while (0)
     AG_SG_DMA(0, 0);
 #else
@@ -374,12 +371,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
                 const uint4 u_ = w1s[((((b_) * 2 + s_) * 3 + p) * 2 + fh) * 32 + (lane & 31)];         \
                 wa_[p] = *reinterpret_cast<const bf16x8*>(&u_);                                        \
             }                                                                                          \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[2], xq[s_][0], hacc, 0, 0, 0);          \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[0], xq[s_][2], hacc, 0, 0, 0);          \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[1], xq[s_][1], hacc, 0, 0, 0);          \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[1], xq[s_][0], hacc, 0, 0, 0);          \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[0], xq[s_][1], hacc, 0, 0, 0);          \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_[0], xq[s_][0], hacc, 0, 0, 0);          \
+            AG_MFMA_SPLIT(hacc, wa_[0], wa_[1], wa_[2], xq[s_][0], xq[s_][1], xq[s_][2]);                 \
         }                                                                                              \
     } while (0)
     // half q of the block (registers 8 q .. 8 q + 7) -> chunk 2 b + q: ELU, split, the three plane units of (row, k-half h)
@@ -394,8 +386,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         uint4 p1_, p2_, p3_;                                                                           \
         split8(hs0, hs1, p1_, p2_, p3_);                                                               \
         sa_[(0 * 2 + fh) * BM + frow] = p1_;                                                           \
-        sa_[(1 * 2 + fh) * BM + frow] = p2_;                                                           \
-        sa_[(2 * 2 + fh) * BM + frow] = p3_;                                                           \
+        if (kPlanes == 3) {                                                                            \
+            sa_[(1 * 2 + fh) * BM + frow] = p2_;                                                       \
+            sa_[(2 * 2 + fh) * BM + frow] = p3_;                                                       \
+        }                                                                                              \
     } while (0)
     // ... and the same values to HBM (the backward reads h1), issued BEHIND the step's vmcnt(0) (which then finds only stores a
     // whole chunk old): features hoff .. + 3 and hoff + 8 .. + 11 of the lane's row
@@ -503,12 +497,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
             const bf16x8 b2_ = *reinterpret_cast<const bf16x8*>(&ub2_);                                \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
                 f32x16& d_ = acc[i * 4 + j];                                                           \
-                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][2], b0_, d_, 0, 0, 0);              \
-                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][0], b2_, d_, 0, 0, 0);              \
-                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][1], b1_, d_, 0, 0, 0);              \
-                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][1], b0_, d_, 0, 0, 0);              \
-                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][0], b1_, d_, 0, 0, 0);              \
-                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i][0], b0_, d_, 0, 0, 0);              \
+                AG_MFMA_SPLIT(d_, a_[i][0], a_[i][1], a_[i][2], b0_, b1_, b2_);                        \
             }                                                                                          \
         }                                                                                              \
     } while (0)
@@ -790,8 +779,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
             uint4 p1, p2, p3;
             split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
             xp[(0 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p1;
-            xp[(1 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p2;
-            xp[(2 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p3;
+            if (kPlanes == 3) {
+                xp[(1 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p2;
+                xp[(2 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p3;
+            }
         }
         __syncthreads();
         const uint4* xp_lane = xp + (wm * 2 + khalf) * DW + min(l31, RW);
@@ -831,12 +822,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
                         const uint4 u_ = w1s[(((blk * 2 + st) * 3 + p) * 2 + khalf) * 32 + l31];
                         wb[p] = *reinterpret_cast<const bf16x8*>(&u_);
                     }
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][0], wb[2], z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][2], wb[0], z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][1], wb[1], z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][0], wb[1], z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][1], wb[0], z, 0, 0, 0);
-                    z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[st][0], wb[0], z, 0, 0, 0);
+                    AG_MFMA_SPLIT(z, xq[st][0], xq[st][1], xq[st][2], wb[0], wb[1], wb[2]);
                 }
                 f32x16 g;
 #pragma unroll
@@ -857,12 +843,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
                     const uint4 ua1 = xp_lane[(0 * 4 + s) * XS], ua2 = xp_lane[(1 * 4 + s) * XS], ua3 = xp_lane[(2 * 4 + s) * XS];
                     const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&ua1), a2 = *reinterpret_cast<const bf16x8*>(&ua2),
                                  a3 = *reinterpret_cast<const bf16x8*>(&ua3);
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, c1, g, 0, 0, 0);
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c3, g, 0, 0, 0);
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c2, g, 0, 0, 0);
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, c1, g, 0, 0, 0);
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c2, g, 0, 0, 0);
-                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, c1, g, 0, 0, 0);
+                    AG_MFMA_SPLIT(g, a1, a2, a3, c1, c2, c3);
                 }
                 // g: column c = this lane's column of tile J, rows d = (r & 3) + 8 (r >> 2) + 4 h; d = DIN: the bias gradient.  The
                 // second row tile adds to the first one's entry (lane-private slot, fixed order: deterministic)
@@ -906,8 +887,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
             uint4 p1, p2, p3;
             split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
             xp[(0 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p1;
-            xp[(1 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p2;
-            xp[(2 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p3;
+            if (kPlanes == 3) {
+                xp[(1 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p2;
+                xp[(2 * 4 + st) * XS + (w2 * 2 + h) * DW + d] = p3;
+            }
         }
         __syncthreads();
         const float* hcol = ep.h1 + wn * 128 + l31 + late;
@@ -968,8 +951,11 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
 
 }  // namespace
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" long long ag_split_gemm_plane_bytes(void) { return (long long)(KDIM / BK) * B_UNITS * 16; }
+#endif
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n, int k, int transpose, void* stream) {
     if (!W_dev || !planes_dev) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
@@ -978,7 +964,9 @@ extern "C" int ag_split_gemm_prepare(const float* W_dev, void* planes_dev, int n
                        (uint4*)planes_dev, transpose, (uint4*)nullptr);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
+#endif
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, void* planes_t_dev, int n, int k, void* stream) {
     if (!W_dev || !planes_dev || !planes_t_dev) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;
@@ -987,6 +975,7 @@ extern "C" int ag_split_gemm_prepare_pair(const float* W_dev, void* planes_dev, 
                        (uint4*)planes_dev, 0, (uint4*)planes_t_dev);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
+#endif
 
 // Row-tile size of the launches: WM = 2 (128 rows, 4 waves, two workgroups per CU) or 4 (256 rows, 8 waves, one per CU).
 // Shipped: 4 - every B-plane chunk fetched from L2 feeds twice the MFMAs and a thread copies 3 instead of 6 plane units per
@@ -996,11 +985,13 @@ constexpr int kDefaultWM = AG_SPLIT_DEFAULT_WM;
 #ifdef AG_EXPERIMENTS
 #include <stdlib.h>
 static int g_split_wm = [] { const char* e = getenv("AIRGYM_SPLIT_WM"); return (e && atoi(e) == 4) ? 4 : ((e && atoi(e) == 2) ? 2 : kDefaultWM); }();
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_debug_split_gemm_variant(int wm) {      // 2 | 4; -1 = default
     if (wm != -1 && wm != 2 && wm != 4) return AG_ERR_INVALID_ARG;
     g_split_wm = wm < 0 ? kDefaultWM : wm;
     return AG_OK;
 }
+#endif
 #else
 constexpr int g_split_wm = kDefaultWM;
 #endif
@@ -1043,7 +1034,7 @@ static int launch_split_any(const float* A_dev, const void* planes_dev, float* C
 #define AG_SG_DISPATCH(call2, call4) (call2)
 #endif
 
-extern "C" int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
+extern "C" int AG_PREC(ag_split_gemm_elu_heads)(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
                                        const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1,
                                        void* stream) {
     if (!A_dev || !planes_dev || !bias_dev || !Wh_dev || !bh_dev || !Z_dev || !heads_dev || M <= 0) return AG_ERR_INVALID_ARG;
@@ -1057,9 +1048,11 @@ extern "C" int ag_split_gemm_elu_heads(const float* A_dev, const void* planes_de
 #undef AG_SGH
 }
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_loss_rows(void) { return g_split_wm * 64; }
+#endif
 
-extern "C" int ag_split_gemm_loss_heads_bwd(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
+extern "C" int AG_PREC(ag_split_gemm_loss_heads_bwd)(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
                                             const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* L, int M, int n, int k, int A1,
                                             void* stream) {
     if (!A_dev || !planes_dev || !bias_dev || !Wh_dev || !bh_dev || !dZ_dev || !L || M <= 0) return AG_ERR_INVALID_ARG;
@@ -1084,9 +1077,13 @@ extern "C" int ag_split_gemm_loss_heads_bwd(const float* A_dev, const void* plan
 }
 
 // widths with the first layer formed inside the forward GEMM (Hovering's 18 and the neighbouring even widths); 256-row tiles only
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_input_fwd_supported(int D) { return (g_split_wm == 4 && (D == 16 || D == 18 || D == 20)) ? 1 : 0; }
+#endif
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" long long ag_split_gemm_input_image_bytes(void) { return (long long)kInImageW1Bytes + (long long)(KDIM / BK) * B_UNITS * 16; }
+#endif
 
 static int launch_in_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev, void* planes_t_dev,
                              void* stream) {
@@ -1099,20 +1096,24 @@ static int launch_in_prepare(const float* W1_dev, const float* b1_dev, int D, co
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_input_prepare(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev,
                                            void* stream) {
     return launch_in_prepare(W1_dev, b1_dev, D, W2_dev, image_dev, nullptr, stream);
 }
+#endif
 
 // ... and, in the same launch, the backward planes of W2 (what ag_split_gemm_prepare(transpose = 1) writes): one weight-image launch per
 // optimizer step instead of two
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_input_prepare_pair(const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev,
                                                 void* planes_t_dev, void* stream) {
     if (!planes_t_dev) return AG_ERR_INVALID_ARG;
     return launch_in_prepare(W1_dev, b1_dev, D, W2_dev, image_dev, planes_t_dev, stream);
 }
+#endif
 
-extern "C" int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void* image_dev, const float* bias_dev,
+extern "C" int AG_PREC(ag_split_gemm_input_loss_heads_bwd)(const ag_input_layer_args* in, const void* image_dev, const float* bias_dev,
                                                   const float* Wh_dev, const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* L,
                                                   int M, int n, int k, int A1, void* stream) {
     if (!in || !image_dev || !bias_dev || !Wh_dev || !bh_dev || !dZ_dev || !L || M <= 0) return AG_ERR_INVALID_ARG;
@@ -1147,12 +1148,16 @@ extern "C" int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in,
 #undef AG_SGF
 }
 
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_input_wgrad_rows(void) { return g_split_wm * 64; }
+#endif
 
 // input widths with a fused first-layer backward: Hovering 18 (16 / 20: the neighbouring even widths), Tracking 48
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_input_wgrad_supported(int D) { return (D == 16 || D == 18 || D == 20 || D == 48) ? 1 : 0; }
+#endif
 
-extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
+extern "C" int AG_PREC(ag_split_gemm_input_wgrad)(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
                                          float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream) {
     if (!dZ_dev || !planes_dev || !h1_dev || !x_dev || !dw_partials_dev || !db_partials_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM || !ag_split_gemm_input_wgrad_supported(D)) return AG_ERR_UNSUPPORTED;
@@ -1170,9 +1175,11 @@ extern "C" int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes
 }
 
 // widths whose first-layer backward can recompute h1 in the dX epilogue (256-row tiles; the LDS layout holds D + 2 <= 20 columns)
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_gemm_input_wgrad_recompute_supported(int D) { return (g_split_wm == 4 && (D == 16 || D == 18)) ? 1 : 0; }
+#endif
 
-extern "C" int ag_split_gemm_input_wgrad_recompute(const float* dZ_dev, const void* planes_dev, const void* image_dev, const float* x_dev,
+extern "C" int AG_PREC(ag_split_gemm_input_wgrad_recompute)(const float* dZ_dev, const void* planes_dev, const void* image_dev, const float* x_dev,
                                                    float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D,
                                                    void* stream) {
     if (!dZ_dev || !planes_dev || !image_dev || !x_dev || !dw_partials_dev || !db_partials_dev || M <= 0) return AG_ERR_INVALID_ARG;
@@ -1186,7 +1193,7 @@ extern "C" int ag_split_gemm_input_wgrad_recompute(const float* dZ_dev, const vo
     return launch_split_any<false, 0, 18, 4, false, 0, true>(dZ_dev, planes_dev, nullptr, M, ep, stream);
 }
 
-extern "C" int ag_split_gemm(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
+extern "C" int AG_PREC(ag_split_gemm)(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k,
                              void* stream) {
     if (!A_dev || !planes_dev || !C_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM) return AG_ERR_UNSUPPORTED;

@@ -73,8 +73,10 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_kernel(const float* __rest
         split_pair(x0, x1, h1_.x, h2_.x, h3_.x);                                                     \
         split_pair(x2, x3, h1_.y, h2_.y, h3_.y);                                                     \
         dst_[(0 * 2 * WN + (q_) * 64) * 2] = h1_;                                                    \
-        dst_[(1 * 2 * WN + (q_) * 64) * 2] = h2_;                                                    \
-        dst_[(2 * 2 * WN + (q_) * 64) * 2] = h3_;                                                    \
+        if (kPlanes == 3) {                                                                          \
+            dst_[(1 * 2 * WN + (q_) * 64) * 2] = h2_;                                                \
+            dst_[(2 * 2 * WN + (q_) * 64) * 2] = h3_;                                                \
+        }                                                                                            \
     } while (0)
 #define AG_WG_WRITE(stage_, tail_, v, nvalid)                                                        \
     do {                                                                                             \
@@ -120,16 +122,18 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_kernel(const float* __rest
             const bf16x8 b2_ = *reinterpret_cast<const bf16x8*>(&ub2_);                                \
             f32x16& d0_ = acc[j];                                                                      \
             f32x16& d1_ = acc[4 + j];                                                                  \
-            d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][2], b0_, d0_, 0, 0, 0);                \
-            d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][2], b0_, d1_, 0, 0, 0);                \
-            d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][0], b2_, d0_, 0, 0, 0);                \
-            d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][0], b2_, d1_, 0, 0, 0);                \
-            d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][1], b1_, d0_, 0, 0, 0);                \
-            d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][1], b1_, d1_, 0, 0, 0);                \
-            d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][1], b0_, d0_, 0, 0, 0);                \
-            d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][1], b0_, d1_, 0, 0, 0);                \
-            d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][0], b1_, d0_, 0, 0, 0);                \
-            d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][0], b1_, d1_, 0, 0, 0);                \
+            if (kPlanes == 3) {                                                                        \
+                d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][2], b0_, d0_, 0, 0, 0);            \
+                d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][2], b0_, d1_, 0, 0, 0);            \
+                d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][0], b2_, d0_, 0, 0, 0);            \
+                d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][0], b2_, d1_, 0, 0, 0);            \
+                d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][1], b1_, d0_, 0, 0, 0);            \
+                d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][1], b1_, d1_, 0, 0, 0);            \
+                d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][1], b0_, d0_, 0, 0, 0);            \
+                d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][1], b0_, d1_, 0, 0, 0);            \
+                d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][0], b1_, d0_, 0, 0, 0);            \
+                d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][0], b1_, d1_, 0, 0, 0);            \
+            }                                                                                          \
             d0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0][0], b0_, d0_, 0, 0, 0);                \
             d1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1][0], b0_, d1_, 0, 0, 0);                \
         }                                                                                              \
@@ -181,13 +185,13 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_kernel(const float* __rest
         __builtin_amdgcn_sched_barrier(0);      // the loads stay at the top: sunk to the end of the chunk (where LLVM puts them
         AG_WG_COMPUTE(0);                       // to shorten live ranges) the next chunk opens waiting for HBM
         AG_WG_WRITE(1, 0, vb, nvb);
-        if (ORDERED) AG_WG_ORDER();
+        if (ORDERED && kPlanes == 3) AG_WG_ORDER();
         __syncthreads();
         AG_WG_LOAD(t + 3, vb, nvb);
         __builtin_amdgcn_sched_barrier(0);
         AG_WG_COMPUTE(1);
         AG_WG_WRITE(0, 0, va, nva);
-        if (ORDERED) AG_WG_ORDER();
+        if (ORDERED && kPlanes == 3) AG_WG_ORDER();
         __syncthreads();
     }
     // peeled trips (t even here): at most three chunks are left; rows past M are zeroed where a chunk is staged
@@ -283,8 +287,10 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         split_pair(x0, x1, h1_.x, h2_.x, h3_.x);                                                     \
         split_pair(x2, x3, h1_.y, h2_.y, h3_.y);                                                     \
         dst_[(0 * 2 * WN + (q_) * 64) * 2] = h1_;                                                    \
-        dst_[(1 * 2 * WN + (q_) * 64) * 2] = h2_;                                                    \
-        dst_[(2 * 2 * WN + (q_) * 64) * 2] = h3_;                                                    \
+        if (kPlanes == 3) {                                                                          \
+            dst_[(1 * 2 * WN + (q_) * 64) * 2] = h2_;                                                \
+            dst_[(2 * 2 * WN + (q_) * 64) * 2] = h3_;                                                \
+        }                                                                                            \
     } while (0)
     // block slot bs (0 / 1) -> chunk slots 2 bs, 2 bs + 1
 #define AG_WF_WRITE(bs_)                                                                             \
@@ -342,12 +348,7 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
                 const uint4 u_ = w1s[(((wave * 2 + s_) * 3 + p) * 2 + khalf) * 32 + l31];            \
                 wb_[p] = *reinterpret_cast<const bf16x8*>(&u_);                                      \
             }                                                                                        \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb_[2], hacc, 0, 0, 0);        \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][2], wb_[0], hacc, 0, 0, 0);        \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb_[1], hacc, 0, 0, 0);        \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb_[1], hacc, 0, 0, 0);        \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb_[0], hacc, 0, 0, 0);        \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb_[0], hacc, 0, 0, 0);        \
+            AG_MFMA_SPLIT(hacc, xq[s_][0], xq[s_][1], xq[s_][2], wb_[0], wb_[1], wb_[2]);               \
         }                                                                                            \
     } while (0)
     // ELU + split of the tile -> the B fragments of its block's two chunks
@@ -382,12 +383,7 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
             const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(&ua1_);                              \
             const bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(&ua2_);                              \
             f32x16& d_ = acc[i];                                                                     \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[q_][0], d_, 0, 0, 0);            \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][2], d_, 0, 0, 0);            \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[q_][1], d_, 0, 0, 0);            \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[q_][0], d_, 0, 0, 0);            \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][1], d_, 0, 0, 0);            \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][0], d_, 0, 0, 0);            \
+            AG_MFMA_SPLIT(d_, a0_, a1_, a2_, bfrag[q_][0], bfrag[q_][1], bfrag[q_][2]);                 \
         }                                                                                            \
     } while (0)
 
@@ -405,23 +401,22 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
 #define AG_WF_TILE(slot_, q_, i_)                                                                    \
     do {                                                                                             \
         AG_WF_TILE_READ(slot_, i_);                                                                  \
-        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[q_][0], d_, 0, 0, 0);                \
-        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][2], d_, 0, 0, 0);                \
-        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[q_][1], d_, 0, 0, 0);                \
-        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[q_][0], d_, 0, 0, 0);                \
-        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][1], d_, 0, 0, 0);                \
-        d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[q_][0], d_, 0, 0, 0);                \
+        AG_MFMA_SPLIT(d_, a0_, a1_, a2_, bfrag[q_][0], bfrag[q_][1], bfrag[q_][2]);                     \
     } while (0)
     // production MFMAs k .. k + 2 (of 6) of K step s_: (x1 w3, x3 w1, x2 w2 | x1 w2, x2 w1, x1 w1), the forward's order
 #define AG_WF_PROD3(s_, half_)                                                                       \
     do {                                                                                             \
         if ((half_) == 0) {                                                                          \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][2], hacc, 0, 0, 0);     \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][2], wb[s_][0], hacc, 0, 0, 0);     \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][1], hacc, 0, 0, 0);     \
+            if (kPlanes == 3) {                                                                      \
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][2], hacc, 0, 0, 0); \
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][2], wb[s_][0], hacc, 0, 0, 0); \
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][1], hacc, 0, 0, 0); \
+            }                                                                                        \
         } else {                                                                                     \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][1], hacc, 0, 0, 0);     \
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][0], hacc, 0, 0, 0);     \
+            if (kPlanes == 3) {                                                                      \
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][1], hacc, 0, 0, 0); \
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][1], wb[s_][0], hacc, 0, 0, 0); \
+            }                                                                                        \
             hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xq[s_][0], wb[s_][0], hacc, 0, 0, 0);     \
         }                                                                                            \
     } while (0)
@@ -431,7 +426,11 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         wb[s_][p] = *reinterpret_cast<const bf16x8*>(&u_);                                           \
     }
     // issue-order groups (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x100 DS read, 0x200 DS write, 0x020 VMEM read)
+#if AG_SPLIT_PLANES == 3
 #define AG_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0)
+#else
+#define AG_SGB(mask_, n_) do { } while (0)      // (the pinned order counts six MFMAs per tile)
+#endif
 
     if constexpr (!PIPE) {
         // ---- the plain schedule (AIRGYM_WGRAD_PIPE=0; kept for A/B): block t's X side is produced at the top of trip t, the next
@@ -498,12 +497,16 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
 #define AG_WF_TILE_P(i_, s_)                                                                         \
         do {                                                                                         \
             AG_WF_TILE_READ(2 * bs, i_);                                                             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[0][0], d_, 0, 0, 0);             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][2], d_, 0, 0, 0);             \
+            if (kPlanes == 3) {                                                                      \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, bfrag[0][0], d_, 0, 0, 0);         \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][2], d_, 0, 0, 0);         \
+            }                                                                                        \
             AG_WF_PROD3(s_, (i_) & 1);                                                               \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][1], d_, 0, 0, 0);             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][0], d_, 0, 0, 0);             \
-            d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][1], d_, 0, 0, 0);             \
+            if (kPlanes == 3) {                                                                      \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][1], d_, 0, 0, 0);         \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, bfrag[0][0], d_, 0, 0, 0);         \
+                d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][1], d_, 0, 0, 0);         \
+            }                                                                                        \
             d_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, bfrag[0][0], d_, 0, 0, 0);             \
         } while (0)
         AG_WF_TILE_P(4, 0);
@@ -598,18 +601,22 @@ int device_cus() {
 
 static int g_wgrad_ordered = 1;
 #ifdef AG_EXPERIMENTS
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_debug_split_wgrad_ordered(int on) { g_wgrad_ordered = on ? 1 : 0; return AG_OK; }
+#endif
 #endif
 
 // one workgroup per CU (each owns the whole 256 x 256 output for its rows), never more slices than 16-row chunks
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_wgrad_slices(int M) {
     if (M <= 0) return 0;
     const int chunks = (M + WBK - 1) / WBK;
     const int s = device_cus();
     return chunks < s ? chunks : s;
 }
+#endif
 
-extern "C" int ag_split_wgrad(const float* dZ_dev, const float* X_dev, float* partials_dev, int M, int n, int k, int slices,
+extern "C" int AG_PREC(ag_split_wgrad)(const float* dZ_dev, const float* X_dev, float* partials_dev, int M, int n, int k, int slices,
                               void* stream) {
     if (!dZ_dev || !X_dev || !partials_dev || M <= 0 || slices <= 0) return AG_ERR_INVALID_ARG;
     if (n != WN || k != WN) return AG_ERR_UNSUPPORTED;
@@ -639,17 +646,21 @@ extern "C" int ag_split_wgrad(const float* dZ_dev, const float* X_dev, float* pa
 // ---- the weight gradient with its X operand produced from the network input (split_wgrad_fin_kernel)
 #include <stdlib.h>
 static const int g_wgrad_pipe = [] { const char* e = getenv("AIRGYM_WGRAD_PIPE"); return (e && atoi(e) == 0) ? 0 : 1; }();
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_wgrad_input_supported(int D) { return (D == 16 || D == 18 || D == 20) ? 1 : 0; }
+#endif
 
 // one workgroup per CU, never more slices than 32-row blocks
+#if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_wgrad_input_slices(int M) {
     if (M <= 0) return 0;
     const int blocks = (M + 31) / 32;
     const int s = device_cus();
     return blocks < s ? blocks : s;
 }
+#endif
 
-extern "C" int ag_split_wgrad_input(const float* dZ_dev, const float* x_dev, const void* image_dev, float* partials_dev, int M, int n,
+extern "C" int AG_PREC(ag_split_wgrad_input)(const float* dZ_dev, const float* x_dev, const void* image_dev, float* partials_dev, int M, int n,
                                     int k, int D, int slices, void* stream) {
     if (!dZ_dev || !x_dev || !image_dev || !partials_dev || M <= 0 || slices <= 0) return AG_ERR_INVALID_ARG;
     if (n != WN || k != WN || !ag_split_wgrad_input_supported(D)) return AG_ERR_UNSUPPORTED;

@@ -213,13 +213,12 @@ class A2CAgent:
                 config["device"] = "cuda:" + str(self.local_rank)
             if self.global_rank != 0:
                 config["print_stats"] = False
-        # `mixed_precision` (reference: torch.cuda.amp autocast + GradScaler, lib/agent/a2c_base.py:236-237,566,582) is not
-        # implemented: this build's update is float32 throughout (the 256-wide products run float32-ACCURATE on the bf16
-        # matrix cores).  A YAML that asks for it must not silently train in another precision.
-        if bool(config.get("mixed_precision", False)):
-            raise NotImplementedError(
-                "config.mixed_precision: true is not supported by airgym_amd (the PPO update is float32; see DESIGN.md 4.3) "
-                "- set it to false")
+        # `mixed_precision` (reference: torch.cuda.amp autocast + GradScaler around the model forward of the rollout and of
+        # calc_gradients, lib/agent/a2c_base.py:236-237,566,582): honoured where EVERY matrix product of the configuration runs in
+        # the hand-written kernels - they have one-bf16-MFMA-per-product twins (f32 accumulate, f32 master weights; no loss scaling:
+        # bf16 has float32's exponent range).  A configuration that would leave part of its products with the float32 library
+        # GEMMs (other widths, CNN / dict observations, CPU) is refused below rather than silently trained in another precision.
+        self.mixed_precision = bool(config.get("mixed_precision", False))
         self.ppo_device = config.get("device", "cuda:0")
         if str(self.ppo_device).startswith("cuda"):
             torch.cuda.set_device(self.ppo_device)
@@ -339,6 +338,11 @@ class A2CAgent:
             self.writer = make_writer(self.summaries_dir)
         from airgym_amd.lib.agent.fused_update import FusedMLPStep
         self._fused_step = FusedMLPStep(self) if FusedMLPStep.supported(self) else None
+        if self.mixed_precision and not (self._fused_step is not None and self._fused_step.covers_all_products):
+            raise NotImplementedError(
+                "config.mixed_precision: true needs the hand-written update path for every layer ([D -> 256 -> 256] trunk with "
+                "D in {16, 18}, float32 observations, CUDA): this configuration would run part of its products in the float32 "
+                "library GEMMs - set mixed_precision to false")
         self._graphs = {}
         # minibatch graphs: only where launches dominate (small minibatches).  With multi_gpu the gradient all-reduce is captured
         # inside the graph when RCCL allows it (`capture_gradient_allreduce`; train_actor_critic falls back to a capture split
@@ -465,6 +469,9 @@ class A2CAgent:
             self._term_tiles = torch.zeros(H, (N + 63) // 64, 12, **f)
         from airgym_amd.lib.agent.fused_update import FusedRolloutStep
         self._fused_rollout = FusedRolloutStep(self) if FusedRolloutStep.supported(self) else None
+        if self.mixed_precision and not (self._fused_rollout is not None and self._fused_rollout.chain is not None):
+            raise NotImplementedError("config.mixed_precision: true needs the one-launch policy forward (ag_mlp_chain_forward) in the "
+                                      "rollout; this configuration would run it in float32 - set mixed_precision to false")
         if self._fused_rollout is not None and getattr(self, "_restored_noise_counter", None) is not None:
             self._fused_rollout.counter.fill_(int(self._restored_noise_counter))
         if self.config.get("print_paths", True) and getattr(self, "global_rank", 0) == 0:

@@ -36,8 +36,9 @@ class SplitGemm256:
         return (bool(config.get("use_split_gemm", True)) and weight.is_cuda and tuple(weight.shape) == (256, 256)
                 and weight.dtype == torch.float32)
 
-    def __init__(self, weight, backward=True):
+    def __init__(self, weight, backward=True, bf16=False):
         self.lib = N.load()
+        self.sfx = "_bf16" if bf16 else ""      # mixed_precision: the one-MFMA-per-product twins of the compute entry points
         self.w = weight
         nbytes = self.lib.ag_split_gemm_plane_bytes()
         self.fwd = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
@@ -57,13 +58,13 @@ class SplitGemm256:
 
     def forward(self, x, out, bias=None):
         """out [M, 256] = x [M, 256] W^T (+ bias)"""
-        N.check(self.lib.ag_split_gemm(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr() if bias is not None else None,
+        N.check(getattr(self.lib, "ag_split_gemm" + self.sfx)(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr() if bias is not None else None,
                                        out.data_ptr(), x.shape[0], 256, 256, self._stream()), "ag_split_gemm")
 
     def forward_elu_heads(self, x, z, bias, heads_w, heads_b, heads):
         """z [M, 256] = x W^T (bias-free pre-activation), heads [M, A1] = ELU(z + bias) heads_w^T + heads_b: the GEMM and
         what used to be the ag_elu_heads pass over z, in one launch (ag_split_gemm_elu_heads)."""
-        N.check(self.lib.ag_split_gemm_elu_heads(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr(), heads_w.data_ptr(),
+        N.check(getattr(self.lib, "ag_split_gemm_elu_heads" + self.sfx)(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr(), heads_w.data_ptr(),
                                                  heads_b.data_ptr(), z.data_ptr(), heads.data_ptr(), x.shape[0], 256, 256,
                                                  heads_w.shape[0], self._stream()), "ag_split_gemm_elu_heads")
 
@@ -71,7 +72,7 @@ class SplitGemm256:
         """The GEMM of forward_elu_heads with the PPO loss and the head layer's backward in its epilogue
         (ag_split_gemm_loss_heads_bwd): dz [M, 256] = (d_heads heads_w) * ELU'(h) and the per-tile partials named in `loss`
         (an AgLossEpilogue) - heads, d_heads and the pre-activation never go through HBM."""
-        N.check(self.lib.ag_split_gemm_loss_heads_bwd(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr(), heads_w.data_ptr(),
+        N.check(getattr(self.lib, "ag_split_gemm_loss_heads_bwd" + self.sfx)(x.data_ptr(), self.fwd.data_ptr(), bias.data_ptr(), heads_w.data_ptr(),
                                                       heads_b.data_ptr(), dz.data_ptr(), ctypes.byref(loss), x.shape[0], 256, 256,
                                                       heads_w.shape[0], self._stream()), "ag_split_gemm_loss_heads_bwd")
 
@@ -91,7 +92,7 @@ class SplitGemm256:
     def forward_input_loss_heads_bwd(self, inp, M, dz, bias, heads_w, heads_b, loss):
         """forward_loss_heads_bwd with the FIRST layer formed inside the launch (ag_split_gemm_input_loss_heads_bwd): `inp` is an
         AgInputLayerArgs (observations, normaliser statistics; xn and h1 are written as by-products); weights: prepare_input_image."""
-        N.check(self.lib.ag_split_gemm_input_loss_heads_bwd(ctypes.byref(inp), self.in_image.data_ptr(), bias.data_ptr(),
+        N.check(getattr(self.lib, "ag_split_gemm_input_loss_heads_bwd" + self.sfx)(ctypes.byref(inp), self.in_image.data_ptr(), bias.data_ptr(),
                                                             heads_w.data_ptr(), heads_b.data_ptr(), dz.data_ptr(), ctypes.byref(loss),
                                                             M, 256, 256, heads_w.shape[0], self._stream()),
                 "ag_split_gemm_input_loss_heads_bwd")
@@ -99,13 +100,13 @@ class SplitGemm256:
     def backward_input_wgrad(self, dz, h_prev, x_prev, dw_partials, db_partials):
         """dX = dz W of this layer, consumed in the epilogue by the PREVIOUS (first) layer's backward: ELU'(h_prev), then
         dw_partials [tiles, 256, D] / db_partials [tiles, 256] against its inputs x_prev [M, D] (ag_split_gemm_input_wgrad)."""
-        N.check(self.lib.ag_split_gemm_input_wgrad(dz.data_ptr(), self.bwd.data_ptr(), h_prev.data_ptr(), x_prev.data_ptr(),
+        N.check(getattr(self.lib, "ag_split_gemm_input_wgrad" + self.sfx)(dz.data_ptr(), self.bwd.data_ptr(), h_prev.data_ptr(), x_prev.data_ptr(),
                                                    dw_partials.data_ptr(), db_partials.data_ptr(), dz.shape[0], 256, 256,
                                                    x_prev.shape[1], self._stream()), "ag_split_gemm_input_wgrad")
 
     def backward_input(self, dz, out):
         """out [M, 256] = dz [M, 256] W"""
-        N.check(self.lib.ag_split_gemm(dz.data_ptr(), self.bwd.data_ptr(), None, out.data_ptr(), dz.shape[0], 256, 256,
+        N.check(getattr(self.lib, "ag_split_gemm" + self.sfx)(dz.data_ptr(), self.bwd.data_ptr(), None, out.data_ptr(), dz.shape[0], 256, 256,
                                        self._stream()), "ag_split_gemm")
 
 
@@ -212,13 +213,21 @@ class FusedMLPStep:
         self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
         self.wt_last = torch.empty(self.layers[-1][0].shape[1], Cl, **f)      # W_last^T, refreshed before every forward
         # 256 x 256 layers: float32-accurate GEMMs on the bf16 matrix cores (forward and dX); other widths stay with the library
-        self.split = {li: SplitGemm256(w) for li, (w, _, _, _) in enumerate(self.layers)
+        self.bf16 = bool(getattr(agent, "mixed_precision", False))
+        self.sfx = "_bf16" if self.bf16 else ""
+        self.split = {li: SplitGemm256(w, bf16=self.bf16) for li, (w, _, _, _) in enumerate(self.layers)
                       if li >= 1 and SplitGemm256.applies(w, agent.config)}
         # ... and for the last of them the ELU + head product rides in the GEMM epilogue (ag_split_gemm_elu_heads)
         self.fuse_gemm_heads = bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 in (5, 6)
         self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 8, **f)
         self.k = 0
         self.last_launches = {}       # the step's dominant launches as (entry point, replayable closure) - for bench.py
+
+    @property
+    def covers_all_products(self):
+        """True when every matrix product of the update runs in the hand-written kernels (what `mixed_precision` needs: the
+        library GEMMs and the vector-ALU first layer have no bf16 twin)."""
+        return bool(self.fuse_gemm_input and self.recompute_h1 and self.fuse_gemm_loss and self.split_wgrad == {1})
 
     def describe_paths(self):
         """Which implementation each layer of the update took (bench.py `config.paths`; printed once at agent start-up)."""
@@ -262,6 +271,8 @@ class FusedMLPStep:
                 dw = lib_gemm + " split-K bmm"
             dx = ("split-bf16 GEMM (ag_split_gemm / ..._input_wgrad*)" if sg else lib_gemm)
             out[key] = {"forward": fwd, "dW": dw, "dX": dx}
+        out["product_arithmetic"] = ("mixed_precision: one bf16 MFMA per product, f32 accumulate (_bf16 entry points)" if self.bf16
+                                     else "float32-accurate: exact 3-way bf16 split, six MFMAs per product (library GEMM layers: f32 MFMA)")
         return out
 
     @staticmethod
@@ -452,11 +463,11 @@ class FusedMLPStep:
             if li == 1 and self.recompute_h1:
                 # X operand (h1) and ELU'(h1) are produced from the network inputs + the first-layer image of the forward launch
                 wp, img, x0 = self.wgrad_partials[1], self.split[1].in_image, inputs[0]
-                wg = ("ag_split_wgrad_input", lambda dz=dz, wp=wp, img=img, x0=x0: N.check(lib.ag_split_wgrad_input(
+                wg = ("ag_split_wgrad_input", lambda dz=dz, wp=wp, img=img, x0=x0: N.check(getattr(lib, "ag_split_wgrad_input" + self.sfx)(
                     dz.data_ptr(), x0.data_ptr(), img.data_ptr(), wp.data_ptr(), M, C, K, x0.shape[1], wp.shape[0], st),
                     "ag_split_wgrad_input"))
                 dx = ("ag_split_gemm_input_wgrad_recompute", lambda dz=dz, img=img, x0=x0: N.check(
-                    lib.ag_split_gemm_input_wgrad_recompute(dz.data_ptr(), self.split[1].bwd.data_ptr(), img.data_ptr(), x0.data_ptr(),
+                    getattr(lib, "ag_split_gemm_input_wgrad_recompute" + self.sfx)(dz.data_ptr(), self.split[1].bwd.data_ptr(), img.data_ptr(), x0.data_ptr(),
                                                             self.wgrad_partials[0].data_ptr(), self.bias_partials[0].data_ptr(), M, 256,
                                                             256, x0.shape[1], st), "ag_split_gemm_input_wgrad_recompute"))
                 wg[1]()
@@ -465,7 +476,7 @@ class FusedMLPStep:
                 break
             if li in self.split_wgrad:
                 wp = self.wgrad_partials[li]
-                wg = ("ag_split_wgrad", lambda dz=dz, xin=xin, wp=wp: N.check(lib.ag_split_wgrad(
+                wg = ("ag_split_wgrad", lambda dz=dz, xin=xin, wp=wp: N.check(getattr(lib, "ag_split_wgrad" + self.sfx)(
                     dz.data_ptr(), xin.data_ptr(), wp.data_ptr(), M, C, K, wp.shape[0], st), "ag_split_wgrad"))
                 wg[1]()
                 if li == last:
@@ -532,7 +543,8 @@ class FusedRolloutStep:
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
         self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0
         self.wt_last = torch.empty(self.layers[-1][0].shape[1], Cl, **f)
-        self.split = {li: SplitGemm256(w, backward=False) for li, (w, _) in enumerate(self.layers)
+        self.bf16 = bool(getattr(agent, "mixed_precision", False))
+        self.split = {li: SplitGemm256(w, backward=False, bf16=self.bf16) for li, (w, _) in enumerate(self.layers)
                       if li >= 1 and SplitGemm256.applies(w, agent.config)}
         self.fuse_gemm_heads = bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 in (5, 6)
         # the whole policy forward as ONE launch with the activations in registers (csrc/mlp_chain.hip): [D -> 256 -> 256] trunks
@@ -627,7 +639,8 @@ class FusedRolloutStep:
         w0, b0 = self.layers[0]
         D, C0 = obs.shape[1], w0.shape[0]
         if self.chain is not None:
-            N.check(lib.ag_mlp_chain_forward(obs.data_ptr(), rms.running_mean.data_ptr() if rms is not None else None,
+            N.check(getattr(lib, "ag_mlp_chain_forward" + ("_bf16" if self.bf16 else ""))(
+                obs.data_ptr(), rms.running_mean.data_ptr() if rms is not None else None,
                                              rms.running_var.data_ptr() if rms is not None else None,
                                              float(rms.epsilon) if rms is not None else 0.0, 5.0, self.chain.data_ptr(),
                                              self.layers[1][1].data_ptr(), ag.heads_b.data_ptr(), self.heads.data_ptr(), None, None,

@@ -220,6 +220,32 @@ def side_config_tracking(args, epochs=3, warmup=2):
     return out
 
 
+def side_config_bf16(args, epochs=5, warmup=3):
+    """The headline configuration with `mixed_precision: true` (the reference's torch.cuda.amp switch, a2c_base.py:236-237,566,582):
+    one bf16 MFMA per product in every matrix-core kernel of the rollout and the update, f32 accumulate, f32 master weights.
+    Opt-in and NEVER the headline: `value` of the line is the float32 job."""
+    from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    params = build_params(args, 1)
+    params["config"]["mixed_precision"] = True
+    agent = A2CAgent("bench_bf16", params)
+    el, st, play, upd = _time_epochs(agent, epochs, warmup)
+    out = {"value": args.envs * agent.horizon_length * epochs / el, "unit": "env-steps/s", "ms_per_step": el / epochs * 1e3,
+           "steps": epochs, "warmup": warmup, "dtype": "bf16",
+           "config": {"workload": "hovering_ctbr_ppo_epoch", "mixed_precision": True, "envs_per_gpu": args.envs,
+                      "minibatch_size": agent.minibatch_size, "policy": "MLP(256,256) actor-critic, fixed sigma",
+                      "arithmetic": "one bf16 MFMA per product (operands rounded to nearest), f32 accumulate, f32 master weights, "
+                                    "everything outside the products in f32", "paths": agent.compute_paths()},
+           "last_kl": st["kl"], "finite": bool(st["kl"] == st["kl"] and st["a_loss"] == st["a_loss"])}
+    try:
+        from airgym_amd.utils.kernel_bench import measure_update_sequence
+        out["update_kernels"] = [{k: v for k, v in e.items() if k in ("entry_point", "us_per_launch", "in_step")}
+                                 for e in measure_update_sequence(agent)]
+    except Exception as e:
+        out["update_kernels"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    agent.vec_env.env.hip.close()
+    return out
+
+
 def side_config_planning(envs=16384, epochs=3, warmup=1, minibatches=24):
     """BASELINE config 4 on one GPU: Planning, 16 384 envs, CTBR, 212 x 120 depth image every 4th step, the trainable CNN
     policy of the shipped YAML (reference: airgym/envs/task/planning.py:138-184, scripts/config/ppo_planning.yaml:31,
@@ -571,6 +597,7 @@ def _run_rank(args, world, rank, on_gpu, stage):
             # (3 epochs each; not part of `value`)
             side = {}
             for name, fn in (("tracking_lv", lambda: side_config_tracking(args)),
+                             ("hovering_bf16", lambda: side_config_bf16(args)),
                              ("planning_cnn_16384", lambda: side_config_planning())):
                 try:
                     side[name] = fn()

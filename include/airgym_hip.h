@@ -478,6 +478,31 @@ int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void
                                        const float* Wh_dev, const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* loss, int M,
                                        int n, int k, int A1, void* stream);
 
+/* mixed_precision (the reference's torch.cuda.amp switch, lib/agent/a2c_base.py:236-237,566,582: autocast around the model forward
+ * of the rollout and of calc_gradients): every matrix-core entry point above exists a second time with the suffix _bf16 and the
+ * SAME arguments - ONE bf16 MFMA per product instead of six (operands rounded to bf16, round to nearest; float32 accumulate; the
+ * float32 master weights and the same prepared weight images, of which only the leading plane is read).  Everything around the
+ * products (normaliser, ELU, PPO loss, reductions, Adam) stays float32.  Error per product <= 2^-7 |a||b| (both operands rounded). */
+int ag_split_gemm_bf16(const float* A_dev, const void* planes_dev, const float* bias_dev, float* C_dev, int M, int n, int k, void* stream);
+int ag_split_gemm_elu_heads_bf16(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
+                                 const float* bh_dev, float* Z_dev, float* heads_dev, int M, int n, int k, int A1, void* stream);
+int ag_split_gemm_loss_heads_bwd_bf16(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
+                                      const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* loss, int M, int n, int k, int A1,
+                                      void* stream);
+int ag_split_gemm_input_loss_heads_bwd_bf16(const ag_input_layer_args* in, const void* image_dev, const float* bias_dev,
+                                            const float* Wh_dev, const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* loss, int M,
+                                            int n, int k, int A1, void* stream);
+int ag_split_gemm_input_wgrad_bf16(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
+                                   float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
+int ag_split_gemm_input_wgrad_recompute_bf16(const float* dZ_dev, const void* planes_dev, const void* image_dev, const float* x_dev,
+                                             float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
+int ag_split_wgrad_bf16(const float* dZ_dev, const float* X_dev, float* partials_dev, int M, int n, int k, int slices, void* stream);
+int ag_split_wgrad_input_bf16(const float* dZ_dev, const float* x_dev, const void* image_dev, float* partials_dev, int M, int n, int k,
+                              int D, int slices, void* stream);
+int ag_mlp_chain_forward_bf16(const float* obs_dev, const double* mean_dev, const double* var_dev, float eps, float clip,
+                              const void* image_dev, const float* b2_dev, const float* bh_dev, float* heads_dev, float* xn_dev,
+                              float* h1_dev, float* h2_dev, int M, int D, int A1, void* stream);
+
 /* ReLU followed by BatchNorm2d on [N, C, H, W] float32 (NCHW, C <= 64) for the depth-image feature extractor (reference:
  * lib/network/cnn.py:3-33: Conv2d -> ReLU -> BatchNorm2d, three times) - airgym_amd/csrc/cnn_kernels.hip.  The ReLU output is
  * never materialised; x is the CONVOLUTION output.  HW = H * W.  blocks = ceil(N * C / ag_relu_bn_planes_per_block()).

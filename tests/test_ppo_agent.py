@@ -558,7 +558,8 @@ def test_weighted_indexed_normaliser_moments_across_two_ranks():
 
 
 def test_mixed_precision_is_refused_not_ignored():
-    """a2c_base.py:236-237 reads `mixed_precision`; this build has no autocast path, so the key must raise, not be dropped."""
+    """a2c_base.py:236-237 reads `mixed_precision`.  This build honours it only where every matrix product runs in the hand-written
+    kernels (their _bf16 twins; tests/test_gpu_mixed_precision.py); anywhere else - here: CPU - the key must raise, not be dropped."""
     params = _stub_env.ppo_params(num_actors=16, horizon=4, mini_epochs=1, max_epochs=1)
     params["config"]["mixed_precision"] = True
     with pytest.raises(NotImplementedError, match="mixed_precision"):
