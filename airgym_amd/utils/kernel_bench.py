@@ -257,7 +257,7 @@ def env_kernel_source_sha():
     import os
     here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
     h = hashlib.sha256()
-    for f in ("step_kernel.hip", "env_math.hpp", "kernel_args.hpp"):
+    for f in ("step_kernel.hip", "env_math.hpp", "kernel_args.hpp", "rollout_math.hpp", "build.py"):      # (build.py: the compile flags)
         with open(os.path.join(here, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -27,7 +27,7 @@ for form, (key, entry, fused) in keys.items():
         continue
     (f, nf), (w, nw) = vals[(form, "FETCH_SIZE")], vals[(form, "WRITE_SIZE")]
     algo = fused_algo_bytes("hovering", "rate", 18, 4) if fused else ALGO_BYTES_PER_ENV_STEP[("hovering", "rate")]
-    out[key] = {"kernel": kernel_name("hovering", "rate", fused), "entry_point": entry, "envs": envs,
+    out[key] = {"kernel": kernel_name("hovering", "rate", fused, single=form in ("rollout", "api")), "entry_point": entry, "envs": envs,
                 "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w, "fetch_correction": 2.0,
                 "traffic_bytes_per_launch": int(round((2.0 * f + w) * 1024)), "algorithmic_bytes_per_launch": algo * envs,
                 "source_sha": sha,
