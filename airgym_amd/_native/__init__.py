@@ -124,7 +124,7 @@ class AgLossEpilogue(ctypes.Structure):
         ("new_sigma_dev", ctypes.c_void_p), ("heads_dev", ctypes.c_void_p), ("loss_partials_dev", ctypes.c_void_p),
         ("dwh_partials_dev", ctypes.c_void_p), ("db_partials_dev", ctypes.c_void_p),
         ("e_clip", ctypes.c_float), ("critic_coef", ctypes.c_float), ("bounds_loss_coef", ctypes.c_float),
-        ("clip_value", ctypes.c_int), ("bound_type", ctypes.c_int),
+        ("clip_value", ctypes.c_int), ("bound_type", ctypes.c_int), ("tile_rows", ctypes.c_int),
     ]
 
 
@@ -205,7 +205,8 @@ SYMBOLS = [
     ("ag_split_wgrad_input", ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_split_gemm_input_wgrad_recompute_supported", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_gemm_input_wgrad_recompute", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                                           ctypes.c_int, _P]),
+                                                           ctypes.c_int, ctypes.c_int, _P]),
+    ("ag_split_gemm_pick_tile_rows", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_gemm_input_wgrad_rows", ctypes.c_int, []),
     ("ag_split_gemm_input_wgrad_supported", ctypes.c_int, [ctypes.c_int]),
     ("ag_split_gemm_input_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -268,8 +268,8 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     static_assert(WM == 2 || WM == 4, "4 or 8 waves");
     static_assert(A1 == 0 || DIN == 0, "one fused epilogue at a time");
     static_assert((DIN & 1) == 0 && DIN <= 62, "input width: even, at most two 32-wide tiles with the bias column");
-    static_assert(FIN == 0 || (WM == 4 && (FIN & 1) == 0 && FIN >= 16 && FIN <= 20), "fused first layer: 256-row tiles, widths 16 / 18 / 20");
-    static_assert(!RC || FIN > 0 || (DIN > 0 && WM == 4 && DIN <= 18), "recomputed h1: the fused forward, or the 256-row dX epilogue (widths <= 18)");
+    static_assert(FIN == 0 || ((FIN & 1) == 0 && FIN >= 16 && FIN <= 20), "fused first layer: widths 16 / 18 / 20");
+    static_assert(!RC || FIN > 0 || (DIN > 0 && DIN <= 18), "recomputed h1: the fused forward, or the dX epilogue (widths <= 18)");
     const float* __restrict__ bias = ep.bias;
     const float* __restrict__ Wh = ep.Wh;
     const float* __restrict__ bh = ep.bh;
@@ -859,7 +859,8 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         __syncthreads();
         for (int idx = tid; idx < BN * RW; idx += NT) {     // the WM row blocks in a fixed order
             const int c = idx / RW, d = idx - c * RW;
-            const float v = ((red[idx] + red[BN * RW + idx]) + red[2 * BN * RW + idx]) + red[3 * BN * RW + idx];
+            float v = red[idx] + red[BN * RW + idx];
+            if (WM == 4) v = (v + red[2 * BN * RW + idx]) + red[3 * BN * RW + idx];
             if (d < DIN) ep.dw_partials[((size_t)tile * BN + c) * DIN + d] = v;
             else ep.db_partials[(size_t)tile * BN + c] = v;
         }
@@ -1025,6 +1026,21 @@ static int launch_split_any(const float* A_dev, const void* planes_dev, float* C
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
+// Small minibatches (round 5): with fewer 256-row tiles than CUs half the chip idles (M = 32 768, the reference's minibatch ratio
+// at 65 536 envs: 128 tiles on 256 CUs), so the caller may ask for 128-row tiles (4 waves per workgroup) per launch - `tile_rows` of
+// ag_loss_epilogue / ag_split_gemm_input_wgrad_recompute; ag_split_gemm_pick_tile_rows(M) is the rule the agent uses.
+#if AG_SPLIT_PLANES == 3
+extern "C" int ag_split_gemm_pick_tile_rows(int M) {
+    if (M <= 0) return 256;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return ((M + 255) / 256 < cus && M % 128 == 0) ? 128 : 256;
+}
+#endif
+
 // dispatch on the runtime tile choice (a constant in the shipped build: only that instantiation is compiled)
 #ifdef AG_EXPERIMENTS
 #define AG_SG_DISPATCH(call2, call4) (g_split_wm == 4 ? (call4) : (call2))
@@ -1058,7 +1074,9 @@ extern "C" int AG_PREC(ag_split_gemm_loss_heads_bwd)(const float* A_dev, const v
     if (!A_dev || !planes_dev || !bias_dev || !Wh_dev || !bh_dev || !dZ_dev || !L || M <= 0) return AG_ERR_INVALID_ARG;
     if (L->struct_size != sizeof(ag_loss_epilogue)) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM || A1 != 5) return AG_ERR_UNSUPPORTED;      // four actions + the value head
-    if (M % (g_split_wm * 64) != 0) return AG_ERR_UNSUPPORTED;           // whole row tiles only (the dZ stores are unguarded)
+    if (L->tile_rows != 0 && L->tile_rows != 128 && L->tile_rows != 256) return AG_ERR_INVALID_ARG;
+    const int rows_ = L->tile_rows == 128 ? 128 : (L->tile_rows == 256 ? 256 : g_split_wm * 64);
+    if (M % rows_ != 0) return AG_ERR_UNSUPPORTED;                        // whole row tiles only (the dZ stores are unguarded)
     if (!L->logstd_dev || !L->actions_dev || !L->old_neglogp_dev || !L->advantages_dev || !L->returns_dev || !L->old_values_dev ||
         !L->old_mu_dev || !L->old_sigma_dev || !L->loss_partials_dev || !L->dwh_partials_dev || !L->db_partials_dev)
         return AG_ERR_INVALID_ARG;
@@ -1072,7 +1090,7 @@ extern "C" int AG_PREC(ag_split_gemm_loss_heads_bwd)(const float* A_dev, const v
     ep.dwh_partials = L->dwh_partials_dev; ep.db2_partials = L->db_partials_dev;
     ep.lp = agloss::LossParams{L->e_clip, L->critic_coef, L->bounds_loss_coef, 1.0f / (float)M, L->clip_value, L->bound_type};
 #define AG_SGL(W) launch_split_any<true, 5, 0, W, true>(A_dev, planes_dev, dZ_dev, M, ep, stream)
-    return AG_SG_DISPATCH(AG_SGL(2), AG_SGL(4));
+    return rows_ == 128 ? AG_SGL(2) : AG_SGL(4);
 #undef AG_SGL
 }
 
@@ -1122,7 +1140,9 @@ extern "C" int AG_PREC(ag_split_gemm_input_loss_heads_bwd)(const ag_input_layer_
     const bool norm = in->mean_dev != nullptr;
     if (norm != (in->var_dev != nullptr) || norm != (in->xn_dev != nullptr)) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM || A1 != 5 || !ag_split_gemm_input_fwd_supported(in->D)) return AG_ERR_UNSUPPORTED;
-    if (M % 256 != 0) return AG_ERR_UNSUPPORTED;                          // whole row tiles only
+    if (L->tile_rows != 0 && L->tile_rows != 128 && L->tile_rows != 256) return AG_ERR_INVALID_ARG;
+    const bool small_ = L->tile_rows == 128;
+    if (M % (small_ ? 128 : 256) != 0) return AG_ERR_UNSUPPORTED;         // whole row tiles only
     if (!L->logstd_dev || !L->actions_dev || !L->old_neglogp_dev || !L->advantages_dev || !L->returns_dev || !L->old_values_dev ||
         !L->old_mu_dev || !L->old_sigma_dev || !L->loss_partials_dev || !L->dwh_partials_dev || !L->db_partials_dev)
         return AG_ERR_INVALID_ARG;
@@ -1138,14 +1158,16 @@ extern "C" int AG_PREC(ag_split_gemm_input_loss_heads_bwd)(const ag_input_layer_
     ep.in_mean = in->mean_dev; ep.in_var = in->var_dev; ep.w1img = reinterpret_cast<const uint4*>(image_dev); ep.xn_out = in->xn_dev;
     ep.h1_out = in->h1_dev; ep.in_eps = in->eps; ep.in_clip = in->clip;
     const void* planes_dev = reinterpret_cast<const char*>(image_dev) + kInImageW1Bytes;
-#define AG_SGF(F) (in->h1_dev ? launch_split_any<true, 5, 0, 4, true, F, false>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream) \
-                              : launch_split_any<true, 5, 0, 4, true, F, true>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream))
+#define AG_SGF_(F, W) (in->h1_dev ? launch_split_any<true, 5, 0, W, true, F, false>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream) \
+                                  : launch_split_any<true, 5, 0, W, true, F, true>(in->obs_dev, planes_dev, dZ_dev, M, ep, stream))
+#define AG_SGF(F) (small_ ? AG_SGF_(F, 2) : AG_SGF_(F, 4))
     switch (in->D) {
         case 16: return AG_SGF(16);
         case 18: return AG_SGF(18);
         default: return AG_SGF(20);
     }
 #undef AG_SGF
+#undef AG_SGF_
 }
 
 #if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
@@ -1181,7 +1203,7 @@ extern "C" int ag_split_gemm_input_wgrad_recompute_supported(int D) { return (g_
 
 extern "C" int AG_PREC(ag_split_gemm_input_wgrad_recompute)(const float* dZ_dev, const void* planes_dev, const void* image_dev, const float* x_dev,
                                                    float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D,
-                                                   void* stream) {
+                                                   int tile_rows, void* stream) {
     if (!dZ_dev || !planes_dev || !image_dev || !x_dev || !dw_partials_dev || !db_partials_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if (n != BN || k != KDIM || !ag_split_gemm_input_wgrad_recompute_supported(D)) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)dZ_dev & 15) || ((uintptr_t)planes_dev & 15) || ((uintptr_t)image_dev & 15) || ((uintptr_t)x_dev & 7))
@@ -1189,6 +1211,11 @@ extern "C" int AG_PREC(ag_split_gemm_input_wgrad_recompute)(const float* dZ_dev,
     SplitEpilogue ep = {};
     ep.x = x_dev; ep.dw_partials = dw_partials_dev; ep.db_partials = db_partials_dev;
     ep.w1img = reinterpret_cast<const uint4*>(image_dev);
+    if (tile_rows != 0 && tile_rows != 128 && tile_rows != 256) return AG_ERR_INVALID_ARG;
+    if (tile_rows == 128) {      // partials: one per 128 rows
+        if (D == 16) return launch_split_any<false, 0, 16, 2, false, 0, true>(dZ_dev, planes_dev, nullptr, M, ep, stream);
+        return launch_split_any<false, 0, 18, 2, false, 0, true>(dZ_dev, planes_dev, nullptr, M, ep, stream);
+    }
     if (D == 16) return launch_split_any<false, 0, 16, 4, false, 0, true>(dZ_dev, planes_dev, nullptr, M, ep, stream);
     return launch_split_any<false, 0, 18, 4, false, 0, true>(dZ_dev, planes_dev, nullptr, M, ep, stream);
 }

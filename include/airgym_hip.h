@@ -391,7 +391,8 @@ int ag_split_gemm_input_wgrad(const float* dZ_dev, const void* planes_dev, const
  * With both, ag_split_gemm_input_loss_heads_bwd may be given h1_dev = NULL: it then does not write h1 at all. */
 int ag_split_gemm_input_wgrad_recompute_supported(int D);
 int ag_split_gemm_input_wgrad_recompute(const float* dZ_dev, const void* planes_dev, const void* image_dev, const float* x_dev,
-                                        float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
+                                        float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, int tile_rows,
+                                        void* stream);      /* tile_rows: 0 / 256 or 128 (partials per that many rows) */
 int ag_split_wgrad_input_supported(int D);
 int ag_split_wgrad_input_slices(int M);
 int ag_split_wgrad_input(const float* dZ_dev, const float* x_dev, const void* image_dev, float* partials_dev, int M, int n, int k,
@@ -442,7 +443,10 @@ typedef struct ag_loss_epilogue {
     float* db_partials_dev;            /* [tiles, 256] */
     float e_clip, critic_coef, bounds_loss_coef;
     int clip_value, bound_type;        /* as ag_ppo_loss */
+    int tile_rows;                     /* 0 / 256: one partial per 256 rows (8-wave workgroups); 128: per 128 rows (4-wave workgroups;
+                                          for minibatches with fewer 256-row tiles than CUs - ag_split_gemm_pick_tile_rows) */
 } ag_loss_epilogue;
+int ag_split_gemm_pick_tile_rows(int M);   /* 128 when ceil(M / 256) < CUs and M % 128 == 0, else 256 */
 int ag_split_gemm_loss_rows(void);
 int ag_split_gemm_loss_heads_bwd(const float* A_dev, const void* planes_dev, const float* bias_dev, const float* Wh_dev,
                                  const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* loss, int M, int n, int k, int A1,
@@ -495,7 +499,8 @@ int ag_split_gemm_input_loss_heads_bwd_bf16(const ag_input_layer_args* in, const
 int ag_split_gemm_input_wgrad_bf16(const float* dZ_dev, const void* planes_dev, const float* h1_dev, const float* x_dev,
                                    float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
 int ag_split_gemm_input_wgrad_recompute_bf16(const float* dZ_dev, const void* planes_dev, const void* image_dev, const float* x_dev,
-                                             float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, void* stream);
+                                             float* dw_partials_dev, float* db_partials_dev, int M, int n, int k, int D, int tile_rows,
+                                             void* stream);
 int ag_split_wgrad_bf16(const float* dZ_dev, const float* X_dev, float* partials_dev, int M, int n, int k, int slices, void* stream);
 int ag_split_wgrad_input_bf16(const float* dZ_dev, const float* x_dev, const void* image_dev, float* partials_dev, int M, int n, int k,
                               int D, int slices, void* stream);
