@@ -144,7 +144,11 @@ class FusedMLPStep:
         self.wg_blocks = (M + wrows - 1) // wrows
         # ... or, with the loss and the head layer's backward in the last GEMM's epilogue (ag_split_gemm_loss_heads_bwd), one
         # partial per GEMM row tile
-        lrows = self.lib.ag_split_gemm_loss_rows()
+        # row tile of the loss / recompute launches: 256 rows (8-wave workgroups) unless the minibatch has fewer such tiles than
+        # the device has CUs - then 128 rows (4-wave workgroups), so that e.g. the reference's 32 768-sample minibatches at 65 536
+        # envs use the whole chip (ag_split_gemm_pick_tile_rows); `split_tile_rows: 128 | 256` overrides
+        self.tile_rows = int(agent.config.get("split_tile_rows", 0) or self.lib.ag_split_gemm_pick_tile_rows(M))
+        lrows = self.tile_rows
         self.fuse_gemm_loss = (L >= 2 and bool(agent.config.get("fuse_gemm_loss", True))
                                and bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 == 5
                                and SplitGemm256.applies(self.layers[-1][0], agent.config) and M % lrows == 0
@@ -153,7 +157,7 @@ class FusedMLPStep:
             self.wg_blocks = M // lrows
         # ... and, for a [D -> 256 -> 256] trunk, with the first layer formed inside that launch as well (no ag_mlp_input_layer)
         self.fuse_gemm_input = (self.fuse_gemm_loss and L == 2 and bool(agent.config.get("fuse_gemm_input", True))
-                                and self.layers[0][0].shape[0] == 256 and M % 256 == 0
+                                and self.layers[0][0].shape[0] == 256 and M % self.tile_rows == 0
                                 and bool(self.lib.ag_split_gemm_input_fwd_supported(D)))
         # small weight gradients folded into the ELU' passes (head: always; first layer: D in {16,18,20}, >= 2 layers)
         # ... and for a [D -> 256 -> 256] trunk the first layer's whole backward rides in the epilogue of the second layer's
@@ -170,7 +174,7 @@ class FusedMLPStep:
                              and bool(self.lib.ag_split_wgrad_input_supported(D)))
         self.fuse_input_wgrad = L >= 2 and (self.lib.ag_input_wgrad_rows(D) > 0 or self.fuse_gemm_input_wgrad)
         if self.fuse_gemm_input_wgrad:
-            irows = self.lib.ag_split_gemm_input_wgrad_rows()
+            irows = self.tile_rows if self.recompute_h1 else self.lib.ag_split_gemm_input_wgrad_rows()
         self.in_wg_blocks = (M + irows - 1) // irows
         self.head_wg_partials = torch.empty(self.wg_blocks, self.A + 1, self.layers[-1][0].shape[0], **f)
         self.bias_partials, self.wgrad_partials = [], []
@@ -377,6 +381,7 @@ class FusedMLPStep:
                 Lp.bounds_loss_coef = float(ag.bounds_loss_coef or 0.0)
                 Lp.clip_value = int(bool(ag.clip_value))
                 Lp.bound_type = int(BOUND_TYPES[ag.bound_loss_type] if ag.bounds_loss_coef is not None else 0)
+                Lp.tile_rows = self.tile_rows
                 dz_out = self.dz[:M * w.shape[0]].view(M, w.shape[0])
                 if in_args is not None:
                     fwd = ("ag_split_gemm_input_loss_heads_bwd" + (" (h1 not stored)" if self.recompute_h1 else ""),
@@ -469,7 +474,7 @@ class FusedMLPStep:
                 dx = ("ag_split_gemm_input_wgrad_recompute", lambda dz=dz, img=img, x0=x0: N.check(
                     getattr(lib, "ag_split_gemm_input_wgrad_recompute" + self.sfx)(dz.data_ptr(), self.split[1].bwd.data_ptr(), img.data_ptr(), x0.data_ptr(),
                                                             self.wgrad_partials[0].data_ptr(), self.bias_partials[0].data_ptr(), M, 256,
-                                                            256, x0.shape[1], st), "ag_split_gemm_input_wgrad_recompute"))
+                                                            256, x0.shape[1], self.tile_rows, st), "ag_split_gemm_input_wgrad_recompute"))
                 wg[1]()
                 dx[1]()
                 self.last_launches["wgrad"], self.last_launches["dx"] = wg, dx

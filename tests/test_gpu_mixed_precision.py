@@ -84,7 +84,7 @@ def test_update_kernels_bf16_twins_against_float64(lib, M, D):
         dw1 = torch.full((tiles, 256, D), float("nan"), device="cuda")
         db1 = torch.full((tiles, 256), float("nan"), device="cuda")
         N.check(lib.ag_split_gemm_input_wgrad_recompute_bf16(dz2.data_ptr(), bwd.data_ptr(), image.data_ptr(), x.data_ptr(),
-                                                             dw1.data_ptr(), db1.data_ptr(), M, 256, 256, D, _stream()), "dx bf16")
+                                                             dw1.data_ptr(), db1.data_ptr(), M, 256, 256, D, 0, _stream()), "dx bf16")
         dh1 = dz2.double() @ W2.double()
         dz1 = dh1 * torch.where(z1 > 0, torch.ones_like(z1), torch.exp(z1))
         habs = dz2.double().abs() @ W2.double().abs()

@@ -103,12 +103,14 @@ def test_weight_gradient_with_produced_x_rejects_bad_arguments(lib):
     assert lib.ag_split_wgrad_input(p, p, p, p, 64, 128, 256, 18, 2, None) == N.AG_ERR_UNSUPPORTED
     assert lib.ag_split_wgrad_input(p, p, p, p, 64, 256, 256, 48, 2, None) == N.AG_ERR_UNSUPPORTED
     assert lib.ag_split_wgrad_input(p, p, p, p, 48, 256, 256, 18, 1, None) == N.AG_ERR_UNSUPPORTED      # M % 32
-    assert lib.ag_split_gemm_input_wgrad_recompute(p, p, p, p, p, p, 256, 256, 256, 20, None) == N.AG_ERR_UNSUPPORTED
-    assert lib.ag_split_gemm_input_wgrad_recompute(p, p, None, p, p, p, 256, 256, 256, 18, None) == -1
+    assert lib.ag_split_gemm_input_wgrad_recompute(p, p, p, p, p, p, 256, 256, 256, 20, 0, None) == N.AG_ERR_UNSUPPORTED
+    assert lib.ag_split_gemm_input_wgrad_recompute(p, p, p, p, p, p, 256, 256, 256, 18, 64, None) == -1      # tile_rows: 0 / 128 / 256
+    assert lib.ag_split_gemm_input_wgrad_recompute(p, p, None, p, p, p, 256, 256, 256, 18, 0, None) == -1
 
 
-@pytest.mark.parametrize("M,D", [(256, 18), (4096, 18), (2048, 16), (1000, 18), (196608, 18)])
-def test_first_layer_backward_with_recomputed_h1(lib, M, D):
+@pytest.mark.parametrize("M,D,tile_rows", [(256, 18, 0), (4096, 18, 0), (2048, 16, 0), (1000, 18, 0), (196608, 18, 0),
+                                           (4096, 18, 128), (32768, 18, 128), (1000, 16, 128)])
+def test_first_layer_backward_with_recomputed_h1(lib, M, D, tile_rows):
     """dW1 / db1 partials of the recomputing epilogue == the stored-h1 epilogue (ag_split_gemm_input_wgrad fed with a float32 h1)
     and == float64 autograd of the two layers."""
     from airgym_amd import _native as N
@@ -118,14 +120,15 @@ def test_first_layer_backward_with_recomputed_h1(lib, M, D):
     dz2 = torch.randn(M, 256, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g)
     planes = torch.empty(lib.ag_split_gemm_plane_bytes(), dtype=torch.uint8, device="cuda")
     N.check(lib.ag_split_gemm_prepare(W2.data_ptr(), planes.data_ptr(), 256, 256, 1, _stream()), "prepare (transposed)")
-    rows = lib.ag_split_gemm_input_wgrad_rows()
+    rows = tile_rows or lib.ag_split_gemm_input_wgrad_rows()
     tiles = (M + rows - 1) // rows
     dw = torch.full((tiles, 256, D), float("nan"), device="cuda")
     db = torch.full((tiles, 256), float("nan"), device="cuda")
     N.check(lib.ag_split_gemm_input_wgrad_recompute(dz2.data_ptr(), planes.data_ptr(), image.data_ptr(), x.data_ptr(), dw.data_ptr(),
-                                                    db.data_ptr(), M, 256, 256, D, _stream()), "recompute")
+                                                    db.data_ptr(), M, 256, 256, D, tile_rows, _stream()), "recompute")
     h32 = h64.float()
-    dw0, db0 = torch.empty_like(dw), torch.empty_like(db)
+    t0 = (M + 255) // 256
+    dw0, db0 = torch.empty(t0, 256, D, device="cuda"), torch.empty(t0, 256, device="cuda")
     N.check(lib.ag_split_gemm_input_wgrad(dz2.data_ptr(), planes.data_ptr(), h32.data_ptr(), x.data_ptr(), dw0.data_ptr(),
                                           db0.data_ptr(), M, 256, 256, D, _stream()), "stored")
     torch.cuda.synchronize()
@@ -142,8 +145,65 @@ def test_first_layer_backward_with_recomputed_h1(lib, M, D):
     # and the stored-h1 kernel: same computation on activations that differ by float32 rounding
     assert ((got_w - dw0.sum(0, dtype=torch.float64)).abs() / sw).max().item() < 1e-6
     assert ((got_b - db0.sum(0, dtype=torch.float64)).abs() / sb).max().item() < 1e-6
-    # per tile too (a tile's partial is a sum over its own 256 rows only)
-    assert ((dw.double() - dw0.double()).abs().amax(0) / sw).max().item() < 1e-6
+    # per tile too (a tile's partial is a sum over its own rows only; 128-row tiles: pairs against the 256-row reference)
+    dwt = dw.double() if rows == 256 else torch.nn.functional.pad(dw.double(), (0, 0, 0, 0, 0, dw.shape[0] % 2)).view(-1, 2, 256, D).sum(1)
+    assert ((dwt - dw0.double()).abs().amax(0) / sw).max().item() < 1e-6
+
+
+@pytest.mark.parametrize("M,D,normalize", [(4096, 18, True), (2048, 16, False), (196608, 18, True)])
+def test_forward_launch_with_128_row_tiles_equals_256_row_tiles(lib, M, D, normalize):
+    """`tile_rows = 128` (4-wave workgroups, for minibatches with fewer 256-row tiles than CUs) changes the tiling, not the
+    function: dz bit-identical (a row's arithmetic does not depend on its tile), per-tile partials sum pairwise to the 256-row
+    launch's within float32 summation order."""
+    from airgym_amd import _native as N
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_fused_input_layer import _loss_args
+    A = 4
+    g = torch.Generator(device="cuda").manual_seed(900 + M + D)
+    f = dict(device="cuda", dtype=torch.float32)
+    obs = 3.0 * torch.randn(M, D, generator=g, **f)
+    mean = torch.randn(D, generator=g, device="cuda", dtype=torch.float64)
+    var = torch.rand(D, generator=g, device="cuda", dtype=torch.float64) + 0.05
+    W1 = torch.randn(256, D, generator=g, **f) / D ** 0.5
+    b1 = 0.1 * torch.randn(256, generator=g, **f)
+    W2 = torch.randn(256, 256, generator=g, **f) / 16.0
+    b2 = 0.1 * torch.randn(256, generator=g, **f)
+    Wh = torch.randn(A + 1, 256, generator=g, **f) / 16.0
+    bh = 0.1 * torch.randn(A + 1, generator=g, **f)
+    image = torch.empty(lib.ag_split_gemm_input_image_bytes(), dtype=torch.uint8, device="cuda")
+    N.check(lib.ag_split_gemm_input_prepare(W1.data_ptr(), b1.data_ptr(), D, W2.data_ptr(), image.data_ptr(), _stream()), "in_prepare")
+    res = []
+    for rows in (256, 128):
+        gl = torch.Generator(device="cuda").manual_seed(5)
+        L, _, out = _loss_args(N, lib, M, A, gl, M // rows)
+        L.tile_rows = rows
+        xn = torch.full((M, D), 7.0, **f) if normalize else None
+        dz = torch.full((M, 256), 7.0, **f)
+        inp = N.AgInputLayerArgs()
+        inp.struct_size, inp.D = ctypes.sizeof(N.AgInputLayerArgs), D
+        inp.obs_dev = obs.data_ptr()
+        inp.mean_dev = mean.data_ptr() if normalize else None
+        inp.var_dev = var.data_ptr() if normalize else None
+        inp.xn_dev = xn.data_ptr() if normalize else None
+        inp.h1_dev = None
+        inp.eps, inp.clip = 1e-5, 5.0
+        N.check(lib.ag_split_gemm_input_loss_heads_bwd(ctypes.byref(inp), image.data_ptr(), b2.data_ptr(), Wh.data_ptr(), bh.data_ptr(),
+                                                       dz.data_ptr(), ctypes.byref(L), M, 256, 256, A + 1, _stream()), "fused")
+        torch.cuda.synchronize()
+        res.append((dz, xn, out))
+    (dz_a, xn_a, out_a), (dz_b, xn_b, out_b) = res
+    assert torch.equal(dz_a, dz_b) and torch.equal(out_a["new_mu"], out_b["new_mu"]) and torch.equal(out_a["heads"], out_b["heads"])
+    if normalize:
+        assert torch.equal(xn_a, xn_b)
+    for k in ("loss_partials", "dwh_partials", "db_partials"):
+        a, b = out_a[k].double(), out_b[k].double()
+        b2s = b.view(a.shape[0], 2, *b.shape[1:]).sum(1)
+        tol = 2e-5 * a.abs().amax(0, keepdim=True).clamp_min(1e-6)
+        assert ((a - b2s).abs() <= tol).all(), k
+    assert lib.ag_split_gemm_pick_tile_rows(196608) == 256 and lib.ag_split_gemm_pick_tile_rows(32768) == 128
+    assert lib.ag_split_gemm_pick_tile_rows(32768 + 64) == 256          # not a multiple of 128
 
 
 @pytest.mark.parametrize("M,D,normalize", [(4096, 18, True), (2048, 16, False), (196608, 18, True)])

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--D", type=int, default=18)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--recompute", default="both")
+    ap.add_argument("--tile-rows", type=int, default=0, help="0 / 256 or 128: row tile of the forward and dX launches (recompute 1 only)")
     a = ap.parse_args()
     lib = N.load()
     M, D, A = a.M, a.D, 4
@@ -46,7 +47,7 @@ def main():
     N.check(lib.ag_split_gemm_input_prepare(W1.data_ptr(), b1.data_ptr(), D, W2.data_ptr(), image.data_ptr(), st), "in_prepare")
     bwd = torch.empty(lib.ag_split_gemm_plane_bytes(), dtype=torch.uint8, device="cuda")
     N.check(lib.ag_split_gemm_prepare(W2.data_ptr(), bwd.data_ptr(), 256, 256, 1, st), "prepare")
-    tiles = M // 256
+    tiles = M // 128      # (room for 128-row tiles)
     z = lambda *s: torch.zeros(*s, **f)
     keep = {"act": z(M, A), "nlp": z(M), "adv": torch.randn(M, generator=g, **f), "ret": z(M), "val": z(M), "mu": z(M, A),
             "sig": torch.ones(M, A, **f), "lp": z(tiles, lib.ag_ppo_loss_num_sums()), "dwh": z(tiles, A + 1, 256), "db": z(tiles, 256),
@@ -60,6 +61,7 @@ def main():
     L.heads_dev = None
     L.loss_partials_dev, L.dwh_partials_dev, L.db_partials_dev = keep["lp"].data_ptr(), keep["dwh"].data_ptr(), keep["db"].data_ptr()
     L.e_clip, L.critic_coef, L.bounds_loss_coef, L.clip_value, L.bound_type = 0.2, 2.0, 1e-4, 0, 1
+    L.tile_rows = a.tile_rows
     xn, h1, dz = z(M, D), z(M, 256), z(M, 256)
     dw1, db1 = z(tiles, 256, D), z(tiles, 256)
     modes = [0, 1] if a.recompute == "both" else [int(a.recompute)]
@@ -85,7 +87,7 @@ def main():
         def k3():
             if rc:
                 N.check(lib.ag_split_gemm_input_wgrad_recompute(dz.data_ptr(), bwd.data_ptr(), image.data_ptr(), xn.data_ptr(),
-                                                                dw1.data_ptr(), db1.data_ptr(), M, 256, 256, D, st), "k3")
+                                                                dw1.data_ptr(), db1.data_ptr(), M, 256, 256, D, a.tile_rows, st), "k3")
             else:
                 N.check(lib.ag_split_gemm_input_wgrad(dz.data_ptr(), bwd.data_ptr(), h1.data_ptr(), xn.data_ptr(), dw1.data_ptr(),
                                                       db1.data_ptr(), M, 256, 256, D, st), "k3")
@@ -108,7 +110,7 @@ def main():
         nbytes = ([2 * io + act + (0 if rc else act), act + (io if rc else act) + 4.0 * S * 65536, act + io + (0 if rc else act)])
         names = (["ag_split_gemm_input_loss_heads_bwd (h1 not stored)", "ag_split_wgrad_input", "ag_split_gemm_input_wgrad_recompute"] if rc
                  else ["ag_split_gemm_input_loss_heads_bwd", "ag_split_wgrad", "ag_split_gemm_input_wgrad"])
-        print(json.dumps({"recompute_h1": bool(rc), "M": M, "D": D, "iters": a.iters,
+        print(json.dumps({"recompute_h1": bool(rc), "M": M, "D": D, "iters": a.iters, "tile_rows": a.tile_rows or 256,
                           "kernels": [{"entry_point": n, "us": round(u, 1), "algorithmic_MB": round(b * mb, 1),
                                        "GBps_algorithmic": round(b / u / 1e3, 1)} for n, u, b in zip(names, us, nbytes)],
                           "sum_us": round(sum(us), 1), "sum_algorithmic_MB": round(sum(nbytes) * mb, 1)}), flush=True)
