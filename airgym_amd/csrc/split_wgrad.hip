@@ -389,6 +389,10 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
 
     // the same in pieces, for the hand-ordered main loop: one dZ row tile of a chunk (3 fragment reads + 6 MFMAs), optionally with
     // three MFMAs of the next block's production riding between its pairs
+#ifdef AG_WF_ABL_NO_MFMA      // timing ablation: the chunk's MFMAs (and with them their fragment reads) are not issued
+#undef AG_MFMA_SPLIT
+#define AG_MFMA_SPLIT(d, a1, a2, a3, b1, b2, b3) do { (void)(a1); (void)(a2); (void)(a3); (void)(b1); (void)(b2); (void)(b3); } while (0)
+#endif
 #define AG_WF_TILE_READ(slot_, i_)                                                                   \
         const uint4* sa_ = lds + (slot_) * OP_UNITS + khalf * WN + l31;                              \
         const uint4 ua0_ = sa_[(0 * 2) * WN + (i_) * 32];                                            \
@@ -487,8 +491,12 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         AG_WF_TILE(2 * bs, 0, 1);
         AG_WF_TILE(2 * bs, 0, 2);
         AG_WF_TILE(2 * bs, 0, 3);
+#ifndef AG_WF_ABL_NO_PROD
         AG_WF_XSPLIT();                         // x of block t + 1 (requested a block ago)
+#endif
+#ifndef AG_WF_ABL_NO_LOADS
         AG_WF_XLOAD(t2);
+#endif
         bf16x8 wb[2][3];
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[r] = 0.0f;
@@ -535,10 +543,18 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         // ---- second chunk: ELU + split of the produced tile (B fragments of block t + 1) and the split of its dZ quad into the
         //      other slot, spread under the 48 MFMAs; then the loads that refill the quad's registers
         bf16x8 bnext[2][3];
+#ifndef AG_WF_ABL_NO_PROD
         AG_WF_PRODUCE_FINISH(bnext);
+#else
+        for (int q_ = 0; q_ < 2; ++q_) for (int p = 0; p < 3; ++p) bnext[q_][p] = bfrag[q_][p];
+#endif
         AG_WF_COMPUTE(2 * bs + 1, 1);
+#ifndef AG_WF_ABL_NO_STAGE
         AG_WF_WRITE(bs ^ 1);                    // dZ of block t + 1 (requested at the end of the previous trip)
+#endif
+#ifndef AG_WF_ABL_NO_LOADS
         AG_WF_LOAD(t2);
+#endif
         AG_SGB(0x100, 6);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -555,7 +571,9 @@ __global__ __launch_bounds__(512, 2) void split_wgrad_fin_kernel(const float* __
         for (int q_ = 0; q_ < 2; ++q_)
 #pragma unroll
             for (int p = 0; p < 3; ++p) bfrag[q_][p] = bnext[q_][p];
+#ifndef AG_WF_ABL_NO_BARRIER
         __syncthreads();
+#endif
     }
     }
 #undef AG_SGB
