@@ -532,16 +532,43 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         __syncthreads();
         AG_SG_COMPUTE(1);
     } else {
+#ifdef AG_SPLIT_PINGPONG
+        // The two waves of a SIMD (waves w and w + 4 of the 8-wave workgroup) half a chunk out of phase: the first-dispatched half
+        // multiplies chunk c and THEN stages chunk c + 1, the second half stages FIRST and then multiplies - so that one wave's
+        // staging (split arithmetic, LDS stores, address work) runs beside the other's MFMAs instead of beside its staging.
+        const bool stage_first = (WM == 4) && (__builtin_amdgcn_readfirstlane(wave) >= 4);
+        if (stage_first) {
+#pragma unroll 1
+            for (int c = 0; c < NCHUNK - 1; ++c) {
+                const int stage = c & 1;
+                AG_SG_STORE(stage ^ 1);                     // chunk c + 1 (loaded during chunk c - 1)
+                AG_SG_DMA(c + 1, stage ^ 1);                // (behind the store: its wait for the A registers must not cover the DMA)
+                const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;
+                AG_SG_LOAD(cn);
+#ifndef AG_SPLIT_PINGPONG_LOOSE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                AG_SG_COMPUTE(stage);
+                AG_SG_DMA_WAIT();
+                __syncthreads();
+            }
+        } else
+#endif
+        {
 #pragma unroll 1
         for (int c = 0; c < NCHUNK - 1; ++c) {
             const int stage = c & 1;
             AG_SG_DMA(c + 1, stage ^ 1);
             AG_SG_COMPUTE(stage);
+#if defined(AG_SPLIT_PINGPONG) && !defined(AG_SPLIT_PINGPONG_LOOSE)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             AG_SG_STORE(stage ^ 1);                         // chunk c + 1; that stage was last read before the previous barrier
             AG_SG_DMA_WAIT();
             const int cn = (c + 2 < NCHUNK) ? c + 2 : NCHUNK - 1;      // (the last trip reloads a chunk it does not need)
             AG_SG_LOAD(cn);
             __syncthreads();
+        }
         }
         AG_SG_COMPUTE((NCHUNK - 1) & 1);
     }
