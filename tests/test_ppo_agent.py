@@ -566,3 +566,44 @@ def test_mixed_precision_is_refused_not_ignored():
         A2CAgent("mp", params)
     params["config"]["mixed_precision"] = False
     A2CAgent("mp", params)
+
+
+def test_adaptive_scheduler_bounds_are_yaml_keys_with_the_references_defaults():
+    """lib/core/schedulers.py:19-23 hard-codes [1e-6, 1e-2]; here `min_lr` / `max_lr` sit beside `kl_threshold` in the YAML (the opt-in arm
+    of profiles/r05_collapse_trace.md is `max_lr: 1e-3`) and the device-side rule honours them like the host-side one."""
+    params = _stub_env.ppo_params()
+    agent = A2CAgent("run", params)
+    assert (agent.scheduler.min_lr, agent.scheduler.max_lr) == (1e-6, 1e-2)
+    params = _stub_env.ppo_params()
+    params["config"].update(max_lr=1e-3, min_lr=1e-5)
+    agent = A2CAgent("run", params)
+    assert (agent.scheduler.min_lr, agent.scheduler.max_lr) == (1e-5, 1e-3)
+    sch = AdaptiveScheduler(0.008, min_lr=1e-5, max_lr=1e-3)
+    for start, kl in ((9e-4, 0.0), (1e-3, 0.0), (1.2e-5, 0.5), (1e-5, 0.5), (3e-4, 0.008)):
+        agent.optimizer.lr.fill_(start)
+        agent.flat_grad.zero_(); agent.flat_grad[-1] = kl
+        agent._reduce_clip_step()
+        exp = sch.update(start, 0.0, 0, 0, float(np.float32(kl)))[0]
+        assert abs(agent.optimizer.lr.item() - exp) < 1e-15 and 1e-5 <= exp <= 1e-3, (start, kl)
+        lr_t = torch.tensor(start, dtype=torch.float64)
+        assert abs(sch.update_tensor_(lr_t, torch.tensor(kl, dtype=torch.float64)).item() - exp) < 1e-15
+
+
+def test_compute_paths_names_what_runs():
+    """`A2CAgent.compute_paths()` (bench.py `config.paths`, printed at start-up): on a configuration without the HIP library
+    every entry must say 'generic' / library - nothing may claim a hand-written kernel that did not run."""
+    agent = A2CAgent("run", _stub_env.ppo_params())
+    agent.init_tensors()
+    paths = agent.compute_paths()
+    assert paths["rollout_step"].startswith("generic") and isinstance(paths["update"], str) and paths["update"].startswith("generic")
+    assert paths["minibatch_hip_graphs"] is False and "torch" in paths["optimizer"]
+
+
+def test_collectives_count_what_a_captured_graph_replays():
+    from airgym_amd.lib.core import collectives
+    collectives.reset()
+    collectives.count("gradient", 288, calls=3)
+    collectives.count("gradient", 288)
+    assert collectives.snapshot() == {"gradient": {"calls": 4, "bytes": 4 * 288}}
+    collectives.reset()
+    assert collectives.snapshot() == {}
