@@ -223,6 +223,10 @@ SYMBOLS = [
     ("ag_split_gemm_input_loss_heads_bwd", ctypes.c_int, [ctypes.POINTER(AgInputLayerArgs), _P, _P, _P, _P, _P,
                                                           ctypes.POINTER(AgLossEpilogue), ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                           ctypes.c_int, _P]),
+    ("ag_mlp_first_layer_supported", ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    ("ag_mlp_first_layer_image_bytes", ctypes.c_longlong, [ctypes.c_int]),
+    ("ag_mlp_first_layer_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P]),
+    ("ag_mlp_first_layer", ctypes.c_int, [_P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _P, _P, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_mlp_chain_supported", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     ("ag_mlp_chain_image_bytes", ctypes.c_longlong, [ctypes.c_int]),
     ("ag_mlp_chain_prepare", ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, ctypes.c_int, _P, _P]),
@@ -296,7 +300,7 @@ def _build():
 # mixed_precision twins (one bf16 MFMA per product; csrc/split_common.hpp AG_SPLIT_PLANES = 1): same signatures, suffix _bf16
 BF16_TWINS = ("ag_split_gemm", "ag_split_wgrad", "ag_split_wgrad_input", "ag_split_gemm_input_wgrad_recompute",
               "ag_split_gemm_input_wgrad", "ag_split_gemm_elu_heads", "ag_split_gemm_loss_heads_bwd",
-              "ag_split_gemm_input_loss_heads_bwd", "ag_mlp_chain_forward")
+              "ag_split_gemm_input_loss_heads_bwd", "ag_mlp_chain_forward", "ag_mlp_first_layer")
 SYMBOLS = SYMBOLS + [(n + "_bf16", r, a) for (n, r, a) in SYMBOLS if n in BF16_TWINS]
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 22 translation units compiled in parallel).
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 24 translation units compiled in parallel).
 
     python airgym_amd/csrc/build.py [--force] [--jobs N] [--experiments]
 
@@ -48,13 +48,19 @@ def units(experiments=False):
             # kernels that share env_math.hpp): every step kernel then runs the same arithmetic, bit for bit
             out.append((os.path.join(od, f"step_{task}_{ctl}.o"), "step_kernel.hip",
                         [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}", "-ffp-contract=on"] + x))
-    for name in ("airgym_hip", "ppo_kernels", "planning_kernel", "rollout_kernels", "split_gemm", "split_wgrad", "cnn_kernels", "conv_kernels", "mlp_chain"):
+    for name in ("airgym_hip", "ppo_kernels", "planning_kernel", "rollout_kernels", "split_gemm", "split_wgrad", "cnn_kernels", "conv_kernels", "mlp_chain",
+                 "first_layer"):
         # rollout_kernels.hip shares rollout_math.hpp with the fused step kernel (policy sampling, reward shaping): same rule
-        out.append((os.path.join(od, name + ".o"), name + ".hip", (["-ffp-contract=on"] if name == "rollout_kernels" else []) + list(x)))
+        # mlp_chain.hip: the K-step loop of the chain kernel must be unrolled completely (its accumulator tiles are indexed by the
+        # step); at 20 steps (Tracking's 48 inputs) the body exceeds LLVM's default budget for `#pragma unroll`, the loop stays
+        # rolled and the tiles go to scratch (576 B per lane, 186 us instead of ~75 at M = 65 536) - hence the raised threshold
+        flags = ["-ffp-contract=on"] if name == "rollout_kernels" else (["-mllvm", "-pragma-unroll-threshold=100000"] if name == "mlp_chain" else [])
+        out.append((os.path.join(od, name + ".o"), name + ".hip", flags + list(x)))
     # mixed_precision: the three matrix-core sources once more with ONE bf16 plane per operand (one MFMA per product, f32
     # accumulate); their compute entry points are exported with the suffix _bf16 (split_common.hpp)
-    for name in ("split_gemm", "split_wgrad", "mlp_chain"):
-        out.append((os.path.join(od, name + "_bf16.o"), name + ".hip", ["-DAG_SPLIT_PLANES=1"] + list(x)))
+    for name in ("split_gemm", "split_wgrad", "mlp_chain", "first_layer"):
+        out.append((os.path.join(od, name + "_bf16.o"), name + ".hip", ["-DAG_SPLIT_PLANES=1"]
+                    + (["-mllvm", "-pragma-unroll-threshold=100000"] if name == "mlp_chain" else []) + list(x)))
     if experiments:
         out.append((os.path.join(od, "experiments.o"), "experiments.hip", list(x)))
     return out

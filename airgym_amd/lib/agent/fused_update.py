@@ -110,6 +110,10 @@ class SplitGemm256:
                                        self._stream()), "ag_split_gemm")
 
 
+def obs_float32_cuda(agent):
+    return str(agent.ppo_device).startswith("cuda")
+
+
 class FusedMLPStep:
     @staticmethod
     def supported(agent):
@@ -214,6 +218,11 @@ class FusedMLPStep:
         self.sum_scratch = torch.empty(self.lib.ag_sum_rows_groups() * tot, **f)
         C0, Cl = self.layers[0][0].shape[0], self.layers[-1][0].shape[0]
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
+        # first layer as a launch of its own on the matrix cores (csrc/first_layer.hip) where the forward GEMM cannot produce it
+        # itself (Tracking's 48 inputs): replaces ag_mlp_input_layer's vector-ALU kernel (131 -> ~65 us at D = 48, M = 196 608)
+        self.mfma_input = (not self.fuse_gemm_input and bool(agent.config.get("use_mfma_input_layer", True)) and obs_float32_cuda(agent)
+                           and bool(self.lib.ag_mlp_first_layer_supported(D, C0)) and bool(agent.config.get("use_split_gemm", True)))
+        self.in_image = (torch.empty(self.lib.ag_mlp_first_layer_image_bytes(D), dtype=torch.uint8, device=dev) if self.mfma_input else None)
         self.fuse_heads = len(self.layers) >= 2 and 64 <= Cl <= 256 and (Cl & (Cl - 1)) == 0 and self.A + 1 in (5, 6)
         self.wt_last = torch.empty(self.layers[-1][0].shape[1], Cl, **f)      # W_last^T, refreshed before every forward
         # 256 x 256 layers: float32-accurate GEMMs on the bf16 matrix cores (forward and dX); other widths stay with the library
@@ -244,6 +253,8 @@ class FusedMLPStep:
             if li == 0:
                 if self.fuse_gemm_input:
                     fwd = "inside the next layer's forward launch, on the matrix cores (ag_split_gemm_input_loss_heads_bwd)"
+                elif self.mfma_input:
+                    fwd = "ag_mlp_first_layer (normalise + Linear + ELU as a launch of its own on the matrix cores, split-bf16)"
                 elif self.fuse_input:
                     fwd = "ag_mlp_input_layer (normalise + Linear + ELU, HIP, vector ALU)"
                 else:
@@ -330,6 +341,14 @@ class FusedMLPStep:
             in_args.xn_dev = self.xn.data_ptr() if rms is not None else None
             in_args.h1_dev = None if self.recompute_h1 else self.h[0].data_ptr()
             in_args.eps, in_args.clip = (float(rms.epsilon) if rms is not None else 0.0), 5.0
+            x = self.xn if rms is not None else obs
+        elif self.mfma_input:       # normalise + Linear(D -> 256) + ELU on the matrix cores (exact 3-way split, float32-accurate)
+            N.check(lib.ag_mlp_first_layer_prepare(w0.data_ptr(), b0.data_ptr(), D, self.in_image.data_ptr(), st), "ag_mlp_first_layer_prepare")
+            N.check(getattr(lib, "ag_mlp_first_layer" + self.sfx)(
+                obs.data_ptr(), rms.running_mean.data_ptr() if rms is not None else None,
+                rms.running_var.data_ptr() if rms is not None else None, float(rms.epsilon) if rms is not None else 0.0, 5.0,
+                self.in_image.data_ptr(), self.xn.data_ptr() if rms is not None else None, self.h[0].data_ptr(), M, D, st),
+                "ag_mlp_first_layer")
             x = self.xn if rms is not None else obs
         elif self.fuse_input:       # normalise + Linear(D -> C0) + ELU in one pass
             mean_p = rms.running_mean.data_ptr() if rms is not None else None

@@ -70,6 +70,9 @@ def build_params(args, world_size):
     c["fuse_gemm_input"] = bool(getattr(args, "fuse_gemm_input", 1))
     c["recompute_h1"] = bool(getattr(args, "recompute_h1", 1))
     params["seed"] = 0
+    # A/B of any config key without a flag of its own (tools/, profiling): AIRGYM_CFG_OVERRIDES='{"use_mfma_input_layer": false}'
+    if os.environ.get("AIRGYM_CFG_OVERRIDES"):
+        c.update(json.loads(os.environ["AIRGYM_CFG_OVERRIDES"]))
     return params
 
 

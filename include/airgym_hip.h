@@ -482,6 +482,18 @@ int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void
                                        const float* Wh_dev, const float* bh_dev, float* dZ_dev, const ag_loss_epilogue* loss, int M,
                                        int n, int k, int A1, void* stream);
 
+/* The first layer of the trunk as a launch of its own on the matrix cores (airgym_amd/csrc/first_layer.hip): xn = clamp((obs - mean) /
+ * sqrt(var + eps), +-clip) (lib/core/running_mean_std.py:78-79; mean_dev / var_dev NULL: xn = obs, xn_dev not written), h1 = ELU(xn W1^T +
+ * b1) (lib/network/mlp.py:36-39) - what ag_mlp_input_layer computes, with the product as an exact 3-way bf16 split on the MFMA (float32-
+ * accurate, not bit-identical to the FMA chain).  For input widths the forward GEMM cannot produce itself (D + 1 <= 64, e.g. Tracking's
+ * 48, tracking.py:202-214): 256-wide layer only.  prepare: W1 [256, D], b1 [256] -> image (ag_mlp_first_layer_image_bytes(D) bytes,
+ * 16-byte aligned), once per optimizer step. */
+int ag_mlp_first_layer_supported(int D, int C);
+long long ag_mlp_first_layer_image_bytes(int D);
+int ag_mlp_first_layer_prepare(const float* W1_dev, const float* b1_dev, int D, void* image_dev, void* stream);
+int ag_mlp_first_layer(const float* obs_dev, const double* mean_dev, const double* var_dev, float eps, float clip, const void* image_dev,
+                       float* xn_dev, float* h1_dev, int M, int D, void* stream);
+
 /* mixed_precision (the reference's torch.cuda.amp switch, lib/agent/a2c_base.py:236-237,566,582: autocast around the model forward
  * of the rollout and of calc_gradients): every matrix-core entry point above exists a second time with the suffix _bf16 and the
  * SAME arguments - ONE bf16 MFMA per product instead of six (operands rounded to bf16, round to nearest; float32 accumulate; the
@@ -504,6 +516,8 @@ int ag_split_gemm_input_wgrad_recompute_bf16(const float* dZ_dev, const void* pl
 int ag_split_wgrad_bf16(const float* dZ_dev, const float* X_dev, float* partials_dev, int M, int n, int k, int slices, void* stream);
 int ag_split_wgrad_input_bf16(const float* dZ_dev, const float* x_dev, const void* image_dev, float* partials_dev, int M, int n, int k,
                               int D, int slices, void* stream);
+int ag_mlp_first_layer_bf16(const float* obs_dev, const double* mean_dev, const double* var_dev, float eps, float clip,
+                            const void* image_dev, float* xn_dev, float* h1_dev, int M, int D, void* stream);
 int ag_mlp_chain_forward_bf16(const float* obs_dev, const double* mean_dev, const double* var_dev, float eps, float clip,
                               const void* image_dev, const float* b2_dev, const float* bh_dev, float* heads_dev, float* xn_dev,
                               float* h1_dev, float* h2_dev, int M, int D, int A1, void* stream);

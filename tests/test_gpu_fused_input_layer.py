@@ -157,3 +157,54 @@ def test_fused_first_layer_rejects_bad_arguments(lib):
     assert call(xn=False) == -1          # normaliser statistics without an output for the normalised inputs
     assert call(xn=False, mean=False) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,D,normalize", [(196608, 48, True), (1000, 48, True), (4096, 18, True), (2048, 30, False), (777, 21, True),
+                                           (4096, 62, True), (256, 1, False)])
+def test_first_layer_as_its_own_launch_on_the_matrix_cores(lib, M, D, normalize):
+    """ag_mlp_first_layer (csrc/first_layer.hip; Tracking's 48 inputs and every other width the forward GEMM cannot produce itself):
+    the same function as ag_mlp_input_layer - normalised inputs bit-identical, activations float32-accurate against float64 -
+    incl. odd widths (scalar loads), the widest supported input (D + 1 = 63) and ragged row counts."""
+    from airgym_amd import _native as N
+    assert lib.ag_mlp_first_layer_supported(D, 256) and not lib.ag_mlp_first_layer_supported(64, 256)
+    assert not lib.ag_mlp_first_layer_supported(D, 128)
+    g = torch.Generator(device="cuda").manual_seed(500 + M + D)
+    f = dict(device="cuda", dtype=torch.float32)
+    obs = 3.0 * torch.randn(M, D, generator=g, **f)
+    obs[::7, 0] = 40.0                       # clamped by the normaliser
+    mean = torch.randn(D, generator=g, device="cuda", dtype=torch.float64)
+    var = torch.rand(D, generator=g, device="cuda", dtype=torch.float64) + 0.05
+    W1 = torch.randn(256, D, generator=g, **f) / D ** 0.5
+    b1 = 0.1 * torch.randn(256, generator=g, **f)
+    image = torch.empty(lib.ag_mlp_first_layer_image_bytes(D), dtype=torch.uint8, device="cuda")
+    N.check(lib.ag_mlp_first_layer_prepare(W1.data_ptr(), b1.data_ptr(), D, image.data_ptr(), _stream()), "prepare")
+    xn1 = torch.full((M, D), 7.0, **f) if normalize else None
+    h1 = torch.full((M, 256), float("nan"), **f)
+    N.check(lib.ag_mlp_first_layer(obs.data_ptr(), mean.data_ptr() if normalize else None, var.data_ptr() if normalize else None, 1e-5, 5.0,
+                                   image.data_ptr(), xn1.data_ptr() if normalize else None, h1.data_ptr(), M, D, _stream()), "first_layer")
+    xn0 = torch.zeros(M, D, **f) if normalize else None
+    h0 = torch.zeros(M, 256, **f)
+    rc0 = lib.ag_mlp_input_layer(obs.data_ptr(), mean.data_ptr() if normalize else None, var.data_ptr() if normalize else None,
+                                 W1.data_ptr(), b1.data_ptr(), xn0.data_ptr() if normalize else None, h0.data_ptr(), M, D, 256,
+                                 1e-5, 5.0, _stream())
+    have_ref = rc0 == 0                      # (the vector-ALU kernel holds the weights in registers / LDS: not every width)
+    torch.cuda.synchronize()
+    assert torch.isfinite(h1).all()
+    if normalize and have_ref:
+        assert torch.equal(xn1, xn0)
+    xr = torch.clamp((obs.double() - mean) / torch.sqrt(var.float().double() + 1e-5), -5, 5) if normalize else obs.double()
+    z = xr @ W1.double().t() + b1.double()
+    ref = torch.where(z > 0, z, torch.expm1(z))
+    scale = xr.abs() @ W1.double().abs().t() + b1.double().abs() + 1e-30
+    # split product + v_exp_f32; exp(z) - 1 rounds at 1.0, an ABSOLUTE 2^-23 that only shows against a tiny scale (D = 1)
+    assert ((h1.double() - ref).abs() / (scale + 0.25)).max().item() < 6e-7
+    if have_ref:
+        assert (h1 - h0).abs().max() <= 4e-6 * max(1.0, h0.abs().max().item())
+    if normalize:
+        assert torch.equal(xn1, xr.float()) or (xn1.double() - xr).abs().max().item() < 1e-6
+    # bf16 twin: one MFMA per product
+    hb = torch.empty_like(h1)
+    N.check(lib.ag_mlp_first_layer_bf16(obs.data_ptr(), mean.data_ptr() if normalize else None, var.data_ptr() if normalize else None, 1e-5,
+                                        5.0, image.data_ptr(), None, hb.data_ptr(), M, D, _stream()), "first_layer_bf16")
+    eb = ((hb.double() - ref).abs() / (scale + 0.25)).max().item()
+    assert 1e-6 < eb < 2.0 ** -7, eb
