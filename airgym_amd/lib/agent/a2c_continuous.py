@@ -300,6 +300,7 @@ class A2CAgent:
         self.use_hip_graph = config.get("use_hip_graph", False)
         self.sync_normalizers = config.get("sync_normalizers", True)
         self.sync_timers = config.get("sync_timers", bool(config.get("print_stats", True)))
+        self._host_trace = [] if os.environ.get("AIRGYM_HOST_TRACE") else None
         self.frame = 0
         self.epoch_num = 0
         self.curr_frames = 0
@@ -668,6 +669,11 @@ class A2CAgent:
 
     @torch.no_grad()
     def play_steps(self):
+        self._rollout_launch()
+        return self._rollout_tail()
+
+    def _rollout_launch(self):
+        """The H policy + env steps of one rollout (one hipGraph replay once captured)."""
         H = self.horizon_length
         # capture needs an even horizon (device tick ping-pong); the camera tasks (Planning, Avoid) decide on the HOST, at
         # capture time, which steps render (every 4th, planning.py:153-156, avoid.py:181-185), so the cadence survives replay
@@ -705,6 +711,11 @@ class A2CAgent:
                 # rollout - policy inference + env kernel, H launches of the device-tick ping-pong - for replay
                 self._graphs["rollout"] = self._capture(rollout, warmup=False)
         self._rollouts_done += 1
+
+    def _rollout_tail(self):
+        """Bootstrap value, GAE and the [H, N] -> [N * H] flattening of the rollout buffers (a2c_base.py:696-712)."""
+        H = self.horizon_length
+        fr = self._fused_rollout
         self.model.eval()
         if fr is not None:
             # bootstrap value of the last observation through the same fused forward as the rollout steps
@@ -950,10 +961,20 @@ class A2CAgent:
         g.outputs = out
         return g
 
+    def _ht(self, label):
+        """Host-side timeline of the epoch (AIRGYM_HOST_TRACE=1; tools/host_timeline.py): where the enqueueing thread is while
+        the GPU works - or waits."""
+        if self._host_trace is not None:
+            self._host_trace.append((label, time.perf_counter()))
+
     def train_epoch(self):
         """a2c_continuous.py:78-138"""
         play_time_start = time.time()
-        batch_dict = self.play_steps()
+        self._ht("epoch_begin")
+        self._rollout_launch()
+        self._ht("rollout_enqueued")
+        batch_dict = self._rollout_tail()
+        self._ht("rollout_tail_enqueued")
         # without sync_timers the host keeps enqueueing the update while the rollout graph still runs; play_time is then
         # the host-side enqueue time only (the epoch total stays exact: one sync at the end)
         if self.sync_timers and str(self.ppo_device).startswith("cuda"):
@@ -962,7 +983,11 @@ class A2CAgent:
         update_time_start = play_time_end
         self.model.train()
         self.curr_frames = batch_dict.pop("played_frames")
+        # (capturing the rollout's tail + prepare_dataset - ~60 small eager launches, 0.45 ms of GPU idle per epoch at 65 536 envs -
+        # in a hipGraph of their own was tried in round 5 and bought nothing: the graph's copy nodes wait ~80 us each,
+        # `profiles/r05_epoch_gaps.md`)
         self.prepare_dataset(batch_dict)
+        self._ht("dataset_enqueued")
         a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
         if self.normalize_input:
             self.model.running_mean_std.eval()   # statistics are merged explicitly (model.update_stats), never by .train()
@@ -1020,10 +1045,23 @@ class A2CAgent:
                                  torch_ext.mean_list(entropies).float().reshape(()), torch_ext.mean_list(kls).float().reshape(()),
                                  (torch_ext.mean_list(b_losses).float().reshape(()) if b_losses
                                   else torch.zeros((), device=self.ppo_device)),
-                                 self.optimizer.lr.float().reshape(())]).tolist()
+                                 self.optimizer.lr.float().reshape(())])
+        # ... and the episode accounting rides in the same transfer (float64 holds every float32 exactly): after this read the
+        # host has nothing left to wait for, and the next rollout is enqueued one transfer - not three - later
+        log_terms = bool(self._term_names) and self.config.get("log_reward_terms", True)
+        parts = [dev_stats.double()]
+        if log_terms:
+            parts.append((self._term_sums / self.horizon_length).double().reshape(-1))
+        parts.append(self.ep_stats.double().reshape(-1))
+        self._ht("update_enqueued")
+        host = torch.cat(parts).tolist()
+        self._ht("stats_on_host")
         update_time_end = time.time()
+        dev_stats = host[:6]
         self.last_lr = float(dev_stats[5])
-        self._flush_episode_stats()
+        nt = len(self._term_names) if log_terms else 0
+        self._flush_episode_stats(host[6:6 + nt] if log_terms else None, host[6 + nt:])
+        self._ht("epoch_end")
         return {
             "play_time": play_time_end - play_time_start, "update_time": update_time_end - update_time_start,
             "total_time": update_time_end - play_time_start,
@@ -1031,19 +1069,18 @@ class A2CAgent:
             "b_loss": dev_stats[4], "last_lr": self.last_lr,
         }
 
-    def _flush_episode_stats(self):
-        """One device->host read per epoch; replays the reference's per-step AverageMeter updates."""
+    def _flush_episode_stats(self, term_sums, ep_stats):
+        """Replays the reference's per-step AverageMeter updates from the epoch's one device->host read (train_epoch):
+        term_sums = per-step means of the reward terms (or None), ep_stats = the flattened [steps, >= 4] episode accounting rows."""
         self.episode_term_means = {}
-        if self._term_names and self.config.get("log_reward_terms", True):
-            sums = (self._term_sums / self.horizon_length).cpu().tolist()
+        if term_sums is not None:
             self._term_sums.zero_()
-            self.episode_term_means = dict(zip(self._term_names, sums))
-        st = self.ep_stats.cpu().numpy()
-        for n in range(st.shape[0]):
-            cnt = st[n, 0]
-            self.game_rewards.update_from_sum([st[n, 1]], cnt)
-            self.game_shaped_rewards.update_from_sum([st[n, 2]], cnt)
-            self.game_lengths.update_from_sum([st[n, 3]], cnt)
+            self.episode_term_means = dict(zip(self._term_names, term_sums))
+        w = self.ep_stats.shape[1]
+        cnt = ep_stats[0::w]
+        self.game_rewards.update_from_sums(zip(ep_stats[1::w], cnt))
+        self.game_shaped_rewards.update_from_sums(zip(ep_stats[2::w], cnt))
+        self.game_lengths.update_from_sums(zip(ep_stats[3::w], cnt))
 
     # ------------------------------------------------------------------ training loop
     def train(self):

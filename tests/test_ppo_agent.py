@@ -607,3 +607,22 @@ def test_collectives_count_what_a_captured_graph_replays():
     assert collectives.snapshot() == {"gradient": {"calls": 4, "bytes": 4 * 288}}
     collectives.reset()
     assert collectives.snapshot() == {}
+
+
+def test_average_meter_batched_update_is_the_same_arithmetic():
+    """AverageMeter.update_from_sums (one call per epoch and meter) == the per-step update_from_sum calls it replaces, bit for bit,
+    incl. empty steps, the window filling up and a step that overflows the window (torch_ext.py:270-296)."""
+    import numpy as np
+    from airgym_amd.lib.core.torch_ext import AverageMeter
+    rng = np.random.default_rng(5)
+    a, b = AverageMeter(1, 100), AverageMeter(1, 100)
+    for epoch in range(6):
+        counts = rng.integers(0, 60, size=24) * (rng.random(24) > 0.3)
+        if epoch == 3:
+            counts[5] = 250          # more finished episodes in one step than the window holds
+        sums = rng.normal(size=24) * 1000.0 * np.maximum(counts, 1)
+        for s, c in zip(sums.tolist(), counts.tolist()):
+            a.update_from_sum([s], c)
+        b.update_from_sums(zip(sums.tolist(), [float(c) for c in counts]))
+        assert a.current_size == b.current_size and a.get_mean().shape == b.get_mean().shape
+        assert a.get_mean()[0] == b.get_mean()[0]

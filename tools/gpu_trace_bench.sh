@@ -10,3 +10,4 @@ timeout -s KILL 180 rocprofv3 --kernel-trace --stats -d /tmp/trace_$TAG -o t -- 
 DB=$(find /tmp/trace_$TAG -name "*results.db" | head -1)
 python $R/tools/rocprof_summary.py $DB $R/gpurun_out/${TAG}_bench_kernel_trace.md "rocprofv3 --kernel-trace --stats -- $CMD"
 head -40 $R/gpurun_out/${TAG}_bench_kernel_trace.md | cut -c1-200
+python $R/tools/gap_report.py $DB $R/gpurun_out/${TAG}_epoch_gaps.md > /dev/null 2> $R/gpurun_out/${TAG}_epoch_gaps.err; head -70 $R/gpurun_out/${TAG}_epoch_gaps.md; tail -3 $R/gpurun_out/${TAG}_epoch_gaps.err
