@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Where the GPU idles inside a PPO epoch: from a rocprofv3 --kernel-trace database (rocpd sqlite), the epochs of the headline job
-(16 rollout launches of the policy chain kernel followed by 32 forward launches of the update) are located in the dispatch stream and,
+(25 launches of the policy chain kernel - 24 rollout steps + the bootstrap value - followed by 40 forward launches of the update) are
+located in the dispatch stream and,
 per epoch: span, busy time (union of the kernel intervals), and the idle gaps grouped by the pair (kernel before, kernel after).
 
-    python tools/gap_report.py OUT/NAME_results.db [out.md] [--horizon 16] [--steps 32]
+    python tools/gap_report.py OUT/NAME_results.db [out.md] [--horizon 25] [--steps 40] | --window 0.6 1.0
 """
 import argparse
 import collections
@@ -22,13 +23,59 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
     ap.add_argument("out", nargs="?")
-    ap.add_argument("--horizon", type=int, default=16)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--horizon", type=int, default=25, help="chain-kernel launches per epoch")
+    ap.add_argument("--steps", type=int, default=40, help="optimizer steps per epoch")
     ap.add_argument("--chain", default="mlp_chain_fwd_kernel")
     ap.add_argument("--forward", default="split_gemm_kernel<true, 5, 0, 4, true, 18, true>")
+    ap.add_argument("--window", type=float, nargs=2, default=None, metavar=("FROM", "TO"),
+                    help="no epoch detection: analyse the dispatches whose start lies in this fraction of the trace's time span "
+                         "(e.g. 0.6 1.0 = the steady state at the end of a run)")
     a = ap.parse_args()
     cur = sqlite3.connect(a.db).cursor()
     ks = sorted(cur.execute("select name, start, end from kernels"), key=lambda r: r[1])
+    if a.window:
+        t0, t1 = ks[0][1], ks[-1][1]
+        lo, hi = t0 + a.window[0] * (t1 - t0), t0 + a.window[1] * (t1 - t0)
+        seg = [k for k in ks if lo <= k[1] <= hi]
+        busy, cur_end, prev = 0.0, seg[0][1], None
+        pair_tot, pair_cnt, kern_tot, kern_cnt = collections.Counter(), collections.Counter(), collections.Counter(), collections.Counter()
+        for n, s0, e in seg:
+            if prev is not None and s0 > cur_end:
+                pair_tot[(short(prev), short(n))] += (s0 - cur_end) / 1e3
+                pair_cnt[(short(prev), short(n))] += 1
+            busy += (max(e, cur_end) - max(s0, cur_end)) / 1e3
+            kern_tot[short(n)] += (e - s0) / 1e3
+            kern_cnt[short(n)] += 1
+            if e > cur_end:
+                cur_end, prev = e, n
+        span = (cur_end - seg[0][1]) / 1e3
+        out = [f"# GPU idle time, window {a.window[0]:.2f} - {a.window[1]:.2f} of the trace ({len(seg)} dispatches)\n",
+               f"span {span:.0f} us, busy {busy:.0f} us, idle {span - busy:.0f} us ({100 * (span - busy) / span:.1f} %)\n",
+               "| before | after | gaps | idle us | us / gap |\n|---|---|---|---|---|"]
+        for (p_, n_), t in pair_tot.most_common(25):
+            out.append(f"| `{p_}` | `{n_}` | {pair_cnt[(p_, n_)]} | {t:.0f} | {t / pair_cnt[(p_, n_)]:.1f} |")
+        out.append("\n| kernel | launches | us | us / launch |\n|---|---|---|---|")
+        for n_, t in kern_tot.most_common(25):
+            out.append(f"| `{n_}` | {kern_cnt[n_]} | {t:.0f} | {t / kern_cnt[n_]:.2f} |")
+        # one example neighbourhood of each of the three largest gap classes: the 8 dispatches before and after the gap
+        for (p_, n_), _ in pair_tot.most_common(3):
+            cur_end, prev, hit = seg[0][1], None, None
+            for i, (n, s0, e) in enumerate(seg):
+                if prev is not None and s0 > cur_end and (short(prev), short(n)) == (p_, n_) and i > len(seg) // 2:
+                    hit = (i, (s0 - cur_end) / 1e3)
+                    break
+                if e > cur_end:
+                    cur_end, prev = e, n
+            if hit:
+                i, g = hit
+                out.append(f"\nexample: `{p_}` -> `{n_}` ({g:.0f} us idle before dispatch {i}); dispatches {i - 8} .. {i + 7}, (start - gap end) us | duration us | kernel:\n")
+                for n, s0, e in seg[i - 8:i + 8]:
+                    out.append(f"    {(s0 - seg[i][1]) / 1e3:10.1f} | {(e - s0) / 1e3:8.1f} | {short(n)}")
+        text = "\n".join(out) + "\n"
+        if a.out:
+            open(a.out, "w").write(text)
+        print(text)
+        return
     marks = []          # (index into ks, 'C' | 'F')
     for i, (n, s, e) in enumerate(ks):
         if a.chain in n:
