@@ -257,9 +257,16 @@ def env_kernel_source_sha():
     import os
     here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
     h = hashlib.sha256()
-    for f in ("step_kernel.hip", "env_math.hpp", "kernel_args.hpp", "rollout_math.hpp", "build.py"):      # (build.py: the compile flags)
+    for f in ("step_kernel.hip", "env_math.hpp", "kernel_args.hpp", "rollout_math.hpp"):
         with open(os.path.join(here, f), "rb") as fh:
             h.update(fh.read())
+    # ... and the flags those sources are compiled with (build.py's own text would tie the key to every unrelated unit it lists)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_airgym_build", os.path.join(here, "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    flags = sorted({" ".join(d) for (_, src, d) in b.units() if src == "step_kernel.hip" and "-DAG_TASK=0" in d and "-DAG_CTL=3" in d})
+    h.update((" ".join(b.COMMON[1:]) + " | " + " ; ".join(flags)).encode())
     return h.hexdigest()[:16]
 
 

@@ -82,3 +82,18 @@ def test_failing_collective_leaves_one_json_line_with_what_was_seen():
     assert len(att) == 1 and att[0]["exit_code"] != 0                  # cpu: one attempt (no IPC setting to flip)
     assert "hipIpcGetMemHandle" in att[0]["error"] and "initial parameter broadcast" in att[0]["error"]
     assert out["rccl"]["ranks_seen"] == 2 and out["rccl"]["backend"] == "gloo"      # what the group reported before it died
+
+
+def test_committed_pmc_record_was_measured_on_these_kernel_sources():
+    """bench.py quotes `roofline.traffic` only from a PMC record whose provenance key equals the key of the env-step kernel's sources
+    and compile flags in the tree (`env_kernel_source_sha`): the newest committed record must be current, or the driver's line
+    carries `traffic: null`.  (Re-measure with tools/gpu_pmc_env.sh after touching step_kernel.hip / env_math.hpp / kernel_args.hpp /
+    rollout_math.hpp or the step units' flags in build.py.)"""
+    import os
+    from airgym_amd.utils.kernel_bench import kernel_name, pmc_traffic
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for key, kernel in (("hovering_rate_multi24", kernel_name("hovering", "rate", False)),
+                        ("hovering_rate_fused", kernel_name("hovering", "rate", True)),
+                        ("hovering_rate", kernel_name("hovering", "rate", False, True))):
+        traffic, source = pmc_traffic(repo, key, kernel)
+        assert traffic is not None and traffic > 0, (key, source)
