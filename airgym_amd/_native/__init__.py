@@ -124,7 +124,7 @@ class AgLossEpilogue(ctypes.Structure):
         ("new_sigma_dev", ctypes.c_void_p), ("heads_dev", ctypes.c_void_p), ("loss_partials_dev", ctypes.c_void_p),
         ("dwh_partials_dev", ctypes.c_void_p), ("db_partials_dev", ctypes.c_void_p),
         ("e_clip", ctypes.c_float), ("critic_coef", ctypes.c_float), ("bounds_loss_coef", ctypes.c_float),
-        ("clip_value", ctypes.c_int), ("bound_type", ctypes.c_int), ("tile_rows", ctypes.c_int),
+        ("clip_value", ctypes.c_int), ("bound_type", ctypes.c_int), ("tile_rows", ctypes.c_int), ("partial_tiles", ctypes.c_int),
     ]
 
 

@@ -1104,6 +1104,7 @@ extern "C" int AG_PREC(ag_split_gemm_loss_heads_bwd)(const float* A_dev, const v
     if (L->tile_rows != 0 && L->tile_rows != 128 && L->tile_rows != 256) return AG_ERR_INVALID_ARG;
     const int rows_ = L->tile_rows == 128 ? 128 : (L->tile_rows == 256 ? 256 : g_split_wm * 64);
     if (M % rows_ != 0) return AG_ERR_UNSUPPORTED;                        // whole row tiles only (the dZ stores are unguarded)
+    if (L->partial_tiles < 0 || (L->partial_tiles > 0 && M / rows_ > L->partial_tiles)) return AG_ERR_INVALID_ARG;
     if (!L->logstd_dev || !L->actions_dev || !L->old_neglogp_dev || !L->advantages_dev || !L->returns_dev || !L->old_values_dev ||
         !L->old_mu_dev || !L->old_sigma_dev || !L->loss_partials_dev || !L->dwh_partials_dev || !L->db_partials_dev)
         return AG_ERR_INVALID_ARG;
@@ -1170,6 +1171,7 @@ extern "C" int AG_PREC(ag_split_gemm_input_loss_heads_bwd)(const ag_input_layer_
     if (L->tile_rows != 0 && L->tile_rows != 128 && L->tile_rows != 256) return AG_ERR_INVALID_ARG;
     const bool small_ = L->tile_rows == 128;
     if (M % (small_ ? 128 : 256) != 0) return AG_ERR_UNSUPPORTED;         // whole row tiles only
+    if (L->partial_tiles < 0 || (L->partial_tiles > 0 && M / (small_ ? 128 : 256) > L->partial_tiles)) return AG_ERR_INVALID_ARG;
     if (!L->logstd_dev || !L->actions_dev || !L->old_neglogp_dev || !L->advantages_dev || !L->returns_dev || !L->old_values_dev ||
         !L->old_mu_dev || !L->old_sigma_dev || !L->loss_partials_dev || !L->dwh_partials_dev || !L->db_partials_dev)
         return AG_ERR_INVALID_ARG;

@@ -401,6 +401,9 @@ class FusedMLPStep:
                 Lp.clip_value = int(bool(ag.clip_value))
                 Lp.bound_type = int(BOUND_TYPES[ag.bound_loss_type] if ag.bounds_loss_coef is not None else 0)
                 Lp.tile_rows = self.tile_rows
+                # (what the three partial tables were sized for at construction: a launch that would write more tiles is refused)
+                Lp.partial_tiles = min(self.head_wg_partials.shape[0], self.bias_partials[li].shape[0],
+                                       self.loss_partials.shape[0] if self.loss_partials.dim() == 2 else self.wg_blocks)
                 dz_out = self.dz[:M * w.shape[0]].view(M, w.shape[0])
                 if in_args is not None:
                     fwd = ("ag_split_gemm_input_loss_heads_bwd" + (" (h1 not stored)" if self.recompute_h1 else ""),

@@ -445,6 +445,8 @@ typedef struct ag_loss_epilogue {
     int clip_value, bound_type;        /* as ag_ppo_loss */
     int tile_rows;                     /* 0 / 256: one partial per 256 rows (8-wave workgroups); 128: per 128 rows (4-wave workgroups;
                                           for minibatches with fewer 256-row tiles than CUs - ag_split_gemm_pick_tile_rows) */
+    int partial_tiles;                 /* capacity of loss_partials / dwh_partials / db_partials in tiles; the launch writes
+                                          M / tile_rows of them and returns AG_ERR_INVALID_ARG when that is more (0: not checked) */
 } ag_loss_epilogue;
 int ag_split_gemm_pick_tile_rows(int M);   /* 128 when ceil(M / 256) < CUs and M % 128 == 0, else 256 */
 int ag_split_gemm_loss_rows(void);

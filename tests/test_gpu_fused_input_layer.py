@@ -156,6 +156,25 @@ def test_fused_first_layer_rejects_bad_arguments(lib):
     assert call(size=8) == -1
     assert call(xn=False) == -1          # normaliser statistics without an output for the normalised inputs
     assert call(xn=False, mean=False) == 0
+    # the partial tables' capacity (ag_loss_epilogue.partial_tiles): a launch that would write more tiles than they hold is refused
+    L.partial_tiles = M // 256
+    assert call() == 0
+    L.partial_tiles = M // 256 - 1
+    assert call() == -1
+    L.tile_rows, L.partial_tiles = 128, M // 256          # 128-row tiles: twice as many partial rows
+    assert call() == -1
+    L.partial_tiles = -3
+    assert call() == -1
+    L.tile_rows, L.partial_tiles = 0, 0
+    h = torch.zeros(M, 256, **f)
+    planes = torch.zeros(lib.ag_split_gemm_plane_bytes(), dtype=torch.uint8, device="cuda")
+
+    def plain():
+        return lib.ag_split_gemm_loss_heads_bwd(h.data_ptr(), planes.data_ptr(), bufs["b2"].data_ptr(), bufs["Wh"].data_ptr(),
+                                                bufs["bh"].data_ptr(), bufs["dz"].data_ptr(), ctypes.byref(L), M, 256, 256, A + 1, _stream())
+    assert plain() == 0
+    L.partial_tiles = 1
+    assert plain() == -1
     torch.cuda.synchronize()
 
 
