@@ -104,7 +104,7 @@ struct FinalizeArgs {
     float* grad_logstd; float* grad_head_bias; float* kl_out; float* stats;   // stats[8]: a, c, entropy, b, kl, loss, clip_frac, -
 };
 
-__global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const FinalizeArgs k) {
+__device__ __forceinline__ void ppo_loss_finalize_block(const FinalizeArgs& k) {
     __shared__ float red[4][kNumSums];
     __shared__ float tot[kNumSums];
     float acc[kNumSums];
@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const FinalizeAr
         k.stats[7] = 0.0f;
     }
 }
+
+__global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(const FinalizeArgs k) { ppo_loss_finalize_block(k); }
 
 // Running-mean/std input normalisation (lib/core/running_mean_std.py:64-79): out = clamp((x - mean) / sqrt(var + eps),
 // -clip, clip) with the statistics read from the float64 running buffers.  One pass instead of seven eager kernels.
@@ -879,8 +881,17 @@ __device__ __forceinline__ int find_job(const int* block0, int njobs, int b) {
     return j;
 }
 
-// block = 64 float4 columns x 4 row lanes
-__global__ __launch_bounds__(256) void sum_rows_stage1_kernel(const SumJobs k) {
+// block = 64 float4 columns x 4 row lanes.  FIN: one more workgroup behind the last job's blocks runs ppo_loss_finalize's body (its
+// inputs - the loss partials of the forward launch - are long complete, its outputs are other slots of the flat gradient than the
+// jobs'): a launch less per optimizer step
+template <bool FIN>
+__global__ __launch_bounds__(256) void sum_rows_stage1_kernel(const SumJobs k, const FinalizeArgs fin) {
+    if constexpr (FIN) {
+        if ((int)blockIdx.x == k.block0_s1[k.njobs]) {
+            ppo_loss_finalize_block(fin);
+            return;
+        }
+    }
     __shared__ float4 red[256];
     const int j = find_job(k.block0_s1, k.njobs, blockIdx.x);
     const int local = blockIdx.x - k.block0_s1[j];
@@ -940,7 +951,8 @@ __global__ __launch_bounds__(256) void sum_rows_stage2_kernel(const SumJobs k) {
 
 extern "C" int ag_sum_rows_groups(void) { return kSumMaxGroups; }
 
-extern "C" int ag_sum_rows_multi(const ag_sum_job* jobs, int njobs, float* scratch, long long scratch_floats, void* stream) {
+static int sum_rows_multi_launch(const ag_sum_job* jobs, int njobs, float* scratch, long long scratch_floats, const FinalizeArgs* fin,
+                                 void* stream) {
     if (!jobs || !scratch || njobs <= 0) return AG_ERR_INVALID_ARG;
     if (njobs > kMaxSumJobs) return AG_ERR_UNSUPPORTED;
     SumJobs k{};
@@ -969,9 +981,28 @@ extern "C" int ag_sum_rows_multi(const ag_sum_job* jobs, int njobs, float* scrat
     k.block0_s1[njobs] = b1;
     k.block0_s2[njobs] = b2;
     if (off > scratch_floats || (reinterpret_cast<uintptr_t>(scratch) & 15)) return AG_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(sum_rows_stage1_kernel, dim3(b1), dim3(256), 0, (hipStream_t)stream, k);
+    if (fin)
+        hipLaunchKernelGGL(sum_rows_stage1_kernel<true>, dim3(b1 + 1), dim3(256), 0, (hipStream_t)stream, k, *fin);
+    else
+        hipLaunchKernelGGL(sum_rows_stage1_kernel<false>, dim3(b1), dim3(256), 0, (hipStream_t)stream, k, FinalizeArgs{});
     hipLaunchKernelGGL(sum_rows_stage2_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, k);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
+}
+
+extern "C" int ag_sum_rows_multi(const ag_sum_job* jobs, int njobs, float* scratch, long long scratch_floats, void* stream) {
+    return sum_rows_multi_launch(jobs, njobs, scratch, scratch_floats, nullptr, stream);
+}
+
+extern "C" int ag_sum_rows_multi_finalize(const ag_sum_job* jobs, int njobs, float* scratch, long long scratch_floats,
+                                          const float* loss_partials, int num_blocks, int M, int A, const float* logstd,
+                                          float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd,
+                                          float* grad_head_bias, float* kl_out, float* stats, void* stream) {
+    if (!loss_partials || !logstd || !grad_logstd || !grad_head_bias || !kl_out || !stats || num_blocks <= 0 || M <= 0)
+        return AG_ERR_INVALID_ARG;
+    if (A < 1 || A > AG_MAX_ACTIONS) return AG_ERR_UNSUPPORTED;
+    const FinalizeArgs fin{loss_partials, num_blocks, M, A, logstd, entropy_coef, critic_coef, bounds_loss_coef,
+                           grad_logstd, grad_head_bias, kl_out, stats};
+    return sum_rows_multi_launch(jobs, njobs, scratch, scratch_floats, &fin, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -215,6 +215,7 @@ class FusedMLPStep:
             tot += n
         self.use_sum_multi = len(jobs) <= 12 and all(d.numel() % 4 == 0 for _, d in jobs)
         self._sum_pairs = jobs
+        self.fuse_finalize = bool(agent.config.get("fuse_loss_finalize", True))
         self.sum_scratch = torch.empty(self.lib.ag_sum_rows_groups() * tot, **f)
         C0, Cl = self.layers[0][0].shape[0], self.layers[-1][0].shape[0]
         self.fuse_input = (D * C0 + 64 * D) * 4 <= 64 * 1024
@@ -459,10 +460,14 @@ class FusedMLPStep:
         else:
             stats = self.stats_ring[self.k % self.stats_ring.shape[0]]
             self.k += 1
-        N.check(lib.ag_ppo_loss_finalize(self.loss_partials.data_ptr(), nb.value, M, A, logstd.data_ptr(),
-                                         float(ag.entropy_coef), float(ag.critic_coef), bcoef, logstd.grad.data_ptr(),
-                                         ag.heads_b_grad.data_ptr(), ag.flat_grad[-1:].data_ptr(), stats.data_ptr(), st),
-                "ag_ppo_loss_finalize")
+        # (the loss partials -> d loss / d logstd, head bias gradient, KL slot, logged scalars: one workgroup's work; it rides in
+        # the first launch of the partial-sum reductions at the end of the step - `fuse_loss_finalize`, default on - instead of being
+        # a launch of its own here)
+        fin_args = (self.loss_partials.data_ptr(), nb.value, M, A, logstd.data_ptr(), float(ag.entropy_coef), float(ag.critic_coef),
+                    bcoef, logstd.grad.data_ptr(), ag.heads_b_grad.data_ptr(), ag.flat_grad[-1:].data_ptr(), stats.data_ptr())
+        fin_late = self.use_sum_multi and self.fuse_finalize
+        if not fin_late:
+            N.check(lib.ag_ppo_loss_finalize(*fin_args, st), "ag_ppo_loss_finalize")
         # ---- backward.  The head's dX = d_heads Wh and its weight gradient are formed inside the last layer's ELU' pass;
         # the first layer's weight/bias gradients are formed inside ITS ELU' pass (dz of layer 0 is never stored).
         dh = None
@@ -523,7 +528,10 @@ class FusedMLPStep:
                 else:
                     torch.mm(dz, w, out=dh)
         # ---- every partial-sum reduction (bias / weight gradients of all layers + the head) in two launches
-        if self.use_sum_multi:
+        if fin_late:
+            N.check(lib.ag_sum_rows_multi_finalize(self._jobs, len(self._jobs), self.sum_scratch.data_ptr(), self.sum_scratch.numel(),
+                                                   *fin_args, st), "ag_sum_rows_multi_finalize")
+        elif self.use_sum_multi:
             N.check(lib.ag_sum_rows_multi(self._jobs, len(self._jobs), self.sum_scratch.data_ptr(), self.sum_scratch.numel(), st),
                     "ag_sum_rows_multi")
         else:

@@ -706,6 +706,14 @@ typedef struct ag_sum_job {
 } ag_sum_job;
 int ag_sum_rows_groups(void);
 int ag_sum_rows_multi(const ag_sum_job* jobs_host, int njobs, float* scratch_dev, long long scratch_floats, void* stream);
+/* The same two launches with ag_ppo_loss_finalize's work (its arguments, in its order) done by one more workgroup of the first
+ * launch: the end of `calc_gradients`' loss assembly (lib/agent/a2c_continuous.py:330-369) rides along with the reductions that
+ * autograd's accumulation does for the weight gradients - one launch less per optimizer step.  Results bit-identical to the two
+ * separate calls. */
+int ag_sum_rows_multi_finalize(const ag_sum_job* jobs_host, int njobs, float* scratch_dev, long long scratch_floats,
+                               const float* loss_partials_dev, int num_blocks, int M, int A, const float* logstd_dev,
+                               float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd_dev,
+                               float* grad_head_bias_dev, float* kl_out_dev, float* stats_dev, void* stream);
 
 /* ELU backward fused with the bias gradient of the producing Linear (lib/network/mlp.py:36-39 under autograd):
  * dz = dh * ELU'(z) computed from h = ELU(z); db_partials_dev [ceil(M / rows_per_block), C] per-block column sums of dz

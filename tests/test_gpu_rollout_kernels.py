@@ -226,6 +226,39 @@ def test_sum_rows_multi(lib):
     assert torch.equal(first, flat), "fixed summation order: bit-identical on repeat"
 
 
+def test_sum_rows_multi_with_the_loss_finalize_riding_along(lib):
+    """ag_sum_rows_multi_finalize == ag_ppo_loss_finalize + ag_sum_rows_multi, bit for bit (one launch less per optimizer step)."""
+    from airgym_amd import _native as N
+    g = torch.Generator(device="cuda").manual_seed(16)
+    A, M, nb = 4, 196608, 768
+    ns = lib.ag_ppo_loss_num_sums()
+    lp = torch.randn(nb, ns, device="cuda", generator=g)
+    logstd = 0.1 * torch.randn(A, device="cuda", generator=g)
+    shapes = [(768, 1280), (768, 256), (256, 65536), (768, 256), (768, 4608)]
+    parts = [torch.randn(r, n, device="cuda", generator=g) for r, n in shapes]
+    scratch = torch.empty(lib.ag_sum_rows_groups() * sum(n for _, n in shapes), device="cuda")
+    res = []
+    for fused in (False, True):
+        outs = [torch.zeros(n, device="cuda") for _, n in shapes]
+        jobs = (N.AgSumJob * len(shapes))(*[N.AgSumJob(p.data_ptr(), o.data_ptr(), p.shape[0], p.shape[1]) for p, o in zip(parts, outs)])
+        gl, gb, kl, st = (torch.full((k,), 7.0, device="cuda") for k in (A, A + 1, 1, 8))
+        fin = (lp.data_ptr(), nb, M, A, logstd.data_ptr(), 0.01, 2.0, 1e-4, gl.data_ptr(), gb.data_ptr(), kl.data_ptr(), st.data_ptr())
+        if fused:
+            N.check(lib.ag_sum_rows_multi_finalize(jobs, len(shapes), scratch.data_ptr(), scratch.numel(), *fin, _stream()), "fused")
+        else:
+            N.check(lib.ag_ppo_loss_finalize(*fin, _stream()), "finalize")
+            N.check(lib.ag_sum_rows_multi(jobs, len(shapes), scratch.data_ptr(), scratch.numel(), _stream()), "sum")
+        torch.cuda.synchronize()
+        res.append(outs + [gl, gb, kl, st])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert (res[1][-1][:7] != 7.0).all() and res[1][-1][7] == 0.0            # the stats row was written
+    jobs = (N.AgSumJob * 1)(N.AgSumJob(parts[0].data_ptr(), res[0][0].data_ptr(), 768, 1280))
+    assert lib.ag_sum_rows_multi_finalize(jobs, 1, scratch.data_ptr(), scratch.numel(), None, nb, M, A, logstd.data_ptr(), 0.0, 1.0, 0.0,
+                                          res[0][5].data_ptr(), res[0][6].data_ptr(), res[0][7].data_ptr(), res[0][8].data_ptr(),
+                                          _stream()) == -1
+
+
 def test_minibatch_graphs_are_bit_identical_to_eager(lib):
     """use_hip_graph: rollout graph + one captured graph per minibatch step == the eager launch sequence, bit for bit."""
     import os
