@@ -606,6 +606,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
                 float part[A1];
 #pragma unroll
                 for (int a = 0; a < A1; ++a) part[a] = 0.0f;
+#ifdef AG_K1_ABL_NO_PASS1       // timing ablation (results wrong): no ELU + head products in the first pass
+                if (LOSS) part[0] = acc[i * 4][r];
+                else
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = acc[i * 4 + j][r];
@@ -615,11 +619,16 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
                     for (int a = 0; a < A1; ++a) part[a] = fmaf(e, wcol[a][j], part[a]);
                 }
                 float out = 0.0f;
+#ifdef AG_K1_ABL_NO_ROWSUM      // timing ablation (results wrong): no DPP row sums of the head products
+#pragma unroll
+                for (int a = 0; a < A1; ++a) out += part[a];
+#else
 #pragma unroll
                 for (int a = 0; a < A1; ++a) {
                     const float sum = sg_half_sum(part[a]);
                     out = (sel == a) ? sum : out;
                 }
+#endif
                 if ((lane & 16) && sel < A1) hs_lane[(i * 32 + (r & 3) + 8 * (r >> 2)) * A1] = out;
                 __builtin_amdgcn_sched_barrier(0);      // one row group at a time: interleaving them spills
             }
@@ -724,6 +733,10 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
                     for (int a = 0; a < A1; ++a) d[a] = dhs[rloc * A1 + a];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+#ifdef AG_K1_ABL_NO_PASS2       // timing ablation (results wrong): the stores only
+                        const float o = acc[i * 4 + j][r] + d[0];
+                        gw[0][j] += o;
+#else
                         const float e = sg_elu(acc[i * 4 + j][r] + bcol2[j]);
                         float g = 0.0f;
 #pragma unroll
@@ -732,6 +745,7 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
                             gw[a][j] = fmaf(d[a], e, gw[a][j]);
                         }
                         const float o = g * (e > 0.0f ? 1.0f : e + 1.0f);
+#endif
                         C[(size_t)(m0b + rloc) * BN + wn * 128 + j * 32 + l31] = o;
                         db[j] += o;
                     }
