@@ -152,6 +152,12 @@ class FusedMLPStep:
         # the device has CUs - then 128 rows (4-wave workgroups), so that e.g. the reference's 32 768-sample minibatches at 65 536
         # envs use the whole chip (ag_split_gemm_pick_tile_rows); `split_tile_rows: 128 | 256` overrides
         self.tile_rows = int(agent.config.get("split_tile_rows", 0) or self.lib.ag_split_gemm_pick_tile_rows(M))
+        if (not agent.config.get("split_tile_rows") and self.tile_rows == 256 and M % 128 == 0
+                and not self.lib.ag_split_gemm_input_fwd_supported(D)):
+            # input widths whose first layer is NOT formed inside the forward launch (Tracking's 48): without the 48 KB first-layer
+            # image two 4-wave workgroups fit a CU, one's epilogue runs beside the other's main loop: 29.37 -> 29.09 ms per Tracking
+            # epoch in an interleaved A/B.  (With the image only one fits: the headline at 128-row tiles is 25.4 -> 30.3 ms.)
+            self.tile_rows = 128
         lrows = self.tile_rows
         self.fuse_gemm_loss = (L >= 2 and bool(agent.config.get("fuse_gemm_loss", True))
                                and bool(agent.config.get("fuse_gemm_heads", True)) and self.A + 1 == 5
@@ -287,6 +293,9 @@ class FusedMLPStep:
                 dw = lib_gemm + " split-K bmm"
             dx = ("split-bf16 GEMM (ag_split_gemm / ..._input_wgrad*)" if sg else lib_gemm)
             out[key] = {"forward": fwd, "dW": dw, "dX": dx}
+        if self.fuse_gemm_loss:
+            out["forward_row_tile"] = (f"{self.tile_rows} rows per workgroup (" + ("8 waves, one workgroup per CU" if self.tile_rows == 256
+                                       else "4 waves; two workgroups per CU where the first layer is not formed in this launch") + ")")
         out["product_arithmetic"] = ("mixed_precision: one bf16 MFMA per product, f32 accumulate (_bf16 entry points)" if self.bf16
                                      else "float32-accurate: exact 3-way bf16 split, six MFMAs per product (library GEMM layers: f32 MFMA)")
         return out
