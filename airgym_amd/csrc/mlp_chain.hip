@@ -256,13 +256,27 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_fwd_kernel(const ChainFwdArg
         // this lane's input row, k = 16 g + 8 h + i: all loads issued together; columns past D: the all-ones bias column at D,
         // zeros behind it
         float xv[NB1][8];
+        const float* xrow = a.obs + (size_t)row * a.D;
+#ifdef AG_CHAIN_SCALAR_LOADS                   // (A/B switch: the round-4 form, one dword load per column)
+        const bool vec2 = false;
+#else
+        const bool vec2 = (a.D & 1) == 0;      // even width: rows are 8-byte aligned, a lane's 8 columns of a K step are four 8-byte loads
+#endif
 #pragma unroll
-        for (int g = 0; g < NB1; ++g)
+        for (int g = 0; g < NB1; ++g) {
+            const int k0 = 16 * g + 8 * h;
+            if (vec2 && k0 + 8 <= a.D) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kk = 16 * g + 8 * h + i;
-                xv[g][i] = a.obs[(size_t)row * a.D + min(kk, a.D - 1)];
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    const float2 v2 = reinterpret_cast<const float2*>(xrow + k0)[i2];
+                    xv[g][2 * i2] = v2.x;
+                    xv[g][2 * i2 + 1] = v2.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[g][i] = xrow[min(k0 + i, a.D - 1)];
             }
+        }
 #pragma unroll
         for (int g = 0; g < NB1; ++g)
 #pragma unroll
