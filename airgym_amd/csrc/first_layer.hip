@@ -74,27 +74,51 @@ __global__ __launch_bounds__(512, 2) void first_layer_kernel(const float* __rest
     __syncthreads();
     const int ntiles = (M + 255) / 256;
     const bool vec2 = (D & 1) == 0;                        // rows are 8-byte aligned: float2 loads
+    // the lane's input row of a tile, raw: fetched one tile ahead (a workgroup owns the CU - the 96 KB weight image - so nothing else
+    // would cover the latency of these loads at the top of every tile)
+    float xnext[KST][8];
+#define AG_FL_FETCH(tile_)                                                                             \
+    do {                                                                                               \
+        const int rr_ = min((tile_) * 256 + wave * 32 + l31, M - 1);                                   \
+        const float* xr_ = obs + (size_t)rr_ * D;                                                      \
+        _Pragma("unroll") for (int s = 0; s < KST; ++s) {                                              \
+            const int d0 = 16 * s + 8 * fh;                                                            \
+            if (vec2 && d0 + 8 <= D) {                                                                 \
+                _Pragma("unroll") for (int i2 = 0; i2 < 4; ++i2) {                                     \
+                    const float2 v2 = reinterpret_cast<const float2*>(xr_ + d0)[i2];                   \
+                    xnext[s][2 * i2] = v2.x;                                                           \
+                    xnext[s][2 * i2 + 1] = v2.y;                                                       \
+                }                                                                                      \
+            } else {                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) xnext[s][i] = (d0 + i < D) ? xr_[d0 + i] : 0.0f; \
+            }                                                                                          \
+        }                                                                                              \
+    } while (0)
+#ifndef AG_FL_NO_PREFETCH                      // (A/B switch: fetch at the top of the tile that uses the rows)
+    if ((int)blockIdx.x < ntiles) AG_FL_FETCH((int)blockIdx.x);
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row_raw = tile * 256 + wave * 32 + l31;
         const bool row_ok = row_raw < M;
         const int row = row_ok ? row_raw : M - 1;          // rows past M are computed on a copy of the last row, never stored
-        const float* xrow = obs + (size_t)row * D;
         bf16x8 xq[KST][3];
+        float xcur[KST][8];
+#ifdef AG_FL_NO_PREFETCH
+        AG_FL_FETCH(tile);
+#endif
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xcur[s][i] = xnext[s][i];
+#ifndef AG_FL_NO_PREFETCH
+        if (tile + (int)gridDim.x < ntiles) AG_FL_FETCH(tile + (int)gridDim.x);
+#endif
 #pragma unroll
         for (int s = 0; s < KST; ++s) {
             float xv[8];
             const int d0 = 16 * s + 8 * fh;
-            if (vec2 && d0 + 8 <= D) {
 #pragma unroll
-                for (int i2 = 0; i2 < 4; ++i2) {
-                    const float2 v2 = reinterpret_cast<const float2*>(xrow + d0)[i2];
-                    xv[2 * i2] = v2.x;
-                    xv[2 * i2 + 1] = v2.y;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) xv[i] = (d0 + i < D) ? xrow[d0 + i] : 0.0f;
-            }
+            for (int i = 0; i < 8; ++i) xv[i] = xcur[s][i];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int d = d0 + i;
