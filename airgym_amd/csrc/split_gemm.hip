@@ -259,6 +259,17 @@ struct SplitEpilogue {
 // RC (round 5: h1 is recomputed, not stored): with FIN > 0 the launch does not write h1_out; with DIN > 0 the epilogue forms
 // ELU'(h1) from a natural-orientation recomputation of h1 = ELU(W1ext x_ext) on the matrix cores (rc_input_wgrad below) instead of
 // reading the stored activations.
+template <bool LOSS, int DIN>
+constexpr bool split_persistent() {
+#if defined(AG_SPLIT_NOT_PERSISTENT)
+    return false;
+#elif defined(AG_SPLIT_PERSISTENT_ALL)
+    return true;
+#else
+    return !LOSS && DIN <= 20;      // (the loss launches and the 48-input dX launch would spill 96 - 288 B per lane inside the loop)
+#endif
+}
+
 template <bool HAS_BIAS, int A1, int DIN, int WM, bool LOSS = false, int FIN = 0, bool RC = false>
 __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __restrict__ A, const uint4* __restrict__ Bp,
                                                                   float* __restrict__ C, int M, const SplitEpilogue ep) {
@@ -276,12 +287,22 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     float* __restrict__ heads = ep.heads;
     extern __shared__ uint4 lds[];                         // [2 stages][A_UNITS + B_UNITS] 16-byte units
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
-    const int m0 = tile * BM;
     if constexpr (DIN > 0 && RC) {      // the first-layer image, behind the stages / the epilogue's buffers (visible after the first barrier)
         uint4* w1d = lds + rc_w1_offset_units<DIN, WM>();
         for (int u = tid; u < kInImageW1Bytes / 16; u += NT) w1d[u] = ep.w1img[u];
     }
+    // Persistent workgroups (late round 5): the launcher starts at most as many workgroups as fit the chip at once and each walks
+    // the row tiles blockIdx.x, + gridDim.x, ... - the first-layer image is copied into LDS once per workgroup instead of once per
+    // tile, and no workgroup has to be dispatched (LDS allocated, waves started) between a CU's tiles.
+    // (`split_persistent` - also the launcher's rule - says which instantiations: not those the loop would make spill)
+    constexpr bool PERSIST = split_persistent<LOSS, DIN>();
+    const int ntiles_ = (M + BM - 1) / BM;
+    for (int tile_it = blockIdx.x; tile_it < ntiles_; tile_it += gridDim.x) {
+    int tile = tile_it;
+    asm volatile("" : "+s"(tile));      // opaque per iteration: nothing that depends on the tile is hoisted out of the loop
+    const int m0 = tile * BM;
+    const bool first_tile = tile_it == (int)blockIdx.x;
+    if (!first_tile) __syncthreads();   // every wave is done with the previous tile's epilogue buffers (they overlay the stages)
 
     // ---- global -> register staging for one K chunk
     const int a_row = tid >> 1, a_half = tid & 1;                       // BM rows x 2 k-halves: one 32-byte piece per thread
@@ -402,7 +423,9 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         }                                                                                              \
     } while (0)
     if constexpr (FIN > 0) {
-        for (int u = tid; u < 8 * 2 * 3 * 2 * 32; u += NT) w1s[u] = ep.w1img[u];
+        if (first_tile) {
+            for (int u = tid; u < 8 * 2 * 3 * 2 * 32; u += NT) w1s[u] = ep.w1img[u];
+        }
         const bool norm = ep.in_mean != nullptr;
         const int grow = min(m0 + frow, M - 1);
         const float* xrow = A + (size_t)grow * FIN;
@@ -989,6 +1012,8 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
         }
     }
     }
+    if constexpr (!PERSIST) break;      // one tile per workgroup: no back edge, the body compiles as before
+    }      // persistent tile loop
 }
 
 }  // namespace
@@ -1063,7 +1088,21 @@ static int launch_split_any(const float* A_dev, const void* planes_dev, float* C
     }
     constexpr int BM = WM * 64;
     const int tiles = (M + BM - 1) / BM;
-    hipLaunchKernelGGL(fn, dim3(tiles), dim3(WM * 128), lds_bytes, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, C_dev, M, ep);
+    // persistent: as many workgroups as are resident at once (LDS decides: one per CU above 80 KB, else two), each walks its tiles
+    int grid = tiles;
+    if constexpr (split_persistent<LOSS, DIN>()) {
+        static int cus[64];
+        if (dev >= 0 && dev < 64) {
+            if (cus[dev] == 0) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                cus[dev] = n;
+            }
+            const int resident = cus[dev] * (lds_bytes <= 80 * 1024 ? 2 : 1);
+            if (grid > resident) grid = resident;
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(WM * 128), lds_bytes, (hipStream_t)stream, A_dev, (const uint4*)planes_dev, C_dev, M, ep);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
