@@ -266,7 +266,7 @@ constexpr bool split_persistent() {
 #elif defined(AG_SPLIT_PERSISTENT_ALL)
     return true;
 #else
-    return !LOSS && DIN <= 20;      // (the loss launches and the 48-input dX launch would spill 96 - 288 B per lane inside the loop)
+    return !LOSS;                   // (the loss launches are 1.5 - 3 % slower inside the loop: measured, DESIGN_HISTORY.md)
 #endif
 }
 
@@ -286,10 +286,9 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     const float* __restrict__ bh = ep.bh;
     float* __restrict__ heads = ep.heads;
     extern __shared__ uint4 lds[];                         // [2 stages][A_UNITS + B_UNITS] 16-byte units
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if constexpr (DIN > 0 && RC) {      // the first-layer image, behind the stages / the epilogue's buffers (visible after the first barrier)
         uint4* w1d = lds + rc_w1_offset_units<DIN, WM>();
-        for (int u = tid; u < kInImageW1Bytes / 16; u += NT) w1d[u] = ep.w1img[u];
+        for (int u = threadIdx.x; u < kInImageW1Bytes / 16; u += NT) w1d[u] = ep.w1img[u];
     }
     // Persistent workgroups (late round 5): the launcher starts at most as many workgroups as fit the chip at once and each walks
     // the row tiles blockIdx.x, + gridDim.x, ... - the first-layer image is copied into LDS once per workgroup instead of once per
@@ -300,6 +299,9 @@ __global__ __launch_bounds__(WM * 128, 2) void split_gemm_kernel(const float* __
     for (int tile_it = blockIdx.x; tile_it < ntiles_; tile_it += gridDim.x) {
     int tile = tile_it;
     asm volatile("" : "+s"(tile));      // opaque per iteration: nothing that depends on the tile is hoisted out of the loop
+    int tid_op = threadIdx.x;           // ... nor anything that depends on the thread index (it would be live across the epilogue)
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_op));
+    const int tid = tid_op, lane = tid & 63, wave = tid >> 6;
     const int m0 = tile * BM;
     const bool first_tile = tile_it == (int)blockIdx.x;
     if (!first_tile) __syncthreads();   // every wave is done with the previous tile's epilogue buffers (they overlay the stages)
