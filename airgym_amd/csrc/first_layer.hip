@@ -229,6 +229,7 @@ extern "C" int AG_PREC(ag_mlp_first_layer)(const float* obs_dev, const double* m
                                            const void* image_dev, float* xn_dev, float* h1_dev, int M, int D, void* stream) {
     if (!obs_dev || !image_dev || !h1_dev || M <= 0) return AG_ERR_INVALID_ARG;
     if ((mean_dev == nullptr) != (var_dev == nullptr)) return AG_ERR_INVALID_ARG;
+    if ((mean_dev == nullptr) != (xn_dev == nullptr)) return AG_ERR_INVALID_ARG;      // header: xn is written iff the input is normalised here
     if (!ag_mlp_first_layer_supported(D, FL_C)) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)image_dev & 15) || ((uintptr_t)h1_dev & 15)) return AG_ERR_INVALID_ARG;
     if ((D & 1) == 0 && ((uintptr_t)obs_dev & 7)) return AG_ERR_INVALID_ARG;

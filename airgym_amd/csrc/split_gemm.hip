@@ -1114,11 +1114,12 @@ static int launch_split_any(const float* A_dev, const void* planes_dev, float* C
 #if AG_SPLIT_PLANES == 3
 extern "C" int ag_split_gemm_pick_tile_rows(int M) {
     if (M <= 0) return 256;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
+    static int cus_of[64] = {0};          // per device ordinal, as launch_split_any caches it
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus_of[dev] == 0)
+        cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    const int cus = cus_of[dev];
     return ((M + 255) / 256 < cus && M % 128 == 0) ? 128 : 256;
 }
 #endif

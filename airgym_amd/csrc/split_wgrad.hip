@@ -663,7 +663,11 @@ extern "C" int AG_PREC(ag_split_wgrad)(const float* dZ_dev, const float* X_dev, 
 
 // ---- the weight gradient with its X operand produced from the network input (split_wgrad_fin_kernel)
 #include <stdlib.h>
+#ifdef AG_EXPERIMENTS      // the A/B switch exists in the experiments library only: stray environment state cannot change what the product runs
 static const int g_wgrad_pipe = [] { const char* e = getenv("AIRGYM_WGRAD_PIPE"); return (e && atoi(e) == 0) ? 0 : 1; }();
+#else
+static constexpr int g_wgrad_pipe = 1;
+#endif
 #if AG_SPLIT_PLANES == 3      // (exists once: the one-plane build calls the three-plane build's)
 extern "C" int ag_split_wgrad_input_supported(int D) { return (D == 16 || D == 18 || D == 20) ? 1 : 0; }
 #endif

@@ -672,6 +672,7 @@ class A2CAgent:
         self._rollout_launch()
         return self._rollout_tail()
 
+    @torch.no_grad()
     def _rollout_launch(self):
         """The H policy + env steps of one rollout (one hipGraph replay once captured)."""
         H = self.horizon_length
@@ -712,6 +713,7 @@ class A2CAgent:
                 self._graphs["rollout"] = self._capture(rollout, warmup=False)
         self._rollouts_done += 1
 
+    @torch.no_grad()
     def _rollout_tail(self):
         """Bootstrap value, GAE and the [H, N] -> [N * H] flattening of the rollout buffers (a2c_base.py:696-712)."""
         H = self.horizon_length

@@ -151,7 +151,11 @@ class FusedMLPStep:
         # row tile of the loss / recompute launches: 256 rows (8-wave workgroups) unless the minibatch has fewer such tiles than
         # the device has CUs - then 128 rows (4-wave workgroups), so that e.g. the reference's 32 768-sample minibatches at 65 536
         # envs use the whole chip (ag_split_gemm_pick_tile_rows); `split_tile_rows: 128 | 256` overrides
-        self.tile_rows = int(agent.config.get("split_tile_rows", 0) or self.lib.ag_split_gemm_pick_tile_rows(M))
+        cfg_rows = int(agent.config.get("split_tile_rows", 0) or 0)
+        if cfg_rows not in (0, 128, 256):
+            raise ValueError(f"split_tile_rows: {cfg_rows} is not a tile the split GEMM has - use 128, 256, or 0 / absent for the "
+                             f"automatic choice (ag_split_gemm_pick_tile_rows)")
+        self.tile_rows = cfg_rows or self.lib.ag_split_gemm_pick_tile_rows(M)
         if (not agent.config.get("split_tile_rows") and self.tile_rows == 256 and M % 128 == 0
                 and not self.lib.ag_split_gemm_input_fwd_supported(D)):
             # input widths whose first layer is NOT formed inside the forward launch (Tracking's 48): without the 48 KB first-layer

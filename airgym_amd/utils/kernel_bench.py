@@ -290,8 +290,16 @@ def pmc_traffic(repo, key, kernel):
 
 
 def roofline_object(agent, hip, args, repo):
-    """bench.py's `roofline` (+ `env_only`): the env-step kernel exactly as the PPO rollout launches it, 48 launches per hipGraph
-    x 52 replays = 2 496 steps (the 2 400-step time limit fires inside the timed region), HIP events on the launch stream."""
+    """bench.py's `env_kernels` (+ `env_only`): the env-step kernels of this configuration, each timed as a hipGraph of launches
+    with HIP events on the launch stream (2 496 env steps, so the 2 400-step time limit fires inside the timed region) and priced
+    against HBM.  Three forms:
+      in_loop     - what the PPO rollout of the timed region launches (ag_step_rollout_fused, one env step per launch behind the
+                    policy forward), at ITS algorithmic bytes (375 B for Hovering / CTBR);
+      single_step - ag_step_rollout (one step per launch, no policy sample / accounting), SURVEY 8(d)'s 287 B;
+      multi_step  - ag_step_multi, K = 24 steps per launch with the state in registers (the env-only metric): priced at the
+                    bytes it really moves (101 B per env-step); the launch is vector-ALU bound, not HBM bound
+                    (`valu_busy_pct` from the committed SQ counters), `frac_nominal` = the same at 8(d)'s 287 B for continuity.
+    `traffic` = HBM bytes per launch from the committed PMC record, quoted only when the record was measured on these sources."""
     task, ctl = args.task, args.ctl
     fr = getattr(agent, "_fused_rollout", None)
     fused = bool(getattr(fr, "fuse_tail", False))
@@ -299,65 +307,122 @@ def roofline_object(agent, hip, args, repo):
     m = measure_env_multi(hip, K=K, launches_per_graph=2, replays=52)
     r = measure_env_kernel(hip, steps_per_graph=48, replays=52, rollout_form=True)
     r_api = measure_env_kernel(hip, steps_per_graph=48, replays=10, rollout_form=False)
-    kname = kernel_name(task, ctl, False)
-    traffic, tsrc = (None, "PMC passes exist for 65 536 envs per launch only")
-    traffic1, tsrc1 = traffic, tsrc
+    none = (None, "PMC passes exist for 65 536 envs per launch only")
+    traffic, tsrc = none
+    traffic1, tsrc1 = none
+    valu = None
     if args.envs == 65536:
-        traffic, tsrc = pmc_traffic(repo, f"{task}_{ctl}_multi{K}", kname)
+        traffic, tsrc = pmc_traffic(repo, f"{task}_{ctl}_multi{K}", kernel_name(task, ctl, False))
         traffic1, tsrc1 = pmc_traffic(repo, f"{task}_{ctl}", kernel_name(task, ctl, False, True))
+        valu = pmc_field(repo, f"{task}_{ctl}_multi{K}", kernel_name(task, ctl, False), "valu_busy_pct")
     copy_gbps = measure_copy_ceiling(agent.ppo_device)
-    # The dominant env kernel, launched the way the env-only metric of SURVEY 8(d) launches it (actions pre-generated on the
-    # device): ag_step_multi, K steps per launch.  `achieved` = 8(d)'s 287 B x the env-steps one launch processes (envs x K)
-    # / the launch's duration; `frac_own_bytes` prices the same launch at the bytes it really has to move (the state stays
-    # in registers between the K steps) - both are reported, as is the one-step-per-launch form the PPO rollout uses.
-    roof = {
-        "bound": "hbm", "achieved": m["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": m["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
-        "kernel": kname, "entry_point": f"ag_step_multi, {K} env steps per launch (the state held in registers between the "
-                                        f"steps; bit-identical to {K} one-step launches)",
-        "note": "env step ALONE with pre-generated actions (SURVEY 8(d) env-only metric).  The headline's timed region does NOT "
-                "launch this form: with a policy in the loop the rollout issues one ag_step_rollout_fused per step - see "
-                "`in_loop` (same object as `rollout_fused`)",
-        "us_per_launch": m["us_per_launch"], "launches_timed": m["launches_timed"], "steps_per_launch": K,
-        "us_per_env_step_batch": m["us_per_step"],
-        "algo_bytes_per_env_step": m["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
-        "env_steps_per_launch": args.envs * K,
-        "own_bytes_per_env_step": m["own_bytes_per_env_step"], "achieved_own_bytes": m["gbps_own_bytes"],
-        "frac_own_bytes": m["gbps_own_bytes"] / HBM_PEAK_GBPS,
-        "kernel_source_sha": env_kernel_source_sha(),
-        "copy_ceiling_gbps": copy_gbps, "frac_of_copy_ceiling": m["gbps_algorithmic"] / copy_gbps,
-        "single_step_launch": {
-            "entry_point": "ag_step_rollout (one env step per launch: what a policy in the loop allows)",
-            "kernel": kernel_name(task, ctl, False, True),
-            "us_per_launch": r["us_per_step"], "launches_timed": r["steps_timed"], "achieved": r["gbps_algorithmic"],
-            "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": traffic1, "traffic_source": tsrc1},
-        "drop_in_ag_step": {"us_per_launch": r_api["us_per_step"], "frac": r_api["gbps_algorithmic"] / HBM_PEAK_GBPS,
-                            "note": "ag_step: int64 reset_buf + nine per-env item_reward_info arrays + cmd_thrusts "
-                                    "(+59 B/env-step of outputs the reference's Hovering.step exposes)"},
+    n = args.envs
+    kernels = {
+        "single_step": {
+            "bound": "hbm", "kernel": kernel_name(task, ctl, False, True), "entry_point": "ag_step_rollout",
+            "us_per_launch": r["us_per_step"], "launches_timed": r["steps_timed"], "algo_bytes_per_env_step": r["algo_bytes_per_env_step"],
+            "achieved": r["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["gbps_algorithmic"] / HBM_PEAK_GBPS,
+            "traffic": traffic1, "traffic_source": tsrc1,
+            "drop_in_ag_step_us": r_api["us_per_step"]},
+        "multi_step": {
+            "bound": "valu", "kernel": kernel_name(task, ctl, False), "entry_point": f"ag_step_multi ({K} env steps per launch)",
+            "us_per_launch": m["us_per_launch"], "launches_timed": m["launches_timed"], "steps_per_launch": K,
+            "us_per_env_step_batch": m["us_per_step"], "algo_bytes_per_env_step": m["own_bytes_per_env_step"],
+            "achieved": m["gbps_own_bytes"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": m["gbps_own_bytes"] / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": tsrc, "valu_busy_pct": valu,
+            "frac_nominal": m["gbps_algorithmic"] / HBM_PEAK_GBPS, "nominal_bytes_per_env_step": m["algo_bytes_per_env_step"],
+            "note": "state in registers between the K steps: moves 101 B per env-step, not 8(d)'s 287 B; vector-ALU bound"},
+        "copy_ceiling_gbps": copy_gbps, "kernel_source_sha": env_kernel_source_sha(), "envs_per_launch": n,
     }
-    out = {"roofline": roof,
+    out = {"env_kernels": kernels,
            "env_only": {"value": m["env_steps_per_s"], "unit": "env-steps/s",
                         "note": f"env-step kernel only, ag_step_multi ({K} steps per launch), synthetic N(0,1) clamped "
                                 f"actions pre-generated on the device, hipGraph replay",
                         "single_step_launch": r["env_steps_per_s"]}}
     if fused:
         rf = measure_fused_rollout_kernel(agent, steps_per_graph=48, replays=52)
-        ftraffic, fsrc = (None, "PMC passes exist for 65 536 envs per launch only")
+        ftraffic, fsrc = none
         if args.envs == 65536:
             ftraffic, fsrc = pmc_traffic(repo, f"{task}_{ctl}_fused", rf["kernel"])
-        roof["rollout_fused"] = {
-            "bound": "hbm", "achieved": rf["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": rf["gbps_algorithmic"] / HBM_PEAK_GBPS, "traffic": ftraffic, "traffic_source": fsrc,
-            "kernel": rf["kernel"], "entry_point": "ag_step_rollout_fused (what FusedRolloutStep launches: policy sample + env "
-                                                   "step + reward shaping / episode accounting)",
+        kernels["in_loop"] = {
+            "bound": "hbm", "kernel": rf["kernel"], "entry_point": "ag_step_rollout_fused",
             "us_per_launch": rf["us_per_step"], "launches_timed": rf["steps_timed"],
-            "algo_bytes_per_env_step": rf["algo_bytes_per_env_step"], "envs_per_launch": args.envs,
-            "frac_of_copy_ceiling": rf["gbps_algorithmic"] / copy_gbps}
-        # the launch the HEADLINE's timed region really issues for the env step (one per rollout step, behind the policy forward)
-        roof["in_loop"] = dict(roof["rollout_fused"], note="what the PPO rollout of the timed region launches (policy in the loop): "
-                               "ag_step_rollout_fused, one env step per launch; `roofline` itself describes ag_step_multi, the "
-                               "env-only form")
+            "algo_bytes_per_env_step": rf["algo_bytes_per_env_step"],
+            "achieved": rf["gbps_algorithmic"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": rf["gbps_algorithmic"] / HBM_PEAK_GBPS,
+            "traffic": ftraffic, "traffic_source": fsrc, "frac_of_copy_ceiling": rf["gbps_algorithmic"] / copy_gbps,
+            "note": "what the PPO rollout of the timed region launches: policy sample + env step + episode accounting, one env "
+                    "step per launch behind the policy forward"}
+    else:
+        kernels["in_loop"] = dict(kernels["single_step"], note="the rollout of this configuration launches the plain one-step form")
     return out
+
+
+def update_source_sha():
+    """Provenance key of the update's matrix-core kernels (the sources + flags they are compiled from), as env_kernel_source_sha."""
+    import hashlib
+    import os
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    h = hashlib.sha256()
+    for f in ("split_gemm.hip", "split_wgrad.hip", "split_common.hpp", "ppo_loss_math.hpp"):
+        with open(os.path.join(here, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def update_pmc_record(repo, entry_point):
+    """(record, source note) of one update launch from profiles/r*_update_kernels_pmc.json, newest round first; the record is
+    returned only when it was measured on the kernel sources of this tree (`update_source_sha`)."""
+    import glob
+    import json
+    import os
+    sha = update_source_sha()
+    why = "no PMC record for this kernel"
+    for path in sorted(glob.glob(os.path.join(repo, "profiles", "r*_update_kernels_pmc.json")), reverse=True):
+        rec = json.load(open(path)).get(entry_point)
+        if not rec:
+            continue
+        if rec.get("source_sha") != sha:
+            why = (f"stale: {os.path.basename(path)} was measured on kernel sources {rec.get('source_sha')}, this build is {sha} "
+                   f"(re-run tools/gpu_pmc_update.sh)")
+            continue
+        return rec, rec.get("source", os.path.basename(path))
+    return None, why
+
+
+def update_roofline(agent, repo, seq=None, optimizer_steps_per_epoch=None):
+    """bench.py's top-level `roofline`: the dominant kernel of the timed region (the update's forward + loss launch, the largest
+    share of an optimizer step), bound by the bf16 matrix cores.  `achieved` = algorithmic matrix-core FLOPs of ONE launch (every
+    f32 product = 6 bf16 MFMAs, incl. the first-layer product the launch carries: 2 M (32 + 256) 256 x 6) / the launch's duration,
+    HIP events on the launch stream with the step's three launches replayed in the step's order.  `traffic` = HBM bytes per launch
+    (PMC: FETCH_SIZE x 2 + WRITE_SIZE, separate passes) and `mfma_busy_pct` from the committed counters of the same kernel."""
+    seq = measure_update_sequence(agent) if seq is None else seq
+    if not seq:
+        return None
+    e = seq[0]
+    total = seq[-1]["us_per_launch"] if len(seq) > 3 else None
+    rec, src = update_pmc_record(repo, e["entry_point"])
+    out = {"bound": "mfma", "kernel": (rec or {}).get("kernel", "ag::split_gemm_kernel<true,...>"), "entry_point": e["entry_point"],
+           "achieved": e["achieved"], "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": e["frac"],
+           "traffic": (rec or {}).get("traffic_bytes_per_launch"), "traffic_source": src,
+           "mfma_busy_pct": (rec or {}).get("mfma_busy_pct"),
+           "us_per_launch": e["us_per_launch"], "algo_flops_per_launch": 6.0 * e["matrix_core_gflop_f32_equivalent"] * 1e9,
+           "f32_equivalent_tflops": e["f32_equivalent_tflops"], "f32_equivalent_frac_of_f32_mfma_peak": e["f32_equivalent_tflops"] / FP32_MFMA_PEAK_TFLOPS,
+           "hbm_algo_bytes_per_launch": e["hbm"]["algo_bytes"], "launches_per_epoch": optimizer_steps_per_epoch,
+           "three_launch_sum_us": total, "kernel_source_sha": update_source_sha()}
+    return out
+
+
+def pmc_field(repo, key, kernel, field):
+    """One extra field (e.g. `valu_busy_pct`) of the env-kernel PMC record bench.py quotes traffic from; None when stale / absent."""
+    import glob
+    import json
+    import os
+    sha = env_kernel_source_sha()
+    for path in sorted(glob.glob(os.path.join(repo, "profiles", "r*_env_kernel_pmc.json")), reverse=True):
+        rec = json.load(open(path)).get(key)
+        if rec and rec.get("kernel") == kernel and rec.get("source_sha") == sha:
+            return rec.get(field)
+    return None
 
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity figure)

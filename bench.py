@@ -122,6 +122,8 @@ def cpu_baseline(seconds_target=24.0):
                       f"hovering.py:203-459, env step only (no policy), best of a thread sweep "
                       f"{ {t: round(d['env_steps_per_s'] / 1e6, 3) for t, d in swept.items()} } M env-steps/s by torch threads, "
                       f"{swept[best]['seconds']:.1f}s at the best setting on a {host}-core host",
+            "sample_short": f"{swept[best]['steps']} env steps x {n} envs, Hovering CTBR, oracle (torch-CPU) env step only, "
+                            f"best of thread sweep {sweep}",
             "thread_sweep": {str(t): d["env_steps_per_s"] for t, d in swept.items()},
             "config0": {"value": c0, "unit": "env-steps/s", "envs": 64, "threads": c0_threads,
                         "sample": f"BASELINE config 0: Hovering, 64 envs, CTBR, same oracle; 1 thread {v64:.0f}, "
@@ -212,13 +214,13 @@ def side_config_tracking(args, epochs=3, warmup=2):
                       "minibatch_size": agent.minibatch_size, "policy": "MLP(256,256) actor-critic, fixed sigma"},
            "last_kl": st["kl"], "finite": bool(st["kl"] == st["kl"] and st["a_loss"] == st["a_loss"])}
     out["config"]["paths"] = agent.compute_paths()
-    try:      # the env kernels of THIS configuration against its own 543 B / env-step: env-only and in-loop forms
+    try:      # the env kernels of THIS configuration against its own 543 B / env-step: in-loop, one-step and K-step forms
         from airgym_amd.utils.kernel_bench import roofline_object
         ro = roofline_object(agent, agent._hip_env, a, REPO)
-        out["roofline"] = ro["roofline"]
+        out["env_kernels"] = ro["env_kernels"]
         out["env_only"] = ro["env_only"]
     except Exception as e:
-        out["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out["env_kernels"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     agent.vec_env.env.hip.close()
     return out
 
@@ -277,6 +279,114 @@ def side_config_planning(envs=16384, epochs=3, warmup=1, minibatches=24):
            "last_kl": st["kl"], "finite": bool(st["kl"] == st["kl"] and st["a_loss"] == st["a_loss"])}
     agent.vec_env.env.hip.close()
     return out
+
+
+LINE_LIMIT = 4000      # bytes of the ONE stdout line (round 5's 20 KB line was cut off in the driver's record: parsed = null)
+
+
+def _num(x, digits=4):
+    """Numbers of the stdout line: 4 significant digits are what the line is read at; the detail file keeps full precision."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _num(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+_KERNEL_KEYS = ("bound", "kernel", "us_per_launch", "achieved", "peak", "unit", "frac", "traffic", "algo_bytes_per_env_step",
+                "valu_busy_pct", "steps_per_launch")
+
+
+def compact_line(out, limit=LINE_LIMIT, detail_path=None):
+    """The one stdout line: the contract's keys, `roofline` (dominant kernel), `env_kernels` (the three env launch forms),
+    `cpu_baseline`, one-number summaries of the side configurations - and nothing in prose.  Everything else is in the detail
+    file.  Optional blocks are dropped from the end of `droppable` until the line fits `limit` bytes."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data") if k in out}
+    for k in ("error", "devices_visible", "launch_attempts"):
+        if k in out:
+            line[k] = out[k]
+    cfg = out.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "task", "ctl_mode", "envs_per_gpu", "global_envs", "horizon_length", "mini_epochs",
+                                 "minibatch_size", "policy", "parallelism", "hip_graph_rollout", "rollout_launches_per_step",
+                                 "product_arithmetic"))
+    ph = out.get("phases", {})
+    line["phases"] = _pick(ph, ("rollout_host_enqueue_s", "update_s", "last_kl", "finite"))
+    ro = out.get("roofline")
+    if isinstance(ro, dict):
+        line["roofline"] = _pick(ro, ("bound", "kernel", "entry_point", "achieved", "peak", "unit", "frac", "traffic",
+                                      "mfma_busy_pct", "us_per_launch", "launches_per_epoch", "share_of_step",
+                                      "f32_equivalent_tflops", "three_launch_sum_us"))
+        line["roofline"].setdefault("traffic", None)
+    ek = out.get("env_kernels")
+    if isinstance(ek, dict):
+        line["env_kernels"] = {k: _pick(ek[k], _KERNEL_KEYS) for k in ("in_loop", "single_step", "multi_step") if k in ek}
+        for v in line["env_kernels"].values():
+            v.setdefault("traffic", None)
+        line["env_kernels"]["copy_ceiling_gbps"] = ek.get("copy_ceiling_gbps")
+    if "env_only" in out:
+        line["env_only"] = _pick(out["env_only"], ("value", "unit"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "host_cores"))
+        line["cpu_baseline"]["sample"] = cb.get("sample_short", str(cb.get("sample", ""))[:120])
+        if isinstance(cb.get("config0"), dict):
+            line["cpu_baseline"]["config0"] = _pick(cb["config0"], ("value", "envs", "threads"))
+    side = {}
+    for name, sc in (out.get("side_configs") or {}).items():
+        e = _pick(sc, ("value", "ms_per_step", "dtype", "error", "rollout_ms", "update_ms"))
+        ekk = sc.get("env_kernels") if isinstance(sc, dict) else None
+        if isinstance(ekk, dict) and isinstance(ekk.get("in_loop"), dict):
+            e["env_in_loop"] = _pick(ekk["in_loop"], ("kernel", "us_per_launch", "frac", "traffic", "algo_bytes_per_env_step"))
+            e["env_in_loop"].setdefault("traffic", None)
+        if isinstance(sc, dict) and isinstance(sc.get("roofline"), dict):
+            e["roofline"] = _pick(sc["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch"))
+            e["roofline"].setdefault("traffic", None)
+        side[name] = e
+    if "shipped_ratio" in out:
+        side["shipped_ratio_48_minibatches"] = _pick(out["shipped_ratio"], ("value", "ms_per_step", "minibatch_size"))
+    if side:
+        line["side"] = side
+    rc = out.get("rccl")
+    if isinstance(rc, dict):
+        line["rccl"] = {k: v for k, v in rc.items() if k != "note"}
+    if detail_path:
+        line["detail"] = detail_path
+    top = {k: line[k] for k in ("value", "ms_per_step") if k in line}      # the contract's two numbers at full precision
+    line = _num(line)
+    line.update(top)
+    droppable = ["env_only", "phases", "side", "env_kernels"]
+    while len(json.dumps(line)) > limit and droppable:
+        line.pop(droppable.pop(0), None)
+    if len(json.dumps(line)) > limit and "rccl" in line:
+        line["rccl"] = _pick(line["rccl"], ("ranks_seen", "ranks_counted_by_allreduce", "backend", "allreduce_us", "bytes", "per_epoch"))
+    return line
+
+
+def emit(out, args):
+    """Rank 0: the full record goes to the detail file (and to stderr); stdout gets ONE compact JSON line."""
+    detail_dir = os.environ.get("AIRGYM_BENCH_DETAIL_DIR") or (
+        os.path.join(REPO, "gpurun_out") if os.path.isdir(os.path.join(REPO, "gpurun_out")) else REPO)
+    path = os.path.join(detail_dir, "bench_detail.json")
+    rel = None
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        rel = os.path.relpath(path, REPO)
+    except OSError as e:
+        print(f"[bench] detail file not written: {e}", file=sys.stderr)
+    print("[bench] detail: " + json.dumps(out), file=sys.stderr, flush=True)
+    print(json.dumps(compact_line(out, detail_path=rel)), flush=True)
 
 
 def _load_agent_class(spec):
@@ -549,6 +659,8 @@ def _run_rank(args, world, rank, on_gpu, stage):
                    "policy": "MLP(256,256) actor-critic, fixed sigma", "parallelism": f"dp{world}",
                    "hip_graph_rollout": bool(args.graph),
                    "rollout_launches_per_step": getattr(getattr(agent, "_fused_rollout", None), "launches_per_step", None),
+                   "product_arithmetic": ("bf16x6 split of f32 operands, f32 accumulate (f32-accurate)" if getattr(fs, "split", None)
+                                          else "library f32 GEMM"),
                    "hidden_layer_gemm": getattr(fs, "gemm_description", "library f32 GEMM"),
                    "update_forward_launch": ("first layer + hidden layer + heads + PPO loss + head backward in ONE launch "
                                              "(ag_split_gemm_input_loss_heads_bwd)" if getattr(fs, "fuse_gemm_input", False) else
@@ -585,14 +697,23 @@ def _run_rank(args, world, rank, on_gpu, stage):
         out["shipped_ratio"] = shipped_ratio_line(args, world)
     if rank == 0:
         if roof is not None:
-            out.update(roof)
+            out.update(roof)                       # env_kernels, env_only
+            from airgym_amd.utils.kernel_bench import measure_update_kernels, measure_update_sequence, update_roofline
+            # where the epoch's time actually goes: the launches the step really issues, in its order (every rank at N > 1 would
+            # time the same kernels; rank 0 does)
+            seq = measure_update_sequence(agent)
+            # top-level `roofline` = the dominant kernel of the timed region: the update's forward + loss launch (bf16 matrix cores)
+            top = update_roofline(agent, REPO, seq, agent.mini_epochs_num * agent.num_minibatches)
+            if top is not None:
+                top["share_of_step"] = top["us_per_launch"] * top["launches_per_epoch"] / (elapsed / args.steps * 1e6)
+                out["roofline"] = top
+            else:       # no hand-scheduled update on this configuration: the env launch of the rollout is what there is to price
+                out["roofline"] = {k: v for k, v in roof["env_kernels"]["in_loop"].items() if k != "note"}
             if world == 1:
-                from airgym_amd.utils.kernel_bench import measure_update_kernels, measure_update_sequence
-                # where the epoch's time actually goes: first the launches the step really issues, in its order, then reference legs
-                uk = measure_update_sequence(agent) + measure_update_kernels(agent)
+                uk = seq + measure_update_kernels(agent)
                 for e in uk:
                     if e.get("bound") == "hbm":
-                        e["frac_of_copy_ceiling"] = e["achieved"] / out["roofline"]["copy_ceiling_gbps"]
+                        e["frac_of_copy_ceiling"] = e["achieved"] / roof["env_kernels"]["copy_ceiling_gbps"]
                 out["update_kernels"] = uk
         if (world == 1 and on_gpu and not args.no_side_configs and (args.task, args.ctl) == ("hovering", "rate")
                 and hip is not None and args.envs == ENVS_PER_GPU):
@@ -610,7 +731,7 @@ def _run_rank(args, world, rank, on_gpu, stage):
             out["side_configs"] = side
         if world == 1 and on_gpu and not args.no_cpu_baseline and (args.task, args.ctl) == ("hovering", "rate"):
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

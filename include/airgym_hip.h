@@ -485,7 +485,8 @@ int ag_split_gemm_input_loss_heads_bwd(const ag_input_layer_args* in, const void
                                        int n, int k, int A1, void* stream);
 
 /* The first layer of the trunk as a launch of its own on the matrix cores (airgym_amd/csrc/first_layer.hip): xn = clamp((obs - mean) /
- * sqrt(var + eps), +-clip) (lib/core/running_mean_std.py:78-79; mean_dev / var_dev NULL: xn = obs, xn_dev not written), h1 = ELU(xn W1^T +
+ * sqrt(var + eps), +-clip) (lib/core/running_mean_std.py:78-79; mean_dev / var_dev NULL: xn = obs and xn_dev MUST be NULL too; given:
+ * xn_dev MUST be given - AG_ERR_INVALID_ARG otherwise), h1 = ELU(xn W1^T +
  * b1) (lib/network/mlp.py:36-39) - what ag_mlp_input_layer computes, with the product as an exact 3-way bf16 split on the MFMA (float32-
  * accurate, not bit-identical to the FMA chain).  For input widths the forward GEMM cannot produce itself (D + 1 <= 64, e.g. Tracking's
  * 48, tracking.py:202-214): 256-wide layer only.  prepare: W1 [256, D], b1 [256] -> image (ag_mlp_first_layer_image_bytes(D) bytes,

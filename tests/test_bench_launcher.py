@@ -23,6 +23,7 @@ def test_self_launch_two_ranks_gloo():
                      "--steps", "2", "--warmup", "1", "--minibatches", "2"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout          # exactly one JSON line, from rank 0
+    assert len(lines[0]) <= 6000, len(lines[0])      # the driver's record keeps a bounded tail of stdout (round 5: 20 KB -> parsed null)
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_envs"] == 32 and out["config"]["parallelism"] == "dp2"
     assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak" and out["higher_is_better"] is True
@@ -97,3 +98,71 @@ def test_committed_pmc_record_was_measured_on_these_kernel_sources():
                         ("hovering_rate", kernel_name("hovering", "rate", False, True))):
         traffic, source = pmc_traffic(repo, key, kernel)
         assert traffic is not None and traffic > 0, (key, source)
+
+
+def _fat_record():
+    """A full bench record of the size round 5 printed (prose notes, per-kernel lists, nested side configurations)."""
+    prose = "x" * 400
+    kern = {"bound": "hbm", "kernel": "ag::step_kernel_ws2<0,3,true>", "entry_point": prose, "us_per_launch": 10.174405116301317,
+            "achieved": 2415.472916507385, "peak": 8000.0, "unit": "GB/s", "frac": 0.3019341145634231, "traffic": 27096064,
+            "traffic_source": prose, "algo_bytes_per_env_step": 375, "note": prose, "launches_timed": 2496}
+    ek = {"in_loop": kern, "single_step": dict(kern), "multi_step": dict(kern, steps_per_launch=24, valu_busy_pct=87.0),
+          "copy_ceiling_gbps": 5132.929068638738}
+    return {
+        "metric": "env_steps_per_sec_hovering_65536_envs_per_gpu", "value": 63208714.26767838, "unit": "env-steps/s", "n_gpus": 1,
+        "steps": 20, "warmup": 5, "ms_per_step": 24.883657549798954, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "hovering_ctbr_ppo_epoch", "task": "hovering", "ctl_mode": "rate", "envs_per_gpu": 65536,
+                   "global_envs": 65536, "horizon_length": 24, "mini_epochs": 5, "minibatch_size": 196608, "policy": "MLP(256,256)",
+                   "parallelism": "dp1", "hidden_layer_gemm": prose, "paths": {"update": {f"layer{i}": prose for i in range(4)}}},
+        "phases": {"rollout_host_enqueue_s": 0.005, "update_s": 0.49, "last_kl": 0.013, "finite": True, "final_lr": 3e-3},
+        "roofline": {"bound": "mfma", "kernel": "ag::split_gemm_kernel<true,5,0,4,true,18,true>", "entry_point": "ag_split_gemm_input_loss_heads_bwd",
+                     "achieved": 748.1, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.2992, "traffic": 265000000, "traffic_source": prose,
+                     "us_per_launch": 233.6, "launches_per_epoch": 40, "mfma_busy_pct": 32.6},
+        "env_kernels": ek, "env_only": {"value": 1.5e10, "unit": "env-steps/s", "note": prose},
+        "update_kernels": [dict(kern, kernel=prose) for _ in range(14)],
+        "side_configs": {"tracking_lv": {"value": 5.4e7, "ms_per_step": 28.9, "dtype": "f32", "config": {"paths": prose}, "env_kernels": ek},
+                         "hovering_bf16": {"value": 1.09e8, "ms_per_step": 14.4, "dtype": "bf16", "update_kernels": [kern] * 3},
+                         "planning_cnn_16384": {"value": 3.8e5, "ms_per_step": 1026.0, "dtype": "f32", "rollout_ms": 120.0, "update_ms": 900.0,
+                                                "roofline": dict(kern)}},
+        "shipped_ratio": {"value": 3.6e7, "ms_per_step": 43.6, "minibatch_size": 32768, "note": prose},
+        "cpu_baseline": {"value": 1864889.8, "unit": "env-steps/s", "cores": 8, "kind": "port", "host_cores": 256, "sample": prose,
+                         "thread_sweep": {str(t): 1e6 for t in (1, 4, 8, 16, 32, 64)},
+                         "config0": {"value": 30570.9, "envs": 64, "threads": 1, "sample": prose}}}
+
+
+def test_stdout_line_is_compact_and_complete():
+    """the line the driver parses stays under 4 KB whatever the detail record holds, and still carries the
+    contract's keys, `roofline` (bound / achieved / peak / unit / frac / traffic) and `cpu_baseline` (value / unit / cores / kind /
+    sample).  Everything else lives in bench_detail.json."""
+    sys.path.insert(0, REPO)
+    import bench
+    rec = _fat_record()
+    assert len(json.dumps(rec)) > 15000
+    line = bench.compact_line(rec, detail_path="gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT <= 4096, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == rec["value"] and line["ms_per_step"] == rec["ms_per_step"]        # full precision where the driver checks
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    assert line["config"]["workload"] == "hovering_ctbr_ppo_epoch" and "paths" not in line["config"]
+    assert line["env_kernels"]["in_loop"]["frac"] == 0.3019 and line["side"]["planning_cnn_16384"]["value"] == 3.8e5
+    assert not any(isinstance(v, str) and len(v) > 130 for v in _walk(line)), "prose belongs in the detail file"
+    # a record that is too fat even when compacted loses optional blocks, never the contract's keys
+    rec["rccl"] = {"ranks_seen": 8, "collectives_per_epoch": {f"tag{i}": {"calls": 1.0, "bytes": 2.0} for i in range(120)}}
+    small = bench.compact_line(rec)
+    assert len(json.dumps(small)) <= bench.LINE_LIMIT and "roofline" in small and "cpu_baseline" in small and "value" in small
+
+
+def _walk(o):
+    if isinstance(o, dict):
+        for v in o.values():
+            yield from _walk(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _walk(v)
+    else:
+        yield o

@@ -224,6 +224,11 @@ def test_first_layer_as_its_own_launch_on_the_matrix_cores(lib, M, D, normalize)
     # bf16 twin: one MFMA per product
     hb = torch.empty_like(h1)
     N.check(lib.ag_mlp_first_layer_bf16(obs.data_ptr(), mean.data_ptr() if normalize else None, var.data_ptr() if normalize else None, 1e-5,
-                                        5.0, image.data_ptr(), None, hb.data_ptr(), M, D, _stream()), "first_layer_bf16")
+                                        5.0, image.data_ptr(), xn1.data_ptr() if normalize else None, hb.data_ptr(), M, D, _stream()),
+            "first_layer_bf16")
+    # header contract: xn_dev is given iff the statistics are - a mismatch is refused, not silently skipped
+    bad_xn = None if normalize else h0.data_ptr()
+    assert lib.ag_mlp_first_layer(obs.data_ptr(), mean.data_ptr() if normalize else None, var.data_ptr() if normalize else None, 1e-5, 5.0,
+                                  image.data_ptr(), bad_xn, h1.data_ptr(), M, D, _stream()) == -1      # AG_ERR_INVALID_ARG
     eb = ((hb.double() - ref).abs() / (scale + 0.25)).max().item()
     assert 1e-6 < eb < 2.0 ** -7, eb

@@ -108,6 +108,22 @@ def test_train_two_epochs_cpu():
     assert agent.value_mean_std.count.item() == 1 + 2 * 2 * 64 * 8          # values + returns per epoch
 
 
+def test_rollout_builds_no_autograd_graph_generic_path():
+    """train_epoch calls _rollout_launch / _rollout_tail directly; both must run under no_grad, or the
+    bootstrap value of the generic path (CPU, CNN / dict observations, non-256 trunks) drags an autograd graph into the returns and,
+    with normalize_value: false, the second minibatch's backward() raises 'backward through the graph a second time'."""
+    torch.manual_seed(0)
+    agent = A2CAgent("run", _stub_env.ppo_params(num_actors=32, horizon=8, mini_epochs=2, max_epochs=2, normalize_value=False))
+    agent.init_tensors(); agent.obs = agent.env_reset()
+    agent._rollout_launch()
+    batch = agent._rollout_tail()
+    for k in ("returns", "values", "actions", "neglogpacs", "mus", "sigmas"):
+        assert not batch[k].requires_grad, k
+    before = agent.flat_param.clone()
+    agent.train()                                                   # two epochs x two mini-epochs x two minibatches
+    assert agent.epoch_num == 2 and torch.isfinite(agent.flat_param).all() and not torch.equal(before, agent.flat_param)
+
+
 def test_rollout_layout_and_gae_vs_oracle():
     torch.manual_seed(1)
     agent = A2CAgent("run", _stub_env.ppo_params(num_actors=16, horizon=6))

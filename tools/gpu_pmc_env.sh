@@ -6,6 +6,7 @@
 #   bash tools/gpu_pmc_env.sh <tag>
 set -u
 TAG=${1:-r03}
+TASK=${TASK:-hovering}; CTL=${CTL:-rate}      # env: TASK=tracking CTL=vel bash tools/gpu_pmc_env.sh r06_tracking
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -15,19 +16,19 @@ FORMS=${2:-"multi rollout api fused"}
 for FORM in $FORMS; do
   for C in FETCH_SIZE WRITE_SIZE; do
     D=/tmp/pmc_${TAG}_${FORM}_$C; rm -rf $D
-    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o f -- python $REPO/tools/env_kernel_probe.py --forms $FORM --replays 8 --nograph > $OUT/${TAG}_pmc_${FORM}_$C.probe 2> $OUT/${TAG}_pmc_${FORM}_$C.err
+    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o f -- python $REPO/tools/env_kernel_probe.py --task $TASK --ctl $CTL --forms $FORM --replays 8 --nograph > $OUT/${TAG}_pmc_${FORM}_$C.probe 2> $OUT/${TAG}_pmc_${FORM}_$C.err
     echo "form=$FORM $(python $REPO/tools/pmc_summary.py $D $C step_kernel_ | head -1)" >> $OUT/${TAG}_pmc_summary.txt
   done
 done
 cat $OUT/${TAG}_pmc_summary.txt
-python $REPO/tools/pmc_env_json.py $OUT/${TAG}_pmc_summary.txt $TAG > $OUT/${TAG}_env_kernel_pmc.json
-cat $OUT/${TAG}_env_kernel_pmc.json
 if [ "${3:-}" = "sq" ]; then
   rm -f $OUT/${TAG}_env_multi_sq.txt
   for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM"; do
     D=/tmp/pmcsq_${TAG}_$(echo $SET | tr ' ' '_' | cut -c1-20); rm -rf $D
-    timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $D -o f -- python $REPO/tools/env_kernel_probe.py --forms multi --replays 8 --nograph > /dev/null 2>> $OUT/${TAG}_env_multi_sq.err
+    timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $D -o f -- python $REPO/tools/env_kernel_probe.py --task $TASK --ctl $CTL --forms multi --replays 8 --nograph > /dev/null 2>> $OUT/${TAG}_env_multi_sq.err
     for C in $SET; do python $REPO/tools/pmc_summary.py $D $C step_kernel_multi >> $OUT/${TAG}_env_multi_sq.txt 2>&1; done
   done
   cat $OUT/${TAG}_env_multi_sq.txt
 fi
+python $REPO/tools/pmc_env_json.py $OUT/${TAG}_pmc_summary.txt $TAG $TASK $CTL $OUT/${TAG}_env_multi_sq.txt > $OUT/${TAG}_env_kernel_pmc.json
+cat $OUT/${TAG}_env_kernel_pmc.json

@@ -12,6 +12,8 @@ from airgym_amd.utils.kernel_bench import (ALGO_BYTES_PER_ENV_STEP, env_kernel_s
                                            multi_own_bytes)
 
 path, tag = sys.argv[1], sys.argv[2]
+task, ctl = (sys.argv[3], sys.argv[4]) if len(sys.argv) > 4 else ("hovering", "rate")
+NOBS = {"hovering": 18, "tracking": 48}[task]
 vals = {}
 for line in open(path):
     m = re.match(r"form=(\w+) (\w+) \S+\s+n=\s*(\d+) mean=\s*([\d.]+)", line)
@@ -19,20 +21,32 @@ for line in open(path):
         vals[(m.group(1), m.group(2))] = (float(m.group(4)), int(m.group(3)))
 out, envs, sha = {}, 65536, env_kernel_source_sha()
 MULTI_K = 24
-keys = {"rollout": ("hovering_rate", "ag_step_rollout", False), "api": ("hovering_rate_ag_step", "ag_step", False),
-        "fused": ("hovering_rate_fused", "ag_step_rollout_fused", True),
-        "multi": (f"hovering_rate_multi{MULTI_K}", f"ag_step_multi ({MULTI_K} env steps per launch)", False)}
+keys = {"rollout": (f"{task}_{ctl}", "ag_step_rollout", False), "api": (f"{task}_{ctl}_ag_step", "ag_step", False),
+        "fused": (f"{task}_{ctl}_fused", "ag_step_rollout_fused", True),
+        "multi": (f"{task}_{ctl}_multi{MULTI_K}", f"ag_step_multi ({MULTI_K} env steps per launch)", False)}
 for form, (key, entry, fused) in keys.items():
     if (form, "FETCH_SIZE") not in vals or (form, "WRITE_SIZE") not in vals:
         continue
     (f, nf), (w, nw) = vals[(form, "FETCH_SIZE")], vals[(form, "WRITE_SIZE")]
-    algo = fused_algo_bytes("hovering", "rate", 18, 4) if fused else ALGO_BYTES_PER_ENV_STEP[("hovering", "rate")]
-    out[key] = {"kernel": kernel_name("hovering", "rate", fused, single=form in ("rollout", "api")), "entry_point": entry, "envs": envs,
+    algo = fused_algo_bytes(task, ctl, NOBS, 4) if fused else ALGO_BYTES_PER_ENV_STEP[(task, ctl)]
+    out[key] = {"kernel": kernel_name(task, ctl, fused, single=form in ("rollout", "api")), "entry_point": entry, "envs": envs,
                 "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w, "fetch_correction": 2.0,
                 "traffic_bytes_per_launch": int(round((2.0 * f + w) * 1024)), "algorithmic_bytes_per_launch": algo * envs,
                 "source_sha": sha,
                 **({"steps_per_launch": MULTI_K, "algorithmic_bytes_per_launch": algo * envs * MULTI_K,
-                    "own_bytes_per_launch": int(round(multi_own_bytes("hovering", "rate", 18, 4, MULTI_K) * envs * MULTI_K))}
+                    "own_bytes_per_launch": int(round(multi_own_bytes(task, ctl, NOBS, 4, MULTI_K) * envs * MULTI_K))}
                    if form == "multi" else {}),
                 "source": f"profiles/{tag}_env_kernel_pmc.md (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, {nf} / {nw} dispatches)"}
+mk = f"{task}_{ctl}_multi{MULTI_K}"
+sq_path = sys.argv[5] if len(sys.argv) > 5 else None
+if mk in out and sq_path and os.path.exists(sq_path):
+    sq = {}
+    for line in open(sq_path):
+        m = re.match(r"(\w+) step_kernel_multi\s+n=\s*(\d+) mean=\s*([\d.]+)", line)
+        if m:
+            sq[m.group(1)] = float(m.group(3))
+    if "SQ_ACTIVE_INST_VALU" in sq and "SQ_WAVE_CYCLES" in sq:
+        # two waves (physics + noise) are resident on every SIMD for the whole launch: SIMD-resident time = SQ_WAVE_CYCLES / 2
+        out[mk]["valu_busy_pct"] = round(100.0 * sq["SQ_ACTIVE_INST_VALU"] / (sq["SQ_WAVE_CYCLES"] / 2.0), 1)
+        out[mk]["sq"] = {k: sq[k] for k in sorted(sq)}
 print(json.dumps(out, indent=1))
