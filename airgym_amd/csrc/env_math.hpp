@@ -634,11 +634,32 @@ AG_HD float yaw_diff(float a, float b) {
 }
 
 // tracking.py:194-200, reference point k (k = 0..9)
-AG_HD V3 lemniscate_ref(int progress, int k, float dt) {
-    const float t = (float)(progress + 5 * k) * dt * 0.25f;
-    const float st = sinf(t), ct = cosf(t);
+AG_HD V3 lemniscate_point(float st, float ct) {
     const float iden = fast_rcp(1.0f + ct * ct);
     return V3{3.0f * st * iden, 3.0f * st * ct * iden, 1.0f};
+}
+AG_HD V3 lemniscate_ref(int progress, int k, float dt) {
+    const float t = (float)(progress + 5 * k) * dt * 0.25f;
+    return lemniscate_point(sinf(t), cosf(t));
+}
+// All ten look-ahead points with ONE sinf / cosf pair (round 6; the ten pairs were a third of the Tracking step's instructions).
+// The reference rounds every t_k = (progress + 5k) * dt * 0.25 to float32 on its own (tracking.py:196-197), so t_k is formed exactly
+// as before; what changes is how sin / cos of it are evaluated: e_k = t_k - t_0 is a small angle (<= 45 dt * 0.25 plus the two
+// roundings), known to ~1e-8, and sin(t_0 + e_k), cos(t_0 + e_k) follow from the angle-addition formulas with sin e_k / cos e_k as
+// short Taylor sums (e_k <= 0.12 at dt = 0.01: the first dropped terms are e^7 / 5040 < 1e-10 and e^8 / 40320 < 1e-12).
+// k = 0 is sinf / cosf themselves, bit for bit (the reward's ref_positions[:, 0], tracking.py:232).  Valid while 45 dt * 0.25 < 0.5.
+AG_HD void lemniscate_refs(int progress, float dt, V3* r) {
+    const float t0 = (float)progress * dt * 0.25f;
+    const float s0 = sinf(t0), c0 = cosf(t0);
+    r[0] = lemniscate_point(s0, c0);
+#pragma unroll
+    for (int k = 1; k < 10; ++k) {
+        const float e = (float)(progress + 5 * k) * dt * 0.25f - t0;
+        const float e2 = e * e;
+        const float se = e * (1.0f + e2 * (-1.0f / 6.0f + e2 * (1.0f / 120.0f)));
+        const float ce = 1.0f + e2 * (-0.5f + e2 * (1.0f / 24.0f + e2 * (-1.0f / 720.0f)));
+        r[k] = lemniscate_point(s0 * ce + c0 * se, c0 * ce - s0 * se);
+    }
 }
 
 struct StepOut {
@@ -658,12 +679,13 @@ AG_HD void fill_clean_observations(const EnvState& s, const float* R, const Step
     obs[12] = s.v.x; obs[13] = s.v.y; obs[14] = s.v.z;
     obs[15] = s.w.x; obs[16] = s.w.y; obs[17] = s.w.z;
     if (TASK == TASK_TRACKING) {
+        V3 r[10];
+        lemniscate_refs(s.progress, P.dt, r);
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
-            const V3 r = lemniscate_ref(s.progress, k, P.dt);
-            obs[18 + 3 * k + 0] = r.x - s.p.x;
-            obs[18 + 3 * k + 1] = r.y - s.p.y;
-            obs[18 + 3 * k + 2] = r.z - s.p.z;
+            obs[18 + 3 * k + 0] = r[k].x - s.p.x;
+            obs[18 + 3 * k + 1] = r[k].y - s.p.y;
+            obs[18 + 3 * k + 2] = r[k].z - s.p.z;
         }
     }
 }

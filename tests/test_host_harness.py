@@ -360,3 +360,35 @@ def test_stagger_progress_matches_oracle(lib):
     assert out.min() >= 0 and out.max() <= max_len - 2 and len(np.unique(out)) > n // 2
     # default (flag off): all zero, the reference's hovering.py:333
     assert HoveringRef(8, "rate", seed=seed).progress_buf.sum() == 0
+
+
+def test_tracking_lookahead_over_the_whole_episode(lib):
+    """Round 6: the ten lemniscate look-ahead points share ONE sinf / cosf pair (env_math.hpp::lemniscate_refs: angle addition with
+    the small angle t_k - t_0, t_k rounded to float32 exactly as tracking.py:196-197 rounds it).  Sweep progress over the whole
+    36 s episode - t up to 9.1 rad, where one float32 ulp of t is 1e-6 - against the oracle's ten sin / cos pairs: observation columns
+    18:48 within 2e-6 (the tolerance the reference recordings are held to on the GPU)."""
+    n, seed = 3600, 11
+    ora = TrackingRef(n, ctl_mode="vel", seed=seed)
+    har = HarnessEnv(lib, "tracking", "vel", n, seed)
+    prog = np.arange(n, dtype=np.int32)
+    prog[-8:] = 3580                                       # (keep away from the time limit: no reset inside this step)
+    ora.progress_buf[:] = torch.from_numpy(prog.astype(np.int64))
+    har.progress[:] = prog
+    # put every env ON its reference point (one step later), so that nobody leaves the 1 m tube and resets
+    t = (prog + 1).astype(np.float64) * 0.01 * 0.25
+    pos = np.stack([3 * np.sin(t) / (1 + np.cos(t) ** 2), 3 * np.sin(t) * np.cos(t) / (1 + np.cos(t) ** 2), np.ones_like(t)], 1)
+    rs = har.rs.copy()
+    rs[:, 0:3] = pos.astype(np.float32)
+    rs[:, 3:7] = (0, 0, 0, 1)
+    rs[:, 7:13] = 0
+    har.rs[:] = rs
+    ora.root_states[:] = torch.from_numpy(rs)
+    a = np.zeros((n, 4), np.float32)
+    obs, _, rew, reset, _ = ora.step(torch.from_numpy(a))
+    har.step(a)
+    keep = (reset.numpy() == 0) & (har.done == 0)          # envs that reset show the post-reset observation
+    assert keep.sum() > 3000
+    d = np.abs(har.obs[keep, 18:48] - obs.numpy()[keep, 18:48])
+    assert d.max() < 2e-6, d.max()
+    # the first point is the reward's ref_positions[:, 0]: the same sinf / cosf as before this change
+    np.testing.assert_allclose(har.rew[keep], rew.numpy()[keep], rtol=0, atol=1e-5)

@@ -26,8 +26,9 @@ symbols = {}
 if trace and os.path.exists(trace):      # full symbols (template arguments) from the kernel trace of the same build
     for line in open(trace):
         m = re.match(r"\| `([^`]+)` \| (\d+) \| [\d.]+ \| ([\d.]+) ", line)
-        if m:
-            symbols.setdefault(m.group(1).split("(")[0], float(m.group(3)))
+        k = re.search(r"(split_\w+<[^>]*>)", m.group(1)) if m else None
+        if k:       # rows are sorted by total time: the first row of a kernel family is the instantiation the step launches
+            symbols.setdefault(k.group(1).replace(" ", ""), float(m.group(3)))
 launches = {"ag_split_gemm_input_loss_heads_bwd": "split_gemm_kernel<true", "ag_split_wgrad_input": "split_wgrad_fin_kernel",
             "ag_split_gemm_input_wgrad_recompute": "split_gemm_kernel<false"}
 out, sha = {}, update_source_sha()
@@ -35,7 +36,7 @@ for entry, sub in launches.items():
     if (sub, "FETCH_SIZE") not in vals or (sub, "WRITE_SIZE") not in vals:
         continue
     (f, nf), (w, nw) = vals[(sub, "FETCH_SIZE")], vals[(sub, "WRITE_SIZE")]
-    rec = {"kernel": next((s for s in symbols if sub in s and "_bf16" not in s and "planes1" not in s), "ag::" + sub + ",...>"),
+    rec = {"kernel": next((s for s in symbols if sub in s), sub + ",...>"),
            "entry_point": entry, "rows": 196608,
            "FETCH_SIZE_KB_mean": f, "WRITE_SIZE_KB_mean": w, "fetch_correction": 2.0,
            "traffic_bytes_per_launch": int(round((2.0 * f + w) * 1024)), "source_sha": sha,
