@@ -72,13 +72,23 @@ class DedupFrames:
     every env: the camera runs on a global cadence).  Slicing [b0:b1] - what PPODataset does for a minibatch - yields the
     distinct images of those samples, the sample -> image map and the multiplicities."""
 
-    def __init__(self, frames, frame_of_step, horizon, in_place=False):
+    def __init__(self, frames, frame_of_step, horizon, in_place=False, cache=None):
         self.frames = frames
         self.in_place = in_place
         self.S, self.N = frames.shape[0], frames.shape[1]
         self.H = horizon
-        self.frame_of_step = torch.tensor(frame_of_step, dtype=torch.long, device=frames.device)
-        self._slices = {}           # (start, stop) -> index tensors: the mini-epochs of an update ask for the same slices again
+        # (start, stop) -> index tensors: the mini-epochs of an update ask for the same slices again.  `cache` (the agent's, keyed
+        # by the camera's step pattern): the SAME tensors epoch after epoch - the camera runs on a global cadence, so the pattern
+        # repeats - which is what lets a captured minibatch graph keep reading them
+        pattern = tuple(int(f) for f in frame_of_step)
+        if cache is not None:
+            ent = cache.get(pattern)
+            if ent is None:
+                ent = cache[pattern] = {"frame_of_step": torch.tensor(pattern, dtype=torch.long, device=frames.device), "slices": {}}
+            self.frame_of_step, self._slices = ent["frame_of_step"], ent["slices"]
+        else:
+            self.frame_of_step = torch.tensor(pattern, dtype=torch.long, device=frames.device)
+            self._slices = {}
 
     def __len__(self):
         return self.N * self.H
@@ -99,6 +109,7 @@ class DedupFrames:
         flat = self.frames.view((self.S * self.N,) + tuple(self.frames.shape[2:]))
         rows = (uniq - u_env * self.S) * self.N + u_env
         counts = counts.to(torch.float32)
+        counts.ag_sum = float(sl.stop - sl.start)      # sum of the multiplicities, known without a device read (fused_cnn._Trunk)
         self._slices[(sl.start, sl.stop)] = (rows, inverse, counts)
         if self.in_place:       # the model reads flat[rows] where it lies (cnn.forward(..., index)): no [U, 1, 212, 120] copy
             return {"image": flat, "image_index": rows, "image_inverse": inverse, "image_counts": counts}
@@ -355,6 +366,13 @@ class A2CAgent:
         self._graph_update = bool(self._fused_step is not None and self.use_hip_graph
                                   and config.get("use_hip_graph_update", self.minibatch_size <= 32768))
         self._upd_graphs = {}
+        # generic update path (no FusedMLPStep: e.g. Planning's CNN + MLP(64,128,64)): the whole minibatch step - trunk forward,
+        # fused PPO loss, autograd backward, clip + Adam + LR rule, ~150 small launches around the convolutions - as one hipGraph per
+        # (minibatch index, statistics on / off, frame store, gamma-guard answer); `use_hip_graph_update: false` switches it off
+        self._graph_generic = False
+        self._graph_generic_error = None
+        self._upd_pool = None
+        self._dedup_index_cache = {}
         self._ds_bufs = None
         self._rollouts_done = 0
         self.obs = None
@@ -439,6 +457,7 @@ class A2CAgent:
             self._frame_feat = torch.zeros(N, self.model.feature_dim, **f)
             self._frame_of_slot = [0] * (H + 1)
             self._frame_top = 0
+            self._graph_generic = self._generic_graph_ok()
         elif isinstance(self.obs_shape, dict):
             self.obs_buf = {k: torch.zeros((H + 1, N) + tuple(shp), **f) for k, shp in self.obs_shape.items()}
         else:
@@ -501,7 +520,7 @@ class A2CAgent:
         return {"rollout_step": rollout, "update": update,
                 "optimizer": "ag_adam_clip_step (HIP)" if self.config.get("use_fused_adam", True) and str(self.ppo_device).startswith("cuda")
                 else "FlatAdam (torch)",
-                "minibatch_hip_graphs": bool(getattr(self, "_graph_update", False))}
+                "minibatch_hip_graphs": bool(getattr(self, "_graph_update", False) or getattr(self, "_graph_generic", False))}
 
     def _dedup_ok(self):
         m = self.model
@@ -737,7 +756,8 @@ class A2CAgent:
             mb_returns = mb_advs + self.values_buf
         if getattr(self, "_dedup", False):
             obses = {"observation": swap_and_flatten01(self.obs_buf["observation"][:H]),
-                     "frames": DedupFrames(self._frames, self._frame_of_slot[:H], H, in_place=self._frames.is_cuda)}
+                     "frames": DedupFrames(self._frames, self._frame_of_slot[:H], H, in_place=self._frames.is_cuda,
+                                           cache=self._dedup_index_cache)}
         elif isinstance(self.obs_buf, dict):
             obses = {k: swap_and_flatten01(v[:H]) for k, v in self.obs_buf.items()}
         else:
@@ -788,14 +808,77 @@ class A2CAgent:
             "returns": returns, "actions": batch_dict["actions"], "obs": batch_dict["obses"],
             "dones": batch_dict["dones"], "mu": batch_dict["mus"], "sigma": batch_dict["sigmas"],
         }
-        if self._graph_update:
-            # captured minibatch graphs read fixed addresses: keep the dataset in persistent buffers
+        if self._graph_update or self._graph_generic:
+            # captured minibatch graphs read fixed addresses: keep the dataset in persistent buffers (dict observations: the
+            # state vector is copied, the frame store and its cached index tensors are persistent already)
+            def persist(v):
+                return {kk: (torch.empty_like(vv, memory_format=torch.contiguous_format) if torch.is_tensor(vv) else None)
+                        for kk, vv in v.items()} if isinstance(v, dict) else torch.empty_like(v, memory_format=torch.contiguous_format)
             if self._ds_bufs is None:
-                self._ds_bufs = {k: torch.empty_like(v, memory_format=torch.contiguous_format) for k, v in values_dict.items()}
+                self._ds_bufs = {k: persist(v) for k, v in values_dict.items()}
             for k, v in values_dict.items():
-                self._ds_bufs[k].copy_(v)
+                if isinstance(v, dict):
+                    for kk, vv in v.items():
+                        if torch.is_tensor(vv):
+                            self._ds_bufs[k][kk].copy_(vv)
+                        else:
+                            self._ds_bufs[k][kk] = vv
+                else:
+                    self._ds_bufs[k].copy_(v)
             values_dict = self._ds_bufs
         self.dataset.update_values_dict(values_dict)
+
+    def _generic_graph_ok(self):
+        """Minibatch hipGraphs on the generic path: CUDA, the fused PPO loss (no host read between forward and backward), the
+        de-duplicated frame store (persistent image addresses and index tensors), one GPU (the gradient all-reduce of a multi-GPU
+        run stays eager here)."""
+        return (self._fused_step is None and bool(self.config.get("use_hip_graph_update", True)) and getattr(self, "_dedup", False)
+                and self._fused_loss_ok() and not self.multi_gpu and self._graph_generic_error is None)
+
+    def _generic_graph_step(self, idx, mb):
+        """One optimizer step of the generic path as a hipGraph replay (captured on first use from the third epoch on: by then the
+        allocator, the autograd engine and the library workspaces have seen the step)."""
+        cnn = getattr(self.model, "actor_cnn", None)
+        stats_on = bool(self.model.update_stats)
+        fw = bool(cnn.guard_decision(self.ppo_device)) if (cnn is not None and cnn.features[2].training) else False
+        obs = mb["obs"]
+        # (frame store in use, index tensors of this slice: a rollout whose camera pattern differs gets graphs of its own)
+        key = (idx, stats_on, fw, obs["image"].data_ptr() if isinstance(obs, dict) and "image" in obs else 0,
+               obs["image_index"].data_ptr() if isinstance(obs, dict) and "image_index" in obs else 0)
+        entry = self._upd_graphs.get(key)
+        if entry is None:
+            out = torch.zeros(6, dtype=torch.float32, device=self.ppo_device)
+
+            def body():
+                a, c, e, b, mu, sigma = self._loss_and_backward(mb)
+                kl = self._reduce_clip_step()
+                out[0].copy_(a.reshape(())); out[1].copy_(c.reshape(())); out[2].copy_(e.reshape(())); out[3].copy_(b.reshape(()))
+                out[4].copy_(kl.reshape(()))
+                if self._last_clip is not None:
+                    out[5].copy_(self._last_clip.reshape(()))
+            if cnn is not None:
+                cnn.capture_decision = fw
+            try:
+                if self._upd_pool is None:
+                    self._upd_pool = torch.cuda.graph_pool_handle()
+                graph = self._capture(body, warmup=False, pool=self._upd_pool)
+            except Exception as e:      # a stack that refuses the capture: remember why, run eagerly from here on
+                self._graph_generic_error = f"{type(e).__name__}: {e}"[:300]
+                self._graph_generic = False
+                torch.cuda.synchronize()
+                print(f"[airgym_amd] minibatch hipGraph capture failed, eager update from here on: {self._graph_generic_error}",
+                      file=__import__("sys").stderr, flush=True)
+                return None
+            finally:
+                if cnn is not None:
+                    cnn.capture_decision = None
+            entry = (graph, out, mb)       # mb kept alive: the graph reads its views
+            self._upd_graphs[key] = entry
+            # (the capture itself does not execute: fall through to the replay)
+        entry[0].replay()
+        st = entry[1].clone()
+        self._last_clip = st[5]
+        return st[0], st[1], st[2], st[3], st[4].double()
 
     def _fused_loss_ok(self):
         m = self.model
@@ -941,14 +1024,19 @@ class A2CAgent:
             self._last_clip = st[6]
             kl = self._reduce_clip_step(need_kl=self.multi_gpu)      # multi-GPU: the rank-averaged KL
             return st[0], st[1], st[2], st[3], (kl if self.multi_gpu else st[4])
+        if self._graph_generic and self.epoch_num >= 3 and mb["actions"].shape[0] == self.minibatch_size:
+            res = self._generic_graph_step(idx, mb)
+            if res is not None:
+                return res
         a, c, e, b, mu, sigma = self._loss_and_backward(mb)
         kl = self._reduce_clip_step()
         if mu is not None:      # the fused kernel already wrote the new rows back in place
             self.dataset.update_mu_sigma(mu, sigma)
         return a, c, e, b, kl
 
-    def _capture(self, fn, warmup=True):
-        """Capture fn() into a hipGraph on a side stream (torch.cuda.graph); returns the graph."""
+    def _capture(self, fn, warmup=True, pool=None):
+        """Capture fn() into a hipGraph on a side stream (torch.cuda.graph); returns the graph.  pool: a shared graph memory pool
+        (graphs that are replayed one after the other and keep nothing alive between replays may share their scratch memory)."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -958,7 +1046,7 @@ class A2CAgent:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread may issue HIP calls while we capture (multi-GPU runs)
-        with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, pool=pool, stream=s, capture_error_mode="thread_local"):
             out = fn()
         g.outputs = out
         return g

@@ -28,6 +28,7 @@ class CNNFeatureExtractor(nn.Module):
         self._gamma_ratio_host = None      # pinned [1] float32: min_c |gamma_c| / max_c |gamma_c| over the guarded layers
         self._gamma_ratio_event = None
         self.bn_fallback_steps = 0         # training forwards that took the reduction kernels because of the guard
+        self.capture_decision = None       # set by an owner that captures training steps in hipGraphs (see guard_decision)
         self.dgrad_epilogue = True      # (with bn_sums_from_weights) the second layer's ReLU + BatchNorm backward in the epilogue of the
                                         # third convolution's input gradient; False: as a pass of its own (ag_relu_bn_bwd_dx)
         self.conv1_wgrad_fused = True   # (with bn_sums_from_weights) conv2's input gradient + layer 1's backward + conv1's weight gradient
@@ -67,8 +68,10 @@ class CNNFeatureExtractor(nn.Module):
         if not self.bn_sums_from_weights:
             return False
         if torch.cuda.is_current_stream_capturing():
-            # event.synchronize() + a pinned host copy cannot be part of a hipGraph: inside a capture take the reduction kernels
-            return False
+            # event.synchronize() + a pinned host copy cannot be part of a hipGraph.  A caller that captures the step decides
+            # OUTSIDE the capture (guard_decision(), every step, as the eager path does) and keys its graphs by the answer;
+            # without such a caller the captured step takes the reduction kernels (exact for any gamma)
+            return bool(self.capture_decision) if self.capture_decision is not None else False
         g1, g2 = self.features[2].weight, self.features[5].weight
         ratio = torch.minimum(g1.abs().min() / g1.abs().max().clamp_min(1e-30),
                               g2.abs().min() / g2.abs().max().clamp_min(1e-30)).float().reshape(1)
@@ -89,6 +92,14 @@ class CNNFeatureExtractor(nn.Module):
         if not ok:
             self.bn_fallback_steps += 1
         return ok
+
+    def guard_decision(self, device):
+        """The gamma guard's answer for the NEXT training forward, taken outside any capture (refreshes the pinned ratio exactly as an
+        eager step would).  An owner that replays captured steps calls this before every replay, keeps one graph per answer and
+        sets `capture_decision` while it captures."""
+        if not self.bn_sums_from_weights:
+            return False
+        return self._sums_from_weights_ok(device)
 
     def forward(self, x, weights=None, norm=None, index=None):
         """weights [N] (optional, training): image i stands for weights[i] identical images of the minibatch (frame

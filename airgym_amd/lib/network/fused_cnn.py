@@ -253,9 +253,12 @@ class _Trunk(torch.autograd.Function):
             index = index.to(device=img.device, dtype=torch.long).contiguous()
         n = img.shape[0] if index is None else index.shape[0]
         if weights is not None:
+            # the sum of the multiplicities is the number of samples the distinct images stand for: a caller that knows it
+            # (DedupFrames: the length of the minibatch slice) attaches it as `ag_sum`, and the step has no host synchronisation
+            known = getattr(weights, "ag_sum", None)
             weights = weights.to(device=img.device, dtype=torch.float32).contiguous()
             assert weights.shape == (n,)
-            wsum = float(weights.double().sum().item())
+            wsum = float(known) if known is not None else float(weights.double().sum().item())
         else:
             wsum = float(n)
         w1, w2, w3 = w1.contiguous(), w2.contiguous(), w3.contiguous()

@@ -251,7 +251,7 @@ def side_config_bf16(args, epochs=5, warmup=3):
     return out
 
 
-def side_config_planning(envs=16384, epochs=3, warmup=1, minibatches=24):
+def side_config_planning(envs=16384, epochs=3, warmup=4, minibatches=24):
     """BASELINE config 4 on one GPU: Planning, 16 384 envs, CTBR, 212 x 120 depth image every 4th step, the trainable CNN
     policy of the shipped YAML (reference: airgym/envs/task/planning.py:138-184, scripts/config/ppo_planning.yaml:31,
     lib/network/cnn.py:3-33).  The frozen-VAE encoder of BASELINE's wording has no shipped weights (.MISSING_LARGE_BLOBS);
@@ -273,7 +273,10 @@ def side_config_planning(envs=16384, epochs=3, warmup=1, minibatches=24):
                       "image": [1, 212, 120], "camera_every": 4, "horizon_length": agent.horizon_length,
                       "mini_epochs": agent.mini_epochs_num, "minibatch_size": agent.minibatch_size,
                       "policy": "CNNFeatureExtractor(30) + MLP(64,128,64), ppo_planning.yaml",
-                      "frame_dedup": bool(getattr(agent, "_dedup", False))},
+                      "frame_dedup": bool(getattr(agent, "_dedup", False)),
+                      "minibatch_hip_graphs": bool(getattr(agent, "_graph_generic", False)),
+                      "minibatch_graphs_captured": len(getattr(agent, "_upd_graphs", {})),
+                      "minibatch_graph_error": getattr(agent, "_graph_generic_error", None)},
            "rollout_ms": play / epochs * 1e3, "update_ms": upd / epochs * 1e3,
            "mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
            "last_kl": st["kl"], "finite": bool(st["kl"] == st["kl"] and st["a_loss"] == st["a_loss"])}

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--encode-chunk", type=int, default=0, help="vae: images per encoder call (0 = all at once)")
     ap.add_argument("--fused-relu-bn", type=int, default=1, help="ReLU + BatchNorm2d pairs on csrc/cnn_kernels.hip")
+    ap.add_argument("--graph-update", type=int, default=1, help="minibatch steps as hipGraphs (use_hip_graph_update)")
     args = ap.parse_args()
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
@@ -42,6 +43,7 @@ def main():
                                     "interpolation_mode": "bilinear", "return_sampled_latent": False,
                                     "encode_chunk": args.encode_chunk}
     params["seed"] = 0
+    c["use_hip_graph_update"] = bool(args.graph_update)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
     agent = A2CAgent("planning_bench", params)
@@ -67,7 +69,8 @@ def main():
                       "value": args.envs * args.horizon * args.steps / dt, "ms_per_epoch": dt / args.steps * 1e3,
                       "rollout_ms": play / args.steps * 1e3, "update_ms": upd / args.steps * 1e3,
                       "minibatch": c["minibatch_size"], "mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-                      "kl": st["kl"], "a_loss": st["a_loss"]}))
+                      "kl": st["kl"], "a_loss": st["a_loss"], "c_loss": st["c_loss"], "graph_update": bool(getattr(agent, "_graph_generic", False)),
+                      "graphs": len(getattr(agent, "_upd_graphs", {})), "graph_error": getattr(agent, "_graph_generic_error", None)}))
 
 
 if __name__ == "__main__":
