@@ -368,7 +368,8 @@ class A2CAgent:
         self._upd_graphs = {}
         # generic update path (no FusedMLPStep: e.g. Planning's CNN + MLP(64,128,64)): the whole minibatch step - trunk forward,
         # fused PPO loss, autograd backward, clip + Adam + LR rule, ~150 small launches around the convolutions - as one hipGraph per
-        # (minibatch index, statistics on / off, frame store, gamma-guard answer); `use_hip_graph_update: false` switches it off
+        # (minibatch index, statistics on / off, frame store, gamma-guard answer); opt-in (`use_hip_graph_update: true`): measured
+        # slower than the eager step on Planning, see _generic_graph_ok
         self._graph_generic = False
         self._graph_generic_error = None
         self._upd_pool = None
@@ -829,10 +830,13 @@ class A2CAgent:
         self.dataset.update_values_dict(values_dict)
 
     def _generic_graph_ok(self):
-        """Minibatch hipGraphs on the generic path: CUDA, the fused PPO loss (no host read between forward and backward), the
-        de-duplicated frame store (persistent image addresses and index tensors), one GPU (the gradient all-reduce of a multi-GPU
-        run stays eager here)."""
-        return (self._fused_step is None and bool(self.config.get("use_hip_graph_update", True)) and getattr(self, "_dedup", False)
+        """Minibatch hipGraphs on the generic path (OPT-IN, `use_hip_graph_update: true`): CUDA, the fused PPO loss (no host read
+        between forward and backward), the de-duplicated frame store (persistent image addresses and index tensors), one GPU.
+        Measured on Planning at 16 384 envs (round 6, one box, `tools/bench_planning_ppo.py --graph-update 0 | 1`): 96 graphs capture
+        and replay correctly, and the epoch gets SLOWER - 1 059 ms against 1 025 ms eager, +4.7 GB - because the step is 93 % seven
+        convolution kernels of ~1 ms each and the host already runs ahead of them (the one host read of the step, the
+        multiplicity sum in the CNN trunk, is gone); a hipGraph node costs about what an eager launch costs.  Hence off by default."""
+        return (self._fused_step is None and bool(self.config.get("use_hip_graph_update", False)) and getattr(self, "_dedup", False)
                 and self._fused_loss_ok() and not self.multi_gpu and self._graph_generic_error is None)
 
     def _generic_graph_step(self, idx, mb):

@@ -251,7 +251,7 @@ def side_config_bf16(args, epochs=5, warmup=3):
     return out
 
 
-def side_config_planning(envs=16384, epochs=3, warmup=4, minibatches=24):
+def side_config_planning(envs=16384, epochs=3, warmup=2, minibatches=24):
     """BASELINE config 4 on one GPU: Planning, 16 384 envs, CTBR, 212 x 120 depth image every 4th step, the trainable CNN
     policy of the shipped YAML (reference: airgym/envs/task/planning.py:138-184, scripts/config/ppo_planning.yaml:31,
     lib/network/cnn.py:3-33).  The frozen-VAE encoder of BASELINE's wording has no shipped weights (.MISSING_LARGE_BLOBS);

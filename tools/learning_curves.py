@@ -77,6 +77,8 @@ def run(name, envs, minibatches, epochs, every, units=(256, 256), seed=0, extra=
                           "length": round(float(agent.game_lengths.get_mean()[0]), 1) if have else None,
                           "kl": round(st["kl"], 5), "lr": round(st["last_lr"], 7), "a_loss": round(st["a_loss"], 5),
                           "c_loss": round(st["c_loss"], 5),
+                          # mean raw reward per env-step over ALL samples of this epoch's rollout (the whole population)
+                          "step_reward": round(float(agent.raw_rewards_buf.mean()), 4) if hasattr(agent, "raw_rewards_buf") else None,
                           "exp_var": round(float(agent.diag_dict.get("diagnostics/exp_var", float("nan"))), 4)})
     wall = time.time() - t0
     out = {"run": name, "envs": envs, "minibatch_size": agent.minibatch_size,
