@@ -268,11 +268,6 @@ SYMBOLS = [
     ("ag_sum_rows_multi", ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_longlong, _P]),
     ("ag_sum_rows_multi_finalize", ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_longlong, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P,
                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),
-    ("ag_sum_rows_stage1_finalize", ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_longlong, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P,
-                                                   ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P]),
-    ("ag_update_tail_barrier_bytes", ctypes.c_int, []),
-    ("ag_update_tail", ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_longlong, _P, _P, _P, _P, _P, ctypes.c_int] + [ctypes.c_float] * 8
-                                      + [_P, _P, ctypes.c_int, _P, _P, _P, _P, _P]),
     ("ag_heads_bwd_elu_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     ("ag_elu_bwd_input_wgrad", ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P]),
     ("ag_elu_bwd_bias_rows_per_block", ctypes.c_int, []),

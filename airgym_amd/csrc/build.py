@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 25 translation units compiled in parallel).
+"""Build libairgym_hip.so for gfx950 with hipcc (no cmake; 24 translation units compiled in parallel).
 
     python airgym_amd/csrc/build.py [--force] [--jobs N] [--experiments]
 
@@ -24,7 +24,7 @@ ARCH = "gfx950"
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
-HEADERS = ["env_math.hpp", "planning_math.hpp", "kernel_args.hpp", "rollout_math.hpp", "handle.hpp", "split_common.hpp", "ppo_loss_math.hpp", "tail_parts.hpp",
+HEADERS = ["env_math.hpp", "planning_math.hpp", "kernel_args.hpp", "rollout_math.hpp", "handle.hpp", "split_common.hpp", "ppo_loss_math.hpp",
            os.path.join("..", "..", "include", "airgym_hip.h")]
 
 
@@ -49,7 +49,7 @@ def units(experiments=False):
             out.append((os.path.join(od, f"step_{task}_{ctl}.o"), "step_kernel.hip",
                         [f"-DAG_TASK={task}", f"-DAG_CTL={ctl}", "-ffp-contract=on"] + x))
     for name in ("airgym_hip", "ppo_kernels", "planning_kernel", "rollout_kernels", "split_gemm", "split_wgrad", "cnn_kernels", "conv_kernels", "mlp_chain",
-                 "first_layer", "update_tail"):
+                 "first_layer"):
         # rollout_kernels.hip shares rollout_math.hpp with the fused step kernel (policy sampling, reward shaping): same rule
         # mlp_chain.hip: the K-step loop of the chain kernel must be unrolled completely (its accumulator tiles are indexed by the
         # step); at 20 steps (Tracking's 48 inputs) the body exceeds LLVM's default budget for `#pragma unroll`, the loop stays

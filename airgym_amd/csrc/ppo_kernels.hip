@@ -14,7 +14,6 @@
 
 #include "../../include/airgym_hip.h"
 #include "ppo_loss_math.hpp"
-#include "tail_parts.hpp"
 
 namespace {
 
@@ -249,17 +248,37 @@ __global__ __launch_bounds__(256) void elu_bwd_bias_kernel(const float* __restri
 // state_dev: double[2] = {lr, step};  kl is read from grad[n] (the scalar appended to the flat gradient).
 // Replaces ~35 tiny launches per optimizer step (a single-workgroup version took 104 us; this one 14 us).
 // ---------------------------------------------------------------------------------------------------
-// (AdamArgs, kAdamBlocks = 64 workgroups of kAdamThreads = 256 and the device bodies: tail_parts.hpp)
+struct AdamArgs {
+    float* p; float* g; float* m; float* v;
+    double* state;   // unused by the kernels (kept for symmetry with the C entry point)
+    int n;
+    float beta1, beta2, eps, weight_decay, max_grad_norm;   // max_grad_norm <= 0: no clipping
+    float kl_threshold, min_lr, max_lr;                     // kl_threshold <= 0: LR not adapted
+};
 
 // Phase 1 of the optimizer step: per-block partial sums of g^2 (grid = kAdamBlocks).
+constexpr int kAdamBlocks = 64;
+constexpr int kAdamThreads = 256;
+
 // Block 0 also snapshots {lr, step} into `snap`: phase 2 reads the snapshot and publishes the new pair straight into the caller's
 // slot (no block of phase 2 reads what block 0 of phase 2 writes) - the 16-byte device-to-device copy that used to follow is gone.
 __global__ __launch_bounds__(kAdamThreads) void adam_norm_kernel(const float* __restrict__ g, int n, float* __restrict__ partial,
                                                                   const double* __restrict__ state, double* __restrict__ snap) {
     __shared__ float red[kAdamThreads / 64];
     if (blockIdx.x == 0 && threadIdx.x == 0) { snap[0] = state[0]; snap[1] = state[1]; }
-    const float t = adam_norm_block(g, n, blockIdx.x, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    float ss = 0.f;
+    for (int i = blockIdx.x * kAdamThreads + threadIdx.x; i < n; i += kAdamBlocks * kAdamThreads) {
+        const float x = g[i];
+        ss += x * x;
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kAdamThreads / 64; ++w) t += red[w];
+        partial[blockIdx.x] = t;
+    }
 }
 
 // Phase 2: every block re-reduces the 64 partials (deterministic order), reads {lr, step} from state_in (phase 1's snapshot),
@@ -267,12 +286,38 @@ __global__ __launch_bounds__(kAdamThreads) void adam_norm_kernel(const float* __
 __global__ __launch_bounds__(kAdamThreads) void adam_clip_step_kernel(const AdamArgs k, const float* __restrict__ partial,
                                                                        const double* __restrict__ state_in,
                                                                        double* __restrict__ state_out) {
-    const AdamScalars s = adam_scalars(k, partial, state_in[0], state_in[1]);
+    float tot = 0.f;
+    for (int w = 0; w < kAdamBlocks; ++w) tot += partial[w];
+    const float norm = sqrtf(tot);
+    const float coef = (k.max_grad_norm > 0.f) ? fminf(k.max_grad_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+    const double lr = state_in[0];
+    const double step = state_in[1] + 1.0;
+    const double bc1 = 1.0 - pow((double)k.beta1, step);
+    const double bc2 = 1.0 - pow((double)k.beta2, step);
+    const float step_size = (float)(lr / bc1);
+    const float bc2r = (float)(1.0 / sqrt(bc2));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        state_out[0] = adam_next_lr(k, s.lr);
-        state_out[1] = s.step;
+        double nlr = lr;
+        if (k.kl_threshold > 0.f) {      // legacy schedule: evaluated every minibatch, applies to the NEXT step
+            const double kl = (double)k.g[k.n];
+            if (kl > 2.0 * k.kl_threshold) nlr = fmax(lr / 1.5, (double)k.min_lr);
+            if (kl < 0.5 * k.kl_threshold) nlr = fmin(lr * 1.5, (double)k.max_lr);
+        }
+        state_out[0] = nlr;
+        state_out[1] = step;
     }
-    for (int i = blockIdx.x * kAdamThreads + threadIdx.x; i < k.n; i += kAdamBlocks * kAdamThreads) adam_update_element(k, s, i);
+    for (int i = blockIdx.x * kAdamThreads + threadIdx.x; i < k.n; i += kAdamBlocks * kAdamThreads) {
+        float g = k.g[i] * coef;
+        k.g[i] = g;
+        const float p = k.p[i];
+        if (k.weight_decay != 0.f) g += k.weight_decay * p;
+        const float m = k.beta1 * k.m[i] + (1.f - k.beta1) * g;
+        const float v = k.beta2 * k.v[i] + (1.f - k.beta2) * g * g;
+        k.m[i] = m;
+        k.v[i] = v;
+        const float denom = sqrtf(v) * bc2r + k.eps;
+        k.p[i] = p - step_size * (m / denom);
+    }
 }
 
 }  // namespace
@@ -814,7 +859,27 @@ extern "C" int ag_elu_bwd_input_wgrad(const float* dh, const float* h, const flo
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-// (SumJobs, find_job, kSumMaxGroups, the stage-2 body and the host-side job table: tail_parts.hpp)
+constexpr int kSumMaxGroups = 64;        // partial rows are first summed in up to 64 groups per job (>= 8 rows per group)
+constexpr int kMaxSumJobs = AG_MAX_SUM_JOBS;
+
+struct SumJobs {
+    const float* in[kMaxSumJobs];
+    float* out[kMaxSumJobs];
+    int S[kMaxSumJobs];
+    int n4[kMaxSumJobs];
+    int groups[kMaxSumJobs];
+    int block0_s1[kMaxSumJobs + 1];       // first flat block of each job in stage 1 (blocks = ceil(n4/64) * groups)
+    int block0_s2[kMaxSumJobs + 1];       // ... and in stage 2 (blocks = ceil(n4/64))
+    long long scratch_off[kMaxSumJobs];   // in floats, into scratch [sum over jobs of groups * n]
+    float* scratch;
+    int njobs;
+};
+
+__device__ __forceinline__ int find_job(const int* block0, int njobs, int b) {
+    int j = 0;
+    while (j + 1 < njobs && b >= block0[j + 1]) ++j;
+    return j;
+}
 
 // block = 64 float4 columns x 4 row lanes.  FIN: one more workgroup behind the last job's blocks runs ppo_loss_finalize's body (its
 // inputs - the loss partials of the forward launch - are long complete, its outputs are other slots of the flat gradient than the
@@ -858,7 +923,28 @@ __global__ __launch_bounds__(256) void sum_rows_stage1_kernel(const SumJobs k, c
 
 __global__ __launch_bounds__(256) void sum_rows_stage2_kernel(const SumJobs k) {
     __shared__ float4 red[256];
-    sum_stage2_block(k, blockIdx.x, red);
+    const int j = find_job(k.block0_s2, k.njobs, blockIdx.x);
+    const int bx = blockIdx.x - k.block0_s2[j];
+    const int n4 = k.n4[j], G = k.groups[j];
+    const int col = bx * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x >> 6;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < n4) {
+        const float4* src = reinterpret_cast<const float4*>(k.scratch + k.scratch_off[j]);
+#pragma unroll 4
+        for (int g = lane; g < G; g += 4) {
+            const float4 v = src[(size_t)g * n4 + col];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && col < n4) {
+        const float4 s0 = red[threadIdx.x], s1 = red[threadIdx.x + 64], s2 = red[threadIdx.x + 128], s3 = red[threadIdx.x + 192];
+        float* dst = k.out[j] + (size_t)col * 4;
+        dst[0] = (s0.x + s1.x) + (s2.x + s3.x); dst[1] = (s0.y + s1.y) + (s2.y + s3.y);
+        dst[2] = (s0.z + s1.z) + (s2.z + s3.z); dst[3] = (s0.w + s1.w) + (s2.w + s3.w);
+    }
 }
 
 }  // namespace
@@ -866,16 +952,40 @@ __global__ __launch_bounds__(256) void sum_rows_stage2_kernel(const SumJobs k) {
 extern "C" int ag_sum_rows_groups(void) { return kSumMaxGroups; }
 
 static int sum_rows_multi_launch(const ag_sum_job* jobs, int njobs, float* scratch, long long scratch_floats, const FinalizeArgs* fin,
-                                 void* stream, bool stage2 = true) {
-    SumJobs k;
+                                 void* stream) {
+    if (!jobs || !scratch || njobs <= 0) return AG_ERR_INVALID_ARG;
+    if (njobs > kMaxSumJobs) return AG_ERR_UNSUPPORTED;
+    SumJobs k{};
+    k.scratch = scratch;
+    k.njobs = njobs;
+    long long off = 0;
     int b1 = 0, b2 = 0;
-    const int rc = build_sum_jobs(jobs, njobs, scratch, scratch_floats, k, b1, b2);
-    if (rc != AG_OK) return rc;
+    for (int j = 0; j < njobs; ++j) {
+        if (!jobs[j].partials_dev || !jobs[j].out_dev || jobs[j].rows <= 0 || jobs[j].n <= 0) return AG_ERR_INVALID_ARG;
+        if (jobs[j].n % 4 != 0 || (reinterpret_cast<uintptr_t>(jobs[j].partials_dev) & 15)) return AG_ERR_UNSUPPORTED;
+        k.in[j] = jobs[j].partials_dev;
+        k.out[j] = jobs[j].out_dev;
+        k.S[j] = jobs[j].rows;
+        k.n4[j] = jobs[j].n / 4;
+        int G = jobs[j].rows / 8;
+        G = G < 1 ? 1 : (G > kSumMaxGroups ? kSumMaxGroups : G);
+        k.groups[j] = G;
+        k.scratch_off[j] = off;
+        off += (long long)G * jobs[j].n;
+        const int nbx = (k.n4[j] + 63) / 64;
+        k.block0_s1[j] = b1;
+        k.block0_s2[j] = b2;
+        b1 += nbx * G;
+        b2 += nbx;
+    }
+    k.block0_s1[njobs] = b1;
+    k.block0_s2[njobs] = b2;
+    if (off > scratch_floats || (reinterpret_cast<uintptr_t>(scratch) & 15)) return AG_ERR_INVALID_ARG;
     if (fin)
         hipLaunchKernelGGL(sum_rows_stage1_kernel<true>, dim3(b1 + 1), dim3(256), 0, (hipStream_t)stream, k, *fin);
     else
         hipLaunchKernelGGL(sum_rows_stage1_kernel<false>, dim3(b1), dim3(256), 0, (hipStream_t)stream, k, FinalizeArgs{});
-    if (stage2) hipLaunchKernelGGL(sum_rows_stage2_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(sum_rows_stage2_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, k);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;
 }
 
@@ -893,19 +1003,6 @@ extern "C" int ag_sum_rows_multi_finalize(const ag_sum_job* jobs, int njobs, flo
     const FinalizeArgs fin{loss_partials, num_blocks, M, A, logstd, entropy_coef, critic_coef, bounds_loss_coef,
                            grad_logstd, grad_head_bias, kl_out, stats};
     return sum_rows_multi_launch(jobs, njobs, scratch, scratch_floats, &fin, stream);
-}
-
-// Stage 1 (+ the loss finalisation) only: the caller runs stage 2 inside ag_update_tail (update_tail.hip), behind the same job table.
-extern "C" int ag_sum_rows_stage1_finalize(const ag_sum_job* jobs, int njobs, float* scratch, long long scratch_floats,
-                                           const float* loss_partials, int num_blocks, int M, int A, const float* logstd,
-                                           float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd,
-                                           float* grad_head_bias, float* kl_out, float* stats, void* stream) {
-    if (!loss_partials || !logstd || !grad_logstd || !grad_head_bias || !kl_out || !stats || num_blocks <= 0 || M <= 0)
-        return AG_ERR_INVALID_ARG;
-    if (A < 1 || A > AG_MAX_ACTIONS) return AG_ERR_UNSUPPORTED;
-    const FinalizeArgs fin{loss_partials, num_blocks, M, A, logstd, entropy_coef, critic_coef, bounds_loss_coef,
-                           grad_logstd, grad_head_bias, kl_out, stats};
-    return sum_rows_multi_launch(jobs, njobs, scratch, scratch_floats, &fin, stream, false);
 }
 
 // ---------------------------------------------------------------------------------------------------

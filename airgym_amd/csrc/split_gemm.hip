@@ -27,11 +27,11 @@
 #include "../../include/airgym_hip.h"
 #include "ppo_loss_math.hpp"
 #include "split_common.hpp"
-#include "tail_parts.hpp"
 
 namespace {
 
-// (BN = 256, BK = 16, KDIM = 256, B_UNITS = 16-byte units per B stage: tail_parts.hpp)
+constexpr int BN = 256, BK = 16, KDIM = 256;
+constexpr int B_UNITS = 3 * 2 * BN;       // 16-byte units per B stage
 // row tile: WM waves x 64 rows (WM = 2: 128 rows, 4 waves, two workgroups per CU; WM = 4: 256 rows, 8 waves, one per CU)
 constexpr int a_units(int bm) { return 3 * 2 * bm; }          // 16-byte units per A stage
 constexpr int stage_units(int bm) { return a_units(bm) + B_UNITS; }
@@ -62,12 +62,52 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(const float* __restr
     chunk[(2 * 2 + h) * BN + n] = p3;
 }
 
-// Images of ag_split_gemm_input_prepare (the fused first layer, FIN > 0): layout and the per-unit body in tail_parts.hpp
-// (split_in_prepare_unit; the fused tail of the optimizer step, update_tail.hip, runs the same body)
+// Images of ag_split_gemm_input_prepare (the fused first layer, FIN > 0):
+//   [0, kInImageW1Bytes): W1ext [block 8][K step 2][plane 3][h 2][feature 32] x 16 B, W1ext[f][d] = W1[f][d] (d < D), b1[f] (d = D), 0
+//   then the forward planes of W2 in the chain's K order, laid out like ag_split_gemm_prepare's
+constexpr int kInImageW1Bytes = 8 * 2 * 3 * 2 * 32 * 16;
 __global__ __launch_bounds__(256) void split_in_prepare_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D,
                                                                const float* __restrict__ W2, uint4* __restrict__ img,
                                                                uint4* __restrict__ planes_t) {
-    split_in_prepare_unit(blockIdx.x * 256 + threadIdx.x, W1, b1, D, W2, img, planes_t);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 8 * 2 * 2 * 32) {                               // W1ext: one (block, step, h, feature) unit triple per thread
+        const int m = t & 31, h = (t >> 5) & 1, st = (t >> 6) & 1, b = t >> 7;
+        const int f = 32 * b + m;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = 16 * st + 8 * h + i;
+            v[i] = d < D ? W1[(size_t)f * D + d] : (d == D ? b1[f] : 0.0f);
+        }
+        uint4 p1, p2, p3;
+        split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
+        uint4* base = img + (size_t)((b * 2 + st) * 3) * 64 + h * 32 + m;
+        base[0] = p1;
+        base[64] = p2;
+        base[128] = p3;
+        return;
+    }
+    int unit = t - 8 * 2 * 2 * 32;                          // W2 planes: one (chunk, k-half, n) unit triple per thread
+    const bool bwd = unit >= 16 * 2 * BN;                   // ... then (planes_t != null) the backward image: B[n][k] = W2[k][n], natural K
+    if (bwd) unit -= 16 * 2 * BN;
+    if (unit >= 16 * 2 * BN || (bwd && planes_t == nullptr)) return;
+    const int n = unit % BN, h = (unit / BN) & 1, c = unit / (2 * BN);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (bwd) {
+            v[i] = W2[(size_t)(c * BK + h * 8 + i) * BN + n];
+        } else {                                            // forward image in the chain's K order
+            const int f = 32 * (c >> 1) + 16 * (c & 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
+            v[i] = W2[(size_t)n * KDIM + f];
+        }
+    }
+    uint4 p1, p2, p3;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
+    uint4* chunk = (bwd ? planes_t : img + kInImageW1Bytes / 16) + (size_t)c * B_UNITS;
+    chunk[(0 * 2 + h) * BN + n] = p1;
+    chunk[(1 * 2 + h) * BN + n] = p2;
+    chunk[(2 * 2 + h) * BN + n] = p3;
 }
 
 // A1 > 0: the forward of the LAST hidden layer with the actor/critic heads folded into the epilogue
@@ -1152,7 +1192,7 @@ static int launch_in_prepare(const float* W1_dev, const float* b1_dev, int D, co
     if (!W1_dev || !b1_dev || !W2_dev || !image_dev) return AG_ERR_INVALID_ARG;
     if (!ag_split_gemm_input_fwd_supported(D)) return AG_ERR_UNSUPPORTED;
     if (((uintptr_t)image_dev | (uintptr_t)planes_t_dev) & 15) return AG_ERR_INVALID_ARG;
-    const int threads = in_prepare_threads(planes_t_dev != nullptr);
+    const int threads = 8 * 2 * 2 * 32 + (planes_t_dev ? 2 : 1) * 16 * 2 * BN;
     hipLaunchKernelGGL(split_in_prepare_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1_dev, b1_dev, D, W2_dev,
                        (uint4*)image_dev, (uint4*)planes_t_dev);
     return hipGetLastError() == hipSuccess ? AG_OK : AG_ERR_HIP;

@@ -947,13 +947,6 @@ class A2CAgent:
         adaptive = self.is_adaptive_lr and self.schedule_type == "legacy"
         fused_adam = self.flat_grad.is_cuda and self.config.get("use_fused_adam", True)
         kl = self.flat_grad[-1].double() if (need_kl or (adaptive and not fused_adam)) else None   # the torch schedule reads it
-        fs = self._fused_step
-        if fused_adam and fs is not None and fs.tail_pending:
-            # the step stopped after the first reduction stage (defer_tail): second stage, norm, clip + Adam + LR rule and the
-            # next step's weight images are ONE launch (csrc/update_tail.hip); single GPU only
-            fs.run_tail(self.optimizer, self.grad_norm if self.truncate_grads else 0.0, self.kl_threshold if adaptive else 0.0,
-                        getattr(self.scheduler, "min_lr", 0.0), getattr(self.scheduler, "max_lr", 1.0))
-            return kl
         if fused_adam:
             self.optimizer.fused_clip_step(
                 self.flat_grad, self.grad_norm if self.truncate_grads else 0.0,
@@ -997,7 +990,7 @@ class A2CAgent:
                     whole = (not self.multi_gpu) or self._capture_collective
 
                     def body(whole=whole):
-                        self._fused_step.step(mb, stats_out=row, defer_tail=not self.multi_gpu)
+                        self._fused_step.step(mb, stats_out=row)
                         if not self.multi_gpu:
                             self._reduce_clip_step(need_kl=False)
                         elif whole:
@@ -1031,7 +1024,7 @@ class A2CAgent:
                     self._upd_graphs["tail"] = tail
                 tail.replay()
                 return st[0], st[1], st[2], st[3], self.flat_grad[-1].double()      # the rank-averaged KL
-            st = self._fused_step.step(mb, defer_tail=not self.multi_gpu)
+            st = self._fused_step.step(mb)
             self._last_clip = st[6]
             kl = self._reduce_clip_step(need_kl=self.multi_gpu)      # multi-GPU: the rank-averaged KL
             return st[0], st[1], st[2], st[3], (kl if self.multi_gpu else st[4])

@@ -246,12 +246,6 @@ class FusedMLPStep:
         self.stats_ring = torch.zeros(max(1, agent.mini_epochs_num * agent.num_minibatches), 8, **f)
         self.k = 0
         self.last_launches = {}       # the step's dominant launches as (entry point, replayable closure) - for bench.py
-        # the tail of a single-GPU step as ONE launch (csrc/update_tail.hip: second reduction stage + gradient norm + clip / Adam /
-        # LR rule + the next step's weight images behind grid barriers; `fuse_update_tail`, default on): step(defer_tail=True)
-        # stops after the first reduction stage, run_tail() - called by the agent where it would call the optimizer - does the rest
-        self.tail_barrier = torch.zeros(max(1, self.lib.ag_update_tail_barrier_bytes() // 4), dtype=torch.int32, device=dev)
-        self.tail_pending = False
-        self.images_fresh = False     # True: the weight images were written by run_tail() after the last parameter update
 
     @property
     def covers_all_products(self):
@@ -324,30 +318,6 @@ class FusedMLPStep:
 
     def begin_epoch(self):
         self.k = 0
-        self.images_fresh = False     # (parameters may have been loaded / broadcast between epochs: the first step re-splits them)
-
-    def tail_fusable(self):
-        """The one-launch tail covers exactly the headline's structure: first layer fused into the forward launch (one weight image
-        + the backward planes of the one split layer), the loss finalisation riding in the reductions, the HIP optimizer, one GPU."""
-        ag = self.agent
-        return (bool(ag.config.get("fuse_update_tail", True)) and not ag.multi_gpu and bool(ag.config.get("use_fused_adam", True))
-                and self.fuse_gemm_input and self.use_sum_multi and self.fuse_finalize and list(self.split) == [len(self.layers) - 1]
-                and self.split[len(self.layers) - 1].bwd is not None)
-
-    @torch.no_grad()
-    def run_tail(self, optimizer, max_grad_norm, kl_threshold, min_lr, max_lr):
-        """Second half of a step(defer_tail=True): ag_update_tail."""
-        assert self.tail_pending
-        sg = self.split[len(self.layers) - 1]
-        w0, b0 = self.layers[0][0], self.layers[0][1]
-        N.check(self.lib.ag_update_tail(
-            self._jobs, len(self._jobs), self.sum_scratch.data_ptr(), self.sum_scratch.numel(), optimizer.p.data_ptr(),
-            self.agent.flat_grad.data_ptr(), optimizer.exp_avg.data_ptr(), optimizer.exp_avg_sq.data_ptr(), optimizer.state.data_ptr(),
-            optimizer.p.numel(), optimizer.b1, optimizer.b2, optimizer.eps, optimizer.wd, float(max_grad_norm), float(kl_threshold),
-            float(min_lr), float(max_lr), w0.data_ptr(), b0.data_ptr(), w0.shape[1], sg.w.data_ptr(), sg.in_image.data_ptr(),
-            sg.bwd.data_ptr(), self.tail_barrier.data_ptr(), self._stream()), "ag_update_tail")
-        self.tail_pending = False
-        self.images_fresh = True
 
     def next_stats_row(self):
         row = self.stats_ring[self.k % self.stats_ring.shape[0]]
@@ -358,7 +328,7 @@ class FusedMLPStep:
         return ctypes.c_void_p(torch.cuda.current_stream(self.agent.ppo_device).cuda_stream)
 
     @torch.no_grad()
-    def step(self, mb, stats_out=None, defer_tail=False):
+    def step(self, mb, stats_out=None):
         """Forward, loss, backward of minibatch `mb`; gradients (and the KL in the appended slot) are left in
         agent.flat_grad.  Returns the stats row [a_loss, c_loss, entropy, b_loss, kl, loss, clip_frac, 0] (device, no sync);
         `stats_out` overrides where that row is written (hipGraph capture needs a fixed address)."""
@@ -418,9 +388,7 @@ class FusedMLPStep:
             if in_args is None or li_ != len(self.layers) - 1:
                 sg.prepare()
         if in_args is not None:                 # one launch: first-layer image + chain-ordered forward planes + backward planes
-            if not (self.images_fresh and self.split[len(self.layers) - 1].in_image is not None):
-                self.split[len(self.layers) - 1].prepare_input_image(w0, b0)      # (else: the previous step's run_tail() wrote them)
-        self.images_fresh = False
+            self.split[len(self.layers) - 1].prepare_input_image(w0, b0)
         for li in range(1, len(self.layers)):
             w, b = self.layers[li][0], self.layers[li][1]
             inputs.append(x)
@@ -573,11 +541,7 @@ class FusedMLPStep:
                 else:
                     torch.mm(dz, w, out=dh)
         # ---- every partial-sum reduction (bias / weight gradients of all layers + the head) in two launches
-        if fin_late and defer_tail and in_args is not None and self.tail_fusable():
-            N.check(lib.ag_sum_rows_stage1_finalize(self._jobs, len(self._jobs), self.sum_scratch.data_ptr(), self.sum_scratch.numel(),
-                                                    *fin_args, st), "ag_sum_rows_stage1_finalize")
-            self.tail_pending = True             # the caller owes a run_tail()
-        elif fin_late:
+        if fin_late:
             N.check(lib.ag_sum_rows_multi_finalize(self._jobs, len(self._jobs), self.sum_scratch.data_ptr(), self.sum_scratch.numel(),
                                                    *fin_args, st), "ag_sum_rows_multi_finalize")
         elif self.use_sum_multi:

@@ -716,26 +716,6 @@ int ag_sum_rows_multi_finalize(const ag_sum_job* jobs_host, int njobs, float* sc
                                float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd_dev,
                                float* grad_head_bias_dev, float* kl_out_dev, float* stats_dev, void* stream);
 
-/* The tail of a single-GPU optimizer step in TWO launches instead of five (airgym_amd/csrc/update_tail.hip, round 6).
- * ag_sum_rows_stage1_finalize: the first of ag_sum_rows_multi_finalize's two launches only.  ag_update_tail: ONE launch of 128
- * workgroups that runs, separated by grid barriers, (1) the second reduction stage of the same job table, (2) + (3) what
- * ag_adam_clip_step does (trancate_gradients_and_step, lib/agent/a2c_base.py:293-316; schedulers.py:19-32; same arguments) and (4)
- * what ag_split_gemm_input_prepare_pair does with the UPDATED weights (the images the next step's matrix-core launches read;
- * planes_t_dev may be NULL: ag_split_gemm_input_prepare) - every phase through the device body of the launch it replaces:
- * gradients, Adam state, parameters and images are bit-identical to the five-launch sequence.  barrier_dev:
- * ag_update_tail_barrier_bytes() bytes, zeroed ONCE by the caller, private to one stream (the grid barrier's ticket counter).
- * Not for multi-GPU steps: their gradient all-reduce sits between phases (1) and (2). */
-int ag_sum_rows_stage1_finalize(const ag_sum_job* jobs_host, int njobs, float* scratch_dev, long long scratch_floats,
-                                const float* loss_partials_dev, int num_blocks, int M, int A, const float* logstd_dev,
-                                float entropy_coef, float critic_coef, float bounds_loss_coef, float* grad_logstd_dev,
-                                float* grad_head_bias_dev, float* kl_out_dev, float* stats_dev, void* stream);
-int ag_update_tail_barrier_bytes(void);
-int ag_update_tail(const ag_sum_job* jobs_host, int njobs, float* scratch_dev, long long scratch_floats, float* param_dev,
-                   float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, double* state_dev, int n, float beta1, float beta2,
-                   float eps, float weight_decay, float max_grad_norm, float kl_threshold, float min_lr, float max_lr,
-                   const float* W1_dev, const float* b1_dev, int D, const float* W2_dev, void* image_dev, void* planes_t_dev,
-                   void* barrier_dev, void* stream);
-
 /* ELU backward fused with the bias gradient of the producing Linear (lib/network/mlp.py:36-39 under autograd):
  * dz = dh * ELU'(z) computed from h = ELU(z); db_partials_dev [ceil(M / rows_per_block), C] per-block column sums of dz
  * (caller reduces).  C % 4 == 0 and 256 % (C/4) == 0 (C = 64, 128, 256, 512, 1024 ...). */
