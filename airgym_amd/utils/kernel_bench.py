@@ -425,6 +425,73 @@ def pmc_field(repo, key, kernel, field):
     return None
 
 
+def planning_source_sha():
+    """Provenance key of the Planning render kernel (sources it is compiled from), as env_kernel_source_sha."""
+    import hashlib
+    import os
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    h = hashlib.sha256()
+    for f in ("planning_kernel.hip", "planning_math.hpp", "env_math.hpp", "kernel_args.hpp"):
+        with open(os.path.join(here, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measure_planning_render(env, steps=16):
+    """The depth camera of a Planning handle (planning_render_kernel: ray-cast + the reference's post-processing in LDS, one
+    212 x 120 float32 image per env written once, customized.py:386-435) timed in place: `steps` consecutive env steps with HIP
+    events around each; the camera runs every 4th step, so render time = median(step with render) - median(step without).
+    Algorithmic bytes: the image, 101 760 B per env and render - the kernel is vector-ALU bound (ray tests),
+    the HBM fraction says how far from a memory problem it is."""
+    import statistics
+    n = env.num_envs
+    a = torch.zeros(n, 4, device=env.device)
+    a[:, 3] = -0.69
+    for _ in range(4):
+        env.step(a)
+    s = torch.cuda.current_stream(env.device)
+    with_r, without = [], []
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        env.step(a)
+        e1.record(s)
+        e1.synchronize()
+        (with_r if env.last_step_rendered() else without).append(e0.elapsed_time(e1) * 1e3)
+    if not with_r or not without:
+        return None
+    us = statistics.median(with_r) - statistics.median(without)
+    nbytes = float(n) * 212 * 120 * 4
+    return {"us_per_launch": us, "renders_timed": len(with_r), "algo_bytes": nbytes, "achieved": nbytes / us / 1e3,
+            "us_step_with_render": statistics.median(with_r), "us_step_without": statistics.median(without)}
+
+
+def planning_render_roofline(env, repo):
+    m = measure_planning_render(env)
+    if m is None:
+        return None
+    import glob
+    import json
+    import os
+    traffic, src, valu = None, "no PMC record for this kernel", None
+    sha = planning_source_sha()
+    for path in sorted(glob.glob(os.path.join(repo, "profiles", "r*_planning_render_pmc.json")), reverse=True):
+        rec = json.load(open(path))
+        if rec.get("envs") != env.num_envs:
+            continue
+        if rec.get("source_sha") != sha:
+            src = f"stale: {os.path.basename(path)} was measured on kernel sources {rec.get('source_sha')}, this build is {sha}"
+            continue
+        traffic, src, valu = rec["traffic_bytes_per_launch"], rec["source"], rec.get("valu_busy_pct")
+        break
+    return {"bound": "hbm", "kernel": "ag::planning_render_kernel<0>", "entry_point": "ag_step (Planning; the camera launch of every 4th step)",
+            "achieved": m["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": m["achieved"] / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": src, "valu_busy_pct": valu, "us_per_launch": m["us_per_launch"],
+            "algo_bytes_per_env": 212 * 120 * 4, "envs_per_launch": env.num_envs, "renders_timed": m["renders_timed"],
+            "note": "ray-casting kernel: vector-ALU bound, the image crosses HBM once (the post-processing runs in LDS)",
+            "kernel_source_sha": sha}
+
+
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (never the 2:1-sparsity figure)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA = f32 vector rate, 64 FLOP/clk/SIMD
 
