@@ -255,6 +255,8 @@ SYMBOLS = [
     ("ag_cnn_conv_supported", ctypes.c_int, [ctypes.c_int] * 4),
     ("ag_cnn_conv_fwd_bands", ctypes.c_int, [ctypes.c_int] * 4),
     ("ag_cnn_conv_fwd", ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 5 + [_P, _P]),
+    ("ag_cnn_conv_fwd_split_bands", ctypes.c_int, [ctypes.c_int] * 4),
+    ("ag_cnn_conv_fwd_split", ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 5 + [_P, _P]),
     ("ag_cnn_conv_dgrad", ctypes.c_int, [_P] * 3 + [ctypes.c_int] * 5 + [_P, _P]),
     ("ag_cnn_conv_dgrad_bn_rows", ctypes.c_int, [ctypes.c_int] * 5),
     ("ag_cnn_conv_dgrad_bn", ctypes.c_int, [_P] * 7 + [ctypes.c_int] * 5 + [_P, _P]),

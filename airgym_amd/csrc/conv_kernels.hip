@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "../../include/airgym_hip.h"
+#include "split_common.hpp"
 
 namespace {
 
@@ -278,6 +279,311 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
             for (int w = 0; w < WAVES; ++w) t += (&s_red[w][0][0])[u];
             stats[(size_t)blockIdx.x * COUT * 2 + u] = t;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// forward of a 3x3 / stride 2 / pad 1 layer on the BF16 matrix cores at float32 accuracy (round 6): every f32 operand as an exact
+// three-way bf16 split, six v_mfma_f32_32x32x16_bf16 per product block (split_common.hpp; split_gemm.hip has the error analysis:
+// < 2^-23 |ab| dropped per product, i.e. what an f32 FMA chain rounds away anyway).  Six bf16 MFMAs cost 6/16 of the f32-input
+// MFMA the kernel above runs on: the matrix work of a layer falls from ~0.5 ms to ~0.19 ms per 4 750 images and the kernel can
+// become a streaming kernel (2.9 GB / 1.5 GB of activations per pass) - IF the vector work of the split (5.5 instructions per staged
+// value) runs BESIDE the matrix work.  Hence producer / consumer waves:
+//
+//   D[co 32][pixel 32] += W[co][k 16] X[k 16][pixel]   per tap and 16 input channels
+//   A = weights: pre-split once per call into the exact fragment image (pack_fwd_split_kernel); a consumer wave holds the fragments
+//       of its 32 output channels in REGISTERS for the life of the persistent workgroup (9 taps x CIN / 16 x 3 planes x 4
+//       registers; the [32 -> 64] layer keeps 12 of its 18 (tap, K step) pairs there and reads 6 from an LDS copy);
+//   B = activations: a band of 9 input rows (4 output rows) is staged in LDS channel-innermost - one 16-byte unit = 8 consecutive
+//       channels of one position, three planes - with the columns de-interleaved by parity as above (E[j + 1] = column 2j + 1, O[j] =
+//       column 2j, E[0] = left padding), so the 32 lanes of a fragment read 32 (or 2 x 16) consecutive units: conflict-free
+//       ds_read_b128.  ReLU + BatchNorm of the previous layer and the split are applied once per staged element.
+//   Workgroup = 4 PRODUCER waves + 4 CONSUMER waves, one per CU, persistent over (image, band) items, TWO band tiles in LDS:
+//       while the consumers run the 54 / 108 MFMAs and the epilogue of band i out of one tile, the producers convert band i + 1
+//       (loaded into registers one iteration earlier) into the other and issue the loads of band i + 2; one barrier per band.  Every
+//       SIMD hosts one wave of each kind, so the split's vector instructions issue under the other wave's MFMAs.
+//   Pixel tile = 32 slots: one output row of up to 32 pixels (WO = 30), or two rows of up to 16 (WO = 15).  Consumer wave = (pixel
+//   tile of the band, 32-channel output tile).  A producer wave stages ONE 8-channel group (scale / shift in scalar registers).
+// Epilogue as above: + bias, store, per-(image, band) sums of relu(y), relu(y)^2 per output channel (transposing lane reduction,
+// fixed order; written by the producers one band later).
+template <int CIN, int COUT, int WIN>
+struct SplitFwdShape {
+    static constexpr int WO = WIN / 2, PXR = (WO <= 16) ? 2 : 1, TW = 32 / PXR, ROWS = 4, IN_ROWS = 2 * ROWS + 1, PT = ROWS / PXR;
+    static constexpr int KG = CIN / 8, KS = CIN / 16, CT = COUT / 32;
+    static constexpr int NCONS = PT * CT, NPROD = 4, NT = (NCONS + NPROD) * 64;
+    static constexpr int RS = 2 * TW + 1, PLANE = KG * IN_ROWS * RS, TILE = 3 * PLANE;
+    static constexpr int AREG = (9 * KS <= 12) ? 9 * KS : 12;          // (tap, K step) pairs of weight fragments held in registers
+};
+
+// wimg[ct][tap][ks][plane][lane] (16-byte units): lane l supplies row co = 32 ct + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7 of tap
+__global__ void pack_fwd_split_kernel(const float* __restrict__ w, uint4* __restrict__ wimg, int cin, int cout) {
+    const int ks_n = cin / 16, ct_n = cout / 32;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ct_n * 9 * ks_n * 64) return;
+    const int lane = t & 63;
+    int r = t >> 6;
+    const int ks = r % ks_n; r /= ks_n;
+    const int tap = r % 9;
+    const int ct = r / 9;
+    const int co = 32 * ct + (lane & 31), c0 = 16 * ks + 8 * (lane >> 5);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = w[((size_t)co * cin + (c0 + i)) * 9 + tap];
+    uint4 p1, p2, p3;
+    split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p1, p2, p3);
+    uint4* dst = wimg + ((size_t)((ct * 9 + tap) * ks_n + ks) * 3) * 64 + lane;
+    dst[0] = p1;
+    dst[64] = p2;
+    dst[128] = p3;
+}
+
+// lane exchange with the lane whose index differs in bit B (inside each 32-lane half): DPP where a pattern exists, ds_swizzle
+// (bit-mask mode, no LDS memory touched) otherwise
+template <int B>
+__device__ __forceinline__ float xchg_bit(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    if constexpr (B == 0) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false));       // quad_perm [1,0,3,2]
+    else if constexpr (B == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+    else if constexpr (B == 3) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false)); // row_ror:8
+    else return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(x, ((1 << B) << 10) | 0x1F));                          // xor (1 << B)
+}
+// One step of the transposing reduction: V[2m], V[2m + 1] of this lane and of its partner in bit B become ONE value per lane - the
+// partner-pair sum of V[2m] in lanes with bit B clear, of V[2m + 1] in lanes with it set.  After the five steps over 32 values, lane l
+// of a 32-lane half holds the half's total of V[l & 31] (fixed order: deterministic).
+template <int B, int LEN>
+__device__ __forceinline__ void treduce_step(float* v, bool bit) {
+#pragma unroll
+    for (int m = 0; m < LEN / 2; ++m) {
+        const float keep = bit ? v[2 * m + 1] : v[2 * m];
+        const float send = bit ? v[2 * m] : v[2 * m + 1];
+        v[m] = keep + xchg_bit<B>(send);
+    }
+}
+
+// Workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL access
+// (s_waitcnt vmcnt(0)) - here that would be the loads a producer has just issued for the band after next, i.e. their whole latency
+// once per band, with the consumers waiting at the same barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
+
+template <int CIN, int COUT, int HIN, int WIN, bool APPLY>
+__global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_fwd_split_kernel(
+    const float* __restrict__ x, const uint4* __restrict__ wimg, const float* __restrict__ bias, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ y, float* __restrict__ stats, int items) {
+    using S = SplitFwdShape<CIN, COUT, WIN>;
+    constexpr int HO = (HIN - 1) / 2 + 1, WO = S::WO, W2 = WIN / 2;
+    constexpr int PXR = S::PXR, TW = S::TW, ROWS = S::ROWS, IN_ROWS = S::IN_ROWS, PT = S::PT;
+    constexpr int KG = S::KG, KS = S::KS, CT = S::CT, RS = S::RS, PLANE = S::PLANE, TILE = S::TILE;
+    constexpr int NCONS = S::NCONS, NPROD = S::NPROD, AREG = S::AREG, ALDS = 9 * KS - AREG;
+    constexpr int bands = (HO + ROWS - 1) / ROWS;          // (a constant: the item -> (image, band) divisions are multiplications)
+    static_assert(WIN % 2 == 0 && CIN % 16 == 0 && COUT % 32 == 0 && WO <= 32 && PT * PXR == ROWS && NPROD % KG == 0, "shape");
+    __shared__ uint4 s_in[2 * TILE];
+    __shared__ float s_red[2][PT][COUT][2];
+    __shared__ uint4 s_w[ALDS > 0 ? CT * ALDS * 3 * 64 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < NCONS;
+    const int step = gridDim.x;
+
+    // ---- set-up common to both roles: the LDS copy of the weight fragments that do not live in registers, the padding columns
+    if (ALDS > 0) {
+        for (int u = tid; u < CT * ALDS * 3 * 64; u += S::NT) {
+            const int l = u & 63, p = (u >> 6) % 3, r = (u >> 6) / 3;
+            const int pair = AREG + r % ALDS, ct_ = r / ALDS;                  // pair = tap * KS + ks
+            s_w[u] = wimg[((size_t)(ct_ * 9 * KS + pair) * 3 + p) * 64 + l];
+        }
+    }
+    for (int u = tid; u < 2 * 3 * KG * IN_ROWS; u += S::NT) s_in[(size_t)u * RS] = make_uint4(0u, 0u, 0u, 0u);   // E[0] of every row, both tiles
+    __syncthreads();
+
+    if (!consumer) {
+        // =========================== producer: global -> registers -> (ReLU + BatchNorm, split) -> LDS tile =======================
+        constexpr int WPG = NPROD / KG;                              // producer waves per 8-channel group
+        constexpr int UNITS = IN_ROWS * W2, NU = (UNITS + WPG * 64 - 1) / (WPG * 64);
+        const int pw = wave - NCONS, kg = pw / WPG, gt = (pw - kg * WPG) * 64 + lane;
+        float sc8[8], sh8[8];
+        if (APPLY) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { sc8[p] = scale[kg * 8 + p]; sh8[p] = shift[kg * 8 + p]; }
+        }
+        int urow[NU];
+        unsigned uoff[NU];
+        int udst[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int u = gt + k * WPG * 64;
+            const int row = u / W2, j = u - row * W2;
+            urow[k] = u < UNITS ? row : -1000;
+            uoff[k] = (unsigned)((row * WIN + 2 * j) * 4);
+            udst[k] = (kg * IN_ROWS + row) * RS + j;
+        }
+        // two register sets: the loads of band i + 2 are issued at the START of the iteration in which band i + 1 is converted (from the
+        // other set), so a band's loads have more than a whole band time to arrive - one band of look-ahead was not enough, a band
+        // (~2 us) being about one loaded memory latency
+        float2 vinA[NU][8], vinB[NU][8];
+        auto fetch = [&](float2 (&vin)[NU][8], int item_) {
+            const int n_ = item_ / bands, top = 2 * (item_ - n_ * bands) * ROWS - 1;      // input row of staged row 0
+            const __amdgpu_buffer_rsrc_t rx = buf_of(x + ((size_t)n_ * CIN + kg * 8) * HIN * WIN, 8 * HIN * WIN * 4);
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                const int iy = top + urow[k];
+                const unsigned off = (iy >= 0 && iy < HIN) ? uoff[k] + (unsigned)(top * WIN * 4) : kOob;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) vin[k][p] = buf_f2(rx, off, p * (HIN * WIN * 4));
+            }
+        };
+        auto stash = [&](float2 (&vin)[NU][8], int item_, int par) {
+            const int n_ = item_ / bands, top = 2 * (item_ - n_ * bands) * ROWS - 1;
+            uint4* tile = s_in + (size_t)par * TILE;
+#pragma unroll
+            for (int k = 0; k < NU; ++k) {
+                if (urow[k] < 0) continue;
+                const int iy = top + urow[k];
+                float2 v[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) v[p] = vin[k][p];
+                if (APPLY) {
+                    if (iy >= 0 && iy < HIN) {                    // (padding rows stay zero)
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) {
+                            v[p].x = fmaxf(v[p].x, 0.f) * sc8[p] + sh8[p];
+                            v[p].y = fmaxf(v[p].y, 0.f) * sc8[p] + sh8[p];
+                        }
+                    }
+                }
+                uint4 o1, o2, o3, e1, e2, e3;
+                split8(make_float4(v[0].x, v[1].x, v[2].x, v[3].x), make_float4(v[4].x, v[5].x, v[6].x, v[7].x), o1, o2, o3);
+                split8(make_float4(v[0].y, v[1].y, v[2].y, v[3].y), make_float4(v[4].y, v[5].y, v[6].y, v[7].y), e1, e2, e3);
+                uint4* base = tile + udst[k];
+                base[TW + 1] = o1;             // O[j]     = column 2j
+                base[PLANE + TW + 1] = o2;
+                base[2 * PLANE + TW + 1] = o3;
+                base[1] = e1;                  // E[j + 1] = column 2j + 1
+                base[PLANE + 1] = e2;
+                base[2 * PLANE + 1] = e3;
+            }
+        };
+        const int ptid = tid - NCONS * 64;
+        auto flush_stats = [&](int item_, int par) {
+            for (int u = ptid; u < COUT * 2; u += NPROD * 64) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < PT; ++w) t += (&s_red[par][w][0][0])[u];
+                stats[(size_t)item_ * COUT * 2 + u] = t;
+            }
+        };
+        int item = blockIdx.x;
+        if (item < items) {
+            fetch(vinA, item);
+            if (item + step < items) fetch(vinB, item + step);
+            stash(vinA, item, 0);
+        }
+        lds_barrier();                                             // tile 0 published
+        // iteration k: the consumers work on tile k & 1 (band `item`); this wave issues the loads of band item + 2 step, converts band
+        // item + step into tile (k + 1) & 1 and writes out the statistics of band item - step
+        for (int k = 0; item < items; k += 2) {
+            if (item + 2 * step < items) fetch(vinA, item + 2 * step);
+            if (item + step < items) stash(vinB, item + step, 1);
+            if (stats && k > 0) flush_stats(item - step, 1);
+            lds_barrier();
+            item += step;
+            if (item >= items) break;
+            if (item + 2 * step < items) fetch(vinB, item + 2 * step);
+            if (item + step < items) stash(vinA, item + step, 0);
+            if (stats) flush_stats(item - step, 0);
+            lds_barrier();
+            item += step;
+        }
+        if (stats && item - step >= (int)blockIdx.x) {
+            const int last_k = (item - step - (int)blockIdx.x) / step;
+            flush_stats(item - step, last_k & 1);
+        }
+        return;
+    }
+
+    // =============================== consumer: 9 taps x KS x 6 MFMAs per band, epilogue ============================================
+    const int ct = wave % CT, pt = wave / CT;
+    const int slot = lane & 31, pr = slot / TW, ox = slot - pr * TW, kh = lane >> 5;
+    bf16x8 a[AREG][3];
+#pragma unroll
+    for (int pair = 0; pair < AREG; ++pair)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint4 u = wimg[((size_t)(ct * 9 * KS + pair) * 3 + p) * 64 + lane];
+            a[pair][p] = __builtin_bit_cast(bf16x8, u);
+        }
+    const uint4* wl = s_w + (size_t)(ct * ALDS * 3) * 64 + lane;
+    float bs[16];                              // the lane's 16 output channels' bias
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bs[i] = bias[32 * ct + 8 * (i >> 2) + 4 * kh + (i & 3)];
+    const int frag0 = (kh * IN_ROWS + 2 * (pt * PXR + pr)) * RS + ox;       // K step ks adds 2 ks channel groups
+
+    lds_barrier();                                               // tile 0 published
+    int k = 0;
+    for (int item = blockIdx.x; item < items; item += step, ++k) {
+        const int n = item / bands, band = item - n * bands;
+        const int oy0 = band * ROWS;
+        const uint4* tile = s_in + (size_t)(k & 1) * TILE;
+        f32x16 acc0, acc1;                     // two chains: consecutive product blocks do not wait for each other
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+        const bool tile_live = oy0 + pt * PXR < HO;         // (the last band: tiles below the image only take part in the barriers)
+        if (tile_live) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const int co_ = (kx == 1 ? TW + 1 : 0) + (kx == 2 ? 1 : 0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int pair = tap * KS + ks;
+                    const uint4* q = tile + frag0 + (2 * ks * IN_ROWS + ky) * RS + co_;
+                    const bf16x8 b1 = __builtin_bit_cast(bf16x8, q[0]);
+                    const bf16x8 b2 = __builtin_bit_cast(bf16x8, q[PLANE]);
+                    const bf16x8 b3 = __builtin_bit_cast(bf16x8, q[2 * PLANE]);
+                    bf16x8 a1, a2, a3;
+                    if (pair < AREG) {
+                        a1 = a[pair < AREG ? pair : 0][0]; a2 = a[pair < AREG ? pair : 0][1]; a3 = a[pair < AREG ? pair : 0][2];
+                    } else {
+                        const uint4* wq = wl + (size_t)((pair - AREG) * 3) * 64;
+                        a1 = __builtin_bit_cast(bf16x8, wq[0]);
+                        a2 = __builtin_bit_cast(bf16x8, wq[64]);
+                        a3 = __builtin_bit_cast(bf16x8, wq[128]);
+                    }
+                    if (pair & 1) { AG_MFMA_SPLIT(acc1, a1, a2, a3, b1, b2, b3); }
+                    else { AG_MFMA_SPLIT(acc0, a1, a2, a3, b1, b2, b3); }
+                }
+            }
+        }
+        // ---- epilogue: + bias, store, sums of relu(y) and relu(y)^2 over the tile's valid pixels
+        {
+            const int oy = oy0 + pt * PXR + pr;
+            const bool valid = tile_live && oy < HO && ox < WO;
+            // one buffer store per accumulator register: the lane part of the address (pixel, and the 4-channel step of the lane's half)
+            // in the vector offset - out of range for lanes without a pixel, which the hardware then drops -, the register's channel in
+            // the scalar offset
+            const __amdgpu_buffer_rsrc_t ry = buf_of(y + ((size_t)n * COUT + 32 * ct) * HO * WO, 32 * HO * WO * 4);
+            const unsigned voff = valid ? (unsigned)(((4 * kh) * HO * WO + oy * WO + ox) * 4) : kOob;
+            float red[32];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = (acc0[i] + acc1[i]) + bs[i];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, (8 * (i >> 2) + (i & 3)) * (HO * WO * 4), 0);
+                const float rl = valid ? fmaxf(v, 0.f) : 0.f;
+                red[2 * i] = rl;
+                red[2 * i + 1] = rl * rl;
+            }
+            if (stats) {
+                treduce_step<0, 32>(red, (lane & 1) != 0);
+                treduce_step<1, 16>(red, (lane & 2) != 0);
+                treduce_step<2, 8>(red, (lane & 4) != 0);
+                treduce_step<3, 4>(red, (lane & 8) != 0);
+                treduce_step<4, 2>(red, (lane & 16) != 0);
+                // lane l of a half now holds the half's total of value (l & 31): register i = l >> 1 (bits 1..4), statistic l & 1
+                const int i_ = slot >> 1;
+                s_red[k & 1][pt][32 * ct + 8 * (i_ >> 2) + 4 * kh + (i_ & 3)][slot & 1] = red[0];
+            }
+        }
+        lds_barrier();                       // tile (k + 1) & 1 is published, this band's statistics are complete in s_red[k & 1]
     }
 }
 
@@ -1113,7 +1419,7 @@ constexpr int kWgradWorkgroups = 512;              // persistent 12-wave workgro
 
 extern "C" int ag_cnn_conv_workspace_floats(int cin, int cout) {
     if (cin == 1 && cout == 16) return 400;
-    return 9 * cin * cout;
+    return 2 * 9 * cin * cout;      // (the split forward's fragment image: three bf16 planes = 6 bytes per weight)
 }
 
 extern "C" int ag_cnn_conv1_fwd(const float* x_dev, const long long* index_dev, const float* norm_mean_dev, const float* norm_std_dev,
@@ -1186,6 +1492,51 @@ extern "C" int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const
         else AG_CF(32, 64, 53, 30, kL3Waves, false);
     }
 #undef AG_CF
+    return AG_CONV_LAUNCH_OK();
+}
+
+// The same layer on the bf16 matrix cores at float32 accuracy (conv_s2_fwd_split_kernel): bands of 4 output rows, persistent workgroups.
+extern "C" int ag_cnn_conv_fwd_split_bands(int cin, int cout, int hin, int win) {
+    const int layer = layer_of(cin, cout, hin, win);
+    if (layer == 2) return (53 + 3) / 4;
+    if (layer == 3) return (27 + 3) / 4;
+    return AG_ERR_UNSUPPORTED;
+}
+
+extern "C" int ag_cnn_conv_fwd_split(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev,
+                                     const float* b_dev, float* y_dev, float* stats_dev, int n, int cin, int cout, int hin, int win,
+                                     float* workspace_dev, void* stream) {
+    if (!x_dev || !w_dev || !b_dev || !y_dev || !workspace_dev || n <= 0 || (!scale_dev) != (!shift_dev)) return AG_ERR_INVALID_ARG;
+    if ((uintptr_t)workspace_dev & 15) return AG_ERR_INVALID_ARG;
+    const int layer = layer_of(cin, cout, hin, win);
+    if (!layer) return AG_ERR_UNSUPPORTED;
+    const int units = (cout / 32) * 9 * (cin / 16) * 64;
+    hipLaunchKernelGGL(pack_fwd_split_kernel, dim3((units + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_dev, (uint4*)workspace_dev,
+                       cin, cout);
+    const bool apply = scale_dev != nullptr;
+    const int bands = ag_cnn_conv_fwd_split_bands(cin, cout, hin, win);
+    const long long items = (long long)n * bands;
+    if (items > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+#define AG_CFS(CIN_, COUT_, HIN_, WIN_, APPLY_, PER_CU_)                                                                          \
+    do {                                                                                                                          \
+        const long long g = (long long)cus * (PER_CU_);                                                                           \
+        hipLaunchKernelGGL((conv_s2_fwd_split_kernel<CIN_, COUT_, HIN_, WIN_, APPLY_>), dim3((unsigned)(items < g ? items : g)),    \
+                           dim3(SplitFwdShape<CIN_, COUT_, WIN_>::NT), 0, (hipStream_t)stream, x_dev, (const uint4*)workspace_dev,  \
+                           b_dev, scale_dev, shift_dev, y_dev, stats_dev, (int)items);                                           \
+    } while (0)
+    if (layer == 2) {
+        if (apply) AG_CFS(16, 32, 106, 60, true, 1);
+        else AG_CFS(16, 32, 106, 60, false, 1);
+    } else {
+        if (apply) AG_CFS(32, 64, 53, 30, true, 1);
+        else AG_CFS(32, 64, 53, 30, false, 1);
+    }
+#undef AG_CFS
     return AG_CONV_LAUNCH_OK();
 }
 

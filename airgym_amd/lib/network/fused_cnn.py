@@ -63,18 +63,23 @@ def _conv1_fwd(lib, img, index, norm, w, b, want_stats):
     return y, stats
 
 
+# forward of the two 3 x 3 layers on the bf16 matrix cores at float32 accuracy (ag_cnn_conv_fwd_split); False: the f32-input MFMA kernel
+SPLIT_FWD = True
+
+
 def _conv_fwd(lib, x, coef, w, b, want_stats):
     """(y, stats): the layer applied to relu(x) * coef[2] + coef[3]; stats [n, bands, cout, 2] = per (image, band of output rows)
     the sums (relu(y), relu(y)^2) per output channel, or None."""
     n, cin, hin, win = x.shape
     cout = w.shape[0]
     y = torch.empty(n, cout, (hin - 1) // 2 + 1, win // 2, dtype=torch.float32, device=x.device)
-    bands = lib.ag_cnn_conv_fwd_bands(cin, cout, hin, win)
+    bands = (lib.ag_cnn_conv_fwd_split_bands if SPLIT_FWD else lib.ag_cnn_conv_fwd_bands)(cin, cout, hin, win)
     stats = torch.empty(n, bands, cout, 2, dtype=torch.float32, device=x.device) if want_stats else None
     ws = torch.empty(lib.ag_cnn_conv_workspace_floats(cin, cout), dtype=torch.float32, device=x.device)
-    N.check(lib.ag_cnn_conv_fwd(x.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
-                                stats.data_ptr() if want_stats else None, n, cin, cout, hin, win, ws.data_ptr(), _stream(x)),
-            "ag_cnn_conv_fwd")
+    fwd = lib.ag_cnn_conv_fwd_split if SPLIT_FWD else lib.ag_cnn_conv_fwd
+    N.check(fwd(x.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                stats.data_ptr() if want_stats else None, n, cin, cout, hin, win, ws.data_ptr(), _stream(x)),
+            "ag_cnn_conv_fwd_split" if SPLIT_FWD else "ag_cnn_conv_fwd")
     return y, stats
 
 

@@ -661,6 +661,14 @@ int ag_cnn_conv_supported(int cin, int cout, int hin, int win);
 int ag_cnn_conv_fwd_bands(int cin, int cout, int hin, int win);
 int ag_cnn_conv_fwd(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev, const float* b_dev,
                     float* y_dev, float* stats_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev, void* stream);
+/* ag_cnn_conv_fwd on the BF16 matrix cores at float32 accuracy (round 6; conv_s2_fwd_split_kernel): every operand as an exact
+ * three-way bf16 split, six bf16 MFMAs per product block - 6/16 of the f32-input MFMA's time, results within float32 rounding of
+ * the f32 kernel's (not bit-identical: another summation order).  Same arguments and outputs; stats_dev has
+ * ag_cnn_conv_fwd_split_bands(...) rows per image (bands of 4 output rows); workspace_dev (ag_cnn_conv_workspace_floats) 16-byte aligned. */
+int ag_cnn_conv_fwd_split_bands(int cin, int cout, int hin, int win);
+int ag_cnn_conv_fwd_split(const float* x_dev, const float* scale_dev, const float* shift_dev, const float* w_dev, const float* b_dev,
+                          float* y_dev, float* stats_dev, int n, int cin, int cout, int hin, int win, float* workspace_dev,
+                          void* stream);
 int ag_cnn_conv_dgrad(const float* dz_dev, const float* w_dev, float* dx_dev, int n, int cin, int cout, int hin, int win,
                       float* workspace_dev, void* stream);
 int ag_cnn_conv_dgrad_bn_rows(int n, int cin, int cout, int hin, int win);

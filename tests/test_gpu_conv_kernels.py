@@ -385,3 +385,57 @@ def test_input_gradient_feeding_the_first_weight_gradient_in_one_kernel(weighted
     a, b = pa.double().sum(0)[:, :26], pb.double().sum(0)[:, :26]
     assert torch.isfinite(pb[:, :, :26]).all()
     assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item(), ((a - b).abs().max().item(), a.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["conv2", "conv3"])
+@pytest.mark.parametrize("apply", [False, True])
+@pytest.mark.parametrize("n", [1, 7])
+def test_split_bf16_forward_is_float32_accurate(name, apply, n):
+    """ag_cnn_conv_fwd_split (round 6: the 3 x 3 layers' forward on the bf16 matrix cores, exact three-way split of both operands, six
+    MFMAs per product block): output against float64 within the f32 kernel's own tolerance (2e-5 of scale), per-(image, band) sums of
+    relu(y) and relu(y)^2 against float64 sums, with and without the previous layer's ReLU + BatchNorm applied while staging (padding
+    stays zero), every band incl. the partial last one; and not further from float64 than 3x the f32-input-MFMA kernel is."""
+    import ctypes
+    from airgym_amd import _native as N
+    lib = N.load()
+    c, conv, g = _layer(name, 11)
+    x = torch.randn(n, c["cin"], c["hin"], c["win"], generator=g) * 2.0
+    scale = torch.rand(c["cin"], generator=g) + 0.5
+    shift = torch.randn(c["cin"], generator=g)
+    act = torch.relu(x.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) if apply else x.double()
+    yr = F.conv2d(act, conv.weight.double(), conv.bias.double(), stride=2, padding=1)
+    dev = torch.device("cuda")
+    xg, sc, sh = x.to(dev), scale.to(dev), shift.to(dev)
+    w, b = conv.weight.detach().to(dev).contiguous(), conv.bias.detach().to(dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = (c["cin"], c["cout"], c["hin"], c["win"])
+    ho, wo = yr.shape[2], yr.shape[3]
+    bands = lib.ag_cnn_conv_fwd_split_bands(*args)
+    assert bands == (ho + 3) // 4
+    y = torch.full(yr.shape, float("nan"), dtype=torch.float32, device=dev)
+    stats = torch.full((n, bands, c["cout"], 2), float("nan"), dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.ag_cnn_conv_workspace_floats(c["cin"], c["cout"]), dtype=torch.float32, device=dev)
+    N.check(lib.ag_cnn_conv_fwd_split(xg.data_ptr(), sc.data_ptr() if apply else None, sh.data_ptr() if apply else None, w.data_ptr(),
+                                      b.data_ptr(), y.data_ptr(), stats.data_ptr(), n, *args, ws.data_ptr(), stream), "fwd_split")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and torch.isfinite(stats).all()
+    _close(y, yr, 2e-5, name + " split forward")
+    y0 = torch.empty_like(y)
+    N.check(lib.ag_cnn_conv_fwd(xg.data_ptr(), sc.data_ptr() if apply else None, sh.data_ptr() if apply else None, w.data_ptr(),
+                                b.data_ptr(), y0.data_ptr(), None, n, *args, ws.data_ptr(), stream), "fwd")
+    e_split = (y.double().cpu() - yr).abs().max().item()
+    e_f32 = (y0.double().cpu() - yr).abs().max().item()
+    assert e_split <= 3.0 * e_f32 + 1e-7 * yr.abs().max().item(), (e_split, e_f32)
+    # statistics: sums over the band's valid pixels
+    rl = torch.relu(yr)
+    for band in range(bands):
+        rows = rl[:, :, 4 * band:min(4 * band + 4, ho), :]
+        s1, s2 = rows.sum((2, 3)), (rows * rows).sum((2, 3))
+        got = stats[:, band].double().cpu()
+        assert (got[..., 0] - s1).abs().max().item() <= 2e-5 * max(1.0, s1.abs().max().item()), (band, "sum")
+        assert (got[..., 1] - s2).abs().max().item() <= 2e-5 * max(1.0, s2.abs().max().item()), (band, "sum of squares")
+    # without statistics the same output, bit for bit
+    y2 = torch.empty_like(y)
+    N.check(lib.ag_cnn_conv_fwd_split(xg.data_ptr(), sc.data_ptr() if apply else None, sh.data_ptr() if apply else None, w.data_ptr(),
+                                      b.data_ptr(), y2.data_ptr(), None, n, *args, ws.data_ptr(), stream), "fwd_split")
+    assert torch.equal(y, y2)

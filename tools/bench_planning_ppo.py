@@ -27,7 +27,8 @@ def main():
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen find mode)")
     ap.add_argument("--encode-chunk", type=int, default=0, help="vae: images per encoder call (0 = all at once)")
     ap.add_argument("--fused-relu-bn", type=int, default=1, help="ReLU + BatchNorm2d pairs on csrc/cnn_kernels.hip")
-    ap.add_argument("--graph-update", type=int, default=1, help="minibatch steps as hipGraphs (use_hip_graph_update)")
+    ap.add_argument("--graph-update", type=int, default=0, help="minibatch steps as hipGraphs (use_hip_graph_update; opt-in, measured slower)")
+    ap.add_argument("--split-fwd", type=int, default=1, help="forward of the 3x3 layers on the bf16 matrix cores (fused_cnn.SPLIT_FWD)")
     args = ap.parse_args()
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     params = yaml.safe_load(open(os.path.join(repo, "scripts", "config", "ppo_planning.yaml")))["params"]
@@ -46,6 +47,8 @@ def main():
     c["use_hip_graph_update"] = bool(args.graph_update)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    from airgym_amd.lib.network import fused_cnn
+    fused_cnn.SPLIT_FWD = bool(args.split_fwd)
     agent = A2CAgent("planning_bench", params)
     # (channels_last was tried: MIOpen falls back to its naive kernels for these shapes, 137 s per epoch instead of 5.7 s)
     for mod in agent.model.modules():
@@ -69,7 +72,7 @@ def main():
                       "value": args.envs * args.horizon * args.steps / dt, "ms_per_epoch": dt / args.steps * 1e3,
                       "rollout_ms": play / args.steps * 1e3, "update_ms": upd / args.steps * 1e3,
                       "minibatch": c["minibatch_size"], "mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
-                      "kl": st["kl"], "a_loss": st["a_loss"], "c_loss": st["c_loss"], "graph_update": bool(getattr(agent, "_graph_generic", False)),
+                      "kl": st["kl"], "a_loss": st["a_loss"], "c_loss": st["c_loss"], "graph_update": bool(getattr(agent, "_graph_generic", False)), "split_fwd": bool(args.split_fwd),
                       "graphs": len(getattr(agent, "_upd_graphs", {})), "graph_error": getattr(agent, "_graph_generic_error", None)}))
 
 
