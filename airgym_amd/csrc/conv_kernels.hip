@@ -310,9 +310,11 @@ template <int CIN, int COUT, int WIN>
 struct SplitFwdShape {
     static constexpr int WO = WIN / 2, PXR = (WO <= 16) ? 2 : 1, TW = 32 / PXR, ROWS = 4, IN_ROWS = 2 * ROWS + 1, PT = ROWS / PXR;
     static constexpr int KG = CIN / 8, KS = CIN / 16, CT = COUT / 32;
-    static constexpr int NCONS = PT * CT, NPROD = 4, NT = (NCONS + NPROD) * 64;
+    // [16 -> 32]: 8 producer waves (three waves per SIMD: the conversion work has two waves to hide behind), 7 of the 9 taps' weight
+    // fragments in registers (170 registers per wave at three waves per SIMD); [32 -> 64]: 4 producers, 12 of the 18 (tap, K step) pairs
+    static constexpr int NCONS = PT * CT, NPROD = (KS == 1) ? 8 : 4, NT = (NCONS + NPROD) * 64;
     static constexpr int RS = 2 * TW + 1, PLANE = KG * IN_ROWS * RS, TILE = 3 * PLANE;
-    static constexpr int AREG = (9 * KS <= 12) ? 9 * KS : 12;          // (tap, K step) pairs of weight fragments held in registers
+    static constexpr int AREG = (KS == 1) ? 7 : 12;                    // (tap, K step) pairs of weight fragments held in registers
 };
 
 // wimg[ct][tap][ks][plane][lane] (16-byte units): lane l supplies row co = 32 ct + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7 of tap
@@ -368,7 +370,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int CIN, int COUT, int HIN, int WIN, bool APPLY>
 __global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_fwd_split_kernel(
     const float* __restrict__ x, const uint4* __restrict__ wimg, const float* __restrict__ bias, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ y, float* __restrict__ stats, int items) {
+    const float* __restrict__ shift, float* __restrict__ y, float* __restrict__ stats, int n_images) {
     using S = SplitFwdShape<CIN, COUT, WIN>;
     constexpr int HO = (HIN - 1) / 2 + 1, WO = S::WO, W2 = WIN / 2;
     constexpr int PXR = S::PXR, TW = S::TW, ROWS = S::ROWS, IN_ROWS = S::IN_ROWS, PT = S::PT;
@@ -383,7 +385,12 @@ __global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_f
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < NCONS;
-    const int step = gridDim.x;
+    // Item order: a workgroup walks WHOLE images, band after band (image blockIdx.x, blockIdx.x + gridDim.x, ...): its 16 / 32 input
+    // planes and 32 / 64 output planes are then sequential streams in memory, the row a band shares with the next one is still in
+    // cache, and the 480-byte pieces a band writes into every output plane are continued by the same workgroup a band later.
+    const int my_images = (int)blockIdx.x < n_images ? (n_images - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nv = my_images * ((HO + ROWS - 1) / ROWS);                  // this workgroup's items, v = 0 .. nv - 1
+    auto item_of = [&](int v) { constexpr int B_ = (HO + ROWS - 1) / ROWS; const int q = v / B_; return ((int)blockIdx.x + q * (int)gridDim.x) * B_ + (v - q * B_); };
 
     // ---- set-up common to both roles: the LDS copy of the weight fragments that do not live in registers, the padding columns
     if (ALDS > 0) {
@@ -472,32 +479,26 @@ __global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_f
                 stats[(size_t)item_ * COUT * 2 + u] = t;
             }
         };
-        int item = blockIdx.x;
-        if (item < items) {
-            fetch(vinA, item);
-            if (item + step < items) fetch(vinB, item + step);
-            stash(vinA, item, 0);
+        if (nv > 0) {
+            fetch(vinA, item_of(0));
+            if (nv > 1) fetch(vinB, item_of(1));
+            stash(vinA, item_of(0), 0);
         }
         lds_barrier();                                             // tile 0 published
-        // iteration k: the consumers work on tile k & 1 (band `item`); this wave issues the loads of band item + 2 step, converts band
-        // item + step into tile (k + 1) & 1 and writes out the statistics of band item - step
-        for (int k = 0; item < items; k += 2) {
-            if (item + 2 * step < items) fetch(vinA, item + 2 * step);
-            if (item + step < items) stash(vinB, item + step, 1);
-            if (stats && k > 0) flush_stats(item - step, 1);
+        // iteration v: the consumers work on tile v & 1 (item v of this workgroup); this wave issues the loads of item v + 2, converts
+        // item v + 1 into tile (v + 1) & 1 and writes out the statistics of item v - 1
+        for (int v = 0; v < nv; v += 2) {
+            if (v + 2 < nv) fetch(vinA, item_of(v + 2));
+            if (v + 1 < nv) stash(vinB, item_of(v + 1), 1);
+            if (stats && v > 0) flush_stats(item_of(v - 1), 1);
             lds_barrier();
-            item += step;
-            if (item >= items) break;
-            if (item + 2 * step < items) fetch(vinB, item + 2 * step);
-            if (item + step < items) stash(vinA, item + step, 0);
-            if (stats) flush_stats(item - step, 0);
+            if (v + 1 >= nv) break;
+            if (v + 3 < nv) fetch(vinB, item_of(v + 3));
+            if (v + 2 < nv) stash(vinA, item_of(v + 2), 0);
+            if (stats) flush_stats(item_of(v), 0);
             lds_barrier();
-            item += step;
         }
-        if (stats && item - step >= (int)blockIdx.x) {
-            const int last_k = (item - step - (int)blockIdx.x) / step;
-            flush_stats(item - step, last_k & 1);
-        }
+        if (stats && nv > 0) flush_stats(item_of(nv - 1), (nv - 1) & 1);
         return;
     }
 
@@ -519,8 +520,8 @@ __global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_f
     const int frag0 = (kh * IN_ROWS + 2 * (pt * PXR + pr)) * RS + ox;       // K step ks adds 2 ks channel groups
 
     lds_barrier();                                               // tile 0 published
-    int k = 0;
-    for (int item = blockIdx.x; item < items; item += step, ++k) {
+    for (int k = 0; k < nv; ++k) {
+        const int item = item_of(k);
         const int n = item / bands, band = item - n * bands;
         const int oy0 = band * ROWS;
         const uint4* tile = s_in + (size_t)(k & 1) * TILE;
@@ -1515,8 +1516,7 @@ extern "C" int ag_cnn_conv_fwd_split(const float* x_dev, const float* scale_dev,
                        cin, cout);
     const bool apply = scale_dev != nullptr;
     const int bands = ag_cnn_conv_fwd_split_bands(cin, cout, hin, win);
-    const long long items = (long long)n * bands;
-    if (items > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
+    if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, v = 0;
@@ -1525,9 +1525,9 @@ extern "C" int ag_cnn_conv_fwd_split(const float* x_dev, const float* scale_dev,
 #define AG_CFS(CIN_, COUT_, HIN_, WIN_, APPLY_, PER_CU_)                                                                          \
     do {                                                                                                                          \
         const long long g = (long long)cus * (PER_CU_);                                                                           \
-        hipLaunchKernelGGL((conv_s2_fwd_split_kernel<CIN_, COUT_, HIN_, WIN_, APPLY_>), dim3((unsigned)(items < g ? items : g)),    \
+        hipLaunchKernelGGL((conv_s2_fwd_split_kernel<CIN_, COUT_, HIN_, WIN_, APPLY_>), dim3((unsigned)(n < g ? n : g)),            \
                            dim3(SplitFwdShape<CIN_, COUT_, WIN_>::NT), 0, (hipStream_t)stream, x_dev, (const uint4*)workspace_dev,  \
-                           b_dev, scale_dev, shift_dev, y_dev, stats_dev, (int)items);                                           \
+                           b_dev, scale_dev, shift_dev, y_dev, stats_dev, n);                                                    \
     } while (0)
     if (layer == 2) {
         if (apply) AG_CFS(16, 32, 106, 60, true, 1);
