@@ -298,10 +298,10 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
 //       channels of one position, three planes - with the columns de-interleaved by parity as above (E[j + 1] = column 2j + 1, O[j] =
 //       column 2j, E[0] = left padding), so the 32 lanes of a fragment read 32 (or 2 x 16) consecutive units: conflict-free
 //       ds_read_b128.  ReLU + BatchNorm of the previous layer and the split are applied once per staged element.
-//   Workgroup = 4 PRODUCER waves + 4 CONSUMER waves, one per CU, persistent over (image, band) items, TWO band tiles in LDS:
+//   Workgroup = 4 (8 for [16 -> 32]) PRODUCER waves + 4 CONSUMER waves, one per CU, persistent over whole images, TWO band tiles in LDS:
 //       while the consumers run the 54 / 108 MFMAs and the epilogue of band i out of one tile, the producers convert band i + 1
-//       (loaded into registers one iteration earlier) into the other and issue the loads of band i + 2; one barrier per band.  Every
-//       SIMD hosts one wave of each kind, so the split's vector instructions issue under the other wave's MFMAs.
+//       (loaded into registers two iterations earlier) into the other and issue the loads of band i + 3; one barrier per band.  Every
+//       SIMD hosts a consumer and one or two producers, so the split's vector instructions issue under the other wave's MFMAs.
 //   Pixel tile = 32 slots: one output row of up to 32 pixels (WO = 30), or two rows of up to 16 (WO = 15).  Consumer wave = (pixel
 //   tile of the band, 32-channel output tile).  A producer wave stages ONE 8-channel group (scale / shift in scalar registers).
 // Epilogue as above: + bias, store, per-(image, band) sums of relu(y), relu(y)^2 per output channel (transposing lane reduction,
