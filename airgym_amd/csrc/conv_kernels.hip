@@ -298,7 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_s2_fwd_kernel(const float* __
 //       channels of one position, three planes - with the columns de-interleaved by parity as above (E[j + 1] = column 2j + 1, O[j] =
 //       column 2j, E[0] = left padding), so the 32 lanes of a fragment read 32 (or 2 x 16) consecutive units: conflict-free
 //       ds_read_b128.  ReLU + BatchNorm of the previous layer and the split are applied once per staged element.
-//   Workgroup = 4 (8 for [16 -> 32]) PRODUCER waves + 4 CONSUMER waves, one per CU, persistent over whole images, TWO band tiles in LDS:
+//   Workgroup = 4 PRODUCER waves + 4 CONSUMER waves, one per CU, persistent over whole images, TWO band tiles in LDS:
 //       while the consumers run the 54 / 108 MFMAs and the epilogue of band i out of one tile, the producers convert band i + 1
 //       (loaded into registers two iterations earlier) into the other and issue the loads of band i + 3; one barrier per band.  Every
 //       SIMD hosts a consumer and one or two producers, so the split's vector instructions issue under the other wave's MFMAs.
@@ -310,11 +310,11 @@ template <int CIN, int COUT, int WIN>
 struct SplitFwdShape {
     static constexpr int WO = WIN / 2, PXR = (WO <= 16) ? 2 : 1, TW = 32 / PXR, ROWS = 4, IN_ROWS = 2 * ROWS + 1, PT = ROWS / PXR;
     static constexpr int KG = CIN / 8, KS = CIN / 16, CT = COUT / 32;
-    // [16 -> 32]: 8 producer waves (three waves per SIMD: the conversion work has two waves to hide behind), 7 of the 9 taps' weight
-    // fragments in registers (170 registers per wave at three waves per SIMD); [32 -> 64]: 4 producers, 12 of the 18 (tap, K step) pairs
-    static constexpr int NCONS = PT * CT, NPROD = (KS == 1) ? 8 : 4, NT = (NCONS + NPROD) * 64;
+    // 4 producer + 4 consumer waves.  (Measured for [16 -> 32]: 8 producers at three waves per SIMD with 7 of the 9 taps' fragments in
+    // registers - 940 against 986 us in isolation, no difference inside the Planning update: 970 - 981 against 966 - 972 ms per epoch.)
+    static constexpr int NCONS = PT * CT, NPROD = 4, NT = (NCONS + NPROD) * 64;
     static constexpr int RS = 2 * TW + 1, PLANE = KG * IN_ROWS * RS, TILE = 3 * PLANE;
-    static constexpr int AREG = (KS == 1) ? 7 : 12;                    // (tap, K step) pairs of weight fragments held in registers
+    static constexpr int AREG = (KS == 1) ? 9 : 12;                    // (tap, K step) pairs of weight fragments held in registers
 };
 
 // wimg[ct][tap][ks][plane][lane] (16-byte units): lane l supplies row co = 32 ct + (l & 31), k = 16 ks + 8 (l >> 5) .. + 7 of tap
@@ -362,15 +362,15 @@ __device__ __forceinline__ void treduce_step(float* v, bool bit) {
     }
 }
 
-// Workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL access
-// (s_waitcnt vmcnt(0)) - here that would be the loads a producer has just issued for the band after next, i.e. their whole latency
-// once per band, with the consumers waiting at the same barrier.
+// Workgroup barrier that waits for this wave's LDS traffic only - never for the global loads a producer has in flight for the bands
+// ahead.  (This is what __syncthreads() compiles to with this toolchain in the default workgroup mode - s_waitcnt lgkmcnt(0); s_barrier -
+// spelled out here because the kernel's load pipeline depends on it.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
 
 template <int CIN, int COUT, int HIN, int WIN, bool APPLY>
 __global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_fwd_split_kernel(
     const float* __restrict__ x, const uint4* __restrict__ wimg, const float* __restrict__ bias, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ y, float* __restrict__ stats, int n_images) {
+    const float* __restrict__ shift, float* __restrict__ y, float* __restrict__ stats, int n_images, int image_major) {
     using S = SplitFwdShape<CIN, COUT, WIN>;
     constexpr int HO = (HIN - 1) / 2 + 1, WO = S::WO, W2 = WIN / 2;
     constexpr int PXR = S::PXR, TW = S::TW, ROWS = S::ROWS, IN_ROWS = S::IN_ROWS, PT = S::PT;
@@ -385,13 +385,20 @@ __global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_f
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < NCONS;
-    // Item order: a workgroup walks WHOLE images, band after band (image blockIdx.x, blockIdx.x + gridDim.x, ...): its 16 / 32 input
-    // planes and 32 / 64 output planes are then sequential streams in memory, the row a band shares with the next one is still in
-    // cache, and the 480-byte pieces a band writes into every output plane are continued by the same workgroup a band later.
+    // Item order.  image_major (large batches): a workgroup walks WHOLE images, band after band (image blockIdx.x, blockIdx.x +
+    // gridDim.x, ...): its 16 / 32 input planes and 32 / 64 output planes are then sequential streams in memory, the row a band shares
+    // with the next one is still in cache, and the 480-byte pieces a band writes into every output plane are continued by the same
+    // workgroup a band later.  Otherwise (fewer than ~8 images per workgroup: the tail of whole images would idle CUs) items are dealt
+    // round robin: item blockIdx.x, blockIdx.x + gridDim.x, ...
+    constexpr int B_ = (HO + ROWS - 1) / ROWS;
+    const int items = n_images * B_;
     const int my_images = (int)blockIdx.x < n_images ? (n_images - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int nv = my_images * ((HO + ROWS - 1) / ROWS);                  // this workgroup's items, v = 0 .. nv - 1
-    auto item_of = [&](int v) { constexpr int B_ = (HO + ROWS - 1) / ROWS; const int q = v / B_; return ((int)blockIdx.x + q * (int)gridDim.x) * B_ + (v - q * B_); };
-
+    const int nv = image_major ? my_images * B_ : ((int)blockIdx.x < items ? (items - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0);
+    auto item_of = [&](int v) {
+        if (!image_major) return (int)blockIdx.x + v * (int)gridDim.x;
+        const int q = v / B_;
+        return ((int)blockIdx.x + q * (int)gridDim.x) * B_ + (v - q * B_);
+    };
     // ---- set-up common to both roles: the LDS copy of the weight fragments that do not live in registers, the padding columns
     if (ALDS > 0) {
         for (int u = tid; u < CT * ALDS * 3 * 64; u += S::NT) {
@@ -1525,9 +1532,11 @@ extern "C" int ag_cnn_conv_fwd_split(const float* x_dev, const float* scale_dev,
 #define AG_CFS(CIN_, COUT_, HIN_, WIN_, APPLY_, PER_CU_)                                                                          \
     do {                                                                                                                          \
         const long long g = (long long)cus * (PER_CU_);                                                                           \
-        hipLaunchKernelGGL((conv_s2_fwd_split_kernel<CIN_, COUT_, HIN_, WIN_, APPLY_>), dim3((unsigned)(n < g ? n : g)),            \
+        const bool im = (long long)n >= 8 * g;                                                                                    \
+        const long long work = im ? (long long)n : (long long)n * bands;                                                          \
+        hipLaunchKernelGGL((conv_s2_fwd_split_kernel<CIN_, COUT_, HIN_, WIN_, APPLY_>), dim3((unsigned)(work < g ? work : g)),        \
                            dim3(SplitFwdShape<CIN_, COUT_, WIN_>::NT), 0, (hipStream_t)stream, x_dev, (const uint4*)workspace_dev,  \
-                           b_dev, scale_dev, shift_dev, y_dev, stats_dev, n);                                                    \
+                           b_dev, scale_dev, shift_dev, y_dev, stats_dev, n, im ? 1 : 0);                                        \
     } while (0)
     if (layer == 2) {
         if (apply) AG_CFS(16, 32, 106, 60, true, 1);

@@ -280,6 +280,13 @@ def side_config_planning(envs=16384, epochs=3, warmup=2, minibatches=24):
            "rollout_ms": play / epochs * 1e3, "update_ms": upd / epochs * 1e3,
            "mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
            "last_kl": st["kl"], "finite": bool(st["kl"] == st["kl"] and st["a_loss"] == st["a_loss"])}
+    try:      # the camera kernel of THIS configuration against its 101 760 B of image per env and render
+        from airgym_amd.utils.kernel_bench import planning_render_roofline
+        ro = planning_render_roofline(agent._hip_env, REPO)
+        if ro is not None:
+            out["roofline"] = ro
+    except Exception as e:
+        out["roofline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     agent.vec_env.env.hip.close()
     return out
 

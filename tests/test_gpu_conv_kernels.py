@@ -439,3 +439,41 @@ def test_split_bf16_forward_is_float32_accurate(name, apply, n):
     N.check(lib.ag_cnn_conv_fwd_split(xg.data_ptr(), sc.data_ptr() if apply else None, sh.data_ptr() if apply else None, w.data_ptr(),
                                       b.data_ptr(), y2.data_ptr(), None, n, *args, ws.data_ptr(), stream), "fwd_split")
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("name", ["conv2", "conv3"])
+def test_split_forward_large_batch_item_order(name):
+    """From 8 images per CU on, the split forward's persistent workgroups walk whole images (sequential planes) instead of taking
+    (image, band) items round robin - another loop structure around the same arithmetic.  2 100 images (> 8 x 256): output and
+    per-(image, band) statistics against the f32-input-MFMA kernel (two float32 evaluations: 3e-6 of scale), every image and band
+    written exactly once (NaN-prefilled outputs)."""
+    import ctypes
+    from airgym_amd import _native as N
+    lib = N.load()
+    c, conv, g = _layer(name, 13)
+    n = 2100
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(n, c["cin"], c["hin"], c["win"], generator=gen, device=dev)
+    sc = torch.rand(c["cin"], generator=gen, device=dev) + 0.5
+    sh = torch.randn(c["cin"], generator=gen, device=dev)
+    w, b = conv.weight.detach().to(dev).contiguous(), conv.bias.detach().to(dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = (c["cin"], c["cout"], c["hin"], c["win"])
+    ho, wo = (c["hin"] - 1) // 2 + 1, c["win"] // 2
+    ws = torch.empty(lib.ag_cnn_conv_workspace_floats(c["cin"], c["cout"]), dtype=torch.float32, device=dev)
+    y = torch.full((n, c["cout"], ho, wo), float("nan"), dtype=torch.float32, device=dev)
+    bands = lib.ag_cnn_conv_fwd_split_bands(*args)
+    st = torch.full((n, bands, c["cout"], 2), float("nan"), dtype=torch.float32, device=dev)
+    N.check(lib.ag_cnn_conv_fwd_split(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), st.data_ptr(),
+                                      n, *args, ws.data_ptr(), stream), "fwd_split")
+    y0 = torch.empty_like(y)
+    bands0 = lib.ag_cnn_conv_fwd_bands(*args)
+    st0 = torch.empty(n, bands0, c["cout"], 2, dtype=torch.float32, device=dev)
+    N.check(lib.ag_cnn_conv_fwd(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), w.data_ptr(), b.data_ptr(), y0.data_ptr(), st0.data_ptr(),
+                                n, *args, ws.data_ptr(), stream), "fwd")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and torch.isfinite(st).all()
+    assert (y - y0).abs().max().item() <= 3e-6 * y0.abs().max().item()
+    s, s0 = st.sum(1), st0.sum(1)                                   # per image: the band partitions differ between the two kernels
+    assert (s - s0).abs().max().item() <= 2e-5 * s0.abs().max().item()
