@@ -314,7 +314,7 @@ def _pick(d, keys):
 
 
 _KERNEL_KEYS = ("bound", "kernel", "us_per_launch", "achieved", "peak", "unit", "frac", "traffic", "algo_bytes_per_env_step",
-                "valu_busy_pct", "steps_per_launch")
+                "valu_busy_pct", "steps_per_launch", "frac_nominal", "nominal_bytes_per_env_step")
 
 
 def compact_line(out, limit=LINE_LIMIT, detail_path=None):
