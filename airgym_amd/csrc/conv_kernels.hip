@@ -1524,11 +1524,12 @@ extern "C" int ag_cnn_conv_fwd_split(const float* x_dev, const float* scale_dev,
     const bool apply = scale_dev != nullptr;
     const int bands = ag_cnn_conv_fwd_split_bands(cin, cout, hin, win);
     if ((long long)n * bands > 0x7fffffffLL) return AG_ERR_UNSUPPORTED;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
+    static int cus_of[64] = {0};          // CU count per device ordinal
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus_of[dev] == 0)
+        cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    const int cus = cus_of[dev];
 #define AG_CFS(CIN_, COUT_, HIN_, WIN_, APPLY_, PER_CU_)                                                                          \
     do {                                                                                                                          \
         const long long g = (long long)cus * (PER_CU_);                                                                           \
