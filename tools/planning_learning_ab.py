@@ -5,6 +5,7 @@ Trains scripts/config/ppo_planning.yaml (CTBR, 24-step horizon, 2 048-sample min
 arms from the same seeds and prints one JSON object per run (mean episode reward / length over the last `games_to_track` episodes,
 KL, losses every `--every` epochs):
   hip_trunk         the default: frame de-duplication + csrc/conv_kernels.hip + lib/network/fused_cnn.py
+  hip_trunk_f32_forward   the same with the f32-input-MFMA forward of the 3 x 3 layers instead of the bf16-split one (round 6 A/B)
   library_convs     frame de-duplication, torch's conv2d (MIOpen) layer by layer with the ReLU + BatchNorm kernels
   reference_shape   dedup_frames: false + torch's conv2d: every sample's image stored and convolved, as the reference does
 
@@ -34,8 +35,10 @@ def run(arm, envs, epochs, every, seed):
     params["seed"] = seed
     torch.manual_seed(seed)
     from airgym_amd.lib.agent.a2c_continuous import A2CAgent
+    from airgym_amd.lib.network import fused_cnn
+    fused_cnn.SPLIT_FWD = arm != "hip_trunk_f32_forward"      # (round 6) the two 3 x 3 forwards on the bf16 matrix cores, or the f32 kernel
     agent = A2CAgent("planning_ab", params)
-    if arm != "hip_trunk":
+    if arm not in ("hip_trunk", "hip_trunk_f32_forward"):
         for mod in agent.model.modules():
             if hasattr(mod, "fused_trunk"):
                 mod.fused_trunk = False
