@@ -466,8 +466,16 @@ __global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_f
                     }
                 }
                 uint4 o1, o2, o3, e1, e2, e3;
+#ifdef AG_CONVF_SKELETON      /* timing experiment: memory traffic + barriers only (results wrong by construction) */
+                o1 = make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[1].x), __float_as_uint(v[2].x), __float_as_uint(v[3].x));
+                o2 = make_uint4(__float_as_uint(v[4].x), __float_as_uint(v[5].x), __float_as_uint(v[6].x), __float_as_uint(v[7].x));
+                e1 = make_uint4(__float_as_uint(v[0].y), __float_as_uint(v[1].y), __float_as_uint(v[2].y), __float_as_uint(v[3].y));
+                e2 = make_uint4(__float_as_uint(v[4].y), __float_as_uint(v[5].y), __float_as_uint(v[6].y), __float_as_uint(v[7].y));
+                o3 = o1; e3 = e1;
+#else
                 split8(make_float4(v[0].x, v[1].x, v[2].x, v[3].x), make_float4(v[4].x, v[5].x, v[6].x, v[7].x), o1, o2, o3);
                 split8(make_float4(v[0].y, v[1].y, v[2].y, v[3].y), make_float4(v[4].y, v[5].y, v[6].y, v[7].y), e1, e2, e3);
+#endif
                 uint4* base = tile + udst[k];
                 base[TW + 1] = o1;             // O[j]     = column 2j
                 base[PLANE + TW + 1] = o2;
@@ -536,7 +544,12 @@ __global__ __launch_bounds__((SplitFwdShape<CIN, COUT, WIN>::NT)) void conv_s2_f
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
         const bool tile_live = oy0 + pt * PXR < HO;         // (the last band: tiles below the image only take part in the barriers)
+#ifdef AG_CONVF_SKELETON
+        if (tile_live) { const uint4 q0 = tile[frag0]; acc0[0] = __uint_as_float(q0.x); acc1[1] = __uint_as_float(q0.y); }
+        if (false) {
+#else
         if (tile_live) {
+#endif
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
